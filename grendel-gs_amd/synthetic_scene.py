@@ -1,0 +1,110 @@
+"""Seeded synthetic scenes and cameras for tests, smoke() and bench.py.
+
+There is no dataset on the GPU box, so the measured workload is fabricated: Gaussians already
+*activated* the way ``GaussianModel.get_*`` hands them to the op (scene/gaussian_model.py:109-129 of
+the reference) and cameras in the reference's matrix conventions (scene/cameras.py:84-100,
+utils/graphics_utils.py:42-76: world_view_transform = W2C^T, full_proj = wv @ P^T,
+camera_center = inverse(wv)[3,:3], znear 0.01, zfar 100).
+"""
+import math
+
+import torch
+
+
+class SyntheticCamera:
+    """duck-type of scene.cameras.Camera for the fields the hot path reads
+    (gaussian_renderer/__init__.py:927-940, workload_division.py:812,880)."""
+
+    def __init__(self, uid, width, height, fx=None, fy=None, R=None, T=None, device="cpu"):
+        self.uid = uid
+        self.image_name = f"synthetic_{uid:05d}"
+        self.image_width = int(width)
+        self.image_height = int(height)
+        fx = 0.9 * width if fx is None else fx
+        fy = fx if fy is None else fy
+        self.FoVx = 2.0 * math.atan(width / (2.0 * fx))
+        self.FoVy = 2.0 * math.atan(height / (2.0 * fy))
+        self.znear, self.zfar = 0.01, 100.0
+        R = torch.eye(3, dtype=torch.float64) if R is None else R.to(torch.float64)
+        T = torch.zeros(3, dtype=torch.float64) if T is None else T.to(torch.float64)
+        # getWorld2View2(R, t): Rt[:3,:3] = R^T, Rt[:3,3] = t  (utils/graphics_utils.py:42-54)
+        Rt = torch.zeros(4, 4, dtype=torch.float64)
+        Rt[:3, :3] = R.t()
+        Rt[:3, 3] = T
+        Rt[3, 3] = 1.0
+        wv = Rt.to(torch.float32).t().contiguous()
+        tanx, tany = math.tan(self.FoVx / 2), math.tan(self.FoVy / 2)
+        top, right = tany * self.znear, tanx * self.znear
+        P = torch.zeros(4, 4)
+        P[0, 0] = 2.0 * self.znear / (2.0 * right)
+        P[1, 1] = 2.0 * self.znear / (2.0 * top)
+        P[3, 2] = 1.0
+        P[2, 2] = self.zfar / (self.zfar - self.znear)
+        P[2, 3] = -(self.zfar * self.znear) / (self.zfar - self.znear)
+        proj = P.t().contiguous()
+        self.world_view_transform = wv.to(device)
+        self.projection_matrix = proj.to(device)
+        self.full_proj_transform = (wv.unsqueeze(0).bmm(proj.unsqueeze(0))).squeeze(0).to(device)
+        self.camera_center = wv.inverse()[3, :3].contiguous().to(device)
+        self.original_image = None
+        self.original_image_backup = None
+
+    def to(self, device):
+        for k in ("world_view_transform", "projection_matrix", "full_proj_transform", "camera_center"):
+            setattr(self, k, getattr(self, k).to(device))
+        return self
+
+
+def make_gaussians(n, width, height, seed=0, fx=None, device="cpu", sh_rest_sigma=0.1, scale_coef=0.004):
+    """Activated Gaussian attributes in view space of the identity camera (R=I, T=0).
+
+    z ~ U(2,10); x,y ~ U(-1.15,1.15) * z * tanfov (about 13 % outside the frustum, exercising the
+    cull); log-scale ~ N(log(scale_coef*z), 0.5^2) per axis; unit quaternions from N(0,1)^4;
+    opacity = sigmoid(N(0,2^2)); SH dc ~ U(-1,1)/0.28209, rest ~ N(0, 0.1^2)."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    fx = 0.9 * width if fx is None else fx
+    tanx = width / (2.0 * fx)
+    tany = height / (2.0 * fx)
+    z = torch.rand(n, generator=g) * 8.0 + 2.0
+    x = (torch.rand(n, generator=g) * 2.3 - 1.15) * z * tanx
+    y = (torch.rand(n, generator=g) * 2.3 - 1.15) * z * tany
+    means3D = torch.stack([x, y, z], dim=1)
+    log_s = torch.log(scale_coef * z)[:, None] + 0.5 * torch.randn(n, 3, generator=g)
+    scales = torch.exp(log_s)
+    q = torch.randn(n, 4, generator=g)
+    rotations = q / q.norm(dim=1, keepdim=True)
+    opacities = torch.sigmoid(2.0 * torch.randn(n, 1, generator=g))
+    dc = (torch.rand(n, 1, 3, generator=g) * 2.0 - 1.0) / 0.28209479177387814
+    rest = sh_rest_sigma * torch.randn(n, 15, 3, generator=g)
+    shs = torch.cat([dc, rest], dim=1).contiguous()
+    return dict(
+        means3D=means3D.contiguous().to(device),
+        scales=scales.contiguous().to(device),
+        rotations=rotations.contiguous().to(device),
+        shs=shs.to(device),
+        opacities=opacities.contiguous().to(device),
+    )
+
+
+def orbit_cameras(n_views, width, height, device="cpu", centroid_z=6.0):
+    """B cameras rotated about the cloud centroid (0,0,centroid_z) by 360*k/B degrees about the y axis."""
+    cams = []
+    c = torch.tensor([0.0, 0.0, centroid_z], dtype=torch.float64)
+    for k in range(n_views):
+        th = 2.0 * math.pi * k / n_views
+        # world->camera rotation (math convention) about y
+        Rw2c = torch.tensor(
+            [[math.cos(th), 0.0, -math.sin(th)], [0.0, 1.0, 0.0], [math.sin(th), 0.0, math.cos(th)]],
+            dtype=torch.float64,
+        )
+        # p_cam = Rw2c (p - c) + c  ->  t = c - Rw2c c ; Camera stores R = Rw2c^T (COLMAP-style transposed R)
+        t = c - Rw2c @ c
+        cams.append(SyntheticCamera(k, width, height, R=Rw2c.t(), T=t, device=device))
+    return cams
+
+
+def make_gt_image(width, height, seed=1, device="cpu"):
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    return torch.randint(0, 256, (3, height, width), generator=g, dtype=torch.uint8).to(device)

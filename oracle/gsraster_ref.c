@@ -1,0 +1,620 @@
+/*
+ * gsraster_ref.c -- plain-C CPU restatement of the Grendel-GS rasterizer hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is linked, imported or executed by the
+ * product path (grendel-gs_amd/); only tests/, __graft_entry__.smoke() and the cpu_baseline
+ * leg of bench.py use it, and only as the checker / the timed CPU baseline ("port").
+ *
+ * PARITY UNPINNED.  The reference's arithmetic for this path lives in the un-vendored
+ * submodule submodules/diff-gaussian-rasterization (nyu-systems fork; .gitmodules:4-6 of the
+ * reference, directory empty, no pinned SHA) and the reference holds no tests or golden
+ * vectors.  This file restates the published 3D-Gaussian-splatting
+ * rasterizer algorithm in the two-op split Grendel uses, anchored on the call sites
+ *   preprocess_gaussians  gaussian_renderer/__init__.py:949-960   (K1; backward K11)
+ *   render_gaussians      gaussian_renderer/__init__.py:1271-1282 (K3-K8; backward K10)
+ *   get_local2j_ids_bool  gaussian_renderer/workload_division.py:721-744 (K2)
+ * and on the in-repo conventions: SH basis utils/sh_utils.py:26-120, quaternion->R and
+ * Sigma=R S S^T R^T utils/general_utils.py:416-451, row-vector camera matrices
+ * scene/cameras.py:84-100, 16x16 tiles utils/general_utils.py:78-93, NDC-scaled means2D
+ * gradients scene/gaussian_model.py:1046-1064.  Unlike oracle/torch_oracle.py (autograd),
+ * the backward passes here are written out by hand, in the form the CUDA backward is
+ * recalled to have, and are themselves checked against the float64
+ * autograd oracle by tests/test_oracle_cpu.py.
+ *
+ * Per-pixel / per-Gaussian arithmetic is float32 like the reference; gradient SUMS over
+ * pixels are accumulated in double (the reference uses float atomics in arbitrary order,
+ * so no summation order is canonical) and rounded once.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define BLOCK_X 16
+#define BLOCK_Y 16
+
+static const float SH_C0 = 0.28209479177387814f;
+static const float SH_C1 = 0.4886025119029199f;
+static const float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                               -1.0925484305920792f, 0.5462742152960396f};
+static const float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                               0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                               -0.5900435899266435f};
+
+static inline int imin(int a, int b) { return a < b ? a : b; }
+static inline int imax(int a, int b) { return a > b ? a : b; }
+
+/* tile rect of (pixel centre, radius): truncation toward zero, clamped to the grid */
+static void get_rect(float px, float py, int radius, int gx, int gy, int *minx, int *miny, int *maxx, int *maxy) {
+    float r = (float)radius;
+    *minx = imin(gx, imax(0, (int)((px - r) / BLOCK_X)));
+    *miny = imin(gy, imax(0, (int)((py - r) / BLOCK_Y)));
+    *maxx = imin(gx, imax(0, (int)((px + r + BLOCK_X - 1) / BLOCK_X)));
+    *maxy = imin(gy, imax(0, (int)((py + r + BLOCK_Y - 1) / BLOCK_Y)));
+}
+
+/* row-vector convention: out = [p,1] @ M, M row-major 4x4 (scene/cameras.py:84-99) */
+static void xform4x3(const float *p, const float *m, float *o) {
+    o[0] = m[0] * p[0] + m[4] * p[1] + m[8] * p[2] + m[12];
+    o[1] = m[1] * p[0] + m[5] * p[1] + m[9] * p[2] + m[13];
+    o[2] = m[2] * p[0] + m[6] * p[1] + m[10] * p[2] + m[14];
+}
+static void xform4x4(const float *p, const float *m, float *o) {
+    o[0] = m[0] * p[0] + m[4] * p[1] + m[8] * p[2] + m[12];
+    o[1] = m[1] * p[0] + m[5] * p[1] + m[9] * p[2] + m[13];
+    o[2] = m[2] * p[0] + m[6] * p[1] + m[10] * p[2] + m[14];
+    o[3] = m[3] * p[0] + m[7] * p[1] + m[11] * p[2] + m[15];
+}
+
+static void quat_to_R(const float *q, float R[3][3]) {
+    float r = q[0], x = q[1], y = q[2], z = q[3];
+    R[0][0] = 1.f - 2.f * (y * y + z * z); R[0][1] = 2.f * (x * y - r * z); R[0][2] = 2.f * (x * z + r * y);
+    R[1][0] = 2.f * (x * y + r * z); R[1][1] = 1.f - 2.f * (x * x + z * z); R[1][2] = 2.f * (y * z - r * x);
+    R[2][0] = 2.f * (x * z - r * y); R[2][1] = 2.f * (y * z + r * x); R[2][2] = 1.f - 2.f * (x * x + y * y);
+}
+
+/* Sigma = R S S R^T, 6 unique values (xx,xy,xz,yy,yz,zz) */
+static void compute_cov3d(const float *scale, float mod, const float *q, float *cov) {
+    float R[3][3];
+    quat_to_R(q, R);
+    float s[3] = {mod * scale[0], mod * scale[1], mod * scale[2]};
+    float L[3][3];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) L[i][j] = R[i][j] * s[j];
+    float S[3][3];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) S[i][j] = L[i][0] * L[j][0] + L[i][1] * L[j][1] + L[i][2] * L[j][2];
+    cov[0] = S[0][0]; cov[1] = S[0][1]; cov[2] = S[0][2]; cov[3] = S[1][1]; cov[4] = S[1][2]; cov[5] = S[2][2];
+}
+
+/* T = J * Wc (2x3), with the +-1.3 tanfov clamp applied to t for the Jacobian only */
+static void compute_T(const float *t_in, const float *view, float fx, float fy, float tanfovx, float tanfovy,
+                      float T[2][3], float tc[3], int *xin, int *yin) {
+    float limx = 1.3f * tanfovx, limy = 1.3f * tanfovy;
+    float txtz = t_in[0] / t_in[2], tytz = t_in[1] / t_in[2];
+    *xin = !(txtz < -limx || txtz > limx);
+    *yin = !(tytz < -limy || tytz > limy);
+    tc[0] = fminf(limx, fmaxf(-limx, txtz)) * t_in[2];
+    tc[1] = fminf(limy, fmaxf(-limy, tytz)) * t_in[2];
+    tc[2] = t_in[2];
+    float J00 = fx / tc[2], J02 = -(fx * tc[0]) / (tc[2] * tc[2]);
+    float J11 = fy / tc[2], J12 = -(fy * tc[1]) / (tc[2] * tc[2]);
+    /* Wc[m][k] = view[k*4+m] (math-convention world->camera rotation) */
+    for (int k = 0; k < 3; k++) {
+        T[0][k] = J00 * view[k * 4 + 0] + J02 * view[k * 4 + 2];
+        T[1][k] = J11 * view[k * 4 + 1] + J12 * view[k * 4 + 2];
+    }
+}
+
+static void eval_sh(int deg, const float *sh /* [M][3] */, const float *dir, float *out) {
+    float x = dir[0], y = dir[1], z = dir[2];
+    for (int c = 0; c < 3; c++) {
+        float r = SH_C0 * sh[0 * 3 + c];
+        if (deg > 0) {
+            r = r - SH_C1 * y * sh[1 * 3 + c] + SH_C1 * z * sh[2 * 3 + c] - SH_C1 * x * sh[3 * 3 + c];
+            if (deg > 1) {
+                float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                r = r + SH_C2[0] * xy * sh[4 * 3 + c] + SH_C2[1] * yz * sh[5 * 3 + c] +
+                    SH_C2[2] * (2.f * zz - xx - yy) * sh[6 * 3 + c] + SH_C2[3] * xz * sh[7 * 3 + c] +
+                    SH_C2[4] * (xx - yy) * sh[8 * 3 + c];
+                if (deg > 2) {
+                    r = r + SH_C3[0] * y * (3.f * xx - yy) * sh[9 * 3 + c] + SH_C3[1] * xy * z * sh[10 * 3 + c] +
+                        SH_C3[2] * y * (4.f * zz - xx - yy) * sh[11 * 3 + c] +
+                        SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy) * sh[12 * 3 + c] +
+                        SH_C3[4] * x * (4.f * zz - xx - yy) * sh[13 * 3 + c] +
+                        SH_C3[5] * z * (xx - yy) * sh[14 * 3 + c] + SH_C3[6] * x * (xx - 3.f * yy) * sh[15 * 3 + c];
+                }
+            }
+        }
+        out[c] = r;
+    }
+}
+
+/* ------------------------------------------------------------------ K1: preprocess forward */
+void gsref_preprocess_forward(int P, int deg, int M, const float *means3D, const float *scales, float scale_modifier,
+                              const float *rotations, const float *shs, const float *opacities, const float *view,
+                              const float *proj, const float *campos, int W, int H, float tanfovx, float tanfovy,
+                              float *means2D, float *depths, int *radii, float *cov3D, float *conic_opacity,
+                              float *rgb, uint8_t *clamped) {
+    const int gx = (W + BLOCK_X - 1) / BLOCK_X, gy = (H + BLOCK_Y - 1) / BLOCK_Y;
+    const float fx = W / (2.0f * tanfovx), fy = H / (2.0f * tanfovy);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < P; i++) {
+        radii[i] = 0;
+        means2D[2 * i] = means2D[2 * i + 1] = 0.f;
+        depths[i] = 0.f;
+        for (int k = 0; k < 6; k++) cov3D[6 * i + k] = 0.f;
+        for (int k = 0; k < 4; k++) conic_opacity[4 * i + k] = 0.f;
+        for (int k = 0; k < 3; k++) { rgb[3 * i + k] = 0.f; clamped[3 * i + k] = 0; }
+        const float *p = means3D + 3 * i;
+        float t[3];
+        xform4x3(p, view, t);
+        if (t[2] <= 0.2f) continue; /* near-plane cull */
+        float ph[4];
+        xform4x4(p, proj, ph);
+        float pw = 1.0f / (ph[3] + 0.0000001f);
+        float pprojx = ph[0] * pw, pprojy = ph[1] * pw;
+        float cov[6];
+        compute_cov3d(scales + 3 * i, scale_modifier, rotations + 4 * i, cov);
+        float T[2][3], tc[3];
+        int xin, yin;
+        compute_T(t, view, fx, fy, tanfovx, tanfovy, T, tc, &xin, &yin);
+        /* cov2D = T Sigma T^T */
+        float S[3][3] = {{cov[0], cov[1], cov[2]}, {cov[1], cov[3], cov[4]}, {cov[2], cov[4], cov[5]}};
+        float ST0[3], ST1[3];
+        for (int r = 0; r < 3; r++) {
+            ST0[r] = S[r][0] * T[0][0] + S[r][1] * T[0][1] + S[r][2] * T[0][2];
+            ST1[r] = S[r][0] * T[1][0] + S[r][1] * T[1][1] + S[r][2] * T[1][2];
+        }
+        float a = T[0][0] * ST0[0] + T[0][1] * ST0[1] + T[0][2] * ST0[2] + 0.3f;
+        float b = T[0][0] * ST1[0] + T[0][1] * ST1[1] + T[0][2] * ST1[2];
+        float c = T[1][0] * ST1[0] + T[1][1] * ST1[1] + T[1][2] * ST1[2] + 0.3f;
+        float det = a * c - b * b;
+        if (det == 0.0f) continue;
+        float det_inv = 1.f / det;
+        float conic[3] = {c * det_inv, -b * det_inv, a * det_inv};
+        float mid = 0.5f * (a + c);
+        float lam = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+        int radius = (int)ceilf(3.f * sqrtf(lam));
+        float px = ((pprojx + 1.0f) * W - 1.0f) * 0.5f;
+        float py = ((pprojy + 1.0f) * H - 1.0f) * 0.5f;
+        int minx, miny, maxx, maxy;
+        get_rect(px, py, radius, gx, gy, &minx, &miny, &maxx, &maxy);
+        if ((maxx - minx) * (maxy - miny) == 0) continue;
+        float dir[3] = {p[0] - campos[0], p[1] - campos[1], p[2] - campos[2]};
+        float inv = 1.0f / sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+        dir[0] *= inv; dir[1] *= inv; dir[2] *= inv;
+        float col[3];
+        eval_sh(deg, shs + (size_t)i * M * 3, dir, col);
+        for (int k = 0; k < 3; k++) {
+            col[k] += 0.5f;
+            clamped[3 * i + k] = col[k] < 0.f;
+            rgb[3 * i + k] = fmaxf(col[k], 0.f);
+        }
+        depths[i] = t[2];
+        radii[i] = radius;
+        means2D[2 * i] = px;
+        means2D[2 * i + 1] = py;
+        for (int k = 0; k < 6; k++) cov3D[6 * i + k] = cov[k];
+        conic_opacity[4 * i + 0] = conic[0];
+        conic_opacity[4 * i + 1] = conic[1];
+        conic_opacity[4 * i + 2] = conic[2];
+        conic_opacity[4 * i + 3] = opacities[i];
+    }
+}
+
+/* ------------------------------------------------------------------ K11: preprocess backward
+ * dL_dmeans2D arrives in NDC-scaled units (true pixel gradient x (W/2, H/2)); dL_dconic_opacity
+ * holds the TRUE partials (dA, dB, dC, dopacity). */
+void gsref_preprocess_backward(int P, int deg, int M, const float *means3D, const float *scales, float scale_modifier,
+                               const float *rotations, const float *shs, const float *view, const float *proj,
+                               const float *campos, int W, int H, float tanfovx, float tanfovy, const int *radii,
+                               const float *cov3D, const uint8_t *clamped, const float *dL_dmeans2D,
+                               const float *dL_dconic_opacity, const float *dL_drgb, float *dL_dmeans3D,
+                               float *dL_dscales, float *dL_drotations, float *dL_dshs, float *dL_dopacities) {
+    const float fx = W / (2.0f * tanfovx), fy = H / (2.0f * tanfovy);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < P; i++) {
+        for (int k = 0; k < 3; k++) dL_dmeans3D[3 * i + k] = dL_dscales[3 * i + k] = 0.f;
+        for (int k = 0; k < 4; k++) dL_drotations[4 * i + k] = 0.f;
+        for (int k = 0; k < M * 3; k++) dL_dshs[(size_t)i * M * 3 + k] = 0.f;
+        dL_dopacities[i] = 0.f;
+        if (radii[i] <= 0) continue;
+        const float *p = means3D + 3 * i;
+        dL_dopacities[i] = dL_dconic_opacity[4 * i + 3];
+        float gA = dL_dconic_opacity[4 * i + 0], gB = dL_dconic_opacity[4 * i + 1], gC = dL_dconic_opacity[4 * i + 2];
+
+        /* ---- conic -> cov2D -> (cov3D, t) */
+        float t[3];
+        xform4x3(p, view, t);
+        float T[2][3], tc[3];
+        int xin, yin;
+        compute_T(t, view, fx, fy, tanfovx, tanfovy, T, tc, &xin, &yin);
+        const float *cv = cov3D + 6 * i;
+        float S[3][3] = {{cv[0], cv[1], cv[2]}, {cv[1], cv[3], cv[4]}, {cv[2], cv[4], cv[5]}};
+        float ST0[3], ST1[3];
+        for (int r = 0; r < 3; r++) {
+            ST0[r] = S[r][0] * T[0][0] + S[r][1] * T[0][1] + S[r][2] * T[0][2];
+            ST1[r] = S[r][0] * T[1][0] + S[r][1] * T[1][1] + S[r][2] * T[1][2];
+        }
+        float a = T[0][0] * ST0[0] + T[0][1] * ST0[1] + T[0][2] * ST0[2] + 0.3f;
+        float b = T[0][0] * ST1[0] + T[0][1] * ST1[1] + T[0][2] * ST1[2];
+        float c = T[1][0] * ST1[0] + T[1][1] * ST1[1] + T[1][2] * ST1[2] + 0.3f;
+        float denom = a * c - b * b;
+        float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+        float dL_da = 0, dL_db = 0, dL_dc = 0;
+        float dL_dcov[6] = {0, 0, 0, 0, 0, 0};
+        float dL_dt[3] = {0, 0, 0};
+        if (denom2inv != 0) {
+            dL_da = denom2inv * (-c * c * gA + b * c * gB + (denom - a * c) * gC);
+            dL_dc = denom2inv * (-a * a * gC + a * b * gB + (denom - a * c) * gA);
+            dL_db = denom2inv * (2.f * b * c * gA - (denom + 2.f * b * b) * gB + 2.f * a * b * gC);
+            dL_dcov[0] = T[0][0] * T[0][0] * dL_da + T[0][0] * T[1][0] * dL_db + T[1][0] * T[1][0] * dL_dc;
+            dL_dcov[3] = T[0][1] * T[0][1] * dL_da + T[0][1] * T[1][1] * dL_db + T[1][1] * T[1][1] * dL_dc;
+            dL_dcov[5] = T[0][2] * T[0][2] * dL_da + T[0][2] * T[1][2] * dL_db + T[1][2] * T[1][2] * dL_dc;
+            dL_dcov[1] = 2.f * T[0][0] * T[0][1] * dL_da + (T[0][0] * T[1][1] + T[0][1] * T[1][0]) * dL_db +
+                         2.f * T[1][0] * T[1][1] * dL_dc;
+            dL_dcov[2] = 2.f * T[0][0] * T[0][2] * dL_da + (T[0][0] * T[1][2] + T[0][2] * T[1][0]) * dL_db +
+                         2.f * T[1][0] * T[1][2] * dL_dc;
+            dL_dcov[4] = 2.f * T[0][2] * T[0][1] * dL_da + (T[0][1] * T[1][2] + T[0][2] * T[1][1]) * dL_db +
+                         2.f * T[1][1] * T[1][2] * dL_dc;
+        }
+        /* dL/dT rows */
+        float dT0[3], dT1[3];
+        for (int k = 0; k < 3; k++) {
+            dT0[k] = 2.f * ST0[k] * dL_da + ST1[k] * dL_db;
+            dT1[k] = 2.f * ST1[k] * dL_dc + ST0[k] * dL_db;
+        }
+        /* dL/dJ[r][m] = sum_k dT[r][k] * Wc[m][k], Wc[m][k] = view[k*4+m] */
+        float dJ00 = dT0[0] * view[0] + dT0[1] * view[4] + dT0[2] * view[8];
+        float dJ02 = dT0[0] * view[2] + dT0[1] * view[6] + dT0[2] * view[10];
+        float dJ11 = dT1[0] * view[1] + dT1[1] * view[5] + dT1[2] * view[9];
+        float dJ12 = dT1[0] * view[2] + dT1[1] * view[6] + dT1[2] * view[10];
+        float tz = 1.f / tc[2], tz2 = tz * tz, tz3 = tz2 * tz;
+        dL_dt[0] = (xin ? 1.f : 0.f) * (-fx * tz2 * dJ02);
+        dL_dt[1] = (yin ? 1.f : 0.f) * (-fy * tz2 * dJ12);
+        dL_dt[2] = -fx * tz2 * dJ00 - fy * tz2 * dJ11 + (2.f * fx * tc[0]) * tz3 * dJ02 + (2.f * fy * tc[1]) * tz3 * dJ12;
+        /* t = Wc p + trans -> dL/dp = Wc^T dL/dt ; Wc^T[k][m] = view[k*4+m] */
+        float dmean[3];
+        for (int k = 0; k < 3; k++)
+            dmean[k] = view[k * 4 + 0] * dL_dt[0] + view[k * 4 + 1] * dL_dt[1] + view[k * 4 + 2] * dL_dt[2];
+
+        /* ---- means2D (NDC-scaled) -> mean through the perspective divide of proj */
+        float ph[4];
+        xform4x4(p, proj, ph);
+        float mw = 1.0f / (ph[3] + 0.0000001f);
+        float mul1 = ph[0] * mw * mw, mul2 = ph[1] * mw * mw;
+        float g2x = dL_dmeans2D[2 * i], g2y = dL_dmeans2D[2 * i + 1];
+        for (int k = 0; k < 3; k++)
+            dmean[k] += (proj[k * 4 + 0] * mw - proj[k * 4 + 3] * mul1) * g2x +
+                        (proj[k * 4 + 1] * mw - proj[k * 4 + 3] * mul2) * g2y;
+
+        /* ---- colour -> SH coefficients and view direction */
+        {
+            const float *sh = shs + (size_t)i * M * 3;
+            float *dsh = dL_dshs + (size_t)i * M * 3;
+            float dorig[3] = {p[0] - campos[0], p[1] - campos[1], p[2] - campos[2]};
+            float len = sqrtf(dorig[0] * dorig[0] + dorig[1] * dorig[1] + dorig[2] * dorig[2]);
+            float x = dorig[0] / len, y = dorig[1] / len, z = dorig[2] / len;
+            float dL_ddir[3] = {0, 0, 0};
+            for (int ch = 0; ch < 3; ch++) {
+                float g = clamped[3 * i + ch] ? 0.f : dL_drgb[3 * i + ch];
+                float dx = 0, dy = 0, dz = 0;
+                dsh[0 * 3 + ch] = SH_C0 * g;
+                if (deg > 0) {
+                    dsh[1 * 3 + ch] = -SH_C1 * y * g;
+                    dsh[2 * 3 + ch] = SH_C1 * z * g;
+                    dsh[3 * 3 + ch] = -SH_C1 * x * g;
+                    dx = -SH_C1 * sh[3 * 3 + ch];
+                    dy = -SH_C1 * sh[1 * 3 + ch];
+                    dz = SH_C1 * sh[2 * 3 + ch];
+                    if (deg > 1) {
+                        float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                        dsh[4 * 3 + ch] = SH_C2[0] * xy * g;
+                        dsh[5 * 3 + ch] = SH_C2[1] * yz * g;
+                        dsh[6 * 3 + ch] = SH_C2[2] * (2.f * zz - xx - yy) * g;
+                        dsh[7 * 3 + ch] = SH_C2[3] * xz * g;
+                        dsh[8 * 3 + ch] = SH_C2[4] * (xx - yy) * g;
+                        dx += SH_C2[0] * y * sh[4 * 3 + ch] + SH_C2[2] * 2.f * -x * sh[6 * 3 + ch] +
+                              SH_C2[3] * z * sh[7 * 3 + ch] + SH_C2[4] * 2.f * x * sh[8 * 3 + ch];
+                        dy += SH_C2[0] * x * sh[4 * 3 + ch] + SH_C2[1] * z * sh[5 * 3 + ch] +
+                              SH_C2[2] * 2.f * -y * sh[6 * 3 + ch] + SH_C2[4] * 2.f * -y * sh[8 * 3 + ch];
+                        dz += SH_C2[1] * y * sh[5 * 3 + ch] + SH_C2[2] * 2.f * 2.f * z * sh[6 * 3 + ch] +
+                              SH_C2[3] * x * sh[7 * 3 + ch];
+                        if (deg > 2) {
+                            dsh[9 * 3 + ch] = SH_C3[0] * y * (3.f * xx - yy) * g;
+                            dsh[10 * 3 + ch] = SH_C3[1] * xy * z * g;
+                            dsh[11 * 3 + ch] = SH_C3[2] * y * (4.f * zz - xx - yy) * g;
+                            dsh[12 * 3 + ch] = SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy) * g;
+                            dsh[13 * 3 + ch] = SH_C3[4] * x * (4.f * zz - xx - yy) * g;
+                            dsh[14 * 3 + ch] = SH_C3[5] * z * (xx - yy) * g;
+                            dsh[15 * 3 + ch] = SH_C3[6] * x * (xx - 3.f * yy) * g;
+                            dx += SH_C3[0] * sh[9 * 3 + ch] * 3.f * 2.f * xy + SH_C3[1] * sh[10 * 3 + ch] * yz +
+                                  SH_C3[2] * sh[11 * 3 + ch] * -2.f * xy + SH_C3[3] * sh[12 * 3 + ch] * -3.f * 2.f * xz +
+                                  SH_C3[4] * sh[13 * 3 + ch] * (-3.f * xx + 4.f * zz - yy) +
+                                  SH_C3[5] * sh[14 * 3 + ch] * 2.f * xz + SH_C3[6] * sh[15 * 3 + ch] * 3.f * (xx - yy);
+                            dy += SH_C3[0] * sh[9 * 3 + ch] * 3.f * (xx - yy) + SH_C3[1] * sh[10 * 3 + ch] * xz +
+                                  SH_C3[2] * sh[11 * 3 + ch] * (-3.f * yy + 4.f * zz - xx) +
+                                  SH_C3[3] * sh[12 * 3 + ch] * -3.f * 2.f * yz + SH_C3[4] * sh[13 * 3 + ch] * -2.f * xy +
+                                  SH_C3[5] * sh[14 * 3 + ch] * -2.f * yz + SH_C3[6] * sh[15 * 3 + ch] * -3.f * 2.f * xy;
+                            dz += SH_C3[1] * sh[10 * 3 + ch] * xy + SH_C3[2] * sh[11 * 3 + ch] * 4.f * 2.f * yz +
+                                  SH_C3[3] * sh[12 * 3 + ch] * 3.f * (2.f * zz - xx - yy) +
+                                  SH_C3[4] * sh[13 * 3 + ch] * 4.f * 2.f * xz + SH_C3[5] * sh[14 * 3 + ch] * (xx - yy);
+                        }
+                    }
+                }
+                dL_ddir[0] += dx * g;
+                dL_ddir[1] += dy * g;
+                dL_ddir[2] += dz * g;
+            }
+            /* through dir = v/|v| */
+            float dot = x * dL_ddir[0] + y * dL_ddir[1] + z * dL_ddir[2];
+            dmean[0] += (dL_ddir[0] - x * dot) / len;
+            dmean[1] += (dL_ddir[1] - y * dot) / len;
+            dmean[2] += (dL_ddir[2] - z * dot) / len;
+        }
+        for (int k = 0; k < 3; k++) dL_dmeans3D[3 * i + k] = dmean[k];
+
+        /* ---- cov3D -> scales, rotations.  Sigma = M^T M, M = S R^T */
+        {
+            const float *q = rotations + 4 * i;
+            float R[3][3];
+            quat_to_R(q, R);
+            float s[3] = {scale_modifier * scales[3 * i], scale_modifier * scales[3 * i + 1],
+                          scale_modifier * scales[3 * i + 2]};
+            float Mm[3][3]; /* M[i][j] = s_i * R[j][i] */
+            for (int r = 0; r < 3; r++)
+                for (int cc = 0; cc < 3; cc++) Mm[r][cc] = s[r] * R[cc][r];
+            float dS[3][3] = {{dL_dcov[0], 0.5f * dL_dcov[1], 0.5f * dL_dcov[2]},
+                              {0.5f * dL_dcov[1], dL_dcov[3], 0.5f * dL_dcov[4]},
+                              {0.5f * dL_dcov[2], 0.5f * dL_dcov[4], dL_dcov[5]}};
+            float dM[3][3];
+            for (int r = 0; r < 3; r++)
+                for (int cc = 0; cc < 3; cc++)
+                    dM[r][cc] = 2.f * (Mm[r][0] * dS[0][cc] + Mm[r][1] * dS[1][cc] + Mm[r][2] * dS[2][cc]);
+            float dR[3][3];
+            for (int r = 0; r < 3; r++) {
+                /* dL/ds_r = sum_j R[j][r] dM[r][j] */
+                dL_dscales[3 * i + r] = scale_modifier * (R[0][r] * dM[r][0] + R[1][r] * dM[r][1] + R[2][r] * dM[r][2]);
+                for (int j = 0; j < 3; j++) dR[j][r] = s[r] * dM[r][j];
+            }
+            float r_ = q[0], x = q[1], y = q[2], z = q[3];
+            dL_drotations[4 * i + 0] = 2.f * (-z * dR[0][1] + y * dR[0][2] + z * dR[1][0] - x * dR[1][2] - y * dR[2][0] + x * dR[2][1]);
+            dL_drotations[4 * i + 1] = 2.f * (y * dR[0][1] + z * dR[0][2] + y * dR[1][0] - 2.f * x * dR[1][1] - r_ * dR[1][2] +
+                                              z * dR[2][0] + r_ * dR[2][1] - 2.f * x * dR[2][2]);
+            dL_drotations[4 * i + 2] = 2.f * (-2.f * y * dR[0][0] + x * dR[0][1] + r_ * dR[0][2] + x * dR[1][0] + z * dR[1][2] -
+                                              r_ * dR[2][0] + z * dR[2][1] - 2.f * y * dR[2][2]);
+            dL_drotations[4 * i + 3] = 2.f * (-2.f * z * dR[0][0] - r_ * dR[0][1] + x * dR[0][2] + r_ * dR[1][0] -
+                                              2.f * z * dR[1][1] + y * dR[1][2] + x * dR[2][0] + y * dR[2][1]);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ K2: partition test */
+void gsref_get_local2j_ids_bool(int P, int W, int H, int world_size, const float *means2D, const int *radii,
+                                const int *dist_global_strategy, uint8_t *out /* [P][ws] */) {
+    const int gx = (W + BLOCK_X - 1) / BLOCK_X, gy = (H + BLOCK_Y - 1) / BLOCK_Y;
+    for (int i = 0; i < P; i++) {
+        for (int j = 0; j < world_size; j++) out[(size_t)i * world_size + j] = 0;
+        if (radii[i] <= 0) continue;
+        int minx, miny, maxx, maxy;
+        get_rect(means2D[2 * i], means2D[2 * i + 1], radii[i], gx, gy, &minx, &miny, &maxx, &maxy);
+        if (maxx <= minx || maxy <= miny) continue;
+        for (int j = 0; j < world_size; j++) {
+            int lo = dist_global_strategy[j], hi = dist_global_strategy[j + 1];
+            int hit = 0;
+            for (int y = miny; y < maxy && !hit; y++) {
+                int first = y * gx + minx, last = y * gx + maxx - 1; /* tile ids of this rect row */
+                if (first < hi && last >= lo) hit = 1;
+            }
+            out[(size_t)i * world_size + j] = (uint8_t)hit;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ K3-K7: binning + stable sort */
+static int64_t count_touched(int P, int gx, int gy, const float *means2D, const int *radii,
+                             const uint8_t *compute_locally, int32_t *tiles_touched) {
+    int64_t D = 0;
+    for (int i = 0; i < P; i++) {
+        int n = 0;
+        if (radii[i] > 0) {
+            int minx, miny, maxx, maxy;
+            get_rect(means2D[2 * i], means2D[2 * i + 1], radii[i], gx, gy, &minx, &miny, &maxx, &maxy);
+            for (int y = miny; y < maxy; y++)
+                for (int x = minx; x < maxx; x++) n += compute_locally[y * gx + x] ? 1 : 0;
+        }
+        if (tiles_touched) tiles_touched[i] = n;
+        D += n;
+    }
+    return D;
+}
+
+int64_t gsref_bin_count(int P, int W, int H, const float *means2D, const int *radii, const uint8_t *compute_locally,
+                        int32_t *tiles_touched) {
+    const int gx = (W + BLOCK_X - 1) / BLOCK_X, gy = (H + BLOCK_Y - 1) / BLOCK_Y;
+    return count_touched(P, gx, gy, means2D, radii, compute_locally, tiles_touched);
+}
+
+/* key = tile_id << 32 | float bits of depth ; value = Gaussian index; stable LSD radix sort */
+void gsref_bin_sort(int P, int W, int H, const float *means2D, const float *depths, const int *radii,
+                    const uint8_t *compute_locally, int64_t D, uint32_t *point_list /* [D] */,
+                    int32_t *ranges /* [tiles][2] */) {
+    const int gx = (W + BLOCK_X - 1) / BLOCK_X, gy = (H + BLOCK_Y - 1) / BLOCK_Y;
+    uint64_t *keys = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(D > 0 ? D : 1) * 2);
+    uint32_t *vals = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(D > 0 ? D : 1) * 2);
+    uint64_t *k0 = keys, *k1 = keys + D;
+    uint32_t *v0 = vals, *v1 = vals + D;
+    int64_t off = 0;
+    for (int i = 0; i < P; i++) {
+        if (radii[i] <= 0) continue;
+        int minx, miny, maxx, maxy;
+        get_rect(means2D[2 * i], means2D[2 * i + 1], radii[i], gx, gy, &minx, &miny, &maxx, &maxy);
+        uint32_t dbits;
+        memcpy(&dbits, depths + i, 4);
+        for (int y = miny; y < maxy; y++)
+            for (int x = minx; x < maxx; x++)
+                if (compute_locally[y * gx + x]) {
+                    k0[off] = ((uint64_t)(uint32_t)(y * gx + x) << 32) | dbits;
+                    v0[off] = (uint32_t)i;
+                    off++;
+                }
+    }
+    for (int pass = 0; pass < 8; pass++) {
+        int64_t hist[257];
+        memset(hist, 0, sizeof(hist));
+        int sh = pass * 8;
+        for (int64_t j = 0; j < D; j++) hist[((k0[j] >> sh) & 0xFF) + 1]++;
+        for (int d = 0; d < 256; d++) hist[d + 1] += hist[d];
+        for (int64_t j = 0; j < D; j++) {
+            int64_t dst = hist[(k0[j] >> sh) & 0xFF]++;
+            k1[dst] = k0[j];
+            v1[dst] = v0[j];
+        }
+        uint64_t *tk = k0; k0 = k1; k1 = tk;
+        uint32_t *tv = v0; v0 = v1; v1 = tv;
+    }
+    for (int t = 0; t < gx * gy; t++) ranges[2 * t] = ranges[2 * t + 1] = 0;
+    for (int64_t j = 0; j < D; j++) {
+        point_list[j] = v0[j];
+        uint32_t tile = (uint32_t)(k0[j] >> 32);
+        if (j == 0 || tile != (uint32_t)(k0[j - 1] >> 32)) ranges[2 * tile] = (int32_t)j;
+        if (j == D - 1 || tile != (uint32_t)(k0[j + 1] >> 32)) ranges[2 * tile + 1] = (int32_t)(j + 1);
+    }
+    free(keys);
+    free(vals);
+}
+
+/* ------------------------------------------------------------------ K8: composite forward */
+void gsref_render_forward(int W, int H, const int32_t *ranges, const uint32_t *point_list, const float *means2D,
+                          const float *conic_opacity, const float *rgb, const uint8_t *compute_locally,
+                          const float *bg, float *out_color /* [3][H][W] */, float *final_T, int32_t *n_contrib) {
+    const int gx = (W + BLOCK_X - 1) / BLOCK_X, gy = (H + BLOCK_Y - 1) / BLOCK_Y;
+    memset(out_color, 0, sizeof(float) * 3 * (size_t)W * H);
+    for (size_t i = 0; i < (size_t)W * H; i++) { final_T[i] = 1.f; n_contrib[i] = 0; }
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int tile = 0; tile < gx * gy; tile++) {
+        if (!compute_locally[tile]) continue; /* non-local pixels stay 0 */
+        int ty = tile / gx, tx = tile % gx;
+        int s = ranges[2 * tile], e = ranges[2 * tile + 1];
+        for (int py = ty * BLOCK_Y; py < imin((ty + 1) * BLOCK_Y, H); py++)
+            for (int px = tx * BLOCK_X; px < imin((tx + 1) * BLOCK_X, W); px++) {
+                float T = 1.f, C[3] = {0, 0, 0};
+                int contributor = 0, last = 0;
+                float pxf = (float)px, pyf = (float)py;
+                for (int j = s; j < e; j++) {
+                    contributor++;
+                    uint32_t g = point_list[j];
+                    float dx = means2D[2 * g] - pxf, dy = means2D[2 * g + 1] - pyf;
+                    const float *co = conic_opacity + 4 * (size_t)g;
+                    float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                    if (power > 0.0f) continue;
+                    float alpha = fminf(0.99f, co[3] * expf(power));
+                    if (alpha < 1.0f / 255.0f) continue;
+                    float test_T = T * (1 - alpha);
+                    if (test_T < 0.0001f) break; /* this entry is NOT blended */
+                    for (int ch = 0; ch < 3; ch++) C[ch] += rgb[3 * (size_t)g + ch] * alpha * T;
+                    T = test_T;
+                    last = contributor;
+                }
+                size_t pid = (size_t)py * W + px;
+                final_T[pid] = T;
+                n_contrib[pid] = last;
+                for (int ch = 0; ch < 3; ch++) out_color[(size_t)ch * H * W + pid] = C[ch] + T * bg[ch];
+            }
+    }
+}
+
+/* ------------------------------------------------------------------ K10: composite backward
+ * outputs: dL_dmeans2D [P][2] (NDC-scaled: x 0.5W, 0.5H), dL_dconic_opacity [P][4] (true partials),
+ * dL_drgb [P][3].  Sums in double, one rounding at the end. */
+void gsref_render_backward(int P, int W, int H, const int32_t *ranges, const uint32_t *point_list,
+                           const float *means2D, const float *conic_opacity, const float *rgb,
+                           const uint8_t *compute_locally, const float *bg, const float *final_T,
+                           const int32_t *n_contrib, const float *dL_dpixels, float *dL_dmeans2D,
+                           float *dL_dconic_opacity, float *dL_drgb) {
+    const int gx = (W + BLOCK_X - 1) / BLOCK_X, gy = (H + BLOCK_Y - 1) / BLOCK_Y;
+    double *acc = (double *)calloc((size_t)P * 9, sizeof(double));
+    const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int tile = 0; tile < gx * gy; tile++) {
+        if (!compute_locally[tile]) continue;
+        int ty = tile / gx, tx = tile % gx;
+        int s = ranges[2 * tile];
+        for (int py = ty * BLOCK_Y; py < imin((ty + 1) * BLOCK_Y, H); py++)
+            for (int px = tx * BLOCK_X; px < imin((tx + 1) * BLOCK_X, W); px++) {
+                size_t pid = (size_t)py * W + px;
+                const float T_final = final_T[pid];
+                float T = T_final;
+                int last = n_contrib[pid];
+                float accum_rec[3] = {0, 0, 0}, last_color[3] = {0, 0, 0}, last_alpha = 0.f;
+                float dpix[3];
+                for (int ch = 0; ch < 3; ch++) dpix[ch] = dL_dpixels[(size_t)ch * H * W + pid];
+                float bg_dot = bg[0] * dpix[0] + bg[1] * dpix[1] + bg[2] * dpix[2];
+                float pxf = (float)px, pyf = (float)py;
+                for (int j = s + last - 1; j >= s; j--) {
+                    uint32_t g = point_list[j];
+                    float dx = means2D[2 * g] - pxf, dy = means2D[2 * g + 1] - pyf;
+                    const float *co = conic_opacity + 4 * (size_t)g;
+                    float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                    if (power > 0.0f) continue;
+                    float G = expf(power);
+                    float alpha = fminf(0.99f, co[3] * G);
+                    if (alpha < 1.0f / 255.0f) continue;
+                    T = T / (1.f - alpha);
+                    float dchannel_dcolor = alpha * T;
+                    float dL_dalpha = 0.f;
+                    double *a = acc + (size_t)g * 9;
+                    for (int ch = 0; ch < 3; ch++) {
+                        float c = rgb[3 * (size_t)g + ch];
+                        accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
+                        last_color[ch] = c;
+                        dL_dalpha += (c - accum_rec[ch]) * dpix[ch];
+#pragma omp atomic
+                        a[6 + ch] += dchannel_dcolor * dpix[ch];
+                    }
+                    dL_dalpha *= T;
+                    last_alpha = alpha;
+                    dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
+                    float dL_dG = co[3] * dL_dalpha; /* min(0.99,.) treated as identity */
+                    float gdx = G * dx, gdy = G * dy;
+                    float dG_ddelx = -gdx * co[0] - gdy * co[1];
+                    float dG_ddely = -gdy * co[2] - gdx * co[1];
+#pragma omp atomic
+                    a[0] += dL_dG * dG_ddelx * ddelx_dx;
+#pragma omp atomic
+                    a[1] += dL_dG * dG_ddely * ddely_dy;
+#pragma omp atomic
+                    a[2] += -0.5f * gdx * dx * dL_dG;
+#pragma omp atomic
+                    a[3] += -gdx * dy * dL_dG; /* true partial wrt B (no 1/2) */
+#pragma omp atomic
+                    a[4] += -0.5f * gdy * dy * dL_dG;
+#pragma omp atomic
+                    a[5] += G * dL_dalpha;
+                }
+            }
+    }
+    for (int i = 0; i < P; i++) {
+        const double *a = acc + (size_t)i * 9;
+        dL_dmeans2D[2 * i] = (float)a[0];
+        dL_dmeans2D[2 * i + 1] = (float)a[1];
+        dL_dconic_opacity[4 * i + 0] = (float)a[2];
+        dL_dconic_opacity[4 * i + 1] = (float)a[3];
+        dL_dconic_opacity[4 * i + 2] = (float)a[4];
+        dL_dconic_opacity[4 * i + 3] = (float)a[5];
+        dL_drgb[3 * i + 0] = (float)a[6];
+        dL_drgb[3 * i + 1] = (float)a[7];
+        dL_drgb[3 * i + 2] = (float)a[8];
+    }
+    free(acc);
+}
+
+int gsref_num_threads(void) {
+#ifdef _OPENMP
+    extern int omp_get_max_threads(void);
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
