@@ -1,0 +1,320 @@
+// composite.hip -- K8 (alpha-composite forward) and K10 (its backward) for gfx950 / wave64.
+//
+// Unit of work: ONE WAVE = one 8x8 pixel quadrant of a 16x16 tile (lane = pixel); a 256-thread
+// workgroup is the four quadrants of a tile, but the waves never synchronise with each other:
+//   * each wave walks the tile's depth-sorted list in chunks of 64 entries, one entry per lane
+//     (coalesced index read + one 36-byte gather per lane);
+//   * each lane tests ITS entry against the wave's quadrant (bounding box of the alpha >= 1/255
+//     ellipse) and a 64-bit ballot gives the entries that can touch the quadrant at all;
+//   * the wave then iterates over the set bits only, broadcasting the entry lane -> SGPRs with
+//     v_readlane (no LDS traffic, no barriers) and blending per pixel;
+//   * early termination is per wave: __all(done) leaves the loop.
+// Entries skipped by the quadrant test would have been rejected per pixel by the alpha < 1/255 rule,
+// so the image and n_contrib are those of the plain algorithm.
+//
+// Backward: same walk in reverse order; the 9 per-pixel partial gradients are reduced across the
+// wave with DPP adds, accumulated in the registers of the lane that holds the entry, and flushed
+// with one vector atomic per value per 64-entry chunk.
+#include "common.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float ALPHA_MIN = 1.0f / 255.0f;
+constexpr float T_STOP = 0.0001f;
+
+__device__ __forceinline__ float bcast(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+// lane-resident entry of the tile list
+struct Entry {
+    float x, y;        // pixel centre
+    float a2, b2, c2;  // conic pre-scaled to log2 units: p2 = a2 dx^2 + b2 dx dy + c2 dy^2
+    float o;           // opacity
+    bool relevant;
+};
+
+// Load entry `idx` (or an inert one) and test it against the quadrant [qx0,qx0+7]x[qy0,qy0+7].
+__device__ __forceinline__ Entry load_entry(bool have, uint32_t id, const float2 *__restrict__ means2D,
+                                            const float4 *__restrict__ conic_opacity, float qx0, float qy0) {
+    Entry e;
+    e.x = e.y = e.a2 = e.b2 = e.c2 = e.o = 0.f;
+    e.relevant = false;
+    if (have) {
+        const float2 xy = means2D[id];
+        const float4 co = conic_opacity[id];
+        e.x = xy.x;
+        e.y = xy.y;
+        e.a2 = -0.5f * LOG2E * co.x;
+        e.b2 = -LOG2E * co.y;
+        e.c2 = -0.5f * LOG2E * co.z;
+        e.o = co.w;
+        // alpha >= 1/255  <=>  power >= -tau, tau = ln(255 o); needs o >= 1/255
+        const float tau = __logf(255.0f * co.w);
+        if (tau >= 0.f) {
+            const float det = co.x * co.z - co.y * co.y;
+            float ex = 1e30f, ey = 1e30f;
+            if (det > 0.f) {
+                // half extents of the ellipse's bounding box: sqrt(2 tau cov_xx), cov_xx = C / det
+                const float s = 2.0f * tau / det;
+                ex = sqrtf(s * co.z) * 1.01f + 0.5f;  // margins cover rounding in det (cancellation)
+                ey = sqrtf(s * co.x) * 1.01f + 0.5f;
+            }
+            e.relevant = (xy.x + ex >= qx0) && (xy.x - ex <= qx0 + 7.0f) && (xy.y + ey >= qy0) &&
+                         (xy.y - ey <= qy0 + 7.0f);
+        }
+    }
+    return e;
+}
+
+// ------------------------------------------------------------------------------------------- K8
+__global__ void __launch_bounds__(256)
+composite_forward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
+                         const uint32_t *__restrict__ point_list, const float2 *__restrict__ means2D,
+                         const float4 *__restrict__ conic_opacity, const float *__restrict__ rgb,
+                         const uint8_t *__restrict__ compute_locally, const float *__restrict__ bg,
+                         float *__restrict__ out_color, float *__restrict__ final_T, int32_t *__restrict__ n_contrib) {
+    const int tile = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tx = tile % gx, ty = tile / gx;
+    const int qx0 = tx * GSR_BLOCK_X + (wave & 1) * 8, qy0 = ty * GSR_BLOCK_Y + (wave >> 1) * 8;
+    const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
+    const bool inside = px < W && py < H;
+    const size_t pid = (size_t)py * W + px;
+    const size_t HW = (size_t)H * W;
+
+    if (!compute_locally[tile]) {  // not ours: pixels must be exactly 0 (SUM all-reduce assembly)
+        if (inside) {
+            out_color[pid] = 0.f;
+            out_color[HW + pid] = 0.f;
+            out_color[2 * HW + pid] = 0.f;
+            final_T[pid] = 1.f;
+            n_contrib[pid] = 0;
+        }
+        return;
+    }
+    const int2 range = ranges[tile];
+    const int n = range.y - range.x;
+    const float pxf = (float)px, pyf = (float)py;
+
+    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
+    int last = 0;
+    bool done = !inside;
+
+    for (int c = 0; c < n; c += 64) {
+        if (__all(done)) break;
+        const bool have = c + lane < n;
+        const uint32_t id = have ? point_list[range.x + c + lane] : 0u;
+        const Entry e = load_entry(have, id, means2D, conic_opacity, (float)qx0, (float)qy0);
+        float r = 0.f, g = 0.f, b = 0.f;
+        if (e.relevant) {
+            r = rgb[3 * (size_t)id];
+            g = rgb[3 * (size_t)id + 1];
+            b = rgb[3 * (size_t)id + 2];
+        }
+        unsigned long long m = __ballot(e.relevant);
+        while (m) {
+            const int k = __builtin_ctzll(m);
+            m &= m - 1;
+            const float gx_ = bcast(e.x, k), gy_ = bcast(e.y, k);
+            const float a2 = bcast(e.a2, k), b2 = bcast(e.b2, k), c2 = bcast(e.c2, k), o = bcast(e.o, k);
+            const float dx = gx_ - pxf, dy = gy_ - pyf;
+            const float p2 = (a2 * dx + b2 * dy) * dx + c2 * dy * dy;
+            const float alpha = fminf(0.99f, o * __builtin_amdgcn_exp2f(p2));
+            const bool take = !done && p2 <= 0.f && alpha >= ALPHA_MIN;
+            const float test_T = T * (1.0f - alpha);
+            const bool stop = take && test_T < T_STOP;
+            done = done || stop;
+            const bool blend = take && !stop;
+            if (__any(blend)) {  // wave-uniform: colour is only broadcast when some pixel needs it
+                const float cr = bcast(r, k), cg = bcast(g, k), cb = bcast(b, k);
+                if (blend) {
+                    const float w = alpha * T;
+                    C0 += cr * w;
+                    C1 += cg * w;
+                    C2 += cb * w;
+                    T = test_T;
+                    last = c + k + 1;
+                }
+            }
+            if (__all(done)) break;
+        }
+    }
+    if (inside) {
+        out_color[pid] = C0 + T * bg[0];
+        out_color[HW + pid] = C1 + T * bg[1];
+        out_color[2 * HW + pid] = C2 + T * bg[2];
+        final_T[pid] = T;
+        n_contrib[pid] = last;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ K10
+// sum over the 64 lanes, result valid in lane 63 (GFX9 DPP reduction ladder)
+__device__ __forceinline__ float wave_sum_to_63(float v) {
+#define GSR_DPP(x, ctrl, rmask) \
+    __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), ctrl, rmask, 0xf, false))
+    v += GSR_DPP(v, 0x111, 0xf);  // row_shr:1
+    v += GSR_DPP(v, 0x112, 0xf);  // row_shr:2
+    v += GSR_DPP(v, 0x114, 0xf);  // row_shr:4
+    v += GSR_DPP(v, 0x118, 0xf);  // row_shr:8   -> lane 15 of each row holds the row sum
+    v += GSR_DPP(v, 0x142, 0xa);  // row_bcast:15 -> rows 1,3
+    v += GSR_DPP(v, 0x143, 0xc);  // row_bcast:31 -> rows 2,3
+#undef GSR_DPP
+    return v;
+}
+
+__global__ void __launch_bounds__(256)
+composite_backward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
+                          const uint32_t *__restrict__ point_list, const float2 *__restrict__ means2D,
+                          const float4 *__restrict__ conic_opacity, const float *__restrict__ rgb,
+                          const uint8_t *__restrict__ compute_locally, const float *__restrict__ bg,
+                          const float *__restrict__ final_T, const int32_t *__restrict__ n_contrib,
+                          const float *__restrict__ dL_dpixels, float *__restrict__ dL_dmeans2D,
+                          float *__restrict__ dL_dconic_opacity, float *__restrict__ dL_drgb) {
+    const int tile = blockIdx.x;
+    if (!compute_locally[tile]) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tx = tile % gx, ty = tile / gx;
+    const int qx0 = tx * GSR_BLOCK_X + (wave & 1) * 8, qy0 = ty * GSR_BLOCK_Y + (wave >> 1) * 8;
+    const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
+    const bool inside = px < W && py < H;
+    const size_t pid = (size_t)py * W + px;
+    const size_t HW = (size_t)H * W;
+    const int2 range = ranges[tile];
+    const float pxf = (float)px, pyf = (float)py;
+
+    const float T_final = inside ? final_T[pid] : 0.f;
+    const int last = inside ? n_contrib[pid] : 0;
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    if (inside) {
+        g0 = dL_dpixels[pid];
+        g1 = dL_dpixels[HW + pid];
+        g2 = dL_dpixels[2 * HW + pid];
+    }
+    const float bg_dot = bg[0] * g0 + bg[1] * g1 + bg[2] * g2;
+    const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
+
+    // entries beyond the furthest contributor of any pixel of this quadrant are dead for the wave
+    int wmax = last;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) wmax = max(wmax, __shfl_xor(wmax, d, 64));
+    if (wmax == 0) return;
+
+    float T = T_final;
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;      // colour accumulated BEHIND the current entry
+    float lastc0 = 0.f, lastc1 = 0.f, lastc2 = 0.f;
+    float last_alpha = 0.f;
+
+    for (int c = ((wmax - 1) / 64) * 64; c >= 0; c -= 64) {
+        const bool have = c + lane < wmax;
+        const uint32_t id = have ? point_list[range.x + c + lane] : 0u;
+        const Entry e = load_entry(have, id, means2D, conic_opacity, (float)qx0, (float)qy0);
+        float r = 0.f, g = 0.f, b = 0.f;
+        float4 co = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e.relevant) {
+            r = rgb[3 * (size_t)id];
+            g = rgb[3 * (size_t)id + 1];
+            b = rgb[3 * (size_t)id + 2];
+            co = conic_opacity[id];
+        }
+        // this lane's entry: accumulated gradients
+        float s_mx = 0.f, s_my = 0.f, s_a = 0.f, s_b = 0.f, s_c = 0.f, s_o = 0.f, s_r = 0.f, s_g = 0.f, s_bl = 0.f;
+        unsigned long long m = __ballot(e.relevant);
+        const unsigned long long touched = m;
+        while (m) {
+            const int k = 63 - __builtin_clzll(m);
+            m &= ~(1ull << k);
+            const float gx_ = bcast(e.x, k), gy_ = bcast(e.y, k);
+            const float a2 = bcast(e.a2, k), b2 = bcast(e.b2, k), c2 = bcast(e.c2, k), o = bcast(e.o, k);
+            const float cr = bcast(r, k), cg = bcast(g, k), cb = bcast(b, k);
+            const float A = bcast(co.x, k), B = bcast(co.y, k), Cc = bcast(co.z, k);
+            const float dx = gx_ - pxf, dy = gy_ - pyf;
+            const float p2 = (a2 * dx + b2 * dy) * dx + c2 * dy * dy;
+            const float G = __builtin_amdgcn_exp2f(p2);
+            const float alpha = fminf(0.99f, o * G);
+            const bool take = (c + k + 1 <= last) && p2 <= 0.f && alpha >= ALPHA_MIN;
+            float v_mx = 0.f, v_my = 0.f, v_a = 0.f, v_b = 0.f, v_c = 0.f, v_o = 0.f, v_r = 0.f, v_g = 0.f, v_bl = 0.f;
+            if (take) {
+                T = T / (1.f - alpha);
+                const float w = alpha * T;
+                acc0 = last_alpha * lastc0 + (1.f - last_alpha) * acc0;
+                acc1 = last_alpha * lastc1 + (1.f - last_alpha) * acc1;
+                acc2 = last_alpha * lastc2 + (1.f - last_alpha) * acc2;
+                lastc0 = cr; lastc1 = cg; lastc2 = cb;
+                float dL_dalpha = (cr - acc0) * g0 + (cg - acc1) * g1 + (cb - acc2) * g2;
+                dL_dalpha *= T;
+                last_alpha = alpha;
+                dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
+                const float dL_dG = o * dL_dalpha;  // min(0.99,.) treated as identity
+                const float gdx = G * dx, gdy = G * dy;
+                v_mx = dL_dG * (-gdx * A - gdy * B) * ddelx_dx;
+                v_my = dL_dG * (-gdy * Cc - gdx * B) * ddely_dy;
+                v_a = -0.5f * gdx * dx * dL_dG;
+                v_b = -gdx * dy * dL_dG;
+                v_c = -0.5f * gdy * dy * dL_dG;
+                v_o = G * dL_dalpha;
+                v_r = w * g0;
+                v_g = w * g1;
+                v_bl = w * g2;
+            }
+            if (__any(take)) {
+                const float t_mx = bcast(wave_sum_to_63(v_mx), 63), t_my = bcast(wave_sum_to_63(v_my), 63);
+                const float t_a = bcast(wave_sum_to_63(v_a), 63), t_b = bcast(wave_sum_to_63(v_b), 63);
+                const float t_c = bcast(wave_sum_to_63(v_c), 63), t_o = bcast(wave_sum_to_63(v_o), 63);
+                const float t_r = bcast(wave_sum_to_63(v_r), 63), t_g = bcast(wave_sum_to_63(v_g), 63);
+                const float t_bl = bcast(wave_sum_to_63(v_bl), 63);
+                if (lane == k) {
+                    s_mx += t_mx; s_my += t_my; s_a += t_a; s_b += t_b; s_c += t_c; s_o += t_o;
+                    s_r += t_r; s_g += t_g; s_bl += t_bl;
+                }
+            }
+        }
+        if ((touched >> lane) & 1ull) {
+            atomicAdd(&dL_dmeans2D[2 * (size_t)id], s_mx);
+            atomicAdd(&dL_dmeans2D[2 * (size_t)id + 1], s_my);
+            atomicAdd(&dL_dconic_opacity[4 * (size_t)id], s_a);
+            atomicAdd(&dL_dconic_opacity[4 * (size_t)id + 1], s_b);
+            atomicAdd(&dL_dconic_opacity[4 * (size_t)id + 2], s_c);
+            atomicAdd(&dL_dconic_opacity[4 * (size_t)id + 3], s_o);
+            atomicAdd(&dL_drgb[3 * (size_t)id], s_r);
+            atomicAdd(&dL_drgb[3 * (size_t)id + 1], s_g);
+            atomicAdd(&dL_drgb[3 * (size_t)id + 2], s_bl);
+        }
+    }
+}
+
+}  // namespace
+
+int gsr_launch_composite_forward(int P, int W, int H, const int32_t *ranges, const uint32_t *point_list,
+                                 const float *means2D, const float *conic_opacity, const float *rgb,
+                                 const uint8_t *compute_locally, const float *bg, float *out_color, float *final_T,
+                                 int32_t *n_contrib, hipStream_t stream) {
+    (void)P;
+    const int gx = (W + GSR_BLOCK_X - 1) / GSR_BLOCK_X, gy = (H + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y;
+    hipLaunchKernelGGL(composite_forward_kernel, dim3(gx * gy), dim3(256), 0, stream, W, H, gx,
+                       reinterpret_cast<const int2 *>(ranges), point_list, reinterpret_cast<const float2 *>(means2D),
+                       reinterpret_cast<const float4 *>(conic_opacity), rgb, compute_locally, bg, out_color, final_T,
+                       n_contrib);
+    GSR_LAUNCH_CHECK();
+    return 0;
+}
+
+int gsr_launch_composite_backward(int P, int W, int H, const int32_t *ranges, const uint32_t *point_list,
+                                  const float *means2D, const float *conic_opacity, const float *rgb,
+                                  const uint8_t *compute_locally, const float *bg, const float *final_T,
+                                  const int32_t *n_contrib, const float *dL_dpixels, float *dL_dmeans2D,
+                                  float *dL_dconic_opacity, float *dL_drgb, hipStream_t stream) {
+    const int gx = (W + GSR_BLOCK_X - 1) / GSR_BLOCK_X, gy = (H + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y;
+    GSR_HIP(hipMemsetAsync(dL_dmeans2D, 0, sizeof(float) * 2 * (size_t)P, stream));
+    GSR_HIP(hipMemsetAsync(dL_dconic_opacity, 0, sizeof(float) * 4 * (size_t)P, stream));
+    GSR_HIP(hipMemsetAsync(dL_drgb, 0, sizeof(float) * 3 * (size_t)P, stream));
+    if (P == 0) return 0;
+    hipLaunchKernelGGL(composite_backward_kernel, dim3(gx * gy), dim3(256), 0, stream, W, H, gx,
+                       reinterpret_cast<const int2 *>(ranges), point_list, reinterpret_cast<const float2 *>(means2D),
+                       reinterpret_cast<const float4 *>(conic_opacity), rgb, compute_locally, bg, final_T, n_contrib,
+                       dL_dpixels, dL_dmeans2D, dL_dconic_opacity, dL_drgb);
+    GSR_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,534 @@
+// preprocess.hip -- K1 (per-Gaussian projection + SH colour) and K11 (its backward) for gfx950.
+//
+// One lane per Gaussian, 256-thread workgroups (4 waves).  Both kernels are pure HBM streaming:
+// 236 B in / 44+31 B out per Gaussian forward, 552 B per Gaussian backward.
+// Camera matrices are wave-uniform and are read through the scalar cache into SGPRs.
+//
+// What the kernels compute restates SURVEY.md Appendix A.2 / A.6 (reference call site
+// gaussian_renderer/__init__.py:949-960).  The forward geometry is compiled with FP contraction
+// off so that integer outputs (radii, tile rects) are reproducible against a plain C evaluation.
+#include "common.h"
+
+// no FMA contraction in this file: see the header comment (memory-bound kernels, no cost)
+#pragma clang fp contract(off)
+
+namespace {
+
+__constant__ const float SH_C0 = 0.28209479177387814f;
+__constant__ const float SH_C1 = 0.4886025119029199f;
+__constant__ const float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                     -1.0925484305920792f, 0.5462742152960396f};
+__constant__ const float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                     0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                                     -0.5900435899266435f};
+
+struct Cam {
+    float v[16];  // viewmatrix, row-major, row-vector convention
+    float p[16];  // full projection
+    float c[3];   // camera centre
+};
+
+__device__ __forceinline__ Cam load_cam(const float *__restrict__ view, const float *__restrict__ proj,
+                                        const float *__restrict__ campos) {
+    Cam cam;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        cam.v[i] = view[i];
+        cam.p[i] = proj[i];
+    }
+    cam.c[0] = campos[0];
+    cam.c[1] = campos[1];
+    cam.c[2] = campos[2];
+    return cam;
+}
+
+__device__ __forceinline__ void quat_to_R(const float4 q, float R[3][3]) {
+    const float r = q.x, x = q.y, y = q.z, z = q.w;
+    R[0][0] = 1.f - 2.f * (y * y + z * z);
+    R[0][1] = 2.f * (x * y - r * z);
+    R[0][2] = 2.f * (x * z + r * y);
+    R[1][0] = 2.f * (x * y + r * z);
+    R[1][1] = 1.f - 2.f * (x * x + z * z);
+    R[1][2] = 2.f * (y * z - r * x);
+    R[2][0] = 2.f * (x * z - r * y);
+    R[2][1] = 2.f * (y * z + r * x);
+    R[2][2] = 1.f - 2.f * (x * x + y * y);
+}
+
+// T = J * Wc (2x3) with the +-1.3 tanfov clamp applied for the Jacobian only
+__device__ __forceinline__ void compute_T(const float t[3], const float *v, float fx, float fy, float tanfovx,
+                                          float tanfovy, float T[2][3], float tc[3], bool &xin, bool &yin) {
+    const float limx = 1.3f * tanfovx, limy = 1.3f * tanfovy;
+    const float txtz = t[0] / t[2], tytz = t[1] / t[2];
+    xin = !(txtz < -limx || txtz > limx);
+    yin = !(tytz < -limy || tytz > limy);
+    tc[0] = fminf(limx, fmaxf(-limx, txtz)) * t[2];
+    tc[1] = fminf(limy, fmaxf(-limy, tytz)) * t[2];
+    tc[2] = t[2];
+    const float J00 = fx / tc[2], J02 = -(fx * tc[0]) / (tc[2] * tc[2]);
+    const float J11 = fy / tc[2], J12 = -(fy * tc[1]) / (tc[2] * tc[2]);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        T[0][k] = J00 * v[k * 4 + 0] + J02 * v[k * 4 + 2];
+        T[1][k] = J11 * v[k * 4 + 1] + J12 * v[k * 4 + 2];
+    }
+}
+
+template <int DEG>
+__device__ __forceinline__ void eval_sh(const float *__restrict__ sh, float x, float y, float z, float out[3]) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        float r = SH_C0 * sh[0 * 3 + c];
+        if (DEG > 0) {
+            r = r - SH_C1 * y * sh[1 * 3 + c] + SH_C1 * z * sh[2 * 3 + c] - SH_C1 * x * sh[3 * 3 + c];
+            if (DEG > 1) {
+                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                r = r + SH_C2[0] * xy * sh[4 * 3 + c] + SH_C2[1] * yz * sh[5 * 3 + c] +
+                    SH_C2[2] * (2.f * zz - xx - yy) * sh[6 * 3 + c] + SH_C2[3] * xz * sh[7 * 3 + c] +
+                    SH_C2[4] * (xx - yy) * sh[8 * 3 + c];
+                if (DEG > 2) {
+                    r = r + SH_C3[0] * y * (3.f * xx - yy) * sh[9 * 3 + c] + SH_C3[1] * xy * z * sh[10 * 3 + c] +
+                        SH_C3[2] * y * (4.f * zz - xx - yy) * sh[11 * 3 + c] +
+                        SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy) * sh[12 * 3 + c] +
+                        SH_C3[4] * x * (4.f * zz - xx - yy) * sh[13 * 3 + c] +
+                        SH_C3[5] * z * (xx - yy) * sh[14 * 3 + c] + SH_C3[6] * x * (xx - 3.f * yy) * sh[15 * 3 + c];
+                }
+            }
+        }
+        out[c] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------- K1
+template <int DEG>
+__global__ void __launch_bounds__(GSR_ONE_DIM_BLOCK)
+preprocess_forward_kernel(int P, int M, const float *__restrict__ means3D, const float *__restrict__ scales,
+                          float scale_modifier, const float *__restrict__ rotations, const float *__restrict__ shs,
+                          const float *__restrict__ opacities, const float *__restrict__ view,
+                          const float *__restrict__ proj, const float *__restrict__ campos, int W, int H,
+                          float tanfovx, float tanfovy, float2 *__restrict__ means2D, float *__restrict__ depths,
+                          int32_t *__restrict__ radii, float *__restrict__ cov3D, float4 *__restrict__ conic_opacity,
+                          float *__restrict__ rgb, uint8_t *__restrict__ clamped) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const Cam cam = load_cam(view, proj, campos);
+    const int gx = (W + GSR_BLOCK_X - 1) / GSR_BLOCK_X, gy = (H + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y;
+    const float fx = W / (2.0f * tanfovx), fy = H / (2.0f * tanfovy);
+
+    int radius = 0;
+    float2 xy = make_float2(0.f, 0.f);
+    float depth = 0.f;
+    float cov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float4 co = make_float4(0.f, 0.f, 0.f, 0.f);
+    float col[3] = {0.f, 0.f, 0.f};
+    bool cl[3] = {false, false, false};
+
+    const float p[3] = {means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]};
+    float t[3];
+    t[0] = cam.v[0] * p[0] + cam.v[4] * p[1] + cam.v[8] * p[2] + cam.v[12];
+    t[1] = cam.v[1] * p[0] + cam.v[5] * p[1] + cam.v[9] * p[2] + cam.v[13];
+    t[2] = cam.v[2] * p[0] + cam.v[6] * p[1] + cam.v[10] * p[2] + cam.v[14];
+    do {
+        if (t[2] <= 0.2f) break;  // near-plane cull
+        const float phx = cam.p[0] * p[0] + cam.p[4] * p[1] + cam.p[8] * p[2] + cam.p[12];
+        const float phy = cam.p[1] * p[0] + cam.p[5] * p[1] + cam.p[9] * p[2] + cam.p[13];
+        const float phw = cam.p[3] * p[0] + cam.p[7] * p[1] + cam.p[11] * p[2] + cam.p[15];
+        const float pw = 1.0f / (phw + 0.0000001f);
+        const float pprojx = phx * pw, pprojy = phy * pw;
+
+        // Sigma = R S S R^T
+        float R[3][3];
+        quat_to_R(*reinterpret_cast<const float4 *>(rotations + 4 * (size_t)i), R);
+        const float s[3] = {scale_modifier * scales[3 * i], scale_modifier * scales[3 * i + 1],
+                            scale_modifier * scales[3 * i + 2]};
+        float L[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int b = 0; b < 3; b++) L[a][b] = R[a][b] * s[b];
+        float S[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int b = 0; b < 3; b++) S[a][b] = L[a][0] * L[b][0] + L[a][1] * L[b][1] + L[a][2] * L[b][2];
+        float T[2][3], tc[3];
+        bool xin, yin;
+        compute_T(t, cam.v, fx, fy, tanfovx, tanfovy, T, tc, xin, yin);
+        float ST0[3], ST1[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            ST0[r] = S[r][0] * T[0][0] + S[r][1] * T[0][1] + S[r][2] * T[0][2];
+            ST1[r] = S[r][0] * T[1][0] + S[r][1] * T[1][1] + S[r][2] * T[1][2];
+        }
+        const float a = T[0][0] * ST0[0] + T[0][1] * ST0[1] + T[0][2] * ST0[2] + 0.3f;
+        const float b = T[0][0] * ST1[0] + T[0][1] * ST1[1] + T[0][2] * ST1[2];
+        const float c = T[1][0] * ST1[0] + T[1][1] * ST1[1] + T[1][2] * ST1[2] + 0.3f;
+        const float det = a * c - b * b;
+        if (det == 0.0f) break;
+        const float det_inv = 1.f / det;
+        const float mid = 0.5f * (a + c);
+        const float lam = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+        const int rad = (int)ceilf(3.f * sqrtf(lam));
+        const float px = ((pprojx + 1.0f) * W - 1.0f) * 0.5f;
+        const float py = ((pprojy + 1.0f) * H - 1.0f) * 0.5f;
+        int minx, miny, maxx, maxy;
+        gsr_get_rect(px, py, rad, gx, gy, minx, miny, maxx, maxy);
+        if ((maxx - minx) * (maxy - miny) == 0) break;
+
+        // colour from SH, view direction in world space
+        float d[3] = {p[0] - cam.c[0], p[1] - cam.c[1], p[2] - cam.c[2]};
+        const float inv = 1.0f / sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        d[0] *= inv;
+        d[1] *= inv;
+        d[2] *= inv;
+        float shl[(DEG + 1) * (DEG + 1) * 3];
+        const float *shp = shs + (size_t)i * M * 3;
+        if (DEG == 3 && M == 16) {
+            const float4 *s4 = reinterpret_cast<const float4 *>(shp);
+#pragma unroll
+            for (int k = 0; k < 12; k++) {
+                const float4 v = s4[k];
+                shl[4 * k] = v.x;
+                shl[4 * k + 1] = v.y;
+                shl[4 * k + 2] = v.z;
+                shl[4 * k + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < (DEG + 1) * (DEG + 1) * 3; k++) shl[k] = shp[k];
+        }
+        eval_sh<DEG>(shl, d[0], d[1], d[2], col);
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            col[k] += 0.5f;
+            cl[k] = col[k] < 0.f;
+            col[k] = fmaxf(col[k], 0.f);
+        }
+        radius = rad;
+        xy = make_float2(px, py);
+        depth = t[2];
+        cov[0] = S[0][0]; cov[1] = S[0][1]; cov[2] = S[0][2];
+        cov[3] = S[1][1]; cov[4] = S[1][2]; cov[5] = S[2][2];
+        co = make_float4(c * det_inv, -b * det_inv, a * det_inv, opacities[i]);
+    } while (false);
+
+    radii[i] = radius;
+    means2D[i] = xy;
+    depths[i] = depth;
+    conic_opacity[i] = co;
+#pragma unroll
+    for (int k = 0; k < 6; k++) cov3D[6 * (size_t)i + k] = cov[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        rgb[3 * (size_t)i + k] = col[k];
+        clamped[3 * (size_t)i + k] = cl[k] ? 1 : 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ K11
+template <int DEG>
+__global__ void __launch_bounds__(GSR_ONE_DIM_BLOCK)
+preprocess_backward_kernel(int P, int M, const float *__restrict__ means3D, const float *__restrict__ scales,
+                           float scale_modifier, const float *__restrict__ rotations, const float *__restrict__ shs,
+                           const float *__restrict__ view, const float *__restrict__ proj,
+                           const float *__restrict__ campos, int W, int H, float tanfovx, float tanfovy,
+                           const int32_t *__restrict__ radii, const float *__restrict__ cov3D,
+                           const uint8_t *__restrict__ clamped, const float2 *__restrict__ dL_dmeans2D,
+                           const float4 *__restrict__ dL_dconic_opacity, const float *__restrict__ dL_drgb,
+                           float *__restrict__ dL_dmeans3D, float *__restrict__ dL_dscales,
+                           float4 *__restrict__ dL_drotations, float *__restrict__ dL_dshs,
+                           float *__restrict__ dL_dopacities) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    constexpr int NC = (DEG + 1) * (DEG + 1);
+    float *dsh_out = dL_dshs + (size_t)i * M * 3;
+
+    if (radii[i] <= 0) {
+        dL_dmeans3D[3 * (size_t)i] = dL_dmeans3D[3 * (size_t)i + 1] = dL_dmeans3D[3 * (size_t)i + 2] = 0.f;
+        dL_dscales[3 * (size_t)i] = dL_dscales[3 * (size_t)i + 1] = dL_dscales[3 * (size_t)i + 2] = 0.f;
+        dL_drotations[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        dL_dopacities[i] = 0.f;
+        for (int k = 0; k < M * 3; k++) dsh_out[k] = 0.f;
+        return;
+    }
+    const Cam cam = load_cam(view, proj, campos);
+    const float fx = W / (2.0f * tanfovx), fy = H / (2.0f * tanfovy);
+    const float p[3] = {means3D[3 * (size_t)i], means3D[3 * (size_t)i + 1], means3D[3 * (size_t)i + 2]};
+    const float4 gco = dL_dconic_opacity[i];
+    const float gA = gco.x, gB = gco.y, gC = gco.z;
+    dL_dopacities[i] = gco.w;
+
+    // ---- conic -> cov2D -> (cov3D, t)
+    float t[3];
+    t[0] = cam.v[0] * p[0] + cam.v[4] * p[1] + cam.v[8] * p[2] + cam.v[12];
+    t[1] = cam.v[1] * p[0] + cam.v[5] * p[1] + cam.v[9] * p[2] + cam.v[13];
+    t[2] = cam.v[2] * p[0] + cam.v[6] * p[1] + cam.v[10] * p[2] + cam.v[14];
+    float T[2][3], tc[3];
+    bool xin, yin;
+    compute_T(t, cam.v, fx, fy, tanfovx, tanfovy, T, tc, xin, yin);
+    const float *cv = cov3D + 6 * (size_t)i;
+    const float S[3][3] = {{cv[0], cv[1], cv[2]}, {cv[1], cv[3], cv[4]}, {cv[2], cv[4], cv[5]}};
+    float ST0[3], ST1[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        ST0[r] = S[r][0] * T[0][0] + S[r][1] * T[0][1] + S[r][2] * T[0][2];
+        ST1[r] = S[r][0] * T[1][0] + S[r][1] * T[1][1] + S[r][2] * T[1][2];
+    }
+    const float a = T[0][0] * ST0[0] + T[0][1] * ST0[1] + T[0][2] * ST0[2] + 0.3f;
+    const float b = T[0][0] * ST1[0] + T[0][1] * ST1[1] + T[0][2] * ST1[2];
+    const float c = T[1][0] * ST1[0] + T[1][1] * ST1[1] + T[1][2] * ST1[2] + 0.3f;
+    const float denom = a * c - b * b;
+    const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+    float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
+    float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (denom2inv != 0.f) {
+        dL_da = denom2inv * (-c * c * gA + b * c * gB + (denom - a * c) * gC);
+        dL_dc = denom2inv * (-a * a * gC + a * b * gB + (denom - a * c) * gA);
+        dL_db = denom2inv * (2.f * b * c * gA - (denom + 2.f * b * b) * gB + 2.f * a * b * gC);
+        dcov[0] = T[0][0] * T[0][0] * dL_da + T[0][0] * T[1][0] * dL_db + T[1][0] * T[1][0] * dL_dc;
+        dcov[3] = T[0][1] * T[0][1] * dL_da + T[0][1] * T[1][1] * dL_db + T[1][1] * T[1][1] * dL_dc;
+        dcov[5] = T[0][2] * T[0][2] * dL_da + T[0][2] * T[1][2] * dL_db + T[1][2] * T[1][2] * dL_dc;
+        dcov[1] = 2.f * T[0][0] * T[0][1] * dL_da + (T[0][0] * T[1][1] + T[0][1] * T[1][0]) * dL_db +
+                  2.f * T[1][0] * T[1][1] * dL_dc;
+        dcov[2] = 2.f * T[0][0] * T[0][2] * dL_da + (T[0][0] * T[1][2] + T[0][2] * T[1][0]) * dL_db +
+                  2.f * T[1][0] * T[1][2] * dL_dc;
+        dcov[4] = 2.f * T[0][2] * T[0][1] * dL_da + (T[0][1] * T[1][2] + T[0][2] * T[1][1]) * dL_db +
+                  2.f * T[1][1] * T[1][2] * dL_dc;
+    }
+    float dT0[3], dT1[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        dT0[k] = 2.f * ST0[k] * dL_da + ST1[k] * dL_db;
+        dT1[k] = 2.f * ST1[k] * dL_dc + ST0[k] * dL_db;
+    }
+    const float dJ00 = dT0[0] * cam.v[0] + dT0[1] * cam.v[4] + dT0[2] * cam.v[8];
+    const float dJ02 = dT0[0] * cam.v[2] + dT0[1] * cam.v[6] + dT0[2] * cam.v[10];
+    const float dJ11 = dT1[0] * cam.v[1] + dT1[1] * cam.v[5] + dT1[2] * cam.v[9];
+    const float dJ12 = dT1[0] * cam.v[2] + dT1[1] * cam.v[6] + dT1[2] * cam.v[10];
+    const float tz = 1.f / tc[2], tz2 = tz * tz, tz3 = tz2 * tz;
+    float dt[3];
+    dt[0] = (xin ? 1.f : 0.f) * (-fx * tz2 * dJ02);
+    dt[1] = (yin ? 1.f : 0.f) * (-fy * tz2 * dJ12);
+    dt[2] = -fx * tz2 * dJ00 - fy * tz2 * dJ11 + (2.f * fx * tc[0]) * tz3 * dJ02 + (2.f * fy * tc[1]) * tz3 * dJ12;
+    float dmean[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+        dmean[k] = cam.v[k * 4 + 0] * dt[0] + cam.v[k * 4 + 1] * dt[1] + cam.v[k * 4 + 2] * dt[2];
+
+    // ---- means2D (NDC-scaled) -> mean through the perspective divide
+    {
+        const float phx = cam.p[0] * p[0] + cam.p[4] * p[1] + cam.p[8] * p[2] + cam.p[12];
+        const float phy = cam.p[1] * p[0] + cam.p[5] * p[1] + cam.p[9] * p[2] + cam.p[13];
+        const float phw = cam.p[3] * p[0] + cam.p[7] * p[1] + cam.p[11] * p[2] + cam.p[15];
+        const float mw = 1.0f / (phw + 0.0000001f);
+        const float mul1 = phx * mw * mw, mul2 = phy * mw * mw;
+        const float2 g2 = dL_dmeans2D[i];
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+            dmean[k] += (cam.p[k * 4 + 0] * mw - cam.p[k * 4 + 3] * mul1) * g2.x +
+                        (cam.p[k * 4 + 1] * mw - cam.p[k * 4 + 3] * mul2) * g2.y;
+    }
+
+    // ---- colour -> SH coefficients and view direction
+    {
+        const float *sh = shs + (size_t)i * M * 3;
+        const float dox = p[0] - cam.c[0], doy = p[1] - cam.c[1], doz = p[2] - cam.c[2];
+        const float len = sqrtf(dox * dox + doy * doy + doz * doz);
+        const float x = dox / len, y = doy / len, z = doz / len;
+        float ddir[3] = {0.f, 0.f, 0.f};
+        float dsh[NC * 3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            const float g = clamped[3 * (size_t)i + ch] ? 0.f : dL_drgb[3 * (size_t)i + ch];
+            float dx = 0.f, dy = 0.f, dz = 0.f;
+            dsh[0 * 3 + ch] = SH_C0 * g;
+            if (DEG > 0) {
+                dsh[1 * 3 + ch] = -SH_C1 * y * g;
+                dsh[2 * 3 + ch] = SH_C1 * z * g;
+                dsh[3 * 3 + ch] = -SH_C1 * x * g;
+                dx = -SH_C1 * sh[3 * 3 + ch];
+                dy = -SH_C1 * sh[1 * 3 + ch];
+                dz = SH_C1 * sh[2 * 3 + ch];
+                if (DEG > 1) {
+                    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                    dsh[4 * 3 + ch] = SH_C2[0] * xy * g;
+                    dsh[5 * 3 + ch] = SH_C2[1] * yz * g;
+                    dsh[6 * 3 + ch] = SH_C2[2] * (2.f * zz - xx - yy) * g;
+                    dsh[7 * 3 + ch] = SH_C2[3] * xz * g;
+                    dsh[8 * 3 + ch] = SH_C2[4] * (xx - yy) * g;
+                    dx += SH_C2[0] * y * sh[4 * 3 + ch] + SH_C2[2] * 2.f * -x * sh[6 * 3 + ch] +
+                          SH_C2[3] * z * sh[7 * 3 + ch] + SH_C2[4] * 2.f * x * sh[8 * 3 + ch];
+                    dy += SH_C2[0] * x * sh[4 * 3 + ch] + SH_C2[1] * z * sh[5 * 3 + ch] +
+                          SH_C2[2] * 2.f * -y * sh[6 * 3 + ch] + SH_C2[4] * 2.f * -y * sh[8 * 3 + ch];
+                    dz += SH_C2[1] * y * sh[5 * 3 + ch] + SH_C2[2] * 2.f * 2.f * z * sh[6 * 3 + ch] +
+                          SH_C2[3] * x * sh[7 * 3 + ch];
+                    if (DEG > 2) {
+                        dsh[9 * 3 + ch] = SH_C3[0] * y * (3.f * xx - yy) * g;
+                        dsh[10 * 3 + ch] = SH_C3[1] * xy * z * g;
+                        dsh[11 * 3 + ch] = SH_C3[2] * y * (4.f * zz - xx - yy) * g;
+                        dsh[12 * 3 + ch] = SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy) * g;
+                        dsh[13 * 3 + ch] = SH_C3[4] * x * (4.f * zz - xx - yy) * g;
+                        dsh[14 * 3 + ch] = SH_C3[5] * z * (xx - yy) * g;
+                        dsh[15 * 3 + ch] = SH_C3[6] * x * (xx - 3.f * yy) * g;
+                        dx += SH_C3[0] * sh[9 * 3 + ch] * 3.f * 2.f * xy + SH_C3[1] * sh[10 * 3 + ch] * yz +
+                              SH_C3[2] * sh[11 * 3 + ch] * -2.f * xy + SH_C3[3] * sh[12 * 3 + ch] * -3.f * 2.f * xz +
+                              SH_C3[4] * sh[13 * 3 + ch] * (-3.f * xx + 4.f * zz - yy) +
+                              SH_C3[5] * sh[14 * 3 + ch] * 2.f * xz + SH_C3[6] * sh[15 * 3 + ch] * 3.f * (xx - yy);
+                        dy += SH_C3[0] * sh[9 * 3 + ch] * 3.f * (xx - yy) + SH_C3[1] * sh[10 * 3 + ch] * xz +
+                              SH_C3[2] * sh[11 * 3 + ch] * (-3.f * yy + 4.f * zz - xx) +
+                              SH_C3[3] * sh[12 * 3 + ch] * -3.f * 2.f * yz + SH_C3[4] * sh[13 * 3 + ch] * -2.f * xy +
+                              SH_C3[5] * sh[14 * 3 + ch] * -2.f * yz + SH_C3[6] * sh[15 * 3 + ch] * -3.f * 2.f * xy;
+                        dz += SH_C3[1] * sh[10 * 3 + ch] * xy + SH_C3[2] * sh[11 * 3 + ch] * 4.f * 2.f * yz +
+                              SH_C3[3] * sh[12 * 3 + ch] * 3.f * (2.f * zz - xx - yy) +
+                              SH_C3[4] * sh[13 * 3 + ch] * 4.f * 2.f * xz + SH_C3[5] * sh[14 * 3 + ch] * (xx - yy);
+                    }
+                }
+            }
+            ddir[0] += dx * g;
+            ddir[1] += dy * g;
+            ddir[2] += dz * g;
+        }
+        const float dot = x * ddir[0] + y * ddir[1] + z * ddir[2];
+        dmean[0] += (ddir[0] - x * dot) / len;
+        dmean[1] += (ddir[1] - y * dot) / len;
+        dmean[2] += (ddir[2] - z * dot) / len;
+        if (DEG == 3 && M == 16) {
+            float4 *o4 = reinterpret_cast<float4 *>(dsh_out);
+#pragma unroll
+            for (int k = 0; k < 12; k++) o4[k] = make_float4(dsh[4 * k], dsh[4 * k + 1], dsh[4 * k + 2], dsh[4 * k + 3]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < NC * 3; k++) dsh_out[k] = dsh[k];
+            for (int k = NC * 3; k < M * 3; k++) dsh_out[k] = 0.f;
+        }
+    }
+    dL_dmeans3D[3 * (size_t)i] = dmean[0];
+    dL_dmeans3D[3 * (size_t)i + 1] = dmean[1];
+    dL_dmeans3D[3 * (size_t)i + 2] = dmean[2];
+
+    // ---- cov3D -> scales, rotations.  Sigma = M^T M, M = S R^T
+    {
+        const float4 q = *reinterpret_cast<const float4 *>(rotations + 4 * (size_t)i);
+        float R[3][3];
+        quat_to_R(q, R);
+        const float s[3] = {scale_modifier * scales[3 * (size_t)i], scale_modifier * scales[3 * (size_t)i + 1],
+                            scale_modifier * scales[3 * (size_t)i + 2]};
+        float Mm[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int cc = 0; cc < 3; cc++) Mm[r][cc] = s[r] * R[cc][r];
+        const float dS[3][3] = {{dcov[0], 0.5f * dcov[1], 0.5f * dcov[2]},
+                                {0.5f * dcov[1], dcov[3], 0.5f * dcov[4]},
+                                {0.5f * dcov[2], 0.5f * dcov[4], dcov[5]}};
+        float dM[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int cc = 0; cc < 3; cc++)
+                dM[r][cc] = 2.f * (Mm[r][0] * dS[0][cc] + Mm[r][1] * dS[1][cc] + Mm[r][2] * dS[2][cc]);
+        float dR[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            dL_dscales[3 * (size_t)i + r] =
+                scale_modifier * (R[0][r] * dM[r][0] + R[1][r] * dM[r][1] + R[2][r] * dM[r][2]);
+#pragma unroll
+            for (int j = 0; j < 3; j++) dR[j][r] = s[r] * dM[r][j];
+        }
+        const float r_ = q.x, x = q.y, y = q.z, z = q.w;
+        float4 dq;
+        dq.x = 2.f * (-z * dR[0][1] + y * dR[0][2] + z * dR[1][0] - x * dR[1][2] - y * dR[2][0] + x * dR[2][1]);
+        dq.y = 2.f * (y * dR[0][1] + z * dR[0][2] + y * dR[1][0] - 2.f * x * dR[1][1] - r_ * dR[1][2] + z * dR[2][0] +
+                      r_ * dR[2][1] - 2.f * x * dR[2][2]);
+        dq.z = 2.f * (-2.f * y * dR[0][0] + x * dR[0][1] + r_ * dR[0][2] + x * dR[1][0] + z * dR[1][2] - r_ * dR[2][0] +
+                      z * dR[2][1] - 2.f * y * dR[2][2]);
+        dq.w = 2.f * (-2.f * z * dR[0][0] - r_ * dR[0][1] + x * dR[0][2] + r_ * dR[1][0] - 2.f * z * dR[1][1] +
+                      y * dR[1][2] + x * dR[2][0] + y * dR[2][1]);
+        dL_drotations[i] = dq;
+    }
+}
+
+// -------------------------------------------------------------------------------------------- K2
+__global__ void __launch_bounds__(GSR_ONE_DIM_BLOCK)
+local2j_kernel(int P, int W, int H, int ws, const float2 *__restrict__ means2D, const int32_t *__restrict__ radii,
+               const int32_t *__restrict__ div, uint8_t *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const int gx = (W + GSR_BLOCK_X - 1) / GSR_BLOCK_X, gy = (H + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y;
+    const int rad = radii[i];
+    int minx = 0, miny = 0, maxx = 0, maxy = 0;
+    if (rad > 0) {
+        const float2 xy = means2D[i];
+        gsr_get_rect(xy.x, xy.y, rad, gx, gy, minx, miny, maxx, maxy);
+    }
+    const bool nonempty = rad > 0 && maxx > minx && maxy > miny;
+    for (int j = 0; j < ws; j++) {
+        const int lo = div[j], hi = div[j + 1];
+        bool hit = false;
+        if (nonempty) {
+            // rows of the rect whose tile-id span [y*gx+minx, y*gx+maxx-1] meets [lo,hi)
+            // y*gx+minx < hi  <=> y <= (hi-1-minx)/gx ;  y*gx+maxx-1 >= lo <=> y >= ceil((lo-maxx+1)/gx)
+            const int num_hi = hi - 1 - minx;
+            const int y_hi = num_hi < 0 ? -1 : num_hi / gx;
+            const int num_lo = lo - maxx + 1;
+            const int y_lo = num_lo <= 0 ? 0 : (num_lo + gx - 1) / gx;
+            hit = max(y_lo, miny) <= min(y_hi, maxy - 1);
+        }
+        out[(size_t)i * ws + j] = hit ? 1 : 0;
+    }
+}
+
+}  // namespace
+
+#define GSR_DISPATCH_DEG(D, ...)                 \
+    switch (D) {                                 \
+        case 0: { constexpr int DEG = 0; __VA_ARGS__; } break; \
+        case 1: { constexpr int DEG = 1; __VA_ARGS__; } break; \
+        case 2: { constexpr int DEG = 2; __VA_ARGS__; } break; \
+        default: { constexpr int DEG = 3; __VA_ARGS__; } break; \
+    }
+
+int gsr_launch_preprocess_forward(int P, int D, int M, const float *means3D, const float *scales, float scale_modifier,
+                                  const float *rotations, const float *shs, const float *opacities,
+                                  const float *viewmatrix, const float *projmatrix, const float *campos, int W, int H,
+                                  float tanfovx, float tanfovy, float *means2D, float *depths, int32_t *radii,
+                                  float *cov3D, float *conic_opacity, float *rgb, uint8_t *clamped,
+                                  hipStream_t stream) {
+    if (P == 0) return 0;
+    const dim3 grid(gsr_div_up(P, GSR_ONE_DIM_BLOCK)), block(GSR_ONE_DIM_BLOCK);
+    GSR_DISPATCH_DEG(D, hipLaunchKernelGGL(preprocess_forward_kernel<DEG>, grid, block, 0, stream, P, M, means3D,
+                                           scales, scale_modifier, rotations, shs, opacities, viewmatrix, projmatrix,
+                                           campos, W, H, tanfovx, tanfovy, reinterpret_cast<float2 *>(means2D), depths,
+                                           radii, cov3D, reinterpret_cast<float4 *>(conic_opacity), rgb, clamped));
+    GSR_LAUNCH_CHECK();
+    return 0;
+}
+
+int gsr_launch_preprocess_backward(int P, int D, int M, const float *means3D, const float *scales,
+                                   float scale_modifier, const float *rotations, const float *shs,
+                                   const float *viewmatrix, const float *projmatrix, const float *campos, int W,
+                                   int H, float tanfovx, float tanfovy, const int32_t *radii, const float *cov3D,
+                                   const uint8_t *clamped, const float *dL_dmeans2D, const float *dL_dconic_opacity,
+                                   const float *dL_drgb, float *dL_dmeans3D, float *dL_dscales, float *dL_drotations,
+                                   float *dL_dshs, float *dL_dopacities, hipStream_t stream) {
+    if (P == 0) return 0;
+    const dim3 grid(gsr_div_up(P, GSR_ONE_DIM_BLOCK)), block(GSR_ONE_DIM_BLOCK);
+    GSR_DISPATCH_DEG(D, hipLaunchKernelGGL(preprocess_backward_kernel<DEG>, grid, block, 0, stream, P, M, means3D,
+                                           scales, scale_modifier, rotations, shs, viewmatrix, projmatrix, campos, W,
+                                           H, tanfovx, tanfovy, radii, cov3D, clamped,
+                                           reinterpret_cast<const float2 *>(dL_dmeans2D),
+                                           reinterpret_cast<const float4 *>(dL_dconic_opacity), dL_drgb, dL_dmeans3D,
+                                           dL_dscales, reinterpret_cast<float4 *>(dL_drotations), dL_dshs,
+                                           dL_dopacities));
+    GSR_LAUNCH_CHECK();
+    return 0;
+}
+
+int gsr_launch_local2j(int P, int W, int H, int ws, const float *means2D, const int32_t *radii, const int32_t *div,
+                       uint8_t *out, hipStream_t stream) {
+    if (P == 0) return 0;
+    hipLaunchKernelGGL(local2j_kernel, dim3(gsr_div_up(P, GSR_ONE_DIM_BLOCK)), dim3(GSR_ONE_DIM_BLOCK), 0, stream, P,
+                       W, H, ws, reinterpret_cast<const float2 *>(means2D), radii, div, out);
+    GSR_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,355 @@
+"""MI355X-native drop-in for the reference's `diff_gaussian_rasterization` operator module.
+
+Host-side mirror (Python, because the reference's wrapper is Python) of the operator surface the
+reference binds for its hot path -- same names, argument meaning and output order -- on top of the
+C-ABI of include/gsraster.h (libgsraster.so, hand-written HIP for gfx950):
+
+  GaussianRasterizationSettings        built at gaussian_renderer/__init__.py:930-943
+  GaussianRasterizer.preprocess_gaussians   called at gaussian_renderer/__init__.py:949-956
+  GaussianRasterizer.render_gaussians       called at gaussian_renderer/__init__.py:1271-1282
+  _C.get_block_XY                      arguments/__init__.py:254-257
+  _C.get_local2j_ids_bool              gaussian_renderer/workload_division.py:727-738
+  load_image_tiles_by_pos / merge_image_tiles_by_pos / _C.get_touched_locally / ... : only dead
+  callers in the reference (loss_distribution.py:136-213, workload_division.py:483) -> raise.
+
+PyTorch is used for device memory, streams and autograd plumbing only; every kernel on the path is in
+the HIP library and the module refuses to work without it (no CPU / eager fallback).
+"""
+import ctypes
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import check, lib
+
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "_C", "load_image_tiles_by_pos",
+           "merge_image_tiles_by_pos", "set_timing_mode"]
+
+BLOCK_X, BLOCK_Y, ONE_DIM_BLOCK_SIZE = 16, 16, 256
+
+# how render_gaussians fills cuda_args["stats_collector"]["backward_render_time"]:
+#   "sync"  : one HIP-event synchronisation at the end of the backward op -> exact per-call value
+#   "stale" : no extra host sync; reports the most recent backward whose events have completed
+#   "off"   : 0.0 (no events recorded)
+_TIMING_MODE = "auto"
+_last_backward_ms = 0.0
+
+
+def set_timing_mode(mode):
+    global _TIMING_MODE
+    assert mode in ("auto", "sync", "stale", "off")
+    _TIMING_MODE = mode
+
+
+def _timing_mode():
+    if _TIMING_MODE != "auto":
+        return _TIMING_MODE
+    if torch.distributed.is_available() and torch.distributed.is_initialized() and \
+            torch.distributed.get_world_size() > 1:
+        return "sync"  # the load balancer consumes the value (workload_division.py:944-998)
+    return "stale"
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32c(t, name):
+    if not t.is_cuda:
+        raise RuntimeError(f"diff_gaussian_rasterization: `{name}` must live on the gfx950 device "
+                           "(there is no CPU fallback)")
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+# ------------------------------------------------------------------------------------ K1 / K11
+class _PreprocessGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, scales, rotations, shs, opacities, raster_settings, cuda_args):
+        rs = raster_settings
+        means3D, scales, rotations = _f32c(means3D, "means3D"), _f32c(scales, "scales"), _f32c(rotations, "rotations")
+        shs, opacities = _f32c(shs, "shs"), _f32c(opacities, "opacities")
+        P = means3D.shape[0]
+        M = shs.shape[1] if shs.dim() == 3 else 0
+        if shs.dim() != 3 or shs.shape[0] != P or shs.shape[2] != 3:
+            raise ValueError(f"shs must be [P, K, 3], got {tuple(shs.shape)}")
+        if scales.shape != (P, 3) or rotations.shape != (P, 4) or opacities.numel() != P:
+            raise ValueError("scales [P,3], rotations [P,4], opacities [P,1] expected")
+        dev = means3D.device
+        view = _f32c(rs.viewmatrix, "viewmatrix")
+        proj = _f32c(rs.projmatrix, "projmatrix")
+        campos = _f32c(rs.campos, "campos")
+        means2D = torch.empty((P, 2), dtype=torch.float32, device=dev)
+        depths = torch.empty((P,), dtype=torch.float32, device=dev)
+        radii = torch.empty((P,), dtype=torch.int32, device=dev)
+        cov3D = torch.empty((P, 6), dtype=torch.float32, device=dev)
+        conic_opacity = torch.empty((P, 4), dtype=torch.float32, device=dev)
+        rgb = torch.empty((P, 3), dtype=torch.float32, device=dev)
+        clamped = torch.empty((P, 3), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            check(lib.gsr_preprocess_forward(
+                P, int(rs.sh_degree), M, _ptr(means3D), _ptr(scales), float(rs.scale_modifier), _ptr(rotations),
+                _ptr(shs), _ptr(opacities), _ptr(view), _ptr(proj), _ptr(campos), int(rs.image_width),
+                int(rs.image_height), float(rs.tanfovx), float(rs.tanfovy), _ptr(means2D), _ptr(depths), _ptr(radii),
+                _ptr(cov3D), _ptr(conic_opacity), _ptr(rgb), _ptr(clamped), _stream()), "gsr_preprocess_forward")
+        ctx.raster_settings = rs
+        ctx.M = M
+        ctx.save_for_backward(means3D, scales, rotations, shs, view, proj, campos, radii, cov3D, clamped)
+        ctx.mark_non_differentiable(radii, depths)
+        return means2D, rgb, conic_opacity, radii, depths
+
+    @staticmethod
+    def backward(ctx, g_means2D, g_rgb, g_conic_opacity, g_radii, g_depths):
+        rs = ctx.raster_settings
+        means3D, scales, rotations, shs, view, proj, campos, radii, cov3D, clamped = ctx.saved_tensors
+        P, M = means3D.shape[0], ctx.M
+        dev = means3D.device
+
+        def grad_or_zero(g, cols):
+            if g is None:
+                return torch.zeros((P, cols), dtype=torch.float32, device=dev)
+            return g.float().contiguous()
+
+        g_means2D = grad_or_zero(g_means2D, 2)
+        g_rgb = grad_or_zero(g_rgb, 3)
+        g_conic_opacity = grad_or_zero(g_conic_opacity, 4)
+        d_means3D = torch.empty((P, 3), dtype=torch.float32, device=dev)
+        d_scales = torch.empty((P, 3), dtype=torch.float32, device=dev)
+        d_rot = torch.empty((P, 4), dtype=torch.float32, device=dev)
+        d_shs = torch.empty((P, M, 3), dtype=torch.float32, device=dev)
+        d_opac = torch.empty((P, 1), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            check(lib.gsr_preprocess_backward(
+                P, int(rs.sh_degree), M, _ptr(means3D), _ptr(scales), float(rs.scale_modifier), _ptr(rotations),
+                _ptr(shs), _ptr(view), _ptr(proj), _ptr(campos), int(rs.image_width), int(rs.image_height),
+                float(rs.tanfovx), float(rs.tanfovy), _ptr(radii), _ptr(cov3D), _ptr(clamped), _ptr(g_means2D),
+                _ptr(g_conic_opacity), _ptr(g_rgb), _ptr(d_means3D), _ptr(d_scales), _ptr(d_rot), _ptr(d_shs),
+                _ptr(d_opac), _stream()), "gsr_preprocess_backward")
+        return d_means3D, d_scales, d_rot, d_shs, d_opac, None, None
+
+
+# ------------------------------------------------------------------------------- K3..K8 / K10
+def bin_gaussians(means2D, depths, radii, compute_locally, width, height):
+    """K3-K7: returns (point_list uint32-as-int32 [D], ranges int32 [tiles,2], D).  One host sync
+    (the pair count sizes the sort buffers), like the reference's own num_rendered read-back."""
+    P = means2D.shape[0]
+    dev = means2D.device
+    gx, gy = (width + BLOCK_X - 1) // BLOCK_X, (height + BLOCK_Y - 1) // BLOCK_Y
+    ranges = torch.empty((gx * gy, 2), dtype=torch.int32, device=dev)
+    prep_bytes = lib.gsr_bin_prepare_bytes(P, width, height)
+    prep = torch.empty((max(prep_bytes, 4),), dtype=torch.uint8, device=dev)
+    D = ctypes.c_int64(0)
+    check(lib.gsr_bin_prepare(P, width, height, _ptr(means2D), _ptr(depths), _ptr(radii), _ptr(compute_locally),
+                              _ptr(prep), prep_bytes, ctypes.byref(D), _stream()), "gsr_bin_prepare")
+    D = int(D.value)
+    sort_bytes = lib.gsr_bin_sort_bytes(P, D, width, height)
+    scratch = torch.empty((max(sort_bytes, 4),), dtype=torch.uint8, device=dev)
+    point_list = torch.empty((max(D, 1),), dtype=torch.int32, device=dev)
+    check(lib.gsr_bin_sort(P, width, height, _ptr(means2D), _ptr(radii), _ptr(compute_locally), _ptr(prep), D,
+                           _ptr(scratch), sort_bytes, _ptr(point_list), _ptr(ranges), _stream()), "gsr_bin_sort")
+    return point_list, ranges, D
+
+
+class _RenderGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means2D, conic_opacity, rgb, depths, radii, compute_locally, raster_settings, cuda_args):
+        rs = raster_settings
+        means2D, conic_opacity, rgb = _f32c(means2D, "means2D"), _f32c(conic_opacity, "conic_opacity"), _f32c(rgb, "rgb")
+        depths = _f32c(depths, "depths")
+        if not radii.is_cuda:
+            raise RuntimeError("diff_gaussian_rasterization: `radii` must live on the gfx950 device")
+        radii = radii.to(torch.int32).contiguous()
+        H, W = int(rs.image_height), int(rs.image_width)
+        gx, gy = (W + BLOCK_X - 1) // BLOCK_X, (H + BLOCK_Y - 1) // BLOCK_Y
+        P = means2D.shape[0]
+        dev = means2D.device
+        if compute_locally is None:
+            mask = torch.ones((gy * gx,), dtype=torch.uint8, device=dev)
+        else:
+            if compute_locally.numel() != gx * gy:
+                raise ValueError(f"compute_locally must have TILE_Y*TILE_X = {gy}x{gx} entries")
+            mask = compute_locally.to(device=dev).contiguous().view(-1)
+            mask = mask.view(torch.uint8) if mask.dtype == torch.bool else mask.to(torch.uint8)
+        bg = _f32c(rs.bg, "bg")
+        timing = _timing_mode()
+        stats = cuda_args.get("stats_collector") if isinstance(cuda_args, dict) else None
+        with torch.cuda.device(dev):
+            if timing != "off":
+                ev0 = torch.cuda.Event(enable_timing=True)
+                ev1 = torch.cuda.Event(enable_timing=True)
+                ev0.record()
+            point_list, ranges, D = bin_gaussians(means2D, depths, radii, mask, W, H)
+            out = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+            final_T = torch.empty((H, W), dtype=torch.float32, device=dev)
+            n_contrib = torch.empty((H, W), dtype=torch.int32, device=dev)
+            check(lib.gsr_render_forward(P, W, H, _ptr(ranges), _ptr(point_list), _ptr(means2D), _ptr(conic_opacity),
+                                         _ptr(rgb), _ptr(mask), _ptr(bg), _ptr(out), _ptr(final_T), _ptr(n_contrib),
+                                         _stream()), "gsr_render_forward")
+            if timing != "off":
+                ev1.record()
+                ctx.fwd_events = (ev0, ev1)
+        if stats is not None:
+            # placeholders are real floats so that a forward-only caller can read them; the backward
+            # replaces them with measured values (workload_division.py:953-957 reads them afterwards)
+            stats.setdefault("forward_render_time", 0.0)
+            stats.setdefault("backward_render_time", 0.0)
+        ctx.raster_settings = rs
+        ctx.cuda_args = cuda_args
+        ctx.timing = timing
+        ctx.num_rendered = D
+        ctx.save_for_backward(means2D, conic_opacity, rgb, mask, bg, point_list, ranges, final_T, n_contrib)
+        ctx.mark_non_differentiable(n_contrib)
+        return out, n_contrib
+
+    @staticmethod
+    def backward(ctx, g_out, _g_ncontrib):
+        global _last_backward_ms
+        rs = ctx.raster_settings
+        means2D, conic_opacity, rgb, mask, bg, point_list, ranges, final_T, n_contrib = ctx.saved_tensors
+        H, W = int(rs.image_height), int(rs.image_width)
+        P = means2D.shape[0]
+        dev = means2D.device
+        g_out = g_out.float().contiguous()
+        d_means2D = torch.empty((P, 2), dtype=torch.float32, device=dev)
+        d_conic_opacity = torch.empty((P, 4), dtype=torch.float32, device=dev)
+        d_rgb = torch.empty((P, 3), dtype=torch.float32, device=dev)
+        timing = ctx.timing
+        with torch.cuda.device(dev):
+            if timing != "off":
+                ev0 = torch.cuda.Event(enable_timing=True)
+                ev1 = torch.cuda.Event(enable_timing=True)
+                ev0.record()
+            check(lib.gsr_render_backward(P, W, H, _ptr(ranges), _ptr(point_list), _ptr(means2D), _ptr(conic_opacity),
+                                          _ptr(rgb), _ptr(mask), _ptr(bg), _ptr(final_T), _ptr(n_contrib), _ptr(g_out),
+                                          _ptr(d_means2D), _ptr(d_conic_opacity), _ptr(d_rgb), _stream()),
+                  "gsr_render_backward")
+            if timing != "off":
+                ev1.record()
+        stats = ctx.cuda_args.get("stats_collector") if isinstance(ctx.cuda_args, dict) else None
+        if stats is not None and timing != "off":
+            f0, f1 = ctx.fwd_events
+            if timing == "sync":
+                ev1.synchronize()
+                _last_backward_ms = float(ev0.elapsed_time(ev1))
+                stats["forward_render_time"] = float(f0.elapsed_time(f1))
+                stats["backward_render_time"] = _last_backward_ms
+            else:  # "stale": never wait for the device
+                if f1.query():
+                    stats["forward_render_time"] = float(f0.elapsed_time(f1))
+                pend = getattr(_RenderGaussians, "_pending", None)
+                if pend is not None and pend[1].query():
+                    _last_backward_ms = float(pend[0].elapsed_time(pend[1]))
+                _RenderGaussians._pending = (ev0, ev1)
+                stats["backward_render_time"] = float(_last_backward_ms)
+        return d_means2D, d_conic_opacity, d_rgb, None, None, None, None, None
+
+
+class GaussianRasterizer(nn.Module):
+    """one instance per camera per iteration (gaussian_renderer/__init__.py:945)."""
+
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def preprocess_gaussians(self, means3D, scales, rotations, shs, opacities, cuda_args=None):
+        """-> (means2D [N,2], rgb [N,3], conic_opacity [N,4], radii int32 [N], depths [N]);
+        radii == 0 <=> culled.  means2D supports .retain_grad(); its gradient is in NDC-scaled units
+        (pixel gradient x (W/2, H/2)), the convention densification thresholds against
+        (scene/gaussian_model.py:1046-1064)."""
+        return _PreprocessGaussians.apply(means3D, scales, rotations, shs, opacities, self.raster_settings, cuda_args)
+
+    def render_gaussians(self, means2D, conic_opacity, rgb, depths, radii, compute_locally,
+                         extended_compute_locally=None, cuda_args=None):
+        """-> (image [3,H,W], n_render, n_consider, n_contrib).  Pixels of tiles with
+        compute_locally == False are exactly 0.  The last three values are debug statistics the
+        reference's callers discard (gaussian_renderer/__init__.py:1271): n_render = number of
+        (tile, Gaussian) pairs as a Python int, n_consider = None, n_contrib = per-pixel int32 map."""
+        if cuda_args is None:
+            cuda_args = {}
+        fn = _RenderGaussians
+        image, n_contrib = fn.apply(means2D, conic_opacity, rgb, depths, radii, compute_locally,
+                                    self.raster_settings, cuda_args)
+        n_render = None
+        if image.grad_fn is not None and hasattr(image.grad_fn, "num_rendered"):
+            n_render = image.grad_fn.num_rendered
+        return image, n_render, None, n_contrib
+
+
+# ------------------------------------------------------------------------------------------ _C
+class _CNamespace:
+    """stand-in for the reference extension's pybind module `diff_gaussian_rasterization._C`."""
+
+    @staticmethod
+    def get_block_XY():
+        bx, by, bz = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        check(lib.gsr_get_block_xy(ctypes.byref(bx), ctypes.byref(by), ctypes.byref(bz)), "gsr_get_block_xy")
+        return bx.value, by.value, bz.value
+
+    @staticmethod
+    def get_local2j_ids_bool(image_height, image_width, mp_rank, mp_world_size, means2D, radii,
+                             dist_global_strategy, cuda_args=None):
+        """bool [P, mp_world_size]: Gaussian i touches a tile of band j
+        (gaussian_renderer/workload_division.py:727-738)."""
+        means2D = _f32c(means2D.detach(), "means2D")
+        radii = radii.to(torch.int32).contiguous()
+        div = dist_global_strategy.to(device=means2D.device, dtype=torch.int32).contiguous()
+        if div.numel() != mp_world_size + 1:
+            raise ValueError("dist_global_strategy must have world_size + 1 entries")
+        P = means2D.shape[0]
+        out = torch.empty((P, mp_world_size), dtype=torch.uint8, device=means2D.device)
+        with torch.cuda.device(means2D.device):
+            check(lib.gsr_get_local2j_ids_bool(P, int(image_width), int(image_height), int(mp_world_size),
+                                               _ptr(means2D), _ptr(radii), _ptr(div), _ptr(out), _stream()),
+                  "gsr_get_local2j_ids_bool")
+        return out.view(torch.bool)
+
+    @staticmethod
+    def _dead(name):
+        raise NotImplementedError(
+            f"diff_gaussian_rasterization._C.{name}: only reachable from the reference's legacy (non-`final`) "
+            "distribution modes, which train.py never selects (SURVEY.md F4)")
+
+    @staticmethod
+    def get_local2j_ids_bool_adjust_mode6(*a, **k):
+        _CNamespace._dead("get_local2j_ids_bool_adjust_mode6")
+
+    @staticmethod
+    def get_touched_locally(*a, **k):
+        _CNamespace._dead("get_touched_locally")
+
+    @staticmethod
+    def get_pixels_compute_locally_and_in_rect(*a, **k):
+        _CNamespace._dead("get_pixels_compute_locally_and_in_rect")
+
+
+_C = _CNamespace()
+
+
+def load_image_tiles_by_pos(*a, **k):
+    _CNamespace._dead("load_image_tiles_by_pos")
+
+
+def merge_image_tiles_by_pos(*a, **k):
+    _CNamespace._dead("merge_image_tiles_by_pos")

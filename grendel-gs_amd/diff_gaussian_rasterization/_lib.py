@@ -1,0 +1,67 @@
+"""ctypes binding of libgsraster.so -- the C-ABI declared in include/gsraster.h.
+
+There is NO fallback: if the HIP library is missing or an entry point cannot be resolved, importing
+this module raises.  Nothing here touches oracle/.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgsraster.so")
+
+c_int, c_float, c_void_p, c_size_t, c_int64 = (ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t,
+                                                ctypes.c_int64)
+
+# name -> (restype, argtypes); must list every function of include/gsraster.h (tests/test_abi_cpu.py checks)
+SIGNATURES = {
+    "gsr_error_string": (ctypes.c_char_p, [c_int]),
+    "gsr_abi_version": (c_int, []),
+    "gsr_get_block_xy": (c_int, [ctypes.POINTER(c_int)] * 3),
+    "gsr_preprocess_forward": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_void_p,
+                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gsr_preprocess_backward": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
+                                        c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_void_p,
+                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gsr_get_local2j_ids_bool": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_void_p]),
+    "gsr_bin_prepare_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "gsr_bin_prepare": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                ctypes.POINTER(c_int64), c_void_p]),
+    "gsr_bin_sort_bytes": (c_size_t, [c_int, c_int64, c_int, c_int]),
+    "gsr_bin_sort": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
+                             c_size_t, c_void_p, c_void_p, c_void_p]),
+    "gsr_render_forward": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gsr_render_backward": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+}
+
+ABI_VERSION = 1
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the gfx950 HIP library has not been built "
+            "(run `python __graft_entry__.py build` or `python grendel-gs_amd/csrc/build.py`). "
+            "There is no CPU or PyTorch fallback for this operator."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError -> loud failure on a stale library
+        fn.restype = res
+        fn.argtypes = args
+    if lib.gsr_abi_version() != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH}: ABI version {lib.gsr_abi_version()} != expected {ABI_VERSION}; rebuild")
+    return lib
+
+
+lib = _load()
+
+
+def check(code, what):
+    if code != 0:
+        msg = lib.gsr_error_string(code)
+        raise RuntimeError(f"{what} failed: {msg.decode() if msg else code} (code {code})")

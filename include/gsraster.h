@@ -1,0 +1,130 @@
+/*
+ * gsraster.h -- C-ABI of the MI355X (gfx950) Gaussian-splatting rasterizer: the drop-in boundary.
+ *
+ * Every entry point below is what the reference's Python wrapper module
+ * `diff_gaussian_rasterization` (un-vendored submodule, .gitmodules:4-6 of the reference) binds
+ * through its `_C` extension for the hot path; the reference-side call sites are cited per function
+ * (paths relative to the reference root).  The host-side mirror that re-creates the reference's
+ * operator surface on top of this ABI is grendel-gs_amd/diff_gaussian_rasterization/__init__.py;
+ * the binding a maintainer of the reference would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - all data pointers are DEVICE pointers (HBM) unless the name ends in `_host`;
+ *  - fp32 / int32 / uint8, dense row-major ("contiguous") layouts, shapes in the comments;
+ *  - `stream` is a hipStream_t passed as void* (0 = the null stream); every call only ENQUEUES
+ *    work on that stream unless stated otherwise;
+ *  - return value: 0 on success, otherwise a hipError_t value (>0) or a GSR_E* code (<0);
+ *    gsr_error_string() explains either.  No call aborts the process.
+ *  - matrices are in the reference's row-vector convention (scene/cameras.py:84-100):
+ *    p_view = [p,1] @ viewmatrix, p_clip = [p,1] @ projmatrix, both 4x4 row-major.
+ *  - tiles are 16x16 pixels (utils/general_utils.py:78-93); tile id = ty * tiles_x + tx.
+ */
+#ifndef GSRASTER_H
+#define GSRASTER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSR_BLOCK_X 16
+#define GSR_BLOCK_Y 16
+#define GSR_ONE_DIM_BLOCK 256
+
+#define GSR_EINVAL (-1)   /* bad argument (negative size, null pointer, sh_degree > 3, ...) */
+#define GSR_ENOSPACE (-2) /* caller-provided workspace too small */
+
+typedef void *gsr_stream_t;
+
+const char *gsr_error_string(int code);
+
+/* ABI version of this library (bumped on any signature change). */
+int gsr_abi_version(void);
+
+/* `_C.get_block_XY()` -- arguments/__init__.py:254-257.  Always (16, 16, 256). */
+int gsr_get_block_xy(int *block_x, int *block_y, int *one_dim_block);
+
+/* ---------------------------------------------------------------------------------------------
+ * K1  preprocess forward -- GaussianRasterizer.preprocess_gaussians,
+ *     gaussian_renderer/__init__.py:949-956 (outputs consumed at :960).
+ * in : means3D [P,3], scales [P,3] (activated), rotations [P,4] (r,x,y,z, normalised),
+ *      shs [P,sh_coeffs,3], opacities [P] (activated), viewmatrix/projmatrix [4,4], campos [3]
+ * out: means2D [P,2] (pixels), depths [P], radii int32 [P] (0 = culled), cov3D [P,6],
+ *      conic_opacity [P,4] = (A,B,C,opacity), rgb [P,3], clamped uint8 [P,3]
+ * Culled Gaussians get radii 0 and zeros everywhere else. */
+int gsr_preprocess_forward(int P, int sh_degree, int sh_coeffs, const float *means3D, const float *scales,
+                           float scale_modifier, const float *rotations, const float *shs, const float *opacities,
+                           const float *viewmatrix, const float *projmatrix, const float *campos, int width,
+                           int height, float tanfovx, float tanfovy, float *means2D, float *depths, int32_t *radii,
+                           float *cov3D, float *conic_opacity, float *rgb, uint8_t *clamped, gsr_stream_t stream);
+
+/* K11 preprocess backward -- autograd backward of the call above (train_internal.py:194-196).
+ * in : the forward inputs, the saved radii / cov3D / clamped, and the incoming gradients
+ *      dL_dmeans2D [P,2] (NDC-scaled units, scene/gaussian_model.py:1046-1064),
+ *      dL_dconic_opacity [P,4] (true partials wrt A,B,C,opacity), dL_drgb [P,3]
+ * out: dL_dmeans3D [P,3], dL_dscales [P,3], dL_drotations [P,4], dL_dshs [P,sh_coeffs,3],
+ *      dL_dopacities [P]   (fully overwritten, zeros for culled Gaussians) */
+int gsr_preprocess_backward(int P, int sh_degree, int sh_coeffs, const float *means3D, const float *scales,
+                            float scale_modifier, const float *rotations, const float *shs, const float *viewmatrix,
+                            const float *projmatrix, const float *campos, int width, int height, float tanfovx,
+                            float tanfovy, const int32_t *radii, const float *cov3D, const uint8_t *clamped,
+                            const float *dL_dmeans2D, const float *dL_dconic_opacity, const float *dL_drgb,
+                            float *dL_dmeans3D, float *dL_dscales, float *dL_drotations, float *dL_dshs,
+                            float *dL_dopacities, gsr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K2  `_C.get_local2j_ids_bool` -- gaussian_renderer/workload_division.py:721-744.
+ * dist_global_strategy int32 [world_size+1]: band j owns flattened tile ids [d[j], d[j+1]).
+ * out uint8 (bool) [P, world_size]: Gaussian i must be sent to band j. */
+int gsr_get_local2j_ids_bool(int P, int width, int height, int world_size, const float *means2D,
+                             const int32_t *radii, const int32_t *dist_global_strategy, uint8_t *out,
+                             gsr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K3-K7  binning of one camera's (received) Gaussians into the locally computed tiles, in two
+ * calls because the number of (tile, Gaussian) pairs D ("num_rendered") sizes the second one.
+ * Part of GaussianRasterizer.render_gaussians, gaussian_renderer/__init__.py:1271-1282.
+ *
+ * gsr_bin_prepare : per Gaussian, count the locally computed tiles its rect touches, order the
+ *   Gaussians by depth (stable) and prefix-sum the counts in that order.  Writes D to
+ *   *num_rendered_host AFTER synchronising `stream` (the one host sync of the render op).
+ *   `prep` is an opaque device workspace of gsr_bin_prepare_bytes(P, width, height) bytes that must stay
+ *   untouched until gsr_bin_sort returns.
+ * gsr_bin_sort    : emit the D pairs in depth order and stable-sort them by tile id, giving
+ *   point_list uint32 [D] (Gaussian index per pair, grouped by tile, front-to-back inside a
+ *   tile, ties by Gaussian index) and ranges int32 [tiles,2] = [start,end) per tile.
+ *   `scratch` is a device workspace of gsr_bin_sort_bytes(P, D, width, height) bytes. */
+size_t gsr_bin_prepare_bytes(int P, int width, int height);
+int gsr_bin_prepare(int P, int width, int height, const float *means2D, const float *depths, const int32_t *radii,
+                    const uint8_t *compute_locally, void *prep, size_t prep_bytes, int64_t *num_rendered_host,
+                    gsr_stream_t stream);
+size_t gsr_bin_sort_bytes(int P, int64_t num_rendered, int width, int height);
+int gsr_bin_sort(int P, int width, int height, const float *means2D, const int32_t *radii,
+                 const uint8_t *compute_locally, const void *prep, int64_t num_rendered, void *scratch,
+                 size_t scratch_bytes, uint32_t *point_list, int32_t *ranges, gsr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K8  composite forward -- the rest of render_gaussians (gaussian_renderer/__init__.py:1271-1282).
+ * out_color [3,H,W]: sum c*alpha*T + T_final*bg on locally computed tiles, exactly 0 elsewhere
+ * (images are assembled by SUM all-reduce, train_internal.py:466-469); final_T [H,W];
+ * n_contrib int32 [H,W] (1-based position of the last blended entry of the tile's list). */
+int gsr_render_forward(int P, int width, int height, const int32_t *ranges, const uint32_t *point_list,
+                       const float *means2D, const float *conic_opacity, const float *rgb,
+                       const uint8_t *compute_locally, const float *bg, float *out_color, float *final_T,
+                       int32_t *n_contrib, gsr_stream_t stream);
+
+/* K10 composite backward -- autograd backward of render_gaussians.
+ * out (fully overwritten): dL_dmeans2D [P,2] (pixel gradient x (W/2, H/2)), dL_dconic_opacity [P,4],
+ * dL_drgb [P,3]. */
+int gsr_render_backward(int P, int width, int height, const int32_t *ranges, const uint32_t *point_list,
+                        const float *means2D, const float *conic_opacity, const float *rgb,
+                        const uint8_t *compute_locally, const float *bg, const float *final_T,
+                        const int32_t *n_contrib, const float *dL_dpixels, float *dL_dmeans2D,
+                        float *dL_dconic_opacity, float *dL_drgb, gsr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSRASTER_H */

@@ -1,0 +1,261 @@
+"""-m gpu parity tests: HIP path (through the C-ABI, via the operator mirror) vs the CPU oracles.
+
+Tolerances (north_star: 1e-4 relative fp32):
+  * integer / index outputs (radii, point_list, ranges, n_contrib): exact, except that a handful of
+    pixels may flip at the hard thresholds (alpha < 1/255, T < 1e-4) because exp() differs in the
+    last ulp between CPU libm and v_exp_f32 -- bounded as a FRACTION of pixels.
+  * floats: norm-wise relative error <= 1e-4.
+"""
+import math
+
+import pytest
+import torch
+
+import synthetic_scene as S
+from helpers import KEYS, cam_kwargs, frac_bad, oracle_c_chain, rel_err, settings_from
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+
+
+def _gpu(g, dev):
+    return {k: v.to(dev) for k, v in g.items()}
+
+
+def _full_mask(cam, dev="cpu"):
+    gx, gy = (cam.image_width + 15) // 16, (cam.image_height + 15) // 16
+    return torch.ones(gy, gx, dtype=torch.bool, device=dev)
+
+
+SCENES = [
+    # (N, W, H, scale_coef, seed, camera index of 4 orbit views)
+    (2000, 200, 120, 0.01, 3, 1),
+    (10000, 256, 256, 0.004, 0, 0),      # BASELINE config[0] shape
+    (5000, 333, 211, 0.02, 7, 2),        # non-multiple-of-16 image, big splats, long lists
+]
+
+
+@pytest.mark.parametrize("N,W,H,sc,seed,ci", SCENES)
+@pytest.mark.parametrize("sh_degree", [0, 3])
+def test_preprocess_forward_matches_c_oracle(device, N, W, H, sc, seed, ci, sh_degree):
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from oracle import cref as C
+
+    g = S.make_gaussians(N, W, H, seed=seed, scale_coef=sc)
+    cam = S.orbit_cameras(4, W, H)[ci]
+    ref = C.preprocess_forward(*[g[k] for k in KEYS], **cam_kwargs(cam, sh_degree))
+    rast = GaussianRasterizer(settings_from(cam, torch.zeros(3), sh_degree))
+    gg = _gpu(g, device)
+    m2, rgb, co, radii, depths = rast.preprocess_gaussians(gg["means3D"], gg["scales"], gg["rotations"], gg["shs"],
+                                                           gg["opacities"], {})
+    rm2, rrgb, rco, rradii, rdepths = ref[:5]
+    assert (radii.cpu() != rradii).sum().item() <= max(1, N // 100000), "radii must match (FP contraction off)"
+    same = (radii.cpu() == rradii)
+    assert rel_err(m2.cpu()[same], rm2[same]) < 1e-6
+    assert rel_err(depths.cpu()[same], rdepths[same]) < 1e-6
+    assert rel_err(co.cpu()[same], rco[same]) < 1e-5
+    assert rel_err(rgb.cpu()[same], rrgb[same]) < 1e-5
+    # culled Gaussians are all-zero
+    culled = radii == 0
+    assert m2[culled].abs().sum().item() == 0 and co[culled].abs().sum().item() == 0
+
+
+@pytest.mark.parametrize("N,W,H,sc,seed,ci", SCENES)
+def test_binning_matches_oracle_exactly(device, N, W, H, sc, seed, ci):
+    from diff_gaussian_rasterization import bin_gaussians
+    from oracle import cref as C
+
+    g = S.make_gaussians(N, W, H, seed=seed, scale_coef=sc)
+    cam = S.orbit_cameras(4, W, H)[ci]
+    m2, rgb, co, radii, depths, _, _ = C.preprocess_forward(*[g[k] for k in KEYS], **cam_kwargs(cam))
+    mask = _full_mask(cam)
+    mask[1:3, :] = False  # a non-local band
+    mask[-1, ::2] = False  # and a ragged pattern (general masks are allowed by the API)
+    pl_ref, ranges_ref, _ = C.bin_and_sort(m2, radii, depths, mask, W, H)
+    pl, ranges, D = bin_gaussians(m2.to(device), depths.to(device), radii.to(device),
+                                  mask.view(-1).to(torch.uint8).to(device), W, H)
+    assert D == pl_ref.numel()
+    assert torch.equal(pl[:D].cpu(), pl_ref), "per-tile lists must be bit-identical (stable depth order)"
+    lens_ref = ranges_ref[:, 1] - ranges_ref[:, 0]
+    lens = (ranges[:, 1] - ranges[:, 0]).cpu()
+    assert torch.equal(lens, lens_ref)
+    nz = lens_ref > 0
+    assert torch.equal(ranges.cpu()[nz], ranges_ref[nz])
+
+
+@pytest.mark.parametrize("N,W,H,sc,seed,ci", SCENES)
+@pytest.mark.parametrize("bgv", [0.0, 0.7])
+def test_full_chain_matches_c_oracle(device, N, W, H, sc, seed, ci, bgv):
+    """preprocess -> render -> backward through the operator surface vs the C restatement"""
+    from diff_gaussian_rasterization import GaussianRasterizer
+
+    g = S.make_gaussians(N, W, H, seed=seed, scale_coef=sc)
+    cam = S.orbit_cameras(4, W, H)[ci]
+    bg = torch.tensor([bgv, bgv * 0.5, 1.0 - bgv])
+    mask = _full_mask(cam)
+    if bgv > 0:
+        mask[0:2, :] = False
+    gen = torch.Generator().manual_seed(11)
+    wgt = torch.rand(3, H, W, generator=gen)
+    ref = oracle_c_chain(g, cam, bg, mask, wgt)
+
+    rast = GaussianRasterizer(settings_from(cam, bg))
+    gg = {k: v.to(device).requires_grad_(True) for k, v in g.items()}
+    cuda_args = {"stats_collector": {}}
+    m2, rgb, co, radii, depths = rast.preprocess_gaussians(gg["means3D"], gg["scales"], gg["rotations"], gg["shs"],
+                                                           gg["opacities"], cuda_args)
+    m2.retain_grad(); rgb.retain_grad(); co.retain_grad()
+    img, n_render, _, n_contrib = rast.render_gaussians(means2D=m2, conic_opacity=co, rgb=rgb, depths=depths,
+                                                        radii=radii, compute_locally=mask.to(device),
+                                                        extended_compute_locally=None, cuda_args=cuda_args)
+    assert img.shape == (3, H, W)
+    # non-local tiles are exactly zero
+    pm = mask.repeat_interleave(16, 0).repeat_interleave(16, 1)[:H, :W]
+    assert img[:, ~pm.to(device)].abs().sum().item() == 0.0
+    assert rel_err(img, ref["image"]) < RTOL
+    assert frac_bad(img, ref["image"], rtol=1e-3, atol=1e-4) < 2e-4
+    assert (n_contrib.cpu() != ref["n_contrib"]).double().mean().item() < 2e-4
+    (img * wgt.to(device)).sum().backward()
+    assert rel_err(rgb.grad, ref["d_rgb"]) < RTOL
+    assert rel_err(co.grad, ref["d_conic_opacity"]) < RTOL
+    assert rel_err(m2.grad, ref["d_means2D"]) < RTOL
+    for k, rk in [("means3D", "d_means3D"), ("scales", "d_scales"), ("rotations", "d_rotations"), ("shs", "d_shs"),
+                  ("opacities", "d_opacities")]:
+        assert rel_err(gg[k].grad, ref[rk]) < RTOL, k
+    st = cuda_args["stats_collector"]
+    assert isinstance(st["forward_render_time"], float) and isinstance(st["backward_render_time"], float)
+
+
+def test_small_chain_matches_fp64_autograd_oracle(device):
+    """the arbiter: float64 autograd oracle (independent backward derivation)"""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from oracle import torch_oracle as O
+
+    N, W, H = 600, 112, 80
+    g = S.make_gaussians(N, W, H, seed=5, scale_coef=0.015)
+    cam = S.orbit_cameras(4, W, H)[3]
+    bg = torch.tensor([0.1, 0.4, 0.9])
+    mask = _full_mask(cam)
+    gen = torch.Generator().manual_seed(2)
+    wgt = torch.rand(3, H, W, generator=gen)
+    ins = {k: v.double().clone().requires_grad_(True) for k, v in g.items()}
+    kw = cam_kwargs(cam)
+    m2o, rgbo, coo, radiio, deptho = O.preprocess(*[ins[k] for k in KEYS], **kw)
+    imgo, _, _ = O.render(m2o, coo, rgbo, deptho, radiio, mask, bg=bg, W=W, H=H)
+    (imgo * wgt.double()).sum().backward()
+
+    rast = GaussianRasterizer(settings_from(cam, bg))
+    gg = {k: v.to(device).requires_grad_(True) for k, v in g.items()}
+    m2, rgb, co, radii, depths = rast.preprocess_gaussians(*[gg[k] for k in KEYS], {})
+    img, _, _, _ = rast.render_gaussians(m2, co, rgb, depths, radii, mask.to(device), None, {})
+    (img * wgt.to(device)).sum().backward()
+    assert rel_err(img, imgo) < RTOL
+    for k in KEYS:
+        assert rel_err(gg[k].grad, ins[k].grad) < RTOL, k
+
+
+def test_local2j_matches_oracle(device):
+    from diff_gaussian_rasterization import _C
+    from oracle import cref as C
+
+    N, W, H = 4000, 320, 200
+    g = S.make_gaussians(N, W, H, seed=9, scale_coef=0.02)
+    cam = S.orbit_cameras(4, W, H)[0]
+    m2, rgb, co, radii, depths, _, _ = C.preprocess_forward(*[g[k] for k in KEYS], **cam_kwargs(cam))
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    for rows in ([0, 4, 9, gy], [0, gy], [0, 1, 2, 3, gy]):
+        div = torch.tensor(rows, dtype=torch.int32) * gx
+        ref = C.get_local2j_ids_bool(H, W, len(rows) - 1, m2, radii, div)
+        out = _C.get_local2j_ids_bool(H, W, 0, len(rows) - 1, m2.to(device), radii.to(device), div.to(device), {})
+        assert out.dtype == torch.bool and torch.equal(out.cpu(), ref)
+
+
+def test_partition_union_equals_single(device):
+    """W in {2,4} row-band partitions, rendered separately and SUMmed, reproduce the W=1 image
+    exactly (tiles are independent; non-local pixels are 0) and the summed gradients match."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+
+    N, W, H = 6000, 320, 208
+    g = S.make_gaussians(N, W, H, seed=21, scale_coef=0.01)
+    cam = S.orbit_cameras(4, W, H)[1]
+    bg = torch.tensor([0.3, 0.3, 0.3])
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    gen = torch.Generator().manual_seed(4)
+    wgt = torch.rand(3, H, W, generator=gen).to(device)
+    rast = GaussianRasterizer(settings_from(cam, bg))
+
+    def run(bands):
+        gg = {k: v.to(device).requires_grad_(True) for k, v in g.items()}
+        m2, rgb, co, radii, depths = rast.preprocess_gaussians(*[gg[k] for k in KEYS], {})
+        total = torch.zeros(3, H, W, device=device)
+        for (l, r) in bands:
+            mask = torch.zeros(gy, gx, dtype=torch.bool, device=device)
+            mask[l:r] = True
+            img, _, _, _ = rast.render_gaussians(m2, co, rgb, depths, radii, mask, None, {})
+            total = total + img
+        (total * wgt).sum().backward()
+        return total.detach(), {k: gg[k].grad for k in KEYS}
+
+    img1, gr1 = run([(0, gy)])
+    for bands in ([(0, 5), (5, gy)], [(0, 3), (3, 6), (6, 10), (10, gy)]):
+        imgw, grw = run(bands)
+        assert torch.equal(imgw, img1), "forward composite is tile-independent: bitwise equal"
+        for k in KEYS:
+            assert rel_err(grw[k], gr1[k]) < RTOL, k
+
+
+def test_degenerate_inputs(device):
+    from diff_gaussian_rasterization import GaussianRasterizer
+
+    W, H = 64, 48
+    cam = S.SyntheticCamera(0, W, H)
+    bg = torch.tensor([0.2, 0.4, 0.6])
+    rast = GaussianRasterizer(settings_from(cam, bg))
+    mask = _full_mask(cam, device)
+    # behind the camera, zero opacity, a single visible one
+    means = torch.tensor([[0.0, 0.0, -3.0], [0.0, 0.0, 0.1], [0.1, 0.1, 4.0], [0.0, 0.0, 5.0]], device=device)
+    scales = torch.full((4, 3), 0.05, device=device)
+    rots = torch.tensor([[1.0, 0, 0, 0]] * 4, device=device)
+    shs = torch.zeros(4, 16, 3, device=device); shs[:, 0] = 1.0
+    opac = torch.tensor([[0.9], [0.9], [0.001], [0.8]], device=device)
+    m2, rgb, co, radii, depths = rast.preprocess_gaussians(means, scales, rots, shs, opac, {})
+    assert radii[0].item() == 0 and radii[1].item() == 0 and radii[2].item() > 0 and radii[3].item() > 0
+    img, _, _, nc = rast.render_gaussians(m2, co, rgb, depths, radii, mask, None, {})
+    assert torch.isfinite(img).all()
+    # far corner sees only background
+    assert torch.allclose(img[:, 0, 0].cpu(), bg, atol=1e-6)
+    # empty set of Gaussians
+    e = torch.zeros(0, 3, device=device)
+    m2, rgb, co, radii, depths = rast.preprocess_gaussians(e, e, torch.zeros(0, 4, device=device),
+                                                           torch.zeros(0, 16, 3, device=device),
+                                                           torch.zeros(0, 1, device=device), {})
+    img, _, _, _ = rast.render_gaussians(m2, co, rgb, depths, radii, mask, None, {})
+    assert torch.allclose(img.cpu(), bg.view(3, 1, 1).expand(3, H, W))
+
+
+def test_saturating_stack_early_stop(device):
+    """many opaque splats on one pixel: T must stop above 1e-4 and n_contrib must match the oracle"""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from oracle import cref as C
+
+    W, H = 32, 32
+    cam = S.SyntheticCamera(0, W, H)
+    n = 300
+    g = dict(means3D=torch.cat([torch.zeros(n, 2), torch.linspace(2, 9, n)[:, None]], 1),
+             scales=torch.full((n, 3), 0.3), rotations=torch.tensor([[1.0, 0, 0, 0]]).repeat(n, 1),
+             shs=torch.rand(n, 16, 3, generator=torch.Generator().manual_seed(0)) * 0.5,
+             opacities=torch.full((n, 1), 0.6))
+    bg = torch.zeros(3)
+    mask = _full_mask(cam)
+    wgt = torch.ones(3, H, W)
+    ref = oracle_c_chain(g, cam, bg, mask, wgt)
+    rast = GaussianRasterizer(settings_from(cam, bg))
+    gg = {k: v.to(device).requires_grad_(True) for k, v in g.items()}
+    m2, rgb, co, radii, depths = rast.preprocess_gaussians(*[gg[k] for k in KEYS], {})
+    img, _, _, nc = rast.render_gaussians(m2, co, rgb, depths, radii, mask.to(device), None, {})
+    assert ref["final_T"].min().item() >= 1e-4 * 0.99
+    assert (nc.cpu() != ref["n_contrib"]).double().mean().item() < 5e-3
+    assert rel_err(img, ref["image"]) < RTOL
+    img.sum().backward()
+    assert rel_err(gg["opacities"].grad, ref["d_opacities"]) < 5e-4
