@@ -32,6 +32,10 @@ BLOCK_X, BLOCK_Y, ONE_DIM_BLOCK_SIZE = 16, 16, 256
 # how render_gaussians fills cuda_args["stats_collector"]["backward_render_time"]:
 #   "sync"  : one HIP-event synchronisation at the end of the backward op -> exact per-call value
 #   "stale" : no extra host sync; reports the most recent backward whose events have completed
+#   "deferred": like "stale", and additionally leaves the HIP event pairs under the private keys
+#             "_fwd_events" / "_bwd_events" so that a cooperating caller (this package's
+#             gaussian_renderer.workload_division.finish_strategy_final) resolves exact values with the
+#             one sync it performs anyway
 #   "off"   : 0.0 (no events recorded)
 _TIMING_MODE = "auto"
 _last_backward_ms = 0.0
@@ -39,7 +43,7 @@ _last_backward_ms = 0.0
 
 def set_timing_mode(mode):
     global _TIMING_MODE
-    assert mode in ("auto", "sync", "stale", "off")
+    assert mode in ("auto", "sync", "stale", "deferred", "off")
     _TIMING_MODE = mode
 
 
@@ -50,6 +54,43 @@ def _timing_mode():
             torch.distributed.get_world_size() > 1:
         return "sync"  # the load balancer consumes the value (workload_division.py:944-998)
     return "stale"
+
+
+class _KernelTimer:
+    """optional HIP-event brackets around each C-ABI call (bench.py's `roofline` leg): events are
+    recorded on the stream the kernels are launched on and resolved by the caller after a sync."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = {}
+
+    class _Range:
+        def __init__(self, owner, name):
+            self.owner, self.name = owner, name
+
+        def __enter__(self):
+            if self.owner.enabled:
+                self.e0 = torch.cuda.Event(enable_timing=True)
+                self.e1 = torch.cuda.Event(enable_timing=True)
+                self.e0.record()
+
+        def __exit__(self, *exc):
+            if self.owner.enabled:
+                self.e1.record()
+                self.owner.records.setdefault(self.name, []).append((self.e0, self.e1))
+
+    def range(self, name):
+        return _KernelTimer._Range(self, name)
+
+    def reset(self):
+        self.records = {}
+
+    def summary_ms(self):
+        """name -> (launches, mean ms); call after torch.cuda.synchronize()"""
+        return {k: (len(v), sum(a.elapsed_time(b) for a, b in v) / len(v)) for k, v in self.records.items() if v}
+
+
+kernel_timer = _KernelTimer()
 
 
 def _ptr(t):
@@ -108,7 +149,7 @@ class _PreprocessGaussians(torch.autograd.Function):
         conic_opacity = torch.empty((P, 4), dtype=torch.float32, device=dev)
         rgb = torch.empty((P, 3), dtype=torch.float32, device=dev)
         clamped = torch.empty((P, 3), dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), kernel_timer.range("preprocess_forward"):
             check(lib.gsr_preprocess_forward(
                 P, int(rs.sh_degree), M, _ptr(means3D), _ptr(scales), float(rs.scale_modifier), _ptr(rotations),
                 _ptr(shs), _ptr(opacities), _ptr(view), _ptr(proj), _ptr(campos), int(rs.image_width),
@@ -140,7 +181,7 @@ class _PreprocessGaussians(torch.autograd.Function):
         d_rot = torch.empty((P, 4), dtype=torch.float32, device=dev)
         d_shs = torch.empty((P, M, 3), dtype=torch.float32, device=dev)
         d_opac = torch.empty((P, 1), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), kernel_timer.range("preprocess_backward"):
             check(lib.gsr_preprocess_backward(
                 P, int(rs.sh_degree), M, _ptr(means3D), _ptr(scales), float(rs.scale_modifier), _ptr(rotations),
                 _ptr(shs), _ptr(view), _ptr(proj), _ptr(campos), int(rs.image_width), int(rs.image_height),
@@ -200,13 +241,15 @@ class _RenderGaussians(torch.autograd.Function):
                 ev0 = torch.cuda.Event(enable_timing=True)
                 ev1 = torch.cuda.Event(enable_timing=True)
                 ev0.record()
-            point_list, ranges, D = bin_gaussians(means2D, depths, radii, mask, W, H)
+            with kernel_timer.range("binning"):
+                point_list, ranges, D = bin_gaussians(means2D, depths, radii, mask, W, H)
             out = torch.empty((3, H, W), dtype=torch.float32, device=dev)
             final_T = torch.empty((H, W), dtype=torch.float32, device=dev)
             n_contrib = torch.empty((H, W), dtype=torch.int32, device=dev)
-            check(lib.gsr_render_forward(P, W, H, _ptr(ranges), _ptr(point_list), _ptr(means2D), _ptr(conic_opacity),
-                                         _ptr(rgb), _ptr(mask), _ptr(bg), _ptr(out), _ptr(final_T), _ptr(n_contrib),
-                                         _stream()), "gsr_render_forward")
+            with kernel_timer.range("composite_forward"):
+                check(lib.gsr_render_forward(P, W, H, _ptr(ranges), _ptr(point_list), _ptr(means2D),
+                                             _ptr(conic_opacity), _ptr(rgb), _ptr(mask), _ptr(bg), _ptr(out),
+                                             _ptr(final_T), _ptr(n_contrib), _stream()), "gsr_render_forward")
             if timing != "off":
                 ev1.record()
                 ctx.fwd_events = (ev0, ev1)
@@ -219,6 +262,7 @@ class _RenderGaussians(torch.autograd.Function):
         ctx.cuda_args = cuda_args
         ctx.timing = timing
         ctx.num_rendered = D
+        _RenderGaussians.last_num_rendered = D
         ctx.save_for_backward(means2D, conic_opacity, rgb, mask, bg, point_list, ranges, final_T, n_contrib)
         ctx.mark_non_differentiable(n_contrib)
         return out, n_contrib
@@ -241,10 +285,11 @@ class _RenderGaussians(torch.autograd.Function):
                 ev0 = torch.cuda.Event(enable_timing=True)
                 ev1 = torch.cuda.Event(enable_timing=True)
                 ev0.record()
-            check(lib.gsr_render_backward(P, W, H, _ptr(ranges), _ptr(point_list), _ptr(means2D), _ptr(conic_opacity),
-                                          _ptr(rgb), _ptr(mask), _ptr(bg), _ptr(final_T), _ptr(n_contrib), _ptr(g_out),
-                                          _ptr(d_means2D), _ptr(d_conic_opacity), _ptr(d_rgb), _stream()),
-                  "gsr_render_backward")
+            with kernel_timer.range("composite_backward"):
+                check(lib.gsr_render_backward(P, W, H, _ptr(ranges), _ptr(point_list), _ptr(means2D),
+                                              _ptr(conic_opacity), _ptr(rgb), _ptr(mask), _ptr(bg), _ptr(final_T),
+                                              _ptr(n_contrib), _ptr(g_out), _ptr(d_means2D), _ptr(d_conic_opacity),
+                                              _ptr(d_rgb), _stream()), "gsr_render_backward")
             if timing != "off":
                 ev1.record()
         stats = ctx.cuda_args.get("stats_collector") if isinstance(ctx.cuda_args, dict) else None
@@ -255,7 +300,10 @@ class _RenderGaussians(torch.autograd.Function):
                 _last_backward_ms = float(ev0.elapsed_time(ev1))
                 stats["forward_render_time"] = float(f0.elapsed_time(f1))
                 stats["backward_render_time"] = _last_backward_ms
-            else:  # "stale": never wait for the device
+            else:  # "stale" / "deferred": never wait for the device here
+                if timing == "deferred":
+                    stats["_fwd_events"] = (f0, f1)
+                    stats["_bwd_events"] = (ev0, ev1)
                 if f1.query():
                     stats["forward_render_time"] = float(f0.elapsed_time(f1))
                 pend = getattr(_RenderGaussians, "_pending", None)
@@ -291,10 +339,7 @@ class GaussianRasterizer(nn.Module):
         fn = _RenderGaussians
         image, n_contrib = fn.apply(means2D, conic_opacity, rgb, depths, radii, compute_locally,
                                     self.raster_settings, cuda_args)
-        n_render = None
-        if image.grad_fn is not None and hasattr(image.grad_fn, "num_rendered"):
-            n_render = image.grad_fn.num_rendered
-        return image, n_render, None, n_contrib
+        return image, getattr(fn, "last_num_rendered", None), None, n_contrib
 
 
 # ------------------------------------------------------------------------------------------ _C

@@ -1,0 +1,185 @@
+"""Ground-truth staging and band-local loss of the hot path (host side), MI355X build.
+
+From-scratch mirror of the live functions of the reference's gaussian_renderer/loss_distribution.py
+(the eight legacy loss modes at :127-2318 are unreachable, SURVEY.md F4, and are not provided):
+
+  load_camera_from_cpu_to_all_gpu            loss_distribution.py:2395-2533
+  load_camera_from_cpu_to_all_gpu_for_eval   loss_distribution.py:2333-2392
+  final_system_loss_computation              loss_distribution.py:2536-2585
+  batched_loss_computation                   loss_distribution.py:2588-2637
+
+Each rank evaluates L1 and SSIM on ITS row band only, zero-padded at the band edges (no halo), both
+normalised by the FULL image's pixel count, so that the per-rank partial losses of a camera add up to
+the full-image loss up to the band-border SSIM term.
+"""
+import math
+import time
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+import utils.general_utils as utils
+
+_WINDOW_CACHE = {}
+
+
+def get_coverage_y_min(tile_row_l):
+    return tile_row_l * utils.BLOCK_Y
+
+
+def get_coverage_y_max(tile_row_r):
+    return min(tile_row_r * utils.BLOCK_Y, utils.IMG_H)
+
+
+def get_coverage_y_min_max(tile_row_l, tile_row_r):
+    return get_coverage_y_min(tile_row_l), get_coverage_y_max(tile_row_r)
+
+
+# ------------------------------------------------------------------------------- GT staging
+def _band_of(camera, l, r, device):
+    y0, y1 = get_coverage_y_min_max(l, r)
+    return camera.original_image_backup[:, y0:y1, :].to(device, non_blocking=True).contiguous()
+
+
+def load_camera_from_cpu_to_all_gpu(batched_cameras, batched_strategies, gpuid2tasks):
+    """camera.original_image <- exactly the uint8 ground-truth rows [row_l*16, min(row_r*16, H)) this rank
+    renders.  With `distributed_dataset_storage` only the first rank of a node holds the images and
+    sends the other ranks their bands over xGMI (batched isend/irecv)."""
+    args = utils.get_args()
+    dev = utils.device()
+    me = utils.GLOBAL_RANK
+    if not args.distributed_dataset_storage or args.local_sampling or utils.DEFAULT_GROUP.size() == 1:
+        for (k, l, r) in gpuid2tasks[me]:
+            batched_cameras[k].original_image = _band_of(batched_cameras[k], l, r, dev)
+        return
+
+    root = utils.get_first_rank_on_cur_node()
+    ops, bufs = [], []
+    if me == root:
+        node = range(root, root + utils.IN_NODE_GROUP.size())
+        for g in node:
+            for (k, l, r) in gpuid2tasks[g]:
+                band = _band_of(batched_cameras[k], l, r, dev)
+                if g == me:
+                    bufs.append((k, band))
+                else:
+                    ops.append(dist.P2POp(dist.isend, band, g))
+    else:
+        for (k, l, r) in gpuid2tasks[me]:
+            y0, y1 = get_coverage_y_min_max(l, r)
+            buf = torch.empty((3, y1 - y0, utils.IMG_W), dtype=torch.uint8, device=dev)
+            bufs.append((k, buf))
+            ops.append(dist.P2POp(dist.irecv, buf, root))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    for k, band in bufs:
+        batched_cameras[k].original_image = band
+
+
+def load_camera_from_cpu_to_all_gpu_for_eval(batched_cameras, batched_strategies, gpuid2tasks):
+    """evaluation wants the FULL ground-truth image on every rank (PSNR after the image all-reduce)."""
+    args = utils.get_args()
+    dev = utils.device()
+    if not args.distributed_dataset_storage or utils.DEFAULT_GROUP.size() == 1:
+        for camera in batched_cameras:
+            camera.original_image = camera.original_image_backup.to(dev)
+        return
+    root = utils.get_first_rank_on_cur_node()
+    for camera in batched_cameras:
+        if utils.GLOBAL_RANK == root:
+            camera.original_image = camera.original_image_backup.to(dev)
+        else:
+            camera.original_image = torch.empty((3, utils.IMG_H, utils.IMG_W), dtype=torch.uint8, device=dev)
+        dist.broadcast(camera.original_image, src=root, group=utils.IN_NODE_GROUP)
+
+
+# ------------------------------------------------------------------------------------- loss
+def _window(channels, dtype, device):
+    key = (channels, dtype, str(device))
+    if key not in _WINDOW_CACHE:
+        g = torch.tensor([math.exp(-((x - 5) ** 2) / (2 * 1.5 ** 2)) for x in range(11)], dtype=torch.float32)
+        g = g / g.sum()
+        w2 = (g[:, None] @ g[None, :]).to(dtype)
+        _WINDOW_CACHE[key] = w2.expand(channels, 1, 11, 11).contiguous().to(device)
+    return _WINDOW_CACHE[key]
+
+
+def pixelwise_l1_with_mask(img1, img2, pixel_mask=None):
+    d = (img1 - img2).abs()
+    return d if pixel_mask is None else d * pixel_mask.unsqueeze(0)
+
+
+def pixelwise_ssim_with_mask(img1, img2, pixel_mask=None):
+    """SSIM map, 11x11 Gaussian window sigma 1.5, zero padding, C1 = 0.01^2, C2 = 0.03^2
+    (utils/loss_utils.py:98-132)"""
+    ch = img1.shape[-3]
+    w = _window(ch, img1.dtype, img1.device)
+    x, y = img1.unsqueeze(0), img2.unsqueeze(0)
+    stack = torch.cat([x, y, x * x, y * y, x * y], dim=1)  # one depthwise conv over 5 x ch planes
+    f = F.conv2d(stack, w.repeat(5, 1, 1, 1), padding=5, groups=5 * ch).squeeze(0)
+    mu1, mu2, e11, e22, e12 = f[0:ch], f[ch:2 * ch], f[2 * ch:3 * ch], f[3 * ch:4 * ch], f[4 * ch:5 * ch]
+    mu1_sq, mu2_sq, mu12 = mu1 * mu1, mu2 * mu2, mu1 * mu2
+    s11, s22, s12 = e11 - mu1_sq, e22 - mu2_sq, e12 - mu12
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    m = ((2 * mu12 + C1) * (2 * s12 + C2)) / ((mu1_sq + mu2_sq + C1) * (s11 + s22 + C2))
+    return m if pixel_mask is None else m * pixel_mask.unsqueeze(0)
+
+
+def final_system_loss_computation(image, viewpoint_cam, compute_locally, strategy, statistic_collector):
+    """-> (Ll1, ssim) partial sums of this rank's row band, each / (H * W * 3); fills
+    statistic_collector["forward_loss_time"] (ms) for the load balancer."""
+    assert utils.GLOBAL_RANK in strategy.gpu_ids, "The current gpu must be used to render this camera."
+    j = strategy.gpu_ids.index(utils.GLOBAL_RANK)
+    y0, y1 = get_coverage_y_min_max(strategy.division_pos[j], strategy.division_pos[j + 1])
+    band = image[:, y0:y1, :].contiguous()
+    gt = torch.clamp(viewpoint_cam.original_image / 255.0, 0.0, 1.0)
+    n = utils.get_num_pixels() * 3
+
+    timed = image.is_cuda
+    if timed:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    else:
+        t0 = time.time()
+    Ll1 = pixelwise_l1_with_mask(band, gt).sum() / n
+    ssim = pixelwise_ssim_with_mask(band, gt).sum() / n
+    if timed:
+        ev1.record()
+        # no device sync here (the reference synchronises twice per camera, loss_distribution.py:2566,2578):
+        # finish_strategy_final resolves the event pair when -- and only when -- the balancer needs it
+        statistic_collector["_loss_events"] = (ev0, ev1)
+        statistic_collector.setdefault("forward_loss_time", 0.0)
+    else:
+        statistic_collector["forward_loss_time"] = (time.time() - t0) * 1000
+    return Ll1, ssim
+
+
+def batched_loss_computation(batched_image, batched_cameras, batched_compute_locally, batched_strategies,
+                             batched_statistic_collector):
+    """loss = (1 - lambda) * L1 + lambda * (1 - ssim), summed over the cameras this rank renders
+    (x lr_scale_loss); also returns the per-camera [Ll1, ssim] pairs for logging."""
+    args = utils.get_args()
+    timers = utils.get_timers()
+    if timers is not None:
+        timers.start("loss_computation")
+    total = 0
+    parts = []
+    for image, camera, mask, strategy, stats in zip(batched_image, batched_cameras, batched_compute_locally,
+                                                    batched_strategies, batched_statistic_collector):
+        if image is None:  # not rendered here
+            loss = 0
+            parts.append([0.0, 0.0])
+        elif image.dim() == 0:  # scalar stand-in (< 10 Gaussians): keeps the graph, contributes nothing
+            loss = image * 0
+            parts.append([loss, 0.0])
+        else:
+            Ll1, ssim = final_system_loss_computation(image, camera, mask, strategy, stats)
+            loss = (1.0 - args.lambda_dssim) * Ll1 + args.lambda_dssim * (1.0 - ssim)
+            parts.append([Ll1, ssim])
+        total = total + loss
+    assert torch.is_tensor(total) and total.dim() == 0, "The loss_sum must be a scalar tensor."
+    if timers is not None:
+        timers.stop("loss_computation")
+    return total * args.lr_scale_loss, parts

@@ -1,0 +1,225 @@
+"""Pixel-partition API of the hot path (host side), MI355X build.
+
+From-scratch mirror of the `*_final` surface of the reference's gaussian_renderer/workload_division.py
+(names, arguments, return values and cut-point arithmetic identical; the dead non-final classes,
+SURVEY.md F4, are not provided):
+
+  division_pos_heuristic          workload_division.py:75-94
+  DivisionStrategyFinal           workload_division.py:684-803
+  DivisionStrategyHistoryFinal    workload_division.py:806-849
+  start_strategy_final            workload_division.py:852-941
+  finish_strategy_final           workload_division.py:944-998
+
+A batch of B cameras is a list of B*TILE_Y tile ROWS; it is cut into WORLD_SIZE contiguous parts of
+equal estimated cost, so with B >= W whole images land on single GPUs and with B < W an image is split
+into row bands.  Difference from the reference in HOW (not WHAT): the per-row cost heuristics live on the
+host (they are TILE_Y floats per camera), so choosing the cut points costs no device sync per iteration
+(the reference's cumsum/searchsorted run on the GPU and read back, workload_division.py:92).
+"""
+import torch
+
+import diff_gaussian_rasterization
+import utils.general_utils as utils
+
+
+def get_tile_pixel_range(j, i, image_width, image_height):
+    """pixel rect [minx,maxx) x [miny,maxy) of tile (row j, column i)"""
+    x0, y0 = i * utils.BLOCK_X, j * utils.BLOCK_Y
+    return x0, y0, min(x0 + utils.BLOCK_X, image_width), min(y0 + utils.BLOCK_Y, image_height)
+
+
+def get_tile_pixel_cnt(j, i, image_width, image_height):
+    x0, y0, x1, y1 = get_tile_pixel_range(j, i, image_width, image_height)
+    return (x1 - x0) * (y1 - y0)
+
+
+def division_pos_heuristic(heuristic, tile_num, world_size, right=False):
+    """cut `tile_num` rows with per-row cost `heuristic` into `world_size` parts of equal cost:
+    [0, searchsorted(cumsum(h), k * total / W, right) for k = 1..W-1, tile_num]"""
+    assert heuristic.shape[0] == tile_num, "the length of heuristics should be the same as the number of tiles."
+    prefix = torch.cumsum(heuristic.detach().to("cpu", torch.float32), dim=0)
+    per_worker = prefix[-1] / world_size
+    thresholds = torch.arange(1, world_size, dtype=torch.float32) * per_worker
+    cuts = torch.searchsorted(prefix, thresholds, right=right)
+    return [0] + cuts.tolist() + [tile_num]
+
+
+class DivisionStrategyFinal:
+    """row-band partition of ONE camera among the `gpu_ids` that render a part of it"""
+
+    def __init__(self, camera, world_size, gpu_ids, division_pos, gpu_for_this_camera_tilelr):
+        assert world_size > 0, "The world_size must be greater than 0."
+        assert len(gpu_ids) == world_size, "The number of gpu_ids must be equal to the world_size."
+        assert len(division_pos) == world_size + 1, "The number of division_pos must be equal to the world_size+1."
+        assert division_pos[0] == 0, "The first element of division_pos must be 0."
+        assert division_pos[-1] == utils.TILE_Y, \
+            "The last element of division_pos must be equal to the total number of tiles."
+        assert all(b > a for a, b in zip(division_pos[:-1], division_pos[1:])), \
+            "The division_pos must be in ascending order."
+        for k, (l, r) in enumerate(gpu_for_this_camera_tilelr):
+            assert l == division_pos[k] and r == division_pos[k + 1], \
+                "The division_pos must be consistent with gpu_for_this_camera_tilelr."
+        self.camera = camera
+        self.world_size = world_size
+        self.gpu_ids = gpu_ids
+        self.rank = gpu_ids.index(utils.GLOBAL_RANK) if utils.GLOBAL_RANK in gpu_ids else -1
+        self.division_pos = division_pos
+
+    # -- which of my Gaussians does band j need (K2) -------------------------------------------
+    def get_local2j_ids_bool(self, means2D, radii, image_height, image_width, cuda_args=None):
+        div = torch.tensor(self.division_pos, dtype=torch.int32, device=means2D.device) * utils.TILE_X
+        return diff_gaussian_rasterization._C.get_local2j_ids_bool(
+            image_height, image_width, self.rank, self.world_size, means2D, radii, div, cuda_args)
+
+    def get_local2j_ids(self, means2D, radii, raster_settings, cuda_args):
+        """reference-compatible form: (list of [n,1] int64 index tensors, bool [P, ws]).  The fused
+        exchange of this package uses get_local2j_ids_bool directly and never calls nonzero per band."""
+        b = self.get_local2j_ids_bool(means2D, radii, raster_settings.image_height, raster_settings.image_width,
+                                      cuda_args)
+        return [b[:, j].nonzero() for j in range(self.world_size)], b
+
+    # -- which tiles do I render ----------------------------------------------------------------
+    def _my_rows(self):
+        if utils.GLOBAL_RANK not in self.gpu_ids:
+            return None
+        k = self.gpu_ids.index(utils.GLOBAL_RANK)
+        return self.division_pos[k], self.division_pos[k + 1]
+
+    def get_compute_locally(self):
+        rows = self._my_rows()
+        if rows is None:
+            return None
+        mask = torch.zeros((utils.TILE_Y, utils.TILE_X), dtype=torch.bool, device=utils.device())
+        mask[rows[0]:rows[1]] = True
+        return mask
+
+    def get_compute_locally_all(self):
+        if self._my_rows() is None:
+            return None
+        return torch.ones((utils.TILE_Y, utils.TILE_X), dtype=torch.bool, device=utils.device())
+
+    def get_extended_compute_locally(self):
+        return None
+
+
+class DivisionStrategyHistoryFinal:
+    """per-camera row-cost heuristics + a log of measured times"""
+
+    def __init__(self, dataset, world_size, rank):
+        self.world_size = world_size
+        self.rank = rank
+        self.accum_heuristic = {cam.uid: torch.ones((utils.TILE_Y,), dtype=torch.float32) for cam in dataset.cameras}
+        self.history = []
+
+    def store_stats(self, batched_cameras, gpu_camera_running_time, batched_strategies):
+        per_camera = [0.0] * len(batched_cameras)
+        per_gpu = [0.0] * self.world_size
+        infos = []
+        for k, (camera, strategy) in enumerate(zip(batched_cameras, batched_strategies)):
+            times = [gpu_camera_running_time[g][k] for g in strategy.gpu_ids]
+            for g, t in zip(strategy.gpu_ids, times):
+                per_camera[k] += t
+                per_gpu[g] += t
+            infos.append({"camera_id": camera.uid, "gpu_ids": strategy.gpu_ids,
+                          "division_pos": strategy.division_pos, "each_gpu_running_time": times})
+        self.history.append({"iteration": utils.get_cur_iter(), "all_gpu_running_time": per_gpu,
+                             "all_camera_running_time": per_camera, "batched_camera_info": infos})
+
+    def to_json(self):
+        return self.history
+
+
+def _snap_cuts_to_image_borders(cuts, rows_per_image, coeff):
+    """a cut within `coeff` rows of an image boundary moves onto the boundary (saves one tiny band and
+    its kernel launches; workload_division.py:889-902)"""
+    for i in range(1, len(cuts) - 1):
+        rem = cuts[i] % rows_per_image
+        if rem + coeff >= rows_per_image:
+            cuts[i] = (cuts[i] // rows_per_image + 1) * rows_per_image
+        elif rem - coeff <= 0:
+            cuts[i] = (cuts[i] // rows_per_image) * rows_per_image
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        assert a + coeff < b, "Each part between division_pos must be large enough."
+    return cuts
+
+
+def start_strategy_final(batched_cameras, strategy_history):
+    """-> (batched_strategies [B], gpuid2tasks[gpu] = [(camera idx, row_l, row_r), ...])"""
+    args = utils.get_args()
+    W = utils.DEFAULT_GROUP.size()
+    rows = utils.TILE_Y
+    strategies = []
+    gpuid2tasks = [[] for _ in range(W)]
+
+    if args.local_sampling:
+        per_gpu = args.bsz // utils.WORLD_SIZE
+        for k, camera in enumerate(batched_cameras):
+            g = k // per_gpu
+            gpuid2tasks[g].append((k, 0, rows))
+            strategies.append(DivisionStrategyFinal(camera, 1, [g], [0, rows], [(0, rows)]))
+        return strategies, gpuid2tasks
+
+    heur = torch.cat([strategy_history.accum_heuristic[c.uid].to("cpu") for c in batched_cameras], dim=0)
+    cuts = division_pos_heuristic(heur, rows * len(batched_cameras), W, right=True)
+    cuts = _snap_cuts_to_image_borders(cuts, rows, args.border_divpos_coeff)
+
+    for k, camera in enumerate(batched_cameras):
+        lo, hi = k * rows, (k + 1) * rows
+        gpus, bands = [], []
+        for g in range(W):
+            gl, gr = cuts[g], cuts[g + 1]
+            if gr <= lo or hi <= gl:
+                continue
+            band = (max(gl, lo) - lo, min(gr, hi) - lo)
+            gpus.append(g)
+            bands.append(band)
+            gpuid2tasks[g].append((k, band[0], band[1]))
+        strategies.append(DivisionStrategyFinal(camera, len(gpus), gpus, [0] + [b[1] for b in bands], bands))
+    return strategies, gpuid2tasks
+
+
+def _resolve_deferred_timings(st):
+    """exact per-call milliseconds from the HIP event pairs the ops left behind (one wait on the last
+    event instead of the reference's cuda.synchronize() pairs around every loss / render call)"""
+    for key, evkey in (("forward_render_time", "_fwd_events"), ("backward_render_time", "_bwd_events"),
+                       ("forward_loss_time", "_loss_events")):
+        ev = st.pop(evkey, None)
+        if ev is not None:
+            ev[1].synchronize()
+            st[key] = float(ev[0].elapsed_time(ev[1]))
+
+
+def finish_strategy_final(batched_cameras, strategy_history, batched_strategies, batched_statistic_collector):
+    """all-gather each rank's measured (fwd render + bwd render + 2 x fwd loss) ms per camera and turn
+    it into the next per-row cost estimate (same skip rules as workload_division.py:968-978)"""
+    mine = []
+    if utils.DEFAULT_GROUP.size() > 1:
+        for st in batched_statistic_collector:
+            _resolve_deferred_timings(st)
+    for k, strategy in enumerate(batched_strategies):
+        if utils.GLOBAL_RANK not in strategy.gpu_ids:
+            mine.append(-1.0)
+            continue
+        st = batched_statistic_collector[k]
+        mine.append(float(st["forward_render_time"] + st["backward_render_time"] + st["forward_loss_time"] * 2))
+    times = utils.our_allgather_among_cpu_processes_float_list(mine, utils.DEFAULT_GROUP)
+    strategy_history.store_stats(batched_cameras, times, batched_strategies)
+
+    args = utils.get_args()
+    W = utils.DEFAULT_GROUP.size()
+    small = utils.get_img_height() <= 600 or utils.get_img_width() <= 1000
+    whole_images = args.bsz >= W and (utils.get_img_height() <= 1080 or utils.get_img_width() <= 1920)
+    if (utils.get_cur_iter() <= args.adjust_strategy_warmp_iterations or W == 1 or args.no_heuristics_update
+            or whole_images or small):
+        return
+
+    for k, (camera, strategy) in enumerate(zip(batched_cameras, batched_strategies)):
+        new = torch.zeros((utils.TILE_Y,), dtype=torch.float32)
+        for j, g in enumerate(strategy.gpu_ids):
+            l, r = strategy.division_pos[j], strategy.division_pos[j + 1]
+            new[l:r] = times[g][k] / (r - l)
+        if args.heuristic_decay == 0:
+            strategy_history.accum_heuristic[camera.uid] = new
+        else:
+            old = strategy_history.accum_heuristic[camera.uid].to("cpu")
+            strategy_history.accum_heuristic[camera.uid] = old * args.heuristic_decay + new * (1 - args.heuristic_decay)

@@ -108,3 +108,65 @@ def make_gt_image(width, height, seed=1, device="cpu"):
     g = torch.Generator(device="cpu")
     g.manual_seed(seed)
     return torch.randint(0, 256, (3, height, width), generator=g, dtype=torch.uint8).to(device)
+
+
+class SyntheticGaussianModel(torch.nn.Module):
+    """duck-type of scene.gaussian_model.GaussianModel for the hot path: raw parameters in the
+    reference's layout (scene/gaussian_model.py:219-242) and the activations of its getters
+    (scene/gaussian_model.py:109-129).  `rank`/`world_size` keep the contiguous shard this rank owns
+    (scene/gaussian_model.py:181-194)."""
+
+    def __init__(self, n_total, width, height, seed=0, sh_degree=3, rank=0, world_size=1, device="cpu",
+                 scale_coef=0.004):
+        super().__init__()
+        g = make_gaussians(n_total, width, height, seed=seed, scale_coef=scale_coef)
+        chunk = (n_total + world_size - 1) // world_size
+        l, r = rank * chunk, min((rank + 1) * chunk, n_total)
+        sl = slice(l, r)
+        self.active_sh_degree = sh_degree
+        self.max_sh_degree = 3
+        P = torch.nn.Parameter
+        op = g["opacities"][sl].clamp(1e-6, 1 - 1e-6)
+        self._xyz = P(g["means3D"][sl].clone().to(device))
+        self._features_dc = P(g["shs"][sl, 0:1].clone().contiguous().to(device))
+        self._features_rest = P(g["shs"][sl, 1:].clone().contiguous().to(device))
+        self._scaling = P(torch.log(g["scales"][sl]).to(device))
+        self._rotation = P(g["rotations"][sl].clone().to(device))
+        self._opacity = P(torch.log(op / (1 - op)).to(device))
+
+    @property
+    def get_xyz(self):
+        return self._xyz
+
+    @property
+    def get_scaling(self):
+        return torch.exp(self._scaling)
+
+    @property
+    def get_rotation(self):
+        return torch.nn.functional.normalize(self._rotation)
+
+    @property
+    def get_opacity(self):
+        return torch.sigmoid(self._opacity)
+
+    @property
+    def get_features(self):
+        return torch.cat((self._features_dc, self._features_rest), dim=1)
+
+    def param_groups(self):
+        """the reference's Adam groups and learning rates (scene/gaussian_model.py:244-292,
+        arguments/__init__.py:109-118)"""
+        return [
+            {"params": [self._xyz], "lr": 0.00016, "name": "xyz"},
+            {"params": [self._features_dc], "lr": 0.0025, "name": "f_dc"},
+            {"params": [self._features_rest], "lr": 0.0025 / 20.0, "name": "f_rest"},
+            {"params": [self._opacity], "lr": 0.05, "name": "opacity"},
+            {"params": [self._scaling], "lr": 0.005, "name": "scaling"},
+            {"params": [self._rotation], "lr": 0.001, "name": "rotation"},
+        ]
+
+
+class SyntheticDataset:
+    def __init__(self, cameras):
+        self.cameras = cameras
