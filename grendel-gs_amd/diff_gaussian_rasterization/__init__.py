@@ -25,7 +25,7 @@ from . import _lib
 from ._lib import check, lib
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "_C", "load_image_tiles_by_pos",
-           "merge_image_tiles_by_pos", "set_timing_mode"]
+           "merge_image_tiles_by_pos", "set_timing_mode", "fused_l1_ssim_band"]
 
 BLOCK_X, BLOCK_Y, ONE_DIM_BLOCK_SIZE = 16, 16, 256
 
@@ -340,6 +340,62 @@ class GaussianRasterizer(nn.Module):
         image, n_contrib = fn.apply(means2D, conic_opacity, rgb, depths, radii, compute_locally,
                                     self.raster_settings, cuda_args)
         return image, getattr(fn, "last_num_rendered", None), None, n_contrib
+
+
+# ------------------------------------------------------------------------------- N1: fused loss
+class _FusedL1SSIMBand(torch.autograd.Function):
+    """(sum |band - gt|, sum ssim_map(band, gt)) of rows [y0, y1) of `image` [C,H,W] against the uint8
+    ground-truth band [C, y1-y0, W]; the two sums are what final_system_loss_computation divides by
+    H*W*3 (gaussian_renderer/loss_distribution.py:2567-2576)."""
+
+    @staticmethod
+    def forward(ctx, image, gt_u8, y0, y1):
+        if not image.is_cuda:
+            raise RuntimeError("fused_l1_ssim_band: device tensors required (no CPU fallback)")
+        image = image.float().contiguous()
+        C, H, W = image.shape
+        rows = y1 - y0
+        gt_u8 = gt_u8.contiguous()
+        if gt_u8.dtype != torch.uint8 or tuple(gt_u8.shape) != (C, rows, W):
+            raise ValueError(f"gt band must be uint8 [{C},{rows},{W}], got {gt_u8.dtype} {tuple(gt_u8.shape)}")
+        dev = image.device
+        need_grad = ctx.needs_input_grad[0]
+        nb = lib.gsr_l1_ssim_num_partials(C, rows, W)
+        partials = torch.empty((max(nb, 1), 2), dtype=torch.float32, device=dev)
+        maps = torch.empty((3, C, rows, W), dtype=torch.float32, device=dev) if need_grad else None
+        band_ptr = ctypes.c_void_p(image.data_ptr() + 4 * y0 * W)
+        with torch.cuda.device(dev), kernel_timer.range("l1_ssim_forward"):
+            check(lib.gsr_l1_ssim_forward(C, rows, W, band_ptr, H * W, _ptr(gt_u8), _ptr(partials),
+                                          _ptr(maps[0]) if need_grad else None, _ptr(maps[1]) if need_grad else None,
+                                          _ptr(maps[2]) if need_grad else None, _stream()), "gsr_l1_ssim_forward")
+        sums = partials[:nb].sum(dim=0)
+        ctx.y0, ctx.y1 = y0, y1
+        if need_grad:
+            ctx.save_for_backward(image, gt_u8, maps)
+        return sums[0], sums[1]
+
+    @staticmethod
+    def backward(ctx, g_l1, g_ssim):
+        image, gt_u8, maps = ctx.saved_tensors
+        C, H, W = image.shape
+        y0, y1 = ctx.y0, ctx.y1
+        rows = y1 - y0
+        dev = image.device
+        g_l1 = (torch.zeros((), device=dev) if g_l1 is None else g_l1).float().contiguous()
+        g_ssim = (torch.zeros((), device=dev) if g_ssim is None else g_ssim).float().contiguous()
+        grad = torch.empty_like(image) if rows == H else torch.zeros_like(image)
+        band_ptr = ctypes.c_void_p(image.data_ptr() + 4 * y0 * W)
+        gband_ptr = ctypes.c_void_p(grad.data_ptr() + 4 * y0 * W)
+        with torch.cuda.device(dev), kernel_timer.range("l1_ssim_backward"):
+            check(lib.gsr_l1_ssim_backward(C, rows, W, band_ptr, H * W, _ptr(gt_u8), _ptr(maps[0]), _ptr(maps[1]),
+                                           _ptr(maps[2]), _ptr(g_l1), _ptr(g_ssim), gband_ptr, H * W, _stream()),
+                  "gsr_l1_ssim_backward")
+        return grad, None, None, None
+
+
+def fused_l1_ssim_band(image, gt_u8, y0, y1):
+    """-> (sum of |x - gt/255| , sum of the SSIM map) over rows [y0, y1) of image [C,H,W]"""
+    return _FusedL1SSIMBand.apply(image, gt_u8, int(y0), int(y1))
 
 
 # ------------------------------------------------------------------------------------------ _C

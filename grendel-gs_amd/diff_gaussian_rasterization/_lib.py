@@ -34,6 +34,11 @@ SIGNATURES = {
                              c_size_t, c_void_p, c_void_p, c_void_p]),
     "gsr_render_forward": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gsr_l1_ssim_num_partials": (c_int, [c_int, c_int, c_int]),
+    "gsr_l1_ssim_forward": (c_int, [c_int, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_void_p]),
+    "gsr_l1_ssim_backward": (c_int, [c_int, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "gsr_render_backward": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
 }

@@ -21,6 +21,11 @@ import torch.nn.functional as F
 
 import utils.general_utils as utils
 
+try:  # the fused HIP loss of this package's operator module (absent when running on the reference's CUDA op)
+    from diff_gaussian_rasterization import fused_l1_ssim_band as _FUSED
+except ImportError:  # pragma: no cover
+    _FUSED = None
+
 _WINDOW_CACHE = {}
 
 
@@ -133,18 +138,23 @@ def final_system_loss_computation(image, viewpoint_cam, compute_locally, strateg
     assert utils.GLOBAL_RANK in strategy.gpu_ids, "The current gpu must be used to render this camera."
     j = strategy.gpu_ids.index(utils.GLOBAL_RANK)
     y0, y1 = get_coverage_y_min_max(strategy.division_pos[j], strategy.division_pos[j + 1])
-    band = image[:, y0:y1, :].contiguous()
-    gt = torch.clamp(viewpoint_cam.original_image / 255.0, 0.0, 1.0)
     n = utils.get_num_pixels() * 3
-
+    fused = _FUSED is not None and image.is_cuda
     timed = image.is_cuda
     if timed:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
     else:
         t0 = time.time()
-    Ll1 = pixelwise_l1_with_mask(band, gt).sum() / n
-    ssim = pixelwise_ssim_with_mask(band, gt).sum() / n
+    if fused:
+        # one HIP kernel each way (include/gsraster.h: gsr_l1_ssim_forward / _backward)
+        l1_sum, ssim_sum = _FUSED(image, viewpoint_cam.original_image, y0, y1)
+        Ll1, ssim = l1_sum / n, ssim_sum / n
+    else:  # host tensors (unit tests of the partition logic on CPU): plain PyTorch, same arithmetic
+        band = image[:, y0:y1, :].contiguous()
+        gt = torch.clamp(viewpoint_cam.original_image / 255.0, 0.0, 1.0)
+        Ll1 = pixelwise_l1_with_mask(band, gt).sum() / n
+        ssim = pixelwise_ssim_with_mask(band, gt).sum() / n
     if timed:
         ev1.record()
         # no device sync here (the reference synchronises twice per camera, loss_distribution.py:2566,2578):

@@ -124,6 +124,28 @@ int gsr_render_backward(int P, int width, int height, const int32_t *ranges, con
                         const int32_t *n_contrib, const float *dL_dpixels, float *dL_dmeans2D,
                         float *dL_dconic_opacity, float *dL_drgb, gsr_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * N1  fused band-local L1 + SSIM loss -- the arithmetic of final_system_loss_computation,
+ * gaussian_renderer/loss_distribution.py:2536-2585 (pixelwise_l1_with_mask / pixelwise_ssim_with_mask,
+ * utils/loss_utils.py:88-132): 11x11 Gaussian window (sigma 1.5), zero padding at the band edges,
+ * C1 = 0.01^2, C2 = 0.03^2, ground truth = uint8 / 255.
+ * `image` points at the band's first row of channel 0 inside a [C, H, W] image (row stride = width,
+ * channel stride = image_channel_stride elements); gt is the dense uint8 band [C, rows, width].
+ * forward : partials [gsr_l1_ssim_num_partials()][2] = per-workgroup (sum |x-y|, sum ssim_map); the
+ *           caller adds them up.  dm_* [C, rows, width] receive the derivative maps the backward
+ *           needs (all three NULL for a forward-only evaluation).
+ * backward: grad_image (same addressing as `image`, channel stride grad_channel_stride) =
+ *           *grad_l1_sum * sign(x - y) + *grad_ssim_sum * d(sum ssim)/dx ; both scalars are read on
+ *           the device (no host sync). */
+int gsr_l1_ssim_num_partials(int channels, int rows, int width);
+int gsr_l1_ssim_forward(int channels, int rows, int width, const float *image, int64_t image_channel_stride,
+                        const uint8_t *gt, float *partials, float *dm_dmu1, float *dm_dE11, float *dm_dE12,
+                        gsr_stream_t stream);
+int gsr_l1_ssim_backward(int channels, int rows, int width, const float *image, int64_t image_channel_stride,
+                         const uint8_t *gt, const float *dm_dmu1, const float *dm_dE11, const float *dm_dE12,
+                         const float *grad_l1_sum, const float *grad_ssim_sum, float *grad_image,
+                         int64_t grad_channel_stride, gsr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,119 @@
+"""-m gpu: the fused L1+SSIM HIP loss vs its CPU restatement / golden maps, and one full training
+iteration through the reference-shaped call sequence (gaussian_renderer mirror) vs the oracle chain."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import synthetic_scene as S
+from helpers import KEYS, cam_kwargs, rel_err
+
+pytestmark = pytest.mark.gpu
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_helpers.npz"))
+
+
+def test_fused_loss_matches_golden_maps(device):
+    """sums of the golden per-pixel maps produced by the reference's pixelwise_* functions"""
+    from diff_gaussian_rasterization import fused_l1_ssim_band
+
+    img = torch.from_numpy(GOLD["loss_img"]).to(device)
+    gt = torch.from_numpy(GOLD["loss_gt_u8"]).to(device)
+    C, H, W = img.shape
+    l1, ssim = fused_l1_ssim_band(img, gt, 0, H)
+    assert abs(l1.item() - float(GOLD["loss_l1_map"].astype(np.float64).sum())) < 1e-4 * l1.item()
+    assert abs(ssim.item() - float(GOLD["loss_ssim_map"].astype(np.float64).sum())) < 1e-4 * abs(ssim.item())
+
+
+@pytest.mark.parametrize("H,W,y0,y1", [(83, 131, 0, 83), (96, 160, 16, 64), (1080, 1920, 272, 544)])
+def test_fused_loss_fwd_bwd_matches_torch_restatement(device, H, W, y0, y1):
+    from diff_gaussian_rasterization import fused_l1_ssim_band
+    from oracle.loss_oracle import l1_map, ssim_map
+
+    g = torch.Generator().manual_seed(H + W)
+    img = torch.rand(3, H, W, generator=g)
+    gt = torch.randint(0, 256, (3, y1 - y0, W), generator=g, dtype=torch.uint8)
+    # oracle in float64 on the band, zero padding at the band edges
+    x = img[:, y0:y1].double().clone().requires_grad_(True)
+    y = torch.clamp(gt.double() / 255.0, 0, 1)
+    l1o, sso = l1_map(x, y).sum(), ssim_map(x, y).sum()
+    (0.8 * l1o / 7.0 - 0.2 * sso / 7.0).backward()
+    xi = img.to(device).requires_grad_(True)
+    l1, ss = fused_l1_ssim_band(xi, gt.to(device), y0, y1)
+    (0.8 * l1 / 7.0 - 0.2 * ss / 7.0).backward()
+    assert abs(l1.item() - l1o.item()) < 2e-5 * l1o.item()
+    assert abs(ss.item() - sso.item()) < 2e-5 * abs(sso.item())
+    assert rel_err(xi.grad[:, y0:y1], x.grad) < 1e-4
+    # rows outside the band get exactly zero gradient
+    outside = torch.ones(H, dtype=torch.bool); outside[y0:y1] = False
+    assert xi.grad[:, outside.to(device)].abs().sum().item() == 0.0
+
+
+def test_training_iteration_through_mirror_matches_oracle(device):
+    """start_strategy_final -> GT staging -> preprocess(+exchange) -> render_final -> batched loss ->
+    backward, world size 1, against the C restatement + torch loss restatement"""
+    import utils.general_utils as utils
+    from gaussian_renderer import distributed_preprocess3dgs_and_all2all_final, render_final
+    from gaussian_renderer.loss_distribution import batched_loss_computation, load_camera_from_cpu_to_all_gpu
+    from gaussian_renderer.workload_division import (DivisionStrategyHistoryFinal, finish_strategy_final,
+                                                     start_strategy_final)
+    from oracle import cref as C
+    from oracle.loss_oracle import band_loss
+
+    N, W, H = 4000, 208, 144
+    utils.GLOBAL_RANK, utils.WORLD_SIZE = 0, 1
+    utils.DEFAULT_GROUP = utils.IN_NODE_GROUP = utils.SingleGPUGroup()
+    utils.set_args(utils.default_args(bsz=2))
+    utils.set_img_size(H, W)
+    utils.set_cur_iter(1)
+    model = S.SyntheticGaussianModel(N, W, H, seed=4, device=device, scale_coef=0.012)
+    cams = S.orbit_cameras(2, W, H, device=device)
+    for k, c in enumerate(cams):
+        c.original_image_backup = S.make_gt_image(W, H, seed=10 + k)
+    hist = DivisionStrategyHistoryFinal(S.SyntheticDataset(cams), 1, 0)
+    bg = torch.tensor([0.1, 0.2, 0.3], device=device)
+    pipe = type("P", (), {"debug": False})()
+
+    strategies, tasks = start_strategy_final(cams, hist)
+    assert tasks == [[(0, 0, utils.TILE_Y), (1, 0, utils.TILE_Y)]]
+    load_camera_from_cpu_to_all_gpu(cams, strategies, tasks)
+    pkg = distributed_preprocess3dgs_and_all2all_final(cams, model, pipe, bg, batched_strategies=strategies)
+    for key in ("batched_locally_preprocessed_mean2D", "batched_locally_preprocessed_visibility_filter",
+                "batched_locally_preprocessed_radii", "batched_rasterizers", "batched_cuda_args",
+                "batched_means2D_redistributed", "batched_rgb_redistributed", "batched_conic_opacity_redistributed",
+                "batched_radii_redistributed", "batched_depths_redistributed", "gpui_to_gpuj_imgk_size"):
+        assert key in pkg
+    images, masks = render_final(pkg, strategies)
+    stats = [ca["stats_collector"] for ca in pkg["batched_cuda_args"]]
+    loss, parts = batched_loss_computation(images, cams, masks, strategies, stats)
+    loss.backward()
+    finish_strategy_final(cams, hist, strategies, stats)
+    for st in stats:
+        for key in ("forward_render_time", "backward_render_time", "forward_loss_time"):
+            assert isinstance(st[key], float)
+    # densification's input: NDC-scaled means2D gradient of the locally preprocessed Gaussians
+    assert pkg["batched_locally_preprocessed_mean2D"][0].grad is not None
+
+    # ---- oracle: same two cameras, summed loss
+    g = {"means3D": model.get_xyz, "scales": model.get_scaling, "rotations": model.get_rotation,
+         "shs": model.get_features, "opacities": model.get_opacity}
+    g = {k: v.detach().cpu() for k, v in g.items()}
+    total = 0.0
+    d_means = torch.zeros(N, 3, dtype=torch.float64)
+    mask = torch.ones(utils.TILE_Y, utils.TILE_X, dtype=torch.bool)
+    for k, cam in enumerate(cams):
+        camc = S.orbit_cameras(2, W, H)[k]
+        kw = cam_kwargs(camc)
+        m2, rgb, co, radii, depths, cov3D, clamped = C.preprocess_forward(*[g[x] for x in KEYS], **kw)
+        pl, ranges, _ = C.bin_and_sort(m2, radii, depths, mask, W, H)
+        img, fT, nc = C.render_forward(m2, co, rgb, mask, bg.cpu(), W, H, pl, ranges)
+        x = img.double().clone().requires_grad_(True)
+        l, _, _ = band_loss(x, cam.original_image_backup, H, W)
+        l.backward()
+        total += l.item()
+        d2, dco, drgb = C.render_backward(m2, co, rgb, mask, bg.cpu(), W, H, pl, ranges, fT, nc, x.grad.float())
+        d_means += C.preprocess_backward(g["means3D"], g["scales"], g["rotations"], g["shs"], radii, cov3D, clamped,
+                                         d2, dco, drgb, **kw)[0].double()
+    assert abs(loss.item() - total) < 1e-4 * abs(total)
+    assert rel_err(model._xyz.grad, d_means) < 2e-4
