@@ -35,11 +35,14 @@ def _stale(target, deps):
 def build(force=False, verbose=False):
     units = [u for u in UNITS if os.path.exists(os.path.join(HERE, u + ".hip"))]
     hipcc = _hipcc()
+    extra = os.environ.get("GSR_DEFINES", "").split()  # experiment switches (ablations); empty in production
+    if extra:
+        force = True
 
     def compile_one(u):
         src, obj = os.path.join(HERE, u + ".hip"), os.path.join(HERE, u + ".o")
         if force or _stale(obj, [src] + HEADERS):
-            cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+            cmd = [hipcc] + FLAGS + extra + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             r = subprocess.run(cmd, capture_output=True, text=True)

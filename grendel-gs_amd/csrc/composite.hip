@@ -196,70 +196,82 @@ composite_backward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
     const float bg_dot = bg[0] * g0 + bg[1] * g1 + bg[2] * g2;
     const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
 
-    // entries beyond the furthest contributor of any pixel of this quadrant are dead for the wave
+    // entries beyond the furthest contributor of any pixel of this quadrant are dead for the wave;
+    // the four waves of the tile walk the SAME chunk sequence so that their per-entry sums can be
+    // combined in LDS and leave the workgroup as ONE set of atomics per (tile, entry)
+    __shared__ float sacc[4][9][64];
+    __shared__ int s_wmax[4];
     int wmax = last;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) wmax = max(wmax, __shfl_xor(wmax, d, 64));
-    if (wmax == 0) return;
+    if (lane == 0) s_wmax[wave] = wmax;
+    __syncthreads();
+    const int bmax = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
+    if (bmax == 0) return;
 
     float T = T_final;
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;      // colour accumulated BEHIND the current entry
     float lastc0 = 0.f, lastc1 = 0.f, lastc2 = 0.f;
     float last_alpha = 0.f;
 
-    for (int c = ((wmax - 1) / 64) * 64; c >= 0; c -= 64) {
-        const bool have = c + lane < wmax;
-        const uint32_t id = have ? point_list[range.x + c + lane] : 0u;
-        const Entry e = load_entry(have, id, means2D, conic_opacity, (float)qx0, (float)qy0);
-        float r = 0.f, g = 0.f, b = 0.f;
-        float4 co = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (e.relevant) {
-            r = rgb[3 * (size_t)id];
-            g = rgb[3 * (size_t)id + 1];
-            b = rgb[3 * (size_t)id + 2];
-            co = conic_opacity[id];
-        }
+    for (int c = ((bmax - 1) / 64) * 64; c >= 0; c -= 64) {
         // this lane's entry: accumulated gradients
         float s_mx = 0.f, s_my = 0.f, s_a = 0.f, s_b = 0.f, s_c = 0.f, s_o = 0.f, s_r = 0.f, s_g = 0.f, s_bl = 0.f;
-        unsigned long long m = __ballot(e.relevant);
-        const unsigned long long touched = m;
-        while (m) {
-            const int k = 63 - __builtin_clzll(m);
-            m &= ~(1ull << k);
-            const float gx_ = bcast(e.x, k), gy_ = bcast(e.y, k);
-            const float a2 = bcast(e.a2, k), b2 = bcast(e.b2, k), c2 = bcast(e.c2, k), o = bcast(e.o, k);
-            const float cr = bcast(r, k), cg = bcast(g, k), cb = bcast(b, k);
-            const float A = bcast(co.x, k), B = bcast(co.y, k), Cc = bcast(co.z, k);
-            const float dx = gx_ - pxf, dy = gy_ - pyf;
-            const float p2 = (a2 * dx + b2 * dy) * dx + c2 * dy * dy;
-            const float G = __builtin_amdgcn_exp2f(p2);
-            const float alpha = fminf(0.99f, o * G);
-            const bool take = (c + k + 1 <= last) && p2 <= 0.f && alpha >= ALPHA_MIN;
-            float v_mx = 0.f, v_my = 0.f, v_a = 0.f, v_b = 0.f, v_c = 0.f, v_o = 0.f, v_r = 0.f, v_g = 0.f, v_bl = 0.f;
-            if (take) {
-                T = T / (1.f - alpha);
-                const float w = alpha * T;
-                acc0 = last_alpha * lastc0 + (1.f - last_alpha) * acc0;
-                acc1 = last_alpha * lastc1 + (1.f - last_alpha) * acc1;
-                acc2 = last_alpha * lastc2 + (1.f - last_alpha) * acc2;
-                lastc0 = cr; lastc1 = cg; lastc2 = cb;
-                float dL_dalpha = (cr - acc0) * g0 + (cg - acc1) * g1 + (cb - acc2) * g2;
-                dL_dalpha *= T;
-                last_alpha = alpha;
-                dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
-                const float dL_dG = o * dL_dalpha;  // min(0.99,.) treated as identity
-                const float gdx = G * dx, gdy = G * dy;
-                v_mx = dL_dG * (-gdx * A - gdy * B) * ddelx_dx;
-                v_my = dL_dG * (-gdy * Cc - gdx * B) * ddely_dy;
-                v_a = -0.5f * gdx * dx * dL_dG;
-                v_b = -gdx * dy * dL_dG;
-                v_c = -0.5f * gdy * dy * dL_dG;
-                v_o = G * dL_dalpha;
-                v_r = w * g0;
-                v_g = w * g1;
-                v_bl = w * g2;
+        if (c < wmax) {  // wave-uniform
+            const bool have = c + lane < wmax;
+            const uint32_t id = have ? point_list[range.x + c + lane] : 0u;
+            const Entry e = load_entry(have, id, means2D, conic_opacity, (float)qx0, (float)qy0);
+            float r = 0.f, g = 0.f, b = 0.f;
+            float4 co = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e.relevant) {
+                r = rgb[3 * (size_t)id];
+                g = rgb[3 * (size_t)id + 1];
+                b = rgb[3 * (size_t)id + 2];
+                co = conic_opacity[id];
             }
-            if (__any(take)) {
+            unsigned long long m = __ballot(e.relevant);
+            while (m) {
+                const int k = 63 - __builtin_clzll(m);
+                m &= ~(1ull << k);
+                const float gx_ = bcast(e.x, k), gy_ = bcast(e.y, k);
+                const float a2 = bcast(e.a2, k), b2 = bcast(e.b2, k), c2 = bcast(e.c2, k), o = bcast(e.o, k);
+                const float dx = gx_ - pxf, dy = gy_ - pyf;
+                const float p2 = (a2 * dx + b2 * dy) * dx + c2 * dy * dy;
+                const float G = __builtin_amdgcn_exp2f(p2);
+                const float alpha = fminf(0.99f, o * G);
+                const bool take = (c + k + 1 <= last) && p2 <= 0.f && alpha >= ALPHA_MIN;
+                if (!__any(take)) continue;
+                const float cr = bcast(r, k), cg = bcast(g, k), cb = bcast(b, k);
+                const float A = bcast(co.x, k), B = bcast(co.y, k), Cc = bcast(co.z, k);
+                float v_mx = 0.f, v_my = 0.f, v_a = 0.f, v_b = 0.f, v_c = 0.f, v_o = 0.f, v_r = 0.f, v_g = 0.f,
+                      v_bl = 0.f;
+                if (take) {
+                    T = T / (1.f - alpha);
+                    const float w = alpha * T;
+                    acc0 = last_alpha * lastc0 + (1.f - last_alpha) * acc0;
+                    acc1 = last_alpha * lastc1 + (1.f - last_alpha) * acc1;
+                    acc2 = last_alpha * lastc2 + (1.f - last_alpha) * acc2;
+                    lastc0 = cr; lastc1 = cg; lastc2 = cb;
+                    float dL_dalpha = (cr - acc0) * g0 + (cg - acc1) * g1 + (cb - acc2) * g2;
+                    dL_dalpha *= T;
+                    last_alpha = alpha;
+                    dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
+                    const float dL_dG = o * dL_dalpha;  // min(0.99,.) treated as identity
+                    const float gdx = G * dx, gdy = G * dy;
+                    v_mx = dL_dG * (-gdx * A - gdy * B) * ddelx_dx;
+                    v_my = dL_dG * (-gdy * Cc - gdx * B) * ddely_dy;
+                    v_a = -0.5f * gdx * dx * dL_dG;
+                    v_b = -gdx * dy * dL_dG;
+                    v_c = -0.5f * gdy * dy * dL_dG;
+                    v_o = G * dL_dalpha;
+                    v_r = w * g0;
+                    v_g = w * g1;
+                    v_bl = w * g2;
+                }
+#ifdef GSR_ABL_NOREDUCE
+                s_mx += v_mx; s_my += v_my; s_a += v_a; s_b += v_b; s_c += v_c; s_o += v_o;
+                s_r += v_r; s_g += v_g; s_bl += v_bl;
+#else
                 const float t_mx = bcast(wave_sum_to_63(v_mx), 63), t_my = bcast(wave_sum_to_63(v_my), 63);
                 const float t_a = bcast(wave_sum_to_63(v_a), 63), t_b = bcast(wave_sum_to_63(v_b), 63);
                 const float t_c = bcast(wave_sum_to_63(v_c), 63), t_o = bcast(wave_sum_to_63(v_o), 63);
@@ -269,19 +281,33 @@ composite_backward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
                     s_mx += t_mx; s_my += t_my; s_a += t_a; s_b += t_b; s_c += t_c; s_o += t_o;
                     s_r += t_r; s_g += t_g; s_bl += t_bl;
                 }
+#endif
             }
         }
-        if ((touched >> lane) & 1ull) {
-            atomicAdd(&dL_dmeans2D[2 * (size_t)id], s_mx);
-            atomicAdd(&dL_dmeans2D[2 * (size_t)id + 1], s_my);
-            atomicAdd(&dL_dconic_opacity[4 * (size_t)id], s_a);
-            atomicAdd(&dL_dconic_opacity[4 * (size_t)id + 1], s_b);
-            atomicAdd(&dL_dconic_opacity[4 * (size_t)id + 2], s_c);
-            atomicAdd(&dL_dconic_opacity[4 * (size_t)id + 3], s_o);
-            atomicAdd(&dL_drgb[3 * (size_t)id], s_r);
-            atomicAdd(&dL_drgb[3 * (size_t)id + 1], s_g);
-            atomicAdd(&dL_drgb[3 * (size_t)id + 2], s_bl);
+        sacc[wave][0][lane] = s_mx; sacc[wave][1][lane] = s_my;
+        sacc[wave][2][lane] = s_a;  sacc[wave][3][lane] = s_b;
+        sacc[wave][4][lane] = s_c;  sacc[wave][5][lane] = s_o;
+        sacc[wave][6][lane] = s_r;  sacc[wave][7][lane] = s_g; sacc[wave][8][lane] = s_bl;
+        __syncthreads();
+        // flush: thread (part = wave, entry = lane) owns 2-3 of the 9 values of entry `lane`
+        if (c + lane < bmax) {
+            const uint32_t id = point_list[range.x + c + lane];
+            const int v0 = wave * 2, nv = wave == 3 ? 3 : 2;
+            float *dst = wave == 0 ? dL_dmeans2D + 2 * (size_t)id
+                       : wave == 1 ? dL_dconic_opacity + 4 * (size_t)id
+                       : wave == 2 ? dL_dconic_opacity + 4 * (size_t)id + 2
+                                   : dL_drgb + 3 * (size_t)id;
+            for (int j = 0; j < nv; j++) {
+                const float v = sacc[0][v0 + j][lane] + sacc[1][v0 + j][lane] + sacc[2][v0 + j][lane] +
+                                sacc[3][v0 + j][lane];
+#ifndef GSR_ABL_NOATOMIC
+                if (v != 0.f) atomicAdd(dst + j, v);
+#else
+                asm volatile("" ::"v"(v), "v"(dst));
+#endif
+            }
         }
+        __syncthreads();
     }
 }
 
