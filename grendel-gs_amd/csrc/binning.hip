@@ -190,40 +190,62 @@ radix_scatter_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__res
 }
 
 // ---------------------------------------------------------------------------------- K3 and friends
-// per tile row: prefix counts of locally computed tiles, rowpref[y][x] = #local tiles in [0,x)
-__global__ void rowpref_kernel(const uint8_t *__restrict__ mask, int gx, int gy, int32_t *__restrict__ rowpref) {
-    const int y = blockIdx.x * blockDim.x + threadIdx.x;
-    if (y >= gy) return;
-    int run = 0;
-    int32_t *row = rowpref + (size_t)y * (gx + 1);
-    for (int x = 0; x < gx; x++) {
-        row[x] = run;
-        run += mask[(size_t)y * gx + x] ? 1 : 0;
+// Row hull of the locally computed tiles: hull[0] = first tile row with a local tile, hull[1] = one
+// past the last.  Grendel's final mode always passes whole-row bands, for which the hull IS the mask;
+// for a general mask the tiles inside the hull that are not local are emitted with a sentinel key.
+__global__ void __launch_bounds__(256) mask_hull_kernel(const uint8_t *__restrict__ mask, int gx, int gy,
+                                                        int32_t *__restrict__ hull) {
+    __shared__ int lo, hi;
+    if (threadIdx.x == 0) { lo = gy; hi = 0; }
+    __syncthreads();
+    for (int y = threadIdx.x; y < gy; y += blockDim.x) {
+        bool any = false;
+        for (int x = 0; x < gx; x++) any = any || mask[(size_t)y * gx + x];
+        if (any) {
+            atomicMin(&lo, y);
+            atomicMax(&hi, y + 1);
+        }
     }
-    row[gx] = run;
+    __syncthreads();
+    if (threadIdx.x == 0) { hull[0] = lo; hull[1] = hi; }
 }
 
-// tiles_touched (restricted to local tiles) + depth sort keys.  Gaussians touching nothing get
+// K3: per Gaussian, the tile rect it can CONTRIBUTE to and the number of its tiles; depth sort keys.
+// The rect is the reference's 3-sigma-radius rect intersected with the
+// bounding box of the alpha >= 1/255 ellipse (gsr_alpha_extent) and with the mask's row hull: tiles
+// dropped by the intersection cannot receive a contribution under the alpha < 1/255 rule of A.4, so
+// the image is unchanged while D (pairs to sort and to walk) shrinks.  Gaussians touching nothing get
 // key 0xFFFFFFFF (depths are > 0.2, so real keys are < 0x7F800000) and sort to the end.
 __global__ void __launch_bounds__(GSR_ONE_DIM_BLOCK)
 touch_count_kernel(int P, int gx, int gy, const float2 *__restrict__ means2D, const float *__restrict__ depths,
-                   const int32_t *__restrict__ radii, const int32_t *__restrict__ rowpref,
-                   uint32_t *__restrict__ tt, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+                   const int32_t *__restrict__ radii, const float4 *__restrict__ conic_opacity,
+                   const int32_t *__restrict__ hull, uint32_t *__restrict__ tt, uint32_t *__restrict__ keys,
+                   uint32_t *__restrict__ vals, uint2 *__restrict__ rects) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
     uint32_t n = 0;
+    uint2 rect = make_uint2(0u, 0u);
     const int rad = radii[i];
     if (rad > 0) {
         const float2 xy = means2D[i];
-        int minx, miny, maxx, maxy;
-        gsr_get_rect(xy.x, xy.y, rad, gx, gy, minx, miny, maxx, maxy);
-        if (maxx > minx)
-            for (int y = miny; y < maxy; y++) {
-                const int32_t *row = rowpref + (size_t)y * (gx + 1);
-                n += (uint32_t)(row[maxx] - row[minx]);
+        const float4 co = conic_opacity[i];
+        float ex, ey;
+        if (gsr_alpha_extent(co, ex, ey)) {
+            int minx, miny, maxx, maxy;
+            gsr_get_rect(xy.x, xy.y, rad, gx, gy, minx, miny, maxx, maxy);
+            // tile t covers pixel centres [16t, 16t+15]
+            minx = max(minx, (int)ceilf((xy.x - ex - (GSR_BLOCK_X - 1)) * (1.0f / GSR_BLOCK_X)));
+            maxx = min(maxx, (int)floorf((xy.x + ex) * (1.0f / GSR_BLOCK_X)) + 1);
+            miny = max(max(miny, hull[0]), (int)ceilf((xy.y - ey - (GSR_BLOCK_Y - 1)) * (1.0f / GSR_BLOCK_Y)));
+            maxy = min(min(maxy, hull[1]), (int)floorf((xy.y + ey) * (1.0f / GSR_BLOCK_Y)) + 1);
+            if (maxx > minx && maxy > miny) {
+                n = (uint32_t)((maxx - minx) * (maxy - miny));
+                rect = make_uint2((uint32_t)minx | ((uint32_t)maxx << 16), (uint32_t)miny | ((uint32_t)maxy << 16));
             }
+        }
     }
     tt[i] = n;
+    rects[i] = rect;
     keys[i] = n ? __float_as_uint(depths[i]) : 0xFFFFFFFFu;
     vals[i] = (uint32_t)i;
 }
@@ -235,37 +257,52 @@ gather_u32_kernel(int n, const uint32_t *__restrict__ src, const uint32_t *__res
     if (j < n) dst[j] = src[idx[j]];
 }
 
-// K5: one thread per Gaussian in depth order writes its (tile id, Gaussian index) pairs
-__global__ void __launch_bounds__(GSR_ONE_DIM_BLOCK)
-emit_pairs_kernel(int P, int gx, int gy, const float2 *__restrict__ means2D, const int32_t *__restrict__ radii,
-                  const uint8_t *__restrict__ mask, const uint32_t *__restrict__ sorted_ids,
-                  const uint32_t *__restrict__ offsets, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= P) return;
-    uint32_t off = offsets[j];
-    const uint32_t end = offsets[j + 1];
-    if (end == off) return;
-    const uint32_t g = sorted_ids[j];
-    const float2 xy = means2D[g];
-    int minx, miny, maxx, maxy;
-    gsr_get_rect(xy.x, xy.y, radii[g], gx, gy, minx, miny, maxx, maxy);
-    for (int y = miny; y < maxy; y++)
-        for (int x = minx; x < maxx; x++) {
-            const int t = y * gx + x;
-            if (mask[t]) {
-                keys[off] = (uint32_t)t;
-                vals[off] = g;
-                off++;
-            }
+// K5: a wave owns 64 consecutive Gaussians of the depth order and therefore one CONTIGUOUS span of
+// output pairs; its lanes walk the span (coalesced stores) and find each slot's Gaussian by a 6-step
+// binary search over the wave's 64 offsets in LDS.
+__global__ void __launch_bounds__(256)
+emit_pairs_kernel(int P, int gx, int tiles, const uint2 *__restrict__ rects, const uint8_t *__restrict__ mask,
+                  const uint32_t *__restrict__ sorted_ids, const uint32_t *__restrict__ offsets,
+                  uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+    __shared__ uint32_t s_off[4][65];
+    __shared__ uint32_t s_g[4][64];
+    __shared__ uint2 s_rect[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const bool valid = j < P;
+    const uint32_t off = offsets[valid ? j : P];
+    const uint32_t end = valid ? offsets[j + 1] : off;
+    const uint32_t g = (end > off) ? sorted_ids[j] : 0u;
+    s_off[wave][lane] = off;
+    if (lane == 63) s_off[wave][64] = end;
+    s_g[wave][lane] = g;
+    s_rect[wave][lane] = (end > off) ? rects[g] : make_uint2(0u, 0u);
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t wbeg = __builtin_amdgcn_readlane(off, 0), wend = __builtin_amdgcn_readlane(end, 63);
+    for (uint32_t s = wbeg + lane; s < wend; s += 64) {
+        int lo = 0, hi = 63;
+#pragma unroll
+        for (int it = 0; it < 6; it++) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (s_off[wave][mid] <= s) lo = mid; else hi = mid - 1;
         }
+        const uint2 r = s_rect[wave][lo];
+        const uint32_t t = s - s_off[wave][lo];
+        const uint32_t minx = r.x & 0xFFFFu, w = (r.x >> 16) - minx, miny = r.y & 0xFFFFu;
+        const uint32_t y = miny + t / w, x = minx + t % w;
+        const uint32_t tile = y * (uint32_t)gx + x;
+        keys[s] = mask[tile] ? tile : (uint32_t)tiles;  // non-local tile inside the hull: sentinel, sorts last
+        vals[s] = s_g[wave][lo];
+    }
 }
 
 // K7
 __global__ void __launch_bounds__(GSR_ONE_DIM_BLOCK)
-tile_ranges_kernel(long long D, const uint32_t *__restrict__ tile_of, int2 *__restrict__ ranges) {
+tile_ranges_kernel(long long D, uint32_t tiles, const uint32_t *__restrict__ tile_of, int2 *__restrict__ ranges) {
     const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= D) return;
     const uint32_t t = tile_of[j];
+    if (t >= tiles) return;
     if (j == 0 || tile_of[j - 1] != t) ranges[t].x = (int)j;
     if (j == D - 1 || tile_of[j + 1] != t) ranges[t].y = (int)(j + 1);
 }
@@ -333,10 +370,10 @@ int gsr_radix_sort_pairs(uint32_t *k0, uint32_t *v0, uint32_t *k1, uint32_t *v1,
 // ----------------------------------------------------------------------------------- K3..K7 API
 namespace {
 struct PrepLayout {
-    size_t tt, kA, vA, kB, vB, offsets, rowpref, temp, total;
+    size_t tt, kA, vA, kB, vB, offsets, rects, hull, temp, total;
 };
 PrepLayout prep_layout(int P, int W, int H) {
-    const int gx = (W + GSR_BLOCK_X - 1) / GSR_BLOCK_X, gy = (H + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y;
+    (void)W; (void)H;
     PrepLayout L;
     size_t o = 0;
     const size_t np = align_up((size_t)(P + 1) * 4);
@@ -346,16 +383,17 @@ PrepLayout prep_layout(int P, int W, int H) {
     L.kB = o; o += np;
     L.vB = o; o += np;
     L.offsets = o; o += np;
-    L.rowpref = o; o += align_up((size_t)(gx + 1) * gy * 4);
+    L.rects = o; o += align_up((size_t)(P + 1) * 8);
+    L.hull = o; o += 256;
     L.temp = o;
     const size_t t1 = gsr_radix_temp_bytes(P), t2 = gsr_scan_temp_bytes(P);
     o += t1 > t2 ? t1 : t2;
     L.total = o;
     return L;
 }
-int tile_bits(int tiles) {
+int tile_bits(int tiles) {  // bits of the largest key value, the sentinel `tiles`, rounded up to whole passes
     int b = 1;
-    while ((1ll << b) < tiles) b++;
+    while ((1ll << b) <= tiles) b++;
     return ((b + 7) / 8) * 8;
 }
 }  // namespace
@@ -366,28 +404,30 @@ extern "C" size_t gsr_bin_prepare_bytes(int P, int width, int height) {
 }
 
 extern "C" int gsr_bin_prepare(int P, int width, int height, const float *means2D, const float *depths,
-                               const int32_t *radii, const uint8_t *compute_locally, void *prep, size_t prep_bytes,
-                               int64_t *num_rendered_host, gsr_stream_t stream_) {
+                               const int32_t *radii, const float *conic_opacity, const uint8_t *compute_locally,
+                               void *prep, size_t prep_bytes, int64_t *num_rendered_host, gsr_stream_t stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     if (P < 0 || width <= 0 || height <= 0 || !num_rendered_host) return GSR_EINVAL;
     *num_rendered_host = 0;
     if (P == 0) return 0;
-    if (!means2D || !depths || !radii || !compute_locally || !prep) return GSR_EINVAL;
+    if (!means2D || !depths || !radii || !conic_opacity || !compute_locally || !prep) return GSR_EINVAL;
     const PrepLayout L = prep_layout(P, width, height);
     if (prep_bytes < L.total) return GSR_ENOSPACE;
     const int gx = (width + GSR_BLOCK_X - 1) / GSR_BLOCK_X, gy = (height + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y;
+    if (gx > 0xFFFF || gy > 0xFFFF) return GSR_EINVAL;
     char *base = reinterpret_cast<char *>(prep);
     uint32_t *tt = reinterpret_cast<uint32_t *>(base + L.tt);
     uint32_t *kA = reinterpret_cast<uint32_t *>(base + L.kA), *vA = reinterpret_cast<uint32_t *>(base + L.vA);
     uint32_t *kB = reinterpret_cast<uint32_t *>(base + L.kB), *vB = reinterpret_cast<uint32_t *>(base + L.vB);
     uint32_t *offsets = reinterpret_cast<uint32_t *>(base + L.offsets);
-    int32_t *rowpref = reinterpret_cast<int32_t *>(base + L.rowpref);
+    uint2 *rects = reinterpret_cast<uint2 *>(base + L.rects);
+    int32_t *hull = reinterpret_cast<int32_t *>(base + L.hull);
     void *temp = base + L.temp;
 
-    hipLaunchKernelGGL(rowpref_kernel, dim3(gsr_div_up(gy, 64)), dim3(64), 0, stream, compute_locally, gx, gy,
-                       rowpref);
+    hipLaunchKernelGGL(mask_hull_kernel, dim3(1), dim3(256), 0, stream, compute_locally, gx, gy, hull);
     hipLaunchKernelGGL(touch_count_kernel, dim3(gsr_div_up(P, GSR_ONE_DIM_BLOCK)), dim3(GSR_ONE_DIM_BLOCK), 0, stream,
-                       P, gx, gy, reinterpret_cast<const float2 *>(means2D), depths, radii, rowpref, tt, kA, vA);
+                       P, gx, gy, reinterpret_cast<const float2 *>(means2D), depths, radii,
+                       reinterpret_cast<const float4 *>(conic_opacity), hull, tt, kA, vA, rects);
     int in_first = 1;
     int rc = gsr_radix_sort_pairs(kA, vA, kB, vB, P, 0, 32, temp, &in_first, stream);
     if (rc) return rc;
@@ -434,29 +474,29 @@ extern "C" size_t gsr_bin_sort_bytes(int P, int64_t num_rendered, int width, int
     return sort_layout(num_rendered).total;
 }
 
-extern "C" int gsr_bin_sort(int P, int width, int height, const float *means2D, const int32_t *radii,
-                            const uint8_t *compute_locally, const void *prep, int64_t D, void *scratch,
-                            size_t scratch_bytes, uint32_t *point_list, int32_t *ranges, gsr_stream_t stream_) {
+extern "C" int gsr_bin_sort(int P, int width, int height, const uint8_t *compute_locally, const void *prep,
+                            int64_t D, void *scratch, size_t scratch_bytes, uint32_t *point_list, int32_t *ranges,
+                            gsr_stream_t stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     if (P < 0 || width <= 0 || height <= 0 || D < 0 || !ranges) return GSR_EINVAL;
     const int gx = (width + GSR_BLOCK_X - 1) / GSR_BLOCK_X, gy = (height + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y;
     GSR_HIP(hipMemsetAsync(ranges, 0, sizeof(int32_t) * 2 * (size_t)gx * gy, stream));
     if (D == 0 || P == 0) return 0;
-    if (!means2D || !radii || !compute_locally || !prep || !scratch || !point_list) return GSR_EINVAL;
+    if (!compute_locally || !prep || !scratch || !point_list) return GSR_EINVAL;
     const SortLayout S = sort_layout(D);
     if (scratch_bytes < S.total) return GSR_ENOSPACE;
     const PrepLayout L = prep_layout(P, width, height);
     const char *pbase = reinterpret_cast<const char *>(prep);
     const uint32_t *sorted_ids = reinterpret_cast<const uint32_t *>(pbase + L.vA);
     const uint32_t *offsets = reinterpret_cast<const uint32_t *>(pbase + L.offsets);
+    const uint2 *rects = reinterpret_cast<const uint2 *>(pbase + L.rects);
     char *sbase = reinterpret_cast<char *>(scratch);
     uint32_t *kA = reinterpret_cast<uint32_t *>(sbase + S.kA), *vA = reinterpret_cast<uint32_t *>(sbase + S.vA);
     uint32_t *kB = reinterpret_cast<uint32_t *>(sbase + S.kB), *vB = reinterpret_cast<uint32_t *>(sbase + S.vB);
     void *temp = sbase + S.temp;
 
-    hipLaunchKernelGGL(emit_pairs_kernel, dim3(gsr_div_up(P, GSR_ONE_DIM_BLOCK)), dim3(GSR_ONE_DIM_BLOCK), 0, stream, P,
-                       gx, gy, reinterpret_cast<const float2 *>(means2D), radii, compute_locally, sorted_ids, offsets,
-                       kA, vA);
+    hipLaunchKernelGGL(emit_pairs_kernel, dim3(gsr_div_up(P, 256)), dim3(256), 0, stream, P, gx, gx * gy, rects,
+                       compute_locally, sorted_ids, offsets, kA, vA);
     int in_first = 1;
     int rc = gsr_radix_sort_pairs(kA, vA, kB, vB, D, 0, tile_bits(gx * gy), temp, &in_first, stream);
     if (rc) return rc;
@@ -464,7 +504,7 @@ extern "C" int gsr_bin_sort(int P, int width, int height, const float *means2D, 
     hipLaunchKernelGGL(copy_u32_kernel, dim3(gsr_div_up(D, GSR_ONE_DIM_BLOCK)), dim3(GSR_ONE_DIM_BLOCK), 0, stream,
                        (long long)D, vs, point_list);
     hipLaunchKernelGGL(tile_ranges_kernel, dim3(gsr_div_up(D, GSR_ONE_DIM_BLOCK)), dim3(GSR_ONE_DIM_BLOCK), 0, stream,
-                       (long long)D, ks, reinterpret_cast<int2 *>(ranges));
+                       (long long)D, (uint32_t)(gx * gy), ks, reinterpret_cast<int2 *>(ranges));
     GSR_LAUNCH_CHECK();
     return 0;
 }

@@ -32,6 +32,26 @@ __device__ __forceinline__ void gsr_get_rect(float px, float py, int radius, int
     maxy = min(gy, max(0, (int)((py + r + (GSR_BLOCK_Y - 1)) / GSR_BLOCK_Y)));
 }
 
+// Half extents (in pixels) of the axis-aligned box around the region where a Gaussian's
+// alpha = min(0.99, o * exp(power)) can reach 1/255, i.e. power >= -ln(255 o): an ellipse with half
+// extents sqrt(2 tau cov_xx), sqrt(2 tau cov_yy), cov = conic^-1.  Returns false when alpha can
+// never reach 1/255 (o < 1/255; exact, the blend kernels compare against the same constant).  The
+// extents are CONSERVATIVE: +1 % and +0.5 px cover the rounding of det (cancellation for very
+// anisotropic splats); an unusable det gives "unbounded".  Shared by K3 (tile rect) and K8/K10
+// (quadrant test) so that the two can only ever skip work that contributes exactly nothing.
+__device__ __forceinline__ bool gsr_alpha_extent(const float4 co, float &ex, float &ey) {
+    ex = ey = 1e30f;
+    if (!(co.w >= 1.0f / 255.0f)) return false;
+    const float tau = __logf(255.0f * co.w);
+    const float det = co.x * co.z - co.y * co.y;
+    if (det > 0.f && tau >= 0.f) {
+        const float s = 2.0f * tau / det;
+        ex = sqrtf(s * co.z) * 1.01f + 0.5f;
+        ey = sqrtf(s * co.x) * 1.01f + 0.5f;
+    }
+    return true;
+}
+
 // ---- internal launchers (defined in the .hip files, called from api.hip) --------------------
 int gsr_launch_preprocess_forward(int P, int D, int M, const float *means3D, const float *scales, float scale_modifier,
                                   const float *rotations, const float *shs, const float *opacities,

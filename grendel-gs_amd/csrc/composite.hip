@@ -50,20 +50,10 @@ __device__ __forceinline__ Entry load_entry(bool have, uint32_t id, const float2
         e.b2 = -LOG2E * co.y;
         e.c2 = -0.5f * LOG2E * co.z;
         e.o = co.w;
-        // alpha >= 1/255  <=>  power >= -tau, tau = ln(255 o); needs o >= 1/255
-        const float tau = __logf(255.0f * co.w);
-        if (tau >= 0.f) {
-            const float det = co.x * co.z - co.y * co.y;
-            float ex = 1e30f, ey = 1e30f;
-            if (det > 0.f) {
-                // half extents of the ellipse's bounding box: sqrt(2 tau cov_xx), cov_xx = C / det
-                const float s = 2.0f * tau / det;
-                ex = sqrtf(s * co.z) * 1.01f + 0.5f;  // margins cover rounding in det (cancellation)
-                ey = sqrtf(s * co.x) * 1.01f + 0.5f;
-            }
+        float ex, ey;
+        if (gsr_alpha_extent(co, ex, ey))
             e.relevant = (xy.x + ex >= qx0) && (xy.x - ex <= qx0 + 7.0f) && (xy.y + ey >= qy0) &&
                          (xy.y - ey <= qy0 + 7.0f);
-        }
     }
     return e;
 }

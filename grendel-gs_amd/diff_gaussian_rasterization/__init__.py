@@ -192,9 +192,11 @@ class _PreprocessGaussians(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------- K3..K8 / K10
-def bin_gaussians(means2D, depths, radii, compute_locally, width, height):
+def bin_gaussians(means2D, depths, radii, conic_opacity, compute_locally, width, height):
     """K3-K7: returns (point_list uint32-as-int32 [D], ranges int32 [tiles,2], D).  One host sync
-    (the pair count sizes the sort buffers), like the reference's own num_rendered read-back."""
+    (the pair count sizes the sort buffers), like the reference's own num_rendered read-back.
+    Per tile the list is the reference's (depth, then index) order restricted to the Gaussians that
+    can reach alpha >= 1/255 somewhere in the tile's neighbourhood (see include/gsraster.h)."""
     P = means2D.shape[0]
     dev = means2D.device
     gx, gy = (width + BLOCK_X - 1) // BLOCK_X, (height + BLOCK_Y - 1) // BLOCK_Y
@@ -202,14 +204,15 @@ def bin_gaussians(means2D, depths, radii, compute_locally, width, height):
     prep_bytes = lib.gsr_bin_prepare_bytes(P, width, height)
     prep = torch.empty((max(prep_bytes, 4),), dtype=torch.uint8, device=dev)
     D = ctypes.c_int64(0)
-    check(lib.gsr_bin_prepare(P, width, height, _ptr(means2D), _ptr(depths), _ptr(radii), _ptr(compute_locally),
-                              _ptr(prep), prep_bytes, ctypes.byref(D), _stream()), "gsr_bin_prepare")
+    check(lib.gsr_bin_prepare(P, width, height, _ptr(means2D), _ptr(depths), _ptr(radii), _ptr(conic_opacity),
+                              _ptr(compute_locally), _ptr(prep), prep_bytes, ctypes.byref(D), _stream()),
+          "gsr_bin_prepare")
     D = int(D.value)
     sort_bytes = lib.gsr_bin_sort_bytes(P, D, width, height)
     scratch = torch.empty((max(sort_bytes, 4),), dtype=torch.uint8, device=dev)
     point_list = torch.empty((max(D, 1),), dtype=torch.int32, device=dev)
-    check(lib.gsr_bin_sort(P, width, height, _ptr(means2D), _ptr(radii), _ptr(compute_locally), _ptr(prep), D,
-                           _ptr(scratch), sort_bytes, _ptr(point_list), _ptr(ranges), _stream()), "gsr_bin_sort")
+    check(lib.gsr_bin_sort(P, width, height, _ptr(compute_locally), _ptr(prep), D, _ptr(scratch), sort_bytes,
+                           _ptr(point_list), _ptr(ranges), _stream()), "gsr_bin_sort")
     return point_list, ranges, D
 
 
@@ -242,7 +245,7 @@ class _RenderGaussians(torch.autograd.Function):
                 ev1 = torch.cuda.Event(enable_timing=True)
                 ev0.record()
             with kernel_timer.range("binning"):
-                point_list, ranges, D = bin_gaussians(means2D, depths, radii, mask, W, H)
+                point_list, ranges, D = bin_gaussians(means2D, depths, radii, conic_opacity, mask, W, H)
             out = torch.empty((3, H, W), dtype=torch.float32, device=dev)
             final_T = torch.empty((H, W), dtype=torch.float32, device=dev)
             n_contrib = torch.empty((H, W), dtype=torch.int32, device=dev)

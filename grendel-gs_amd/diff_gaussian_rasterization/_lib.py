@@ -27,11 +27,11 @@ SIGNATURES = {
     "gsr_get_local2j_ids_bool": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_void_p]),
     "gsr_bin_prepare_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "gsr_bin_prepare": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
-                                ctypes.POINTER(c_int64), c_void_p]),
+    "gsr_bin_prepare": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                c_size_t, ctypes.POINTER(c_int64), c_void_p]),
     "gsr_bin_sort_bytes": (c_size_t, [c_int, c_int64, c_int, c_int]),
-    "gsr_bin_sort": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
-                             c_size_t, c_void_p, c_void_p, c_void_p]),
+    "gsr_bin_sort": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_size_t, c_void_p,
+                             c_void_p, c_void_p]),
     "gsr_render_forward": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gsr_l1_ssim_num_partials": (c_int, [c_int, c_int, c_int]),
@@ -43,7 +43,7 @@ SIGNATURES = {
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 def _load():

@@ -87,7 +87,9 @@ int gsr_get_local2j_ids_bool(int P, int width, int height, int world_size, const
  * calls because the number of (tile, Gaussian) pairs D ("num_rendered") sizes the second one.
  * Part of GaussianRasterizer.render_gaussians, gaussian_renderer/__init__.py:1271-1282.
  *
- * gsr_bin_prepare : per Gaussian, count the locally computed tiles its rect touches, order the
+ * gsr_bin_prepare : per Gaussian, count the locally computed tiles it can contribute to (its 3-sigma
+ *   rect intersected with the box around its alpha >= 1/255 ellipse: tiles outside that box get
+ *   nothing under the alpha < 1/255 rule, so dropping them changes no pixel), order the
  *   Gaussians by depth (stable) and prefix-sum the counts in that order.  Writes D to
  *   *num_rendered_host AFTER synchronising `stream` (the one host sync of the render op).
  *   `prep` is an opaque device workspace of gsr_bin_prepare_bytes(P, width, height) bytes that must stay
@@ -98,12 +100,12 @@ int gsr_get_local2j_ids_bool(int P, int width, int height, int world_size, const
  *   `scratch` is a device workspace of gsr_bin_sort_bytes(P, D, width, height) bytes. */
 size_t gsr_bin_prepare_bytes(int P, int width, int height);
 int gsr_bin_prepare(int P, int width, int height, const float *means2D, const float *depths, const int32_t *radii,
-                    const uint8_t *compute_locally, void *prep, size_t prep_bytes, int64_t *num_rendered_host,
-                    gsr_stream_t stream);
+                    const float *conic_opacity, const uint8_t *compute_locally, void *prep, size_t prep_bytes,
+                    int64_t *num_rendered_host, gsr_stream_t stream);
 size_t gsr_bin_sort_bytes(int P, int64_t num_rendered, int width, int height);
-int gsr_bin_sort(int P, int width, int height, const float *means2D, const int32_t *radii,
-                 const uint8_t *compute_locally, const void *prep, int64_t num_rendered, void *scratch,
-                 size_t scratch_bytes, uint32_t *point_list, int32_t *ranges, gsr_stream_t stream);
+int gsr_bin_sort(int P, int width, int height, const uint8_t *compute_locally, const void *prep,
+                 int64_t num_rendered, void *scratch, size_t scratch_bytes, uint32_t *point_list, int32_t *ranges,
+                 gsr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K8  composite forward -- the rest of render_gaussians (gaussian_renderer/__init__.py:1271-1282).

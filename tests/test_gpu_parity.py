@@ -62,7 +62,10 @@ def test_preprocess_forward_matches_c_oracle(device, N, W, H, sc, seed, ci, sh_d
 
 
 @pytest.mark.parametrize("N,W,H,sc,seed,ci", SCENES)
-def test_binning_matches_oracle_exactly(device, N, W, H, sc, seed, ci):
+def test_binning_is_ordered_subsequence_of_reference_lists(device, N, W, H, sc, seed, ci):
+    """per tile: the HIP list is a SUBSEQUENCE of the reference-order list (depth, then index), and
+    every Gaussian dropped from a tile has alpha < 1/255 on all of the tile's pixels (float64 check),
+    i.e. the reference algorithm would have skipped it on every pixel"""
     from diff_gaussian_rasterization import bin_gaussians
     from oracle import cref as C
 
@@ -73,15 +76,36 @@ def test_binning_matches_oracle_exactly(device, N, W, H, sc, seed, ci):
     mask[1:3, :] = False  # a non-local band
     mask[-1, ::2] = False  # and a ragged pattern (general masks are allowed by the API)
     pl_ref, ranges_ref, _ = C.bin_and_sort(m2, radii, depths, mask, W, H)
-    pl, ranges, D = bin_gaussians(m2.to(device), depths.to(device), radii.to(device),
+    pl, ranges, D = bin_gaussians(m2.to(device), depths.to(device), radii.to(device), co.to(device),
                                   mask.view(-1).to(torch.uint8).to(device), W, H)
-    assert D == pl_ref.numel()
-    assert torch.equal(pl[:D].cpu(), pl_ref), "per-tile lists must be bit-identical (stable depth order)"
-    lens_ref = ranges_ref[:, 1] - ranges_ref[:, 0]
-    lens = (ranges[:, 1] - ranges[:, 0]).cpu()
-    assert torch.equal(lens, lens_ref)
-    nz = lens_ref > 0
-    assert torch.equal(ranges.cpu()[nz], ranges_ref[nz])
+    pl, ranges = pl.cpu().long(), ranges.cpu()
+    gx = (W + 15) // 16
+    dropped_total, kept_total = 0, 0
+    m2d, cod = m2.double(), co.double()
+    for t in range(ranges.shape[0]):
+        rs, re = int(ranges_ref[t, 0]), int(ranges_ref[t, 1])
+        s, e = int(ranges[t, 0]), int(ranges[t, 1])
+        if not bool(mask.view(-1)[t]):
+            assert e - s == 0 and re - rs == 0
+            continue
+        ref_list, mine = pl_ref[rs:re].long(), pl[s:e]
+        keep = torch.isin(ref_list, mine)
+        assert torch.equal(ref_list[keep], mine), f"tile {t}: not an order-preserving subsequence"
+        drop = ref_list[~keep]
+        dropped_total += drop.numel()
+        kept_total += mine.numel()
+        if drop.numel():
+            ty, tx = divmod(t, gx)
+            py, px = torch.meshgrid(torch.arange(ty * 16, min(ty * 16 + 16, H)),
+                                    torch.arange(tx * 16, min(tx * 16 + 16, W)), indexing="ij")
+            dx = m2d[drop, 0:1] - px.reshape(1, -1).double()
+            dy = m2d[drop, 1:2] - py.reshape(1, -1).double()
+            power = -0.5 * (cod[drop, 0:1] * dx * dx + cod[drop, 2:3] * dy * dy) - cod[drop, 1:2] * dx * dy
+            alpha = cod[drop, 3:4] * torch.exp(power)
+            alpha = torch.where(power > 0, torch.zeros_like(alpha), alpha)
+            assert alpha.max().item() < 1.0 / 255.0, f"tile {t}: a dropped Gaussian would have contributed"
+    assert kept_total > 0
+    print(f"pairs kept {kept_total}, dropped {dropped_total} of {pl_ref.numel()}")
 
 
 @pytest.mark.parametrize("N,W,H,sc,seed,ci", SCENES)
@@ -115,7 +139,7 @@ def test_full_chain_matches_c_oracle(device, N, W, H, sc, seed, ci, bgv):
     assert img[:, ~pm.to(device)].abs().sum().item() == 0.0
     assert rel_err(img, ref["image"]) < RTOL
     assert frac_bad(img, ref["image"], rtol=1e-3, atol=1e-4) < 2e-4
-    assert (n_contrib.cpu() != ref["n_contrib"]).double().mean().item() < 2e-4
+    assert n_contrib.shape == (H, W) and n_contrib.dtype == torch.int32  # positions in the (culled) HIP lists
     (img * wgt.to(device)).sum().backward()
     assert rel_err(rgb.grad, ref["d_rgb"]) < RTOL
     assert rel_err(co.grad, ref["d_conic_opacity"]) < RTOL
@@ -255,7 +279,7 @@ def test_saturating_stack_early_stop(device):
     m2, rgb, co, radii, depths = rast.preprocess_gaussians(*[gg[k] for k in KEYS], {})
     img, _, _, nc = rast.render_gaussians(m2, co, rgb, depths, radii, mask.to(device), None, {})
     assert ref["final_T"].min().item() >= 1e-4 * 0.99
-    assert (nc.cpu() != ref["n_contrib"]).double().mean().item() < 5e-3
+    assert int(nc.max()) <= n and int(nc.max()) < int(ref["n_contrib"].max()) + 1
     assert rel_err(img, ref["image"]) < RTOL
     img.sum().backward()
     assert rel_err(gg["opacities"].grad, ref["d_opacities"]) < 5e-4
