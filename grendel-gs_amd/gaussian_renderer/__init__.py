@@ -119,9 +119,9 @@ def all_to_all_communication_final(batched_rasterizers, batched_screenspace_para
             need[g, k] = band_mask[:, j]
 
     counts = need.sum(dim=2, dtype=torch.int32)  # [W(dst), B]
-    all_counts = torch.empty((W, W, B), dtype=torch.int32, device=dev)
+    all_counts = torch.empty((W * W, B), dtype=torch.int32, device=dev)  # dim-0 concatenation of the [W, B] inputs
     dist.all_gather_into_tensor(all_counts, counts.contiguous(), group=group)
-    sizes = all_counts.cpu().tolist()  # the one host read-back of the exchange; sizes[i][j][k]
+    sizes = all_counts.view(W, W, B).cpu().tolist()  # the one host read-back of the exchange; sizes[i][j][k]
     send_splits = [sum(sizes[me][j]) for j in range(W)]
     recv_splits = [sum(sizes[i][me]) for i in range(W)]
 

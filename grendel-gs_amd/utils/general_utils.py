@@ -156,8 +156,9 @@ def our_allgather_among_cpu_processes_float_list(data, group):
     assert isinstance(data, list) and isinstance(data[0], float), "data should be a list of float"
     t = torch.tensor(data, dtype=torch.float32, device=device())
     if group.size() > 1:
-        out = torch.empty((group.size(), len(data)), dtype=torch.float32, device=t.device)
+        out = torch.empty((group.size() * len(data),), dtype=torch.float32, device=t.device)
         dist.all_gather_into_tensor(out, t, group=group)
+        out = out.view(group.size(), len(data))
     else:
         out = t.unsqueeze(0)
     return out.cpu().tolist()

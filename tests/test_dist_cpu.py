@@ -1,0 +1,199 @@
+"""world_size-2 (and 3) `gloo` tests of the multi-GPU path on CPU: partition strategy, the fused sparse
+all-to-all exchange (forward ordering + backward scatter-add through the mirror all-to-all), render of
+row bands and SUM assembly.  The per-rank device ops (K1, K2, K3-K10) are played by the torch oracle
+-- test infrastructure -- because this container has no GPU; everything else is the product's host code
+(grendel-gs_amd/gaussian_renderer/*, utils/general_utils.py)."""
+import math
+import os
+import socket
+import sys
+import traceback
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, bsz, q):
+    try:
+        for p in (os.path.join(ROOT, "grendel-gs_amd"), ROOT, os.path.join(ROOT, "tests")):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                          MASTER_PORT=str(port))
+        torch.set_num_threads(1)
+        import diff_gaussian_rasterization as dgr
+        import synthetic_scene as S
+        import utils.general_utils as utils
+        from oracle import torch_oracle as O
+
+        utils.init_distributed(backend="gloo")
+        utils.set_args(utils.default_args(bsz=bsz))
+        N, W, H = 1200, 160, 112
+        utils.set_img_size(H, W)
+        utils.set_cur_iter(1)
+
+        # K2 stand-in (the HIP op needs a GPU): same contract, oracle arithmetic
+        def k2(image_height, image_width, mp_rank, mp_world_size, means2D, radii, div, cuda_args=None):
+            return O.get_local2j_ids_bool(image_height, image_width, mp_world_size, means2D.detach(), radii, div)
+
+        dgr._C.get_local2j_ids_bool = staticmethod(k2)
+        from gaussian_renderer import all_to_all_communication_final, get_cuda_args_final
+        from gaussian_renderer.workload_division import (DivisionStrategyHistoryFinal, finish_strategy_final,
+                                                         start_strategy_final)
+
+        cams = S.orbit_cameras(max(bsz, 2), W, H)[:bsz]
+        hist = DivisionStrategyHistoryFinal(S.SyntheticDataset(cams), world, rank)
+        if bsz < world:  # skew the cost so that the cut is not in the middle
+            hist.accum_heuristic[cams[0].uid][: utils.TILE_Y // 2] = 3.0
+        strategies, tasks = start_strategy_final(cams, hist)
+        # every tile row of every camera is rendered by exactly one rank
+        for k in range(bsz):
+            rows = sorted((l, r) for g in range(world) for (kk, l, r) in tasks[g] if kk == k)
+            assert rows[0][0] == 0 and rows[-1][1] == utils.TILE_Y
+            assert all(a[1] == b[0] for a, b in zip(rows[:-1], rows[1:]))
+
+        full = S.make_gaussians(N, W, H, seed=7, scale_coef=0.015)
+        chunk = (N + world - 1) // world
+        sl = slice(rank * chunk, min((rank + 1) * chunk, N))
+        mine = {k: v[sl].double().clone().requires_grad_(True) for k, v in full.items()}
+        keys = ["means3D", "scales", "rotations", "shs", "opacities"]
+        bg = torch.tensor([0.2, 0.3, 0.4], dtype=torch.float64)
+        gen = torch.Generator().manual_seed(3)
+        wgts = [torch.rand(3, H, W, generator=gen).double() for _ in range(bsz)]
+
+        def cam_kw(cam):
+            return dict(viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform,
+                        campos=cam.camera_center, W=W, H=H, tanfovx=math.tan(cam.FoVx / 2),
+                        tanfovy=math.tan(cam.FoVy / 2), sh_degree=3)
+
+        class R:  # rasterizer duck-type: the exchange only reads raster_settings.image_height/width
+            def __init__(self):
+                self.raster_settings = type("RS", (), {"image_height": H, "image_width": W})()
+
+        params, cargs = [], []
+        for cam, st in zip(cams, strategies):
+            m2, rgb, co, radii, depths = O.preprocess(*[mine[k] for k in keys], **cam_kw(cam))
+            params.append([m2, rgb, co, radii, depths])
+            cargs.append(get_cuda_args_final(st, "train"))
+        m2s, rgbs, cos, radiis, depthss, sizes = all_to_all_communication_final([R() for _ in cams], params, cargs,
+                                                                                strategies)
+        assert len(sizes) == world and len(sizes[0]) == world and len(sizes[0][0]) == bsz
+        loss = torch.zeros((), dtype=torch.float64)
+        images = []
+        for k, st in enumerate(strategies):
+            img = torch.zeros(3, H, W, dtype=torch.float64)
+            if rank in st.gpu_ids:
+                mask = st.get_compute_locally()
+                assert m2s[k].shape[0] == sum(sizes[i][rank][k] for i in range(world))
+                if m2s[k].shape[0] > 0:
+                    img, _, _ = O.render(m2s[k], cos[k], rgbs[k], depthss[k], radiis[k], mask, bg=bg, W=W, H=H)
+                loss = loss + (img * wgts[k]).sum()
+            else:
+                assert m2s[k].shape[0] == 0
+            images.append(img.detach())
+        loss = loss + 0.0 * sum(p[0].sum() for p in params)  # keep the graph alive on idle ranks
+        loss.backward()
+        stats = [c["stats_collector"] for c in cargs]
+        for s_ in stats:
+            s_.update(forward_render_time=1.0 + rank, backward_render_time=2.0, forward_loss_time=0.5)
+        finish_strategy_final(cams, hist, strategies, stats)
+        assert len(hist.history) == 1 and len(hist.history[0]["all_gpu_running_time"]) == world
+
+        # SUM assembly of the row bands (train_internal.py:466-469)
+        stack = torch.stack(images)
+        dist.all_reduce(stack)
+        # single-process reference on rank 0
+        grads = [mine[k].grad if mine[k].grad is not None else torch.zeros_like(mine[k]) for k in keys]
+        gathered = []
+        for gtensor in grads:
+            lst = [torch.zeros((min((r + 1) * chunk, N) - r * chunk,) + tuple(gtensor.shape[1:]), dtype=torch.float64)
+                   for r in range(world)]
+            dist.all_gather(lst, gtensor.contiguous())
+            gathered.append(torch.cat(lst, 0))
+        if rank == 0:
+            ref_in = {k: v.double().clone().requires_grad_(True) for k, v in full.items()}
+            ref_loss = 0
+            for k, cam in enumerate(cams):
+                m2, rgb, co, radii, depths = O.preprocess(*[ref_in[x] for x in keys], **cam_kw(cam))
+                mask = torch.ones(utils.TILE_Y, utils.TILE_X, dtype=torch.bool)
+                img, _, _ = O.render(m2, co, rgb, depths, radii, mask, bg=bg, W=W, H=H)
+                err = (img.detach() - stack[k]).abs().max().item()
+                assert err < 1e-9, f"camera {k}: partitioned render differs from the single-rank render by {err}"
+                ref_loss = ref_loss + (img * wgts[k]).sum()
+            ref_loss.backward()
+            for name, gth in zip(keys, gathered):
+                ref = ref_in[name].grad
+                rel = ((gth - ref).norm() / (ref.norm() + 1e-30)).item()
+                assert rel < 1e-9, f"{name}: gradient through the exchange differs, rel {rel}"
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        q.put((rank, traceback.format_exc()))
+
+
+@pytest.mark.parametrize("world,bsz", [(2, 1), (2, 2), (3, 2)])
+def test_partitioned_exchange_render_matches_single_rank(world, bsz):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, bsz, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in results:
+        assert msg == "ok", f"rank {rank}:\n{msg}"
+
+
+def test_start_strategy_cut_points():
+    """cut-point arithmetic of start_strategy_final against hand-computed cases (workload_division.py:852-941)"""
+    sys.path.insert(0, os.path.join(ROOT, "grendel-gs_amd"))
+    import synthetic_scene as S
+    import utils.general_utils as utils
+    from gaussian_renderer.workload_division import (DivisionStrategyHistoryFinal, division_pos_heuristic,
+                                                     start_strategy_final)
+
+    class G:
+        def __init__(self, n):
+            self.n = n
+
+        def size(self):
+            return self.n
+
+        def rank(self):
+            return 0
+
+    utils.GLOBAL_RANK, utils.WORLD_SIZE = 0, 4
+    utils.DEFAULT_GROUP = G(4)
+    utils.set_args(utils.default_args(bsz=1))
+    utils.set_img_size(1080, 1920)  # 68 tile rows
+    cams = S.orbit_cameras(2, 1920, 1080)
+    hist = DivisionStrategyHistoryFinal(S.SyntheticDataset(cams), 4, 0)
+    st, tasks = start_strategy_final(cams[:1], hist)
+    assert st[0].division_pos == [0, 17, 34, 51, 68] and st[0].gpu_ids == [0, 1, 2, 3]
+    assert tasks == [[(0, 0, 17)], [(0, 17, 34)], [(0, 34, 51)], [(0, 51, 68)]]
+    # bsz 2 on 4 ranks: two ranks per image, cuts snap onto the image border
+    utils.set_args(utils.default_args(bsz=2))
+    st, tasks = start_strategy_final(cams, hist)
+    assert [s.gpu_ids for s in st] == [[0, 1], [2, 3]]
+    assert st[0].division_pos == [0, 34, 68] and st[1].division_pos == [0, 34, 68]
+    # skewed cost moves the cut; equal-cost rule of division_pos_heuristic
+    h = torch.ones(68)
+    h[:34] = 3.0
+    assert division_pos_heuristic(h, 68, 2, right=True) == [0, 22, 68]  # prefix 3(i+1): first index with prefix > 68 is 22
+    utils.DEFAULT_GROUP = utils.SingleGPUGroup()
+    utils.WORLD_SIZE = 1
