@@ -52,6 +52,32 @@ __device__ __forceinline__ bool gsr_alpha_extent(const float4 co, float &ex, flo
     return true;
 }
 
+// Exact (up to a conservative tolerance) test "can this Gaussian reach alpha >= 1/255 on some pixel
+// centre inside the box [x0,x1] x [y0,y1]?": alpha >= 1/255 <=> power >= -tau with tau = ln(255 o) and
+// power(d) = -1/2 (A dx^2 + 2 B dx dy + C dy^2) concave, so the question is whether the MINIMUM of the
+// quadratic form over the box is <= 2 tau.  The centre inside the box gives 0; otherwise the minimum
+// lies on the boundary and is the smallest of the four edges' 1-D minima (vertex clamped to the edge).
+// Tolerance: 2 tau is inflated by 0.2 % + 0.01 (alpha error < 1 % of 1/255) -- only ever keeps more.
+__device__ __forceinline__ float gsr_edge_min_q(float a, float b, float c, float u, float v0, float v1) {
+    // min over v in [v0,v1] of a u^2 + 2 b u v + c v^2   (c > 0)
+    const float vs = fminf(v1, fmaxf(v0, -b * u / c));
+    return a * u * u + (2.0f * b * u + c * vs) * vs;
+}
+__device__ __forceinline__ bool gsr_can_touch_box(const float2 xy, const float4 co, float x0, float y0, float x1,
+                                                  float y1) {
+    if (!(co.w >= 1.0f / 255.0f)) return false;
+    const float lim = 2.0f * __logf(255.0f * co.w) * 1.002f + 0.01f;
+    // box in coordinates relative to the centre: d = pixel - centre (sign irrelevant for the form)
+    const float l = x0 - xy.x, r = x1 - xy.x, t = y0 - xy.y, bt = y1 - xy.y;
+    if (l <= 0.f && r >= 0.f && t <= 0.f && bt >= 0.f) return true;
+    if (!(co.x > 0.f && co.z > 0.f)) return true;  // not a proper conic: do not cull
+    float q = gsr_edge_min_q(co.x, co.y, co.z, l, t, bt);           // edge x = x0
+    q = fminf(q, gsr_edge_min_q(co.x, co.y, co.z, r, t, bt));       // edge x = x1
+    q = fminf(q, gsr_edge_min_q(co.z, co.y, co.x, t, l, r));        // edge y = y0
+    q = fminf(q, gsr_edge_min_q(co.z, co.y, co.x, bt, l, r));       // edge y = y1
+    return !(q > lim);  // NaN -> keep
+}
+
 // ---- internal launchers (defined in the .hip files, called from api.hip) --------------------
 int gsr_launch_preprocess_forward(int P, int D, int M, const float *means3D, const float *scales, float scale_modifier,
                                   const float *rotations, const float *shs, const float *opacities,

@@ -23,6 +23,13 @@ constexpr float LOG2E = 1.4426950408889634f;
 constexpr float ALPHA_MIN = 1.0f / 255.0f;
 constexpr float T_STOP = 0.0001f;
 
+#ifdef GSR_STATS
+__device__ unsigned long long g_stats[8];
+#define GSR_STAT(i, v) do { const unsigned long long sv__ = (unsigned long long)(v); if (lane == 0) atomicAdd(&g_stats[i], sv__); } while (0)
+#else
+#define GSR_STAT(i, v) do { } while (0)
+#endif
+
 __device__ __forceinline__ float bcast(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
@@ -50,10 +57,7 @@ __device__ __forceinline__ Entry load_entry(bool have, uint32_t id, const float2
         e.b2 = -LOG2E * co.y;
         e.c2 = -0.5f * LOG2E * co.z;
         e.o = co.w;
-        float ex, ey;
-        if (gsr_alpha_extent(co, ex, ey))
-            e.relevant = (xy.x + ex >= qx0) && (xy.x - ex <= qx0 + 7.0f) && (xy.y + ey >= qy0) &&
-                         (xy.y - ey <= qy0 + 7.0f);
+        e.relevant = gsr_can_touch_box(xy, co, qx0, qy0, qx0 + 7.0f, qy0 + 7.0f);
     }
     return e;
 }
@@ -104,6 +108,8 @@ composite_forward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
             b = rgb[3 * (size_t)id + 2];
         }
         unsigned long long m = __ballot(e.relevant);
+        GSR_STAT(0, __popcll(__ballot(have)));
+        GSR_STAT(1, __popcll(m));
         while (m) {
             const int k = __builtin_ctzll(m);
             m &= m - 1;
@@ -113,6 +119,8 @@ composite_forward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
             const float p2 = (a2 * dx + b2 * dy) * dx + c2 * dy * dy;
             const float alpha = fminf(0.99f, o * __builtin_amdgcn_exp2f(p2));
             const bool take = !done && p2 <= 0.f && alpha >= ALPHA_MIN;
+            GSR_STAT(2, __any(take) ? 1 : 0);
+            GSR_STAT(3, __popcll(__ballot(take)));
             const float test_T = T * (1.0f - alpha);
             const bool stop = take && test_T < T_STOP;
             done = done || stop;
@@ -236,7 +244,8 @@ composite_backward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
                 float v_mx = 0.f, v_my = 0.f, v_a = 0.f, v_b = 0.f, v_c = 0.f, v_o = 0.f, v_r = 0.f, v_g = 0.f,
                       v_bl = 0.f;
                 if (take) {
-                    T = T / (1.f - alpha);
+                    const float inv_1ma = __builtin_amdgcn_rcpf(1.f - alpha);  // 1 ulp; well inside the 1e-4 budget
+                    T = T * inv_1ma;
                     const float w = alpha * T;
                     acc0 = last_alpha * lastc0 + (1.f - last_alpha) * acc0;
                     acc1 = last_alpha * lastc1 + (1.f - last_alpha) * acc1;
@@ -245,7 +254,7 @@ composite_backward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
                     float dL_dalpha = (cr - acc0) * g0 + (cg - acc1) * g1 + (cb - acc2) * g2;
                     dL_dalpha *= T;
                     last_alpha = alpha;
-                    dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
+                    dL_dalpha += (-T_final * inv_1ma) * bg_dot;
                     const float dL_dG = o * dL_dalpha;  // min(0.99,.) treated as identity
                     const float gdx = G * dx, gdy = G * dy;
                     v_mx = dL_dG * (-gdx * A - gdy * B) * ddelx_dx;
@@ -302,6 +311,17 @@ composite_backward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
 }
 
 }  // namespace
+
+#ifdef GSR_STATS
+extern "C" int gsr_debug_stats(unsigned long long *out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_stats), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_stats), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 int gsr_launch_composite_forward(int P, int W, int H, const int32_t *ranges, const uint32_t *point_list,
                                  const float *means2D, const float *conic_opacity, const float *rgb,
