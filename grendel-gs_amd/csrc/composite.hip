@@ -163,6 +163,51 @@ __device__ __forceinline__ float wave_sum_to_63(float v) {
     return v;
 }
 
+// Transposed wave reduction: every lane brings 64 values x[0..63]; on return lane L holds
+// sum over all 64 lanes of x[L].  Butterfly over lane-index bits 5..0; at each stage a lane keeps the
+// half of the values whose index bit equals its lane bit and hands the other half to its partner:
+// v_permlane32_swap / v_permlane16_swap (gfx950) for distances 32 / 16, DPP row rotations and quad
+// permutes below.  ~150 VALU instructions for 64 sums instead of 64 x (6 DPP adds + readlane).
+#define GSR_DPPF(x, ctrl, rmask, bmask, oldv) \
+    __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(oldv), __float_as_int(x), ctrl, rmask, bmask, false))
+__device__ __forceinline__ float transpose_reduce64(float (&x)[64], int lane) {
+    float y[32];
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x[i]), __float_as_uint(x[i + 32]), false, false);
+        y[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    float z[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(y[i]), __float_as_uint(y[i + 16]), false, false);
+        z[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2, b0 = lane & 1;
+    float w[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const float send = b3 ? z[i] : z[i + 8], keep = b3 ? z[i + 8] : z[i];
+        w[i] = keep + GSR_DPPF(send, 0x128, 0xf, 0xf, 0.f);  // row_ror:8 == lane ^ 8 within the row
+    }
+    float u[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const float send = b2 ? w[i] : w[i + 4], keep = b2 ? w[i + 4] : w[i];
+        float recv = GSR_DPPF(send, 0x12C, 0xf, 0x5, 0.f);   // row_ror:12: lanes of banks 0,2 read lane+4
+        recv = GSR_DPPF(send, 0x124, 0xf, 0xa, recv);        // row_ror:4 : lanes of banks 1,3 read lane-4
+        u[i] = keep + recv;
+    }
+    float t[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const float send = b1 ? u[i] : u[i + 2], keep = b1 ? u[i + 2] : u[i];
+        t[i] = keep + GSR_DPPF(send, 0x4E, 0xf, 0xf, 0.f);   // quad_perm [2,3,0,1]
+    }
+    const float send = b0 ? t[0] : t[1], keep = b0 ? t[1] : t[0];
+    return keep + GSR_DPPF(send, 0xB1, 0xf, 0xf, 0.f);       // quad_perm [1,0,3,2]
+}
+
 __global__ void __launch_bounds__(256)
 composite_backward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
                           const uint32_t *__restrict__ point_list, const float2 *__restrict__ means2D,
@@ -212,9 +257,13 @@ composite_backward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
     float lastc0 = 0.f, lastc1 = 0.f, lastc2 = 0.f;
     float last_alpha = 0.f;
 
+    constexpr int EB = 7;  // entries per reduction batch: 7 x 9 = 63 of the 64 butterfly slots
+    const int slot_j = lane / 9, slot_v = lane - 9 * (lane / 9);
+
     for (int c = ((bmax - 1) / 64) * 64; c >= 0; c -= 64) {
-        // this lane's entry: accumulated gradients
-        float s_mx = 0.f, s_my = 0.f, s_a = 0.f, s_b = 0.f, s_c = 0.f, s_o = 0.f, s_r = 0.f, s_g = 0.f, s_bl = 0.f;
+        // per-(entry, value) sums of this wave for this chunk live in its own LDS region
+#pragma unroll
+        for (int v = 0; v < 9; v++) sacc[wave][v][lane] = 0.f;
         if (c < wmax) {  // wave-uniform
             const bool have = c + lane < wmax;
             const uint32_t id = have ? point_list[range.x + c + lane] : 0u;
@@ -229,64 +278,74 @@ composite_backward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
             }
             unsigned long long m = __ballot(e.relevant);
             while (m) {
-                const int k = 63 - __builtin_clzll(m);
-                m &= ~(1ull << k);
-                const float gx_ = bcast(e.x, k), gy_ = bcast(e.y, k);
-                const float a2 = bcast(e.a2, k), b2 = bcast(e.b2, k), c2 = bcast(e.c2, k), o = bcast(e.o, k);
-                const float dx = gx_ - pxf, dy = gy_ - pyf;
-                const float p2 = (a2 * dx + b2 * dy) * dx + c2 * dy * dy;
-                const float G = __builtin_amdgcn_exp2f(p2);
-                const float alpha = fminf(0.99f, o * G);
-                const bool take = (c + k + 1 <= last) && p2 <= 0.f && alpha >= ALPHA_MIN;
-                if (!__any(take)) continue;
-                const float cr = bcast(r, k), cg = bcast(g, k), cb = bcast(b, k);
-                const float A = bcast(co.x, k), B = bcast(co.y, k), Cc = bcast(co.z, k);
-                float v_mx = 0.f, v_my = 0.f, v_a = 0.f, v_b = 0.f, v_c = 0.f, v_o = 0.f, v_r = 0.f, v_g = 0.f,
-                      v_bl = 0.f;
-                if (take) {
-                    const float inv_1ma = __builtin_amdgcn_rcpf(1.f - alpha);  // 1 ulp; well inside the 1e-4 budget
-                    T = T * inv_1ma;
-                    const float w = alpha * T;
-                    acc0 = last_alpha * lastc0 + (1.f - last_alpha) * acc0;
-                    acc1 = last_alpha * lastc1 + (1.f - last_alpha) * acc1;
-                    acc2 = last_alpha * lastc2 + (1.f - last_alpha) * acc2;
-                    lastc0 = cr; lastc1 = cg; lastc2 = cb;
-                    float dL_dalpha = (cr - acc0) * g0 + (cg - acc1) * g1 + (cb - acc2) * g2;
-                    dL_dalpha *= T;
-                    last_alpha = alpha;
-                    dL_dalpha += (-T_final * inv_1ma) * bg_dot;
-                    const float dL_dG = o * dL_dalpha;  // min(0.99,.) treated as identity
-                    const float gdx = G * dx, gdy = G * dy;
-                    v_mx = dL_dG * (-gdx * A - gdy * B) * ddelx_dx;
-                    v_my = dL_dG * (-gdy * Cc - gdx * B) * ddely_dy;
-                    v_a = -0.5f * gdx * dx * dL_dG;
-                    v_b = -gdx * dy * dL_dG;
-                    v_c = -0.5f * gdy * dy * dL_dG;
-                    v_o = G * dL_dalpha;
-                    v_r = w * g0;
-                    v_g = w * g1;
-                    v_bl = w * g2;
+                float xs[64];
+                int ks[EB];
+#pragma unroll
+                for (int j = 0; j < EB; j++) {
+                    // next entry (back to front) that at least one pixel of the quadrant takes
+                    bool got = false, take = false;
+                    int k = 0;
+                    float dx = 0.f, dy = 0.f, o = 0.f, G = 0.f, alpha = 0.f;
+                    while (m) {
+                        k = 63 - __builtin_clzll(m);
+                        m &= ~(1ull << k);
+                        const float gx_ = bcast(e.x, k), gy_ = bcast(e.y, k);
+                        const float a2 = bcast(e.a2, k), b2 = bcast(e.b2, k), c2 = bcast(e.c2, k);
+                        o = bcast(e.o, k);
+                        dx = gx_ - pxf;
+                        dy = gy_ - pyf;
+                        const float p2 = (a2 * dx + b2 * dy) * dx + c2 * dy * dy;
+                        G = __builtin_amdgcn_exp2f(p2);
+                        alpha = fminf(0.99f, o * G);
+                        take = (c + k + 1 <= last) && p2 <= 0.f && alpha >= ALPHA_MIN;
+                        if (__any(take)) {
+                            got = true;
+                            break;
+                        }
+                    }
+                    ks[j] = k;
+                    float v_mx = 0.f, v_my = 0.f, v_a = 0.f, v_b = 0.f, v_c = 0.f, v_o = 0.f, v_r = 0.f, v_g = 0.f,
+                          v_bl = 0.f;
+                    if (got) {  // wave-uniform
+                        const float cr = bcast(r, k), cg = bcast(g, k), cb = bcast(b, k);
+                        const float A = bcast(co.x, k), B = bcast(co.y, k), Cc = bcast(co.z, k);
+                        if (take) {
+                            const float inv_1ma = __builtin_amdgcn_rcpf(1.f - alpha);  // 1 ulp, inside the 1e-4 budget
+                            T = T * inv_1ma;
+                            const float w = alpha * T;
+                            acc0 = last_alpha * lastc0 + (1.f - last_alpha) * acc0;
+                            acc1 = last_alpha * lastc1 + (1.f - last_alpha) * acc1;
+                            acc2 = last_alpha * lastc2 + (1.f - last_alpha) * acc2;
+                            lastc0 = cr; lastc1 = cg; lastc2 = cb;
+                            float dL_dalpha = (cr - acc0) * g0 + (cg - acc1) * g1 + (cb - acc2) * g2;
+                            dL_dalpha *= T;
+                            last_alpha = alpha;
+                            dL_dalpha += (-T_final * inv_1ma) * bg_dot;
+                            const float dL_dG = o * dL_dalpha;  // min(0.99,.) treated as identity
+                            const float gdx = G * dx, gdy = G * dy;
+                            v_mx = dL_dG * (-gdx * A - gdy * B) * ddelx_dx;
+                            v_my = dL_dG * (-gdy * Cc - gdx * B) * ddely_dy;
+                            v_a = -0.5f * gdx * dx * dL_dG;
+                            v_b = -gdx * dy * dL_dG;
+                            v_c = -0.5f * gdy * dy * dL_dG;
+                            v_o = G * dL_dalpha;
+                            v_r = w * g0;
+                            v_g = w * g1;
+                            v_bl = w * g2;
+                        }
+                    }
+                    xs[j * 9 + 0] = v_mx; xs[j * 9 + 1] = v_my; xs[j * 9 + 2] = v_a; xs[j * 9 + 3] = v_b;
+                    xs[j * 9 + 4] = v_c;  xs[j * 9 + 5] = v_o;  xs[j * 9 + 6] = v_r; xs[j * 9 + 7] = v_g;
+                    xs[j * 9 + 8] = v_bl;
                 }
-#ifdef GSR_ABL_NOREDUCE
-                s_mx += v_mx; s_my += v_my; s_a += v_a; s_b += v_b; s_c += v_c; s_o += v_o;
-                s_r += v_r; s_g += v_g; s_bl += v_bl;
-#else
-                const float t_mx = bcast(wave_sum_to_63(v_mx), 63), t_my = bcast(wave_sum_to_63(v_my), 63);
-                const float t_a = bcast(wave_sum_to_63(v_a), 63), t_b = bcast(wave_sum_to_63(v_b), 63);
-                const float t_c = bcast(wave_sum_to_63(v_c), 63), t_o = bcast(wave_sum_to_63(v_o), 63);
-                const float t_r = bcast(wave_sum_to_63(v_r), 63), t_g = bcast(wave_sum_to_63(v_g), 63);
-                const float t_bl = bcast(wave_sum_to_63(v_bl), 63);
-                if (lane == k) {
-                    s_mx += t_mx; s_my += t_my; s_a += t_a; s_b += t_b; s_c += t_c; s_o += t_o;
-                    s_r += t_r; s_g += t_g; s_bl += t_bl;
-                }
-#endif
+                xs[63] = 0.f;
+                const float total = transpose_reduce64(xs, lane);  // lane L: sum over pixels of value L
+                int kk = ks[0];
+#pragma unroll
+                for (int j = 1; j < EB; j++) kk = slot_j == j ? ks[j] : kk;
+                if (lane < EB * 9 && total != 0.f) sacc[wave][slot_v][kk] += total;
             }
         }
-        sacc[wave][0][lane] = s_mx; sacc[wave][1][lane] = s_my;
-        sacc[wave][2][lane] = s_a;  sacc[wave][3][lane] = s_b;
-        sacc[wave][4][lane] = s_c;  sacc[wave][5][lane] = s_o;
-        sacc[wave][6][lane] = s_r;  sacc[wave][7][lane] = s_g; sacc[wave][8][lane] = s_bl;
         __syncthreads();
         // flush: thread (part = wave, entry = lane) owns 2-3 of the 9 values of entry `lane`
         if (c + lane < bmax) {
