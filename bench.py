@@ -141,7 +141,9 @@ def main():
     history = DivisionStrategyHistoryFinal(S.SyntheticDataset(cameras), world, rank)
     bg = torch.zeros(3, dtype=torch.float32, device=dev)
     pipe = type("Pipe", (), {"debug": False})()
-    opt = torch.optim.Adam(model.param_groups(), lr=0.0, eps=1e-15, fused=True)
+    from fused_optim import FusedAdam
+
+    opt = FusedAdam(model.param_groups(), lr=0.0, eps=1e-15)  # scene/gaussian_model.py:292 settings
 
     state = {"it": 0}
 
@@ -162,11 +164,7 @@ def main():
         loss, _ = batched_loss_computation(images, cams, masks, strategies, stats)
         loss.backward()
         finish_strategy_final(cams, history, strategies, stats)
-        if bsz > 1:
-            for p in model.parameters():
-                if p.grad is not None:
-                    p.grad /= bsz
-        opt.step()
+        opt.step(grad_scale=1.0 / bsz)  # grad /= bsz (train_internal.py:319-324) folded into the update
         opt.zero_grad(set_to_none=True)
         for cam in cams:
             cam.original_image = None

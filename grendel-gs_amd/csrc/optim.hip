@@ -1,0 +1,69 @@
+// optim.hip -- fused Adam step (SURVEY.md "next" N3) for gfx950.
+//
+// One pass per parameter tensor: grad *= grad_scale (the reference's `grad /= bsz`,
+// train_internal.py:319-324), first/second moment update, bias-corrected step -- the dense semantics of
+// stock torch.optim.Adam as the reference configures it (scene/gaussian_model.py:292: lr per group,
+// eps 1e-15, no weight decay, no amsgrad).  Moments of Gaussians that were invisible this iteration
+// (zero gradient) still decay and still move the parameter, exactly like the stock optimizer.
+// Pure HBM streaming: 16 B read + 12 B written per element (float4 vectorised).
+#include "common.h"
+
+namespace {
+
+template <typename V>
+__device__ __forceinline__ void adam1(float &p, float g, float &m, float &v, float lr_c, float b1, float b2,
+                                      float omb1, float omb2, float inv_sqrt_bc2, float eps) {
+    m = b1 * m + omb1 * g;  // omb = 1 - beta rounded from double, as the stock optimizer's scalars are
+    v = b2 * v + omb2 * g * g;
+    const float denom = sqrtf(v) * inv_sqrt_bc2 + eps;
+    p -= lr_c * (m / denom);
+}
+
+__global__ void __launch_bounds__(256)
+adam_kernel(long long n, float *__restrict__ param, const float *__restrict__ grad, float *__restrict__ exp_avg,
+            float *__restrict__ exp_avg_sq, float lr_c, float b1, float b2, float omb1, float omb2,
+            float inv_sqrt_bc2, float eps, float grad_scale) {
+    const long long i4 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i4 + 3 < n) {
+        float4 p = *reinterpret_cast<float4 *>(param + i4);
+        float4 g = *reinterpret_cast<const float4 *>(grad + i4);
+        float4 m = *reinterpret_cast<float4 *>(exp_avg + i4);
+        float4 v = *reinterpret_cast<float4 *>(exp_avg_sq + i4);
+        adam1<float>(p.x, g.x * grad_scale, m.x, v.x, lr_c, b1, b2, omb1, omb2, inv_sqrt_bc2, eps);
+        adam1<float>(p.y, g.y * grad_scale, m.y, v.y, lr_c, b1, b2, omb1, omb2, inv_sqrt_bc2, eps);
+        adam1<float>(p.z, g.z * grad_scale, m.z, v.z, lr_c, b1, b2, omb1, omb2, inv_sqrt_bc2, eps);
+        adam1<float>(p.w, g.w * grad_scale, m.w, v.w, lr_c, b1, b2, omb1, omb2, inv_sqrt_bc2, eps);
+        *reinterpret_cast<float4 *>(param + i4) = p;
+        *reinterpret_cast<float4 *>(exp_avg + i4) = m;
+        *reinterpret_cast<float4 *>(exp_avg_sq + i4) = v;
+    } else {
+        for (long long i = i4; i < n; i++) {
+            float p = param[i], m = exp_avg[i], v = exp_avg_sq[i];
+            adam1<float>(p, grad[i] * grad_scale, m, v, lr_c, b1, b2, omb1, omb2, inv_sqrt_bc2, eps);
+            param[i] = p;
+            exp_avg[i] = m;
+            exp_avg_sq[i] = v;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int gsr_adam_step(int64_t n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq, double lr,
+                             double beta1, double beta2, double eps, int64_t step, float grad_scale,
+                             gsr_stream_t stream) {
+    if (n < 0 || step < 1) return GSR_EINVAL;
+    if (n == 0) return 0;
+    if (!param || !grad || !exp_avg || !exp_avg_sq) return GSR_EINVAL;
+    if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return GSR_EINVAL;
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
+    const float lr_c = (float)(lr / bc1);
+    const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    const long long groups = (n + 3) / 4;
+    hipLaunchKernelGGL(adam_kernel, dim3(gsr_div_up(groups, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       (long long)n, param, grad, exp_avg, exp_avg_sq, lr_c, (float)beta1, (float)beta2,
+                       (float)(1.0 - beta1), (float)(1.0 - beta2), inv_sqrt_bc2, (float)eps, grad_scale);
+    GSR_LAUNCH_CHECK();
+    return 0;
+}

@@ -39,6 +39,8 @@ SIGNATURES = {
                                     c_void_p, c_void_p]),
     "gsr_l1_ssim_backward": (c_int, [c_int, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "gsr_adam_step": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_double, ctypes.c_double,
+                              ctypes.c_double, ctypes.c_double, c_int64, c_float, c_void_p]),
     "gsr_render_backward": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
 }

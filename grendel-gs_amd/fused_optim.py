@@ -1,0 +1,50 @@
+"""FusedAdam -- host-side mirror of the optimizer the reference builds at scene/gaussian_model.py:292
+(`torch.optim.Adam(l, lr=0.0, eps=1e-15)`, one param group per attribute with its own lr / betas), running
+the dense Adam update as ONE HIP kernel per parameter tensor (include/gsraster.h: gsr_adam_step) with the
+batch-size gradient scaling of train_internal.py:319-324 folded in.
+
+State layout (`state[p]["step" | "exp_avg" | "exp_avg_sq"]`) is the stock optimizer's, so
+`GaussianModel.capture()/restore()` checkpoints (scene/gaussian_model.py:70-107) stay interchangeable.
+There is no CPU fallback: parameters must live on the gfx950 device."""
+import ctypes
+
+import torch
+
+from diff_gaussian_rasterization import _lib
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale=1.0):
+        """`grad_scale` multiplies every gradient before the update (1 / bsz in the reference's loop)"""
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if not p.is_cuda:
+                    raise RuntimeError("FusedAdam: parameters must live on the gfx950 device (no CPU fallback)")
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.tensor(0.0)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+                g = p.grad
+                if not (p.is_contiguous() and g.is_contiguous() and p.dtype == torch.float32 and
+                        g.dtype == torch.float32):
+                    raise RuntimeError("FusedAdam: dense fp32 parameters and gradients expected")
+                with torch.cuda.device(p.device):
+                    _lib.check(_lib.lib.gsr_adam_step(
+                        p.numel(), ctypes.c_void_p(p.data_ptr()), ctypes.c_void_p(g.data_ptr()),
+                        ctypes.c_void_p(st["exp_avg"].data_ptr()), ctypes.c_void_p(st["exp_avg_sq"].data_ptr()),
+                        float(group["lr"]), float(b1), float(b2), float(group["eps"]), int(st["step"].item()),
+                        float(grad_scale), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "gsr_adam_step")
+        return loss

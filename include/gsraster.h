@@ -148,6 +148,15 @@ int gsr_l1_ssim_backward(int channels, int rows, int width, const float *image, 
                          const float *grad_l1_sum, const float *grad_ssim_sum, float *grad_image,
                          int64_t grad_channel_stride, gsr_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * N3  fused Adam step for one parameter tensor of n fp32 elements (16-byte aligned, dense):
+ * the update stock torch.optim.Adam performs as configured at scene/gaussian_model.py:292
+ * (no weight decay, no amsgrad), with the reference's `grad /= bsz` (train_internal.py:319-324)
+ * folded in as grad_scale.  `step` is the 1-based step count AFTER this update (bias correction).
+ * Hyper-parameters are doubles so that 1 - beta and the bias corrections round like the stock optimizer's. */
+int gsr_adam_step(int64_t n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq, double lr,
+                  double beta1, double beta2, double eps, int64_t step, float grad_scale, gsr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

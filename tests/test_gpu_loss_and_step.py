@@ -117,3 +117,29 @@ def test_training_iteration_through_mirror_matches_oracle(device):
                                          d2, dco, drgb, **kw)[0].double()
     assert abs(loss.item() - total) < 1e-4 * abs(total)
     assert rel_err(model._xyz.grad, d_means) < 2e-4
+
+
+def test_fused_adam_matches_torch_adam(device):
+    """N3: same trajectory as stock torch.optim.Adam with the reference's settings, incl. grad / bsz"""
+    from fused_optim import FusedAdam
+
+    g = torch.Generator().manual_seed(0)
+    shapes = [(1001, 3), (1001, 1, 3), (1001, 15, 3), (1001, 1), (1001, 4)]
+    lrs = [0.00016, 0.0025, 0.000125, 0.05, 0.001]
+    pa = [torch.randn(s, generator=g).to(device).requires_grad_(True) for s in shapes]
+    pb = [p.detach().clone().requires_grad_(True) for p in pa]
+    oa = FusedAdam([{"params": [p], "lr": lr} for p, lr in zip(pa, lrs)], lr=0.0, eps=1e-15)
+    ob = torch.optim.Adam([{"params": [p], "lr": lr} for p, lr in zip(pb, lrs)], lr=0.0, eps=1e-15)
+    bsz = 4
+    for it in range(5):
+        for p, q in zip(pa, pb):
+            gr = torch.randn(p.shape, generator=g).to(device)
+            gr[::3] = 0.0  # invisible Gaussians: zero gradient, moments still decay
+            p.grad = gr.clone()
+            q.grad = gr.clone() / bsz
+        oa.step(grad_scale=1.0 / bsz)
+        ob.step()
+    for p, q in zip(pa, pb):
+        assert rel_err(p, q) < 1e-6
+    for p, q in zip(pa, pb):
+        assert rel_err(oa.state[p]["exp_avg_sq"], ob.state[q]["exp_avg_sq"]) < 1e-6
