@@ -110,9 +110,43 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_final_kernel(const uint32_t
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[n] = block_sums[gridDim.x];
 }
 
+// single-workgroup exclusive scan for short arrays (histogram tables of the depth sort): one launch
+// instead of three.  out[n] = total.  n <= 1024 * SMALL_SCAN_ITEMS.
+constexpr int SMALL_SCAN_THREADS = 1024;
+constexpr int SMALL_SCAN_ITEMS = 64;
+__global__ void __launch_bounds__(SMALL_SCAN_THREADS) scan_small_kernel(const uint32_t *__restrict__ in,
+                                                                        uint32_t *__restrict__ out, int n) {
+    __shared__ uint32_t wsum[SMALL_SCAN_THREADS / 64];
+    const int per = (n + SMALL_SCAN_THREADS - 1) / SMALL_SCAN_THREADS;
+    const int base = threadIdx.x * per;
+    uint32_t s = 0;
+    for (int k = 0; k < per; k++) s += (base + k < n) ? in[base + k] : 0u;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t inc = wave_inclusive_scan(s);
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t wbase = 0, tot = 0;
+    for (int w = 0; w < SMALL_SCAN_THREADS / 64; w++) {
+        const uint32_t v = wsum[w];
+        if (w < wave) wbase += v;
+        tot += v;
+    }
+    uint32_t run = wbase + inc - s;
+    for (int k = 0; k < per; k++) {
+        if (base + k < n) {
+            const uint32_t v = in[base + k];
+            out[base + k] = run;
+            run += v;
+        }
+    }
+    if (threadIdx.x == 0) out[n] = tot;
+}
+
 // ------------------------------------------------------------------------------ radix sort pass
+// digit = (key >> shift) & mask, mask = 2^nbits - 1, nbits <= 8
 __global__ void __launch_bounds__(RADIX_THREADS) radix_hist_kernel(const uint32_t *__restrict__ keys, long long n,
-                                                                   int shift, uint32_t *__restrict__ hist, int nb) {
+                                                                   int shift, uint32_t mask,
+                                                                   uint32_t *__restrict__ hist, int nb) {
     __shared__ uint32_t h[RADIX_DIGITS];
     h[threadIdx.x] = 0;
     __syncthreads();
@@ -120,17 +154,16 @@ __global__ void __launch_bounds__(RADIX_THREADS) radix_hist_kernel(const uint32_
 #pragma unroll
     for (int k = 0; k < RADIX_ITEMS; k++) {
         const long long j = base + k * RADIX_THREADS + threadIdx.x;
-        if (j < n) atomicAdd(&h[(keys[j] >> shift) & 0xFF], 1u);
+        if (j < n) atomicAdd(&h[(keys[j] >> shift) & mask], 1u);
     }
     __syncthreads();
-    hist[(size_t)threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];  // digit-major: one scan gives offsets
+    if (threadIdx.x <= mask) hist[(size_t)threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];  // digit-major
 }
 
-// lanes holding the same 8-bit digit (restricted to `valid` lanes)
-__device__ __forceinline__ unsigned long long match_digit(uint32_t d, bool valid) {
+// lanes holding the same digit (restricted to `valid` lanes)
+__device__ __forceinline__ unsigned long long match_digit(uint32_t d, bool valid, int nbits) {
     unsigned long long m = __ballot(valid);
-#pragma unroll
-    for (int b = 0; b < 8; b++) {
+    for (int b = 0; b < nbits; b++) {
         const bool bit = (d >> b) & 1;
         const unsigned long long bm = __ballot(bit);
         m &= bit ? bm : ~bm;
@@ -138,33 +171,48 @@ __device__ __forceinline__ unsigned long long match_digit(uint32_t d, bool valid
     return m;
 }
 
+// One workgroup = 4096 consecutive pairs.  Stable ranks come from wave64 ballots (match_digit) plus
+// per-wave LDS cursors; the pairs are first placed in digit order INSIDE LDS and then streamed out,
+// so that each digit's run leaves the workgroup as contiguous, coalesced stores.
 __global__ void __launch_bounds__(RADIX_THREADS)
 radix_scatter_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
                      uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, long long n, int shift,
-                     const uint32_t *__restrict__ offsets, int nb) {
+                     int nbits, const uint32_t *__restrict__ offsets, int nb) {
     __shared__ uint32_t wtab[RADIX_WAVES][RADIX_DIGITS];
+    __shared__ uint32_t gbase[RADIX_DIGITS];  // global start of the digit's run minus its local start
+    __shared__ uint32_t skey[RADIX_TILE], sval[RADIX_TILE];
+    __shared__ uint32_t scan_tmp[4];
+    const uint32_t mask = (1u << nbits) - 1u;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int w = 0; w < RADIX_WAVES; w++) wtab[w][threadIdx.x] = 0;
     __syncthreads();
     // wave w owns the contiguous sub-chunk [base + w*1024, +1024), walked in 16 rounds of 64
-    const long long wbase = (long long)blockIdx.x * RADIX_TILE + (long long)wave * (RADIX_ITEMS * 64);
+    const long long bbase = (long long)blockIdx.x * RADIX_TILE;
+    const long long wbase = bbase + (long long)wave * (RADIX_ITEMS * 64);
     uint32_t key[RADIX_ITEMS];
 #pragma unroll
     for (int r = 0; r < RADIX_ITEMS; r++) {
         const long long j = wbase + r * 64 + lane;
         key[r] = j < n ? keys_in[j] : 0xFFFFFFFFu;
-        if (j < n) atomicAdd(&wtab[wave][(key[r] >> shift) & 0xFF], 1u);
+        if (j < n) atomicAdd(&wtab[wave][(key[r] >> shift) & mask], 1u);
     }
     __syncthreads();
-    {  // thread d: turn per-wave counts of digit d into running global positions
+    {  // thread d: per-wave counts of digit d -> local (in-workgroup) start positions
         const int d = threadIdx.x;
-        uint32_t run = offsets[(size_t)d * nb + blockIdx.x];
+        uint32_t cnt[RADIX_WAVES], tot = 0;
 #pragma unroll
         for (int w = 0; w < RADIX_WAVES; w++) {
-            const uint32_t c = wtab[w][d];
+            cnt[w] = wtab[w][d];
+            tot += cnt[w];
+        }
+        uint32_t all;
+        uint32_t run = block_exclusive_scan(tot, scan_tmp, &all);  // local start of digit d
+        gbase[d] = ((uint32_t)d <= mask ? offsets[(size_t)d * nb + blockIdx.x] : 0u) - run;
+#pragma unroll
+        for (int w = 0; w < RADIX_WAVES; w++) {
             wtab[w][d] = run;
-            run += c;
+            run += cnt[w];
         }
     }
     __syncthreads();
@@ -173,8 +221,8 @@ radix_scatter_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__res
     for (int r = 0; r < RADIX_ITEMS; r++) {
         const long long j = wbase + r * 64 + lane;
         const bool valid = j < n;
-        const uint32_t d = (key[r] >> shift) & 0xFF;
-        const unsigned long long m = match_digit(d, valid);
+        const uint32_t d = (key[r] >> shift) & mask;
+        const unsigned long long m = match_digit(d, valid, nbits);
         const uint32_t rank = __popcll(m & lt);
         volatile uint32_t *cursor = wtab[wave];
         uint32_t pos = 0;
@@ -183,8 +231,21 @@ radix_scatter_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__res
         if (valid && rank == 0) cursor[d] = pos + (uint32_t)__popcll(m);  // group leader advances the cursor
         __builtin_amdgcn_wave_barrier();
         if (valid) {
-            keys_out[pos] = key[r];
-            vals_out[pos] = vals_in[j];
+            skey[pos] = key[r];
+            sval[pos] = vals_in[j];
+        }
+    }
+    __syncthreads();
+    const long long rem = n - bbase;
+    const int count = rem < RADIX_TILE ? (int)rem : RADIX_TILE;
+#pragma unroll
+    for (int r = 0; r < RADIX_ITEMS; r++) {
+        const int i = r * RADIX_THREADS + threadIdx.x;
+        if (i < count) {
+            const uint32_t k = skey[i];
+            const uint32_t dst = gbase[(k >> shift) & mask] + (uint32_t)i;
+            keys_out[dst] = k;
+            vals_out[dst] = sval[i];
         }
     }
 }
@@ -329,6 +390,11 @@ int gsr_exclusive_scan_u32(const uint32_t *in, uint32_t *out, long long n, void 
         GSR_HIP(hipMemsetAsync(out, 0, sizeof(uint32_t), stream));
         return 0;
     }
+    if (n <= SMALL_SCAN_THREADS) {  // one element per thread; longer arrays: the coalesced three-phase scan
+        hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(SMALL_SCAN_THREADS), 0, stream, in, out, (int)n);
+        GSR_LAUNCH_CHECK();
+        return 0;
+    }
     const int nb = (int)((n + SCAN_TILE - 1) / SCAN_TILE);
     uint32_t *bs = reinterpret_cast<uint32_t *>(temp);
     hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(SCAN_THREADS), 0, stream, in, n, bs);
@@ -345,20 +411,27 @@ size_t gsr_radix_temp_bytes(long long n) {
 }
 
 int gsr_radix_sort_pairs(uint32_t *k0, uint32_t *v0, uint32_t *k1, uint32_t *v1, long long n, int bit_lo, int bit_hi,
-                         void *temp, int *result_in_first, hipStream_t stream) {
+                         void *temp, int *result_in_first, hipStream_t stream, uint32_t *final_vals) {
     *result_in_first = 1;
     if (n <= 0) return 0;
     const int nb = (int)((n + RADIX_TILE - 1) / RADIX_TILE);
-    const long long nh = (long long)nb * RADIX_DIGITS;
     uint32_t *hist = reinterpret_cast<uint32_t *>(temp);
-    void *scan_temp = reinterpret_cast<char *>(temp) + align_up((size_t)(nh + 1) * sizeof(uint32_t));
+    void *scan_temp = reinterpret_cast<char *>(temp) + align_up((size_t)((long long)nb * RADIX_DIGITS + 1) * sizeof(uint32_t));
+    // split the key bits evenly over the minimum number of <= 8-bit passes (13 tile bits -> 7 + 6)
+    const int total = bit_hi - bit_lo, passes = (total + 7) / 8;
     uint32_t *ki = k0, *vi = v0, *ko = k1, *vo = v1;
-    for (int shift = bit_lo; shift < bit_hi; shift += 8) {
-        hipLaunchKernelGGL(radix_hist_kernel, dim3(nb), dim3(RADIX_THREADS), 0, stream, ki, n, shift, hist, nb);
+    int shift = bit_lo;
+    for (int p = 0; p < passes; p++) {
+        const int nbits = (total - (shift - bit_lo) + (passes - p) - 1) / (passes - p);
+        const long long nh = (long long)nb << nbits;
+        hipLaunchKernelGGL(radix_hist_kernel, dim3(nb), dim3(RADIX_THREADS), 0, stream, ki, n, shift,
+                           (1u << nbits) - 1u, hist, nb);
         int rc = gsr_exclusive_scan_u32(hist, hist, nh, scan_temp, stream);
         if (rc) return rc;
-        hipLaunchKernelGGL(radix_scatter_kernel, dim3(nb), dim3(RADIX_THREADS), 0, stream, ki, vi, ko, vo, n, shift,
-                           hist, nb);
+        uint32_t *vdst = (p == passes - 1 && final_vals) ? final_vals : vo;  // last pass can land the values
+        hipLaunchKernelGGL(radix_scatter_kernel, dim3(nb), dim3(RADIX_THREADS), 0, stream, ki, vi, ko, vdst, n, shift,
+                           nbits, hist, nb);
+        shift += nbits;
         uint32_t *t = ki; ki = ko; ko = t;
         t = vi; vi = vo; vo = t;
         *result_in_first ^= 1;
@@ -391,10 +464,10 @@ PrepLayout prep_layout(int P, int W, int H) {
     L.total = o;
     return L;
 }
-int tile_bits(int tiles) {  // bits of the largest key value, the sentinel `tiles`, rounded up to whole passes
+int tile_bits(int tiles) {  // bits of the largest key value, the sentinel `tiles`
     int b = 1;
     while ((1ll << b) <= tiles) b++;
-    return ((b + 7) / 8) * 8;
+    return b;
 }
 }  // namespace
 
@@ -429,7 +502,7 @@ extern "C" int gsr_bin_prepare(int P, int width, int height, const float *means2
                        P, gx, gy, reinterpret_cast<const float2 *>(means2D), depths, radii,
                        reinterpret_cast<const float4 *>(conic_opacity), hull, tt, kA, vA, rects);
     int in_first = 1;
-    int rc = gsr_radix_sort_pairs(kA, vA, kB, vB, P, 0, 32, temp, &in_first, stream);
+    int rc = gsr_radix_sort_pairs(kA, vA, kB, vB, P, 0, 32, temp, &in_first, stream, nullptr);
     if (rc) return rc;
     // 4 passes -> back in (kA, vA); keep the sorted ids in vA, reuse kB for the gathered counts
     uint32_t *sorted_ids = in_first ? vA : vB;
@@ -498,11 +571,10 @@ extern "C" int gsr_bin_sort(int P, int width, int height, const uint8_t *compute
     hipLaunchKernelGGL(emit_pairs_kernel, dim3(gsr_div_up(P, 256)), dim3(256), 0, stream, P, gx, gx * gy, rects,
                        compute_locally, sorted_ids, offsets, kA, vA);
     int in_first = 1;
-    int rc = gsr_radix_sort_pairs(kA, vA, kB, vB, D, 0, tile_bits(gx * gy), temp, &in_first, stream);
+    // the last pass writes the Gaussian indices straight into point_list
+    int rc = gsr_radix_sort_pairs(kA, vA, kB, vB, D, 0, tile_bits(gx * gy), temp, &in_first, stream, point_list);
     if (rc) return rc;
-    const uint32_t *ks = in_first ? kA : kB, *vs = in_first ? vA : vB;
-    hipLaunchKernelGGL(copy_u32_kernel, dim3(gsr_div_up(D, GSR_ONE_DIM_BLOCK)), dim3(GSR_ONE_DIM_BLOCK), 0, stream,
-                       (long long)D, vs, point_list);
+    const uint32_t *ks = in_first ? kA : kB;
     hipLaunchKernelGGL(tile_ranges_kernel, dim3(gsr_div_up(D, GSR_ONE_DIM_BLOCK)), dim3(GSR_ONE_DIM_BLOCK), 0, stream,
                        (long long)D, (uint32_t)(gx * gy), ks, reinterpret_cast<int2 *>(ranges));
     GSR_LAUNCH_CHECK();
