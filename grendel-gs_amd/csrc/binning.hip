@@ -318,42 +318,67 @@ gather_u32_kernel(int n, const uint32_t *__restrict__ src, const uint32_t *__res
     if (j < n) dst[j] = src[idx[j]];
 }
 
-// K5: a wave owns 64 consecutive Gaussians of the depth order and therefore one CONTIGUOUS span of
-// output pairs; its lanes walk the span (coalesced stores) and find each slot's Gaussian by a 6-step
-// binary search over the wave's 64 offsets in LDS.
+// K5: the D output pairs are cut into chunks of EMIT_CHUNK slots, one wave per chunk, so the work is
+// balanced by OUTPUT (a near-camera splat covering thousands of tiles no longer serialises one wave).
+// The wave finds the Gaussian that owns its first slot with a 64-ary search over the offsets (one
+// coalesced probe per round), then walks windows of 64 depth-consecutive Gaussians staged in LDS; every
+// slot locates its owner by a 6-step binary search in the window and is written with coalesced stores.
+constexpr int EMIT_CHUNK = 2048;
 __global__ void __launch_bounds__(256)
-emit_pairs_kernel(int P, int gx, int tiles, const uint2 *__restrict__ rects, const uint8_t *__restrict__ mask,
-                  const uint32_t *__restrict__ sorted_ids, const uint32_t *__restrict__ offsets,
-                  uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+emit_pairs_kernel(int P, long long D, int gx, int tiles, const uint2 *__restrict__ rects,
+                  const uint8_t *__restrict__ mask, const uint32_t *__restrict__ sorted_ids,
+                  const uint32_t *__restrict__ offsets, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
     __shared__ uint32_t s_off[4][65];
     __shared__ uint32_t s_g[4][64];
     __shared__ uint2 s_rect[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    const bool valid = j < P;
-    const uint32_t off = offsets[valid ? j : P];
-    const uint32_t end = valid ? offsets[j + 1] : off;
-    const uint32_t g = (end > off) ? sorted_ids[j] : 0u;
-    s_off[wave][lane] = off;
-    if (lane == 63) s_off[wave][64] = end;
-    s_g[wave][lane] = g;
-    s_rect[wave][lane] = (end > off) ? rects[g] : make_uint2(0u, 0u);
-    __builtin_amdgcn_wave_barrier();
-    const uint32_t wbeg = __builtin_amdgcn_readlane(off, 0), wend = __builtin_amdgcn_readlane(end, 63);
-    for (uint32_t s = wbeg + lane; s < wend; s += 64) {
-        int lo = 0, hi = 63;
+    const long long chunk = (long long)blockIdx.x * 4 + wave;
+    const long long sb = chunk * EMIT_CHUNK;
+    if (sb >= D) return;
+    const uint32_t s_begin = (uint32_t)sb;
+    const uint32_t s_end = (uint32_t)(sb + EMIT_CHUNK < D ? sb + EMIT_CHUNK : D);
+    // largest j in [0, P] with offsets[j] <= s_begin  (offsets is non-decreasing, offsets[P] = D > s_begin)
+    int lo = 0, hi = P;  // invariant: offsets[lo] <= s_begin < offsets[hi]
+    while (hi - lo > 1) {
+        const int step = (hi - lo + 63) / 64;
+        const int idx = min(lo + lane * step, hi);
+        const bool le = offsets[idx] <= s_begin;
+        const int c = __popcll(__ballot(le));  // probes are monotone: the first c lanes say "<="
+        const int nlo = lo + (c - 1) * step;
+        hi = min(hi, nlo + step);
+        lo = nlo;
+    }
+    int g0 = lo;
+    uint32_t s = s_begin + lane;
+    while (true) {  // one window of 64 Gaussians per iteration (wave-uniform control flow)
+        const int j = g0 + lane;
+        const uint32_t off = offsets[min(j, P)];
+        const uint32_t end = offsets[min(j + 1, P)];
+        const uint32_t g = (j < P && end > off) ? sorted_ids[j] : 0u;
+        __builtin_amdgcn_wave_barrier();
+        s_off[wave][lane] = off;
+        if (lane == 63) s_off[wave][64] = end;
+        s_g[wave][lane] = g;
+        s_rect[wave][lane] = (j < P && end > off) ? rects[g] : make_uint2(0u, 0u);
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t wend = min(__builtin_amdgcn_readlane(end, 63), s_end);
+        for (; s < wend; s += 64) {
+            int a = 0, bnd = 63;
 #pragma unroll
-        for (int it = 0; it < 6; it++) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (s_off[wave][mid] <= s) lo = mid; else hi = mid - 1;
+            for (int it = 0; it < 6; it++) {
+                const int mid = (a + bnd + 1) >> 1;
+                if (s_off[wave][mid] <= s) a = mid; else bnd = mid - 1;
+            }
+            const uint2 r = s_rect[wave][a];
+            const uint32_t t = s - s_off[wave][a];
+            const uint32_t minx = r.x & 0xFFFFu, w = (r.x >> 16) - minx, miny = r.y & 0xFFFFu;
+            const uint32_t y = miny + t / w, x = minx + t % w;
+            const uint32_t tile = y * (uint32_t)gx + x;
+            keys[s] = mask[tile] ? tile : (uint32_t)tiles;  // non-local tile inside the hull: sentinel, sorts last
+            vals[s] = s_g[wave][a];
         }
-        const uint2 r = s_rect[wave][lo];
-        const uint32_t t = s - s_off[wave][lo];
-        const uint32_t minx = r.x & 0xFFFFu, w = (r.x >> 16) - minx, miny = r.y & 0xFFFFu;
-        const uint32_t y = miny + t / w, x = minx + t % w;
-        const uint32_t tile = y * (uint32_t)gx + x;
-        keys[s] = mask[tile] ? tile : (uint32_t)tiles;  // non-local tile inside the hull: sentinel, sorts last
-        vals[s] = s_g[wave][lo];
+        if (wend >= s_end) break;
+        g0 += 64;
     }
 }
 
@@ -568,8 +593,8 @@ extern "C" int gsr_bin_sort(int P, int width, int height, const uint8_t *compute
     uint32_t *kB = reinterpret_cast<uint32_t *>(sbase + S.kB), *vB = reinterpret_cast<uint32_t *>(sbase + S.vB);
     void *temp = sbase + S.temp;
 
-    hipLaunchKernelGGL(emit_pairs_kernel, dim3(gsr_div_up(P, 256)), dim3(256), 0, stream, P, gx, gx * gy, rects,
-                       compute_locally, sorted_ids, offsets, kA, vA);
+    hipLaunchKernelGGL(emit_pairs_kernel, dim3(gsr_div_up(gsr_div_up(D, EMIT_CHUNK), 4)), dim3(256), 0, stream, P,
+                       (long long)D, gx, gx * gy, rects, compute_locally, sorted_ids, offsets, kA, vA);
     int in_first = 1;
     // the last pass writes the Gaussian indices straight into point_list
     int rc = gsr_radix_sort_pairs(kA, vA, kB, vB, D, 0, tile_bits(gx * gy), temp, &in_first, stream, point_list);
