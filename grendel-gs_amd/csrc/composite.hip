@@ -269,12 +269,10 @@ composite_backward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
             const uint32_t id = have ? point_list[range.x + c + lane] : 0u;
             const Entry e = load_entry(have, id, means2D, conic_opacity, (float)qx0, (float)qy0);
             float r = 0.f, g = 0.f, b = 0.f;
-            float4 co = make_float4(0.f, 0.f, 0.f, 0.f);
             if (e.relevant) {
                 r = rgb[3 * (size_t)id];
                 g = rgb[3 * (size_t)id + 1];
                 b = rgb[3 * (size_t)id + 2];
-                co = conic_opacity[id];
             }
             unsigned long long m = __ballot(e.relevant);
             while (m) {
@@ -285,12 +283,14 @@ composite_backward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
                     // next entry (back to front) that at least one pixel of the quadrant takes
                     bool got = false, take = false;
                     int k = 0;
-                    float dx = 0.f, dy = 0.f, o = 0.f, G = 0.f, alpha = 0.f;
+                    float dx = 0.f, dy = 0.f, o = 0.f, G = 0.f, alpha = 0.f, a2 = 0.f, b2 = 0.f, c2 = 0.f;
                     while (m) {
                         k = 63 - __builtin_clzll(m);
                         m &= ~(1ull << k);
                         const float gx_ = bcast(e.x, k), gy_ = bcast(e.y, k);
-                        const float a2 = bcast(e.a2, k), b2 = bcast(e.b2, k), c2 = bcast(e.c2, k);
+                        a2 = bcast(e.a2, k);
+                        b2 = bcast(e.b2, k);
+                        c2 = bcast(e.c2, k);
                         o = bcast(e.o, k);
                         dx = gx_ - pxf;
                         dy = gy_ - pyf;
@@ -304,39 +304,40 @@ composite_backward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
                         }
                     }
                     ks[j] = k;
-                    float v_mx = 0.f, v_my = 0.f, v_a = 0.f, v_b = 0.f, v_c = 0.f, v_o = 0.f, v_r = 0.f, v_g = 0.f,
-                          v_bl = 0.f;
-                    if (got) {  // wave-uniform
-                        const float cr = bcast(r, k), cg = bcast(g, k), cb = bcast(b, k);
-                        const float A = bcast(co.x, k), B = bcast(co.y, k), Cc = bcast(co.z, k);
-                        if (take) {
-                            const float inv_1ma = __builtin_amdgcn_rcpf(1.f - alpha);  // 1 ulp, inside the 1e-4 budget
-                            T = T * inv_1ma;
-                            const float w = alpha * T;
-                            acc0 = last_alpha * lastc0 + (1.f - last_alpha) * acc0;
-                            acc1 = last_alpha * lastc1 + (1.f - last_alpha) * acc1;
-                            acc2 = last_alpha * lastc2 + (1.f - last_alpha) * acc2;
-                            lastc0 = cr; lastc1 = cg; lastc2 = cb;
-                            float dL_dalpha = (cr - acc0) * g0 + (cg - acc1) * g1 + (cb - acc2) * g2;
-                            dL_dalpha *= T;
-                            last_alpha = alpha;
-                            dL_dalpha += (-T_final * inv_1ma) * bg_dot;
-                            const float dL_dG = o * dL_dalpha;  // min(0.99,.) treated as identity
-                            const float gdx = G * dx, gdy = G * dy;
-                            v_mx = dL_dG * (-gdx * A - gdy * B) * ddelx_dx;
-                            v_my = dL_dG * (-gdy * Cc - gdx * B) * ddely_dy;
-                            v_a = -0.5f * gdx * dx * dL_dG;
-                            v_b = -gdx * dy * dL_dG;
-                            v_c = -0.5f * gdy * dy * dL_dG;
-                            v_o = G * dL_dalpha;
-                            v_r = w * g0;
-                            v_g = w * g1;
-                            v_bl = w * g2;
-                        }
-                    }
-                    xs[j * 9 + 0] = v_mx; xs[j * 9 + 1] = v_my; xs[j * 9 + 2] = v_a; xs[j * 9 + 3] = v_b;
-                    xs[j * 9 + 4] = v_c;  xs[j * 9 + 5] = v_o;  xs[j * 9 + 6] = v_r; xs[j * 9 + 7] = v_g;
-                    xs[j * 9 + 8] = v_bl;
+                    // branch-free contribution of this entry for this pixel (lanes that do not `take` are
+                    // masked through G, dL/dG and the weight, never through a multiply by an inf/NaN)
+                    const float cr = bcast(r, k), cg = bcast(g, k), cb = bcast(b, k);
+                    const bool tk = got && take;
+                    const float inv_1ma = __builtin_amdgcn_rcpf(1.f - alpha);  // 1 ulp, inside the 1e-4 budget
+                    const float Tn = T * inv_1ma;                              // transmittance in front of the entry
+                    const float n0 = last_alpha * (lastc0 - acc0) + acc0;      // colour accumulated behind it
+                    const float n1 = last_alpha * (lastc1 - acc1) + acc1;
+                    const float n2 = last_alpha * (lastc2 - acc2) + acc2;
+                    const float dL_dalpha = ((cr - n0) * g0 + (cg - n1) * g1 + (cb - n2) * g2) * Tn -
+                                            T_final * inv_1ma * bg_dot;
+                    const float Gm = tk ? G : 0.f;
+                    const float da = tk ? dL_dalpha : 0.f;
+                    const float wm = tk ? alpha * Tn : 0.f;
+                    const float q = o * da * Gm;                 // G * dL/dG, min(0.99,.) treated as identity
+                    const float qdx = q * dx, qdy = q * dy;
+                    // conic in log2 units: A = -2 a2 / log2e, B = -b2 / log2e, C = -2 c2 / log2e
+                    xs[j * 9 + 0] = (2.f * a2 * qdx + b2 * qdy) * (ddelx_dx / LOG2E);
+                    xs[j * 9 + 1] = (2.f * c2 * qdy + b2 * qdx) * (ddely_dy / LOG2E);
+                    xs[j * 9 + 2] = -0.5f * qdx * dx;
+                    xs[j * 9 + 3] = -qdx * dy;
+                    xs[j * 9 + 4] = -0.5f * qdy * dy;
+                    xs[j * 9 + 5] = Gm * da;
+                    xs[j * 9 + 6] = wm * g0;
+                    xs[j * 9 + 7] = wm * g1;
+                    xs[j * 9 + 8] = wm * g2;
+                    T = tk ? Tn : T;
+                    acc0 = tk ? n0 : acc0;
+                    acc1 = tk ? n1 : acc1;
+                    acc2 = tk ? n2 : acc2;
+                    lastc0 = tk ? cr : lastc0;
+                    lastc1 = tk ? cg : lastc1;
+                    lastc2 = tk ? cb : lastc2;
+                    last_alpha = tk ? alpha : last_alpha;
                 }
                 xs[63] = 0.f;
                 const float total = transpose_reduce64(xs, lane);  // lane L: sum over pixels of value L
