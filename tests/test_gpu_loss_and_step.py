@@ -143,3 +143,79 @@ def test_fused_adam_matches_torch_adam(device):
         assert rel_err(p, q) < 1e-6
     for p, q in zip(pa, pb):
         assert rel_err(oa.state[p]["exp_avg_sq"], ob.state[q]["exp_avg_sq"]) < 1e-6
+
+
+def test_exchange_path_on_device_single_rank_rccl(device):
+    """the W > 1 code path (need mask stacking, size all-gather, nonzero_static, all_to_all_single and
+    its autograd mirror) executed on the GPU through RCCL with a one-rank process group, against the
+    W == 1 shortcut: same images, same gradients."""
+    import torch.distributed as dist
+
+    import gaussian_renderer as gr
+    import utils.general_utils as utils
+    from gaussian_renderer.workload_division import DivisionStrategyHistoryFinal, start_strategy_final
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29577")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        created = True
+    try:
+        N, W, H = 5000, 240, 160
+        utils.GLOBAL_RANK, utils.WORLD_SIZE = 0, 1
+        utils.set_args(utils.default_args(bsz=2))
+        utils.set_img_size(H, W)
+        utils.set_cur_iter(1)
+        cams = S.orbit_cameras(2, W, H, device=device)
+        bg = torch.tensor([0.1, 0.2, 0.3], device=device)
+        pipe = type("P", (), {"debug": False})()
+        wgt = [torch.rand(3, H, W, generator=torch.Generator().manual_seed(k)).to(device) for k in range(2)]
+
+        def run(group):
+            utils.DEFAULT_GROUP = utils.IN_NODE_GROUP = group
+            model = S.SyntheticGaussianModel(N, W, H, seed=4, device=device, scale_coef=0.012)
+            hist = DivisionStrategyHistoryFinal(S.SyntheticDataset(cams), 1, 0)
+            strategies, tasks = start_strategy_final(cams, hist)
+            pkg = gr.distributed_preprocess3dgs_and_all2all_final(cams, model, pipe, bg, batched_strategies=strategies)
+            images, _ = gr.render_final(pkg, strategies)
+            sum((im * w_).sum() for im, w_ in zip(images, wgt)).backward()
+            return [im.detach() for im in images], model._xyz.grad.clone(), model._features_rest.grad.clone(), pkg
+
+        class OneRankButDistributed:  # size() > 1 would need more GPUs; the exchange code only needs the group
+            def __init__(self, g):
+                self.g = g
+
+            def size(self):
+                return 1
+
+            def rank(self):
+                return 0
+
+        img_a, gx_a, gf_a, _ = run(utils.SingleGPUGroup())
+        # force the exchange: call it directly on the preprocessed package of a fresh model
+        utils.DEFAULT_GROUP = utils.IN_NODE_GROUP = dist.group.WORLD
+        model = S.SyntheticGaussianModel(N, W, H, seed=4, device=device, scale_coef=0.012)
+        hist = DivisionStrategyHistoryFinal(S.SyntheticDataset(cams), 1, 0)
+        strategies, tasks = start_strategy_final(cams, hist)
+        utils.DEFAULT_GROUP = utils.SingleGPUGroup()
+        pkg = gr.distributed_preprocess3dgs_and_all2all_final(cams, model, pipe, bg, batched_strategies=strategies)
+        utils.DEFAULT_GROUP = dist.group.WORLD
+        params = [[pkg["batched_means2D_redistributed"][k], pkg["batched_rgb_redistributed"][k],
+                   pkg["batched_conic_opacity_redistributed"][k], pkg["batched_radii_redistributed"][k],
+                   pkg["batched_depths_redistributed"][k]] for k in range(2)]
+        m2, rgb, co, radii, depths, sizes = gr.all_to_all_communication_final(
+            pkg["batched_rasterizers"], params, pkg["batched_cuda_args"], strategies)
+        assert sizes[0][0][0] == int((params[0][3] > 0).sum().item())  # only visible Gaussians travel
+        for name, val in zip(("means2D", "rgb", "conic_opacity", "radii", "depths"), (m2, rgb, co, radii, depths)):
+            pkg[f"batched_{name}_redistributed"] = val
+        images, _ = gr.render_final(pkg, strategies)
+        sum((im * w_).sum() for im, w_ in zip(images, wgt)).backward()
+        for a, b in zip(img_a, images):
+            assert rel_err(b, a) < 1e-6
+        assert rel_err(model._xyz.grad, gx_a) < 1e-5
+        assert rel_err(model._features_rest.grad, gf_a) < 1e-5
+    finally:
+        utils.DEFAULT_GROUP = utils.IN_NODE_GROUP = utils.SingleGPUGroup()
+        if created:
+            dist.destroy_process_group()
