@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--view", type=int, default=0)
     ap.add_argument("--scale-coef", type=float, default=0.004)
+    ap.add_argument("--calib", action="store_true", help="also run a 256 MiB device copy (PMC byte calibration)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     W, H = a.width, a.height
@@ -45,6 +46,11 @@ def main():
         (img * wgt).sum().backward()
         for v in gg.values():
             v.grad = None
+    if a.calib:
+        x = torch.rand(64 * 1024 * 1024, device=dev)  # 256 MiB
+        y = torch.empty_like(x)
+        for _ in range(3):
+            torch.mul(x, 2.0, out=y)  # vectorised elementwise kernel: 256 MiB read (16 B/lane) + 256 MiB written
     torch.cuda.synchronize()
     vis = int((radii > 0).sum())
     print(f"N={a.gaussians} visible={vis} D={D} D/tile={D / (((W + 15) // 16) * ((H + 15) // 16)):.0f} "
