@@ -25,7 +25,7 @@ from . import _lib
 from ._lib import check, lib
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "_C", "load_image_tiles_by_pos",
-           "merge_image_tiles_by_pos", "set_timing_mode", "fused_l1_ssim_band"]
+           "merge_image_tiles_by_pos", "set_timing_mode", "fused_l1_ssim_band", "fused_activations"]
 
 BLOCK_X, BLOCK_Y, ONE_DIM_BLOCK_SIZE = 16, 16, 256
 
@@ -399,6 +399,58 @@ class _FusedL1SSIMBand(torch.autograd.Function):
 def fused_l1_ssim_band(image, gt_u8, y0, y1):
     """-> (sum of |x - gt/255| , sum of the SSIM map) over rows [y0, y1) of image [C,H,W]"""
     return _FusedL1SSIMBand.apply(image, gt_u8, int(y0), int(y1))
+
+
+# ------------------------------------------------------------------------- a19: fused activations
+class _FusedActivations(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, scaling, rotation, opacity, features_dc, features_rest):
+        ts = [scaling, rotation, opacity, features_dc, features_rest]
+        if not all(t.is_cuda for t in ts):
+            raise RuntimeError("fused_activations: device tensors required (no CPU fallback)")
+        scaling, rotation, opacity, features_dc, features_rest = [t.float().contiguous() for t in ts]
+        N, rest = scaling.shape[0], features_rest.shape[1]
+        dev = scaling.device
+        scales = torch.empty((N, 3), dtype=torch.float32, device=dev)
+        rotations = torch.empty((N, 4), dtype=torch.float32, device=dev)
+        opacities = torch.empty((N, 1), dtype=torch.float32, device=dev)
+        shs = torch.empty((N, 1 + rest, 3), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev), kernel_timer.range("activate_forward"):
+            check(lib.gsr_activate_forward(N, rest, _ptr(scaling), _ptr(rotation), _ptr(opacity), _ptr(features_dc),
+                                           _ptr(features_rest), _ptr(scales), _ptr(rotations), _ptr(opacities),
+                                           _ptr(shs), _stream()), "gsr_activate_forward")
+        ctx.save_for_backward(rotation, scales, opacities)
+        ctx.rest = rest
+        return scales, rotations, opacities, shs
+
+    @staticmethod
+    def backward(ctx, g_scales, g_rotations, g_opacities, g_shs):
+        rotation, scales, opacities = ctx.saved_tensors
+        N, rest = scales.shape[0], ctx.rest
+        dev = scales.device
+
+        def z(g, shape):
+            return torch.zeros(shape, dtype=torch.float32, device=dev) if g is None else g.float().contiguous()
+
+        g_scales, g_rotations = z(g_scales, (N, 3)), z(g_rotations, (N, 4))
+        g_opacities, g_shs = z(g_opacities, (N, 1)), z(g_shs, (N, 1 + rest, 3))
+        d_scaling = torch.empty((N, 3), dtype=torch.float32, device=dev)
+        d_rotation = torch.empty((N, 4), dtype=torch.float32, device=dev)
+        d_opacity = torch.empty((N, 1), dtype=torch.float32, device=dev)
+        d_dc = torch.empty((N, 1, 3), dtype=torch.float32, device=dev)
+        d_rest = torch.empty((N, rest, 3), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev), kernel_timer.range("activate_backward"):
+            check(lib.gsr_activate_backward(N, rest, _ptr(rotation), _ptr(scales), _ptr(opacities), _ptr(g_scales),
+                                            _ptr(g_rotations), _ptr(g_opacities), _ptr(g_shs), _ptr(d_scaling),
+                                            _ptr(d_rotation), _ptr(d_opacity), _ptr(d_dc), _ptr(d_rest), _stream()),
+                  "gsr_activate_backward")
+        return d_scaling, d_rotation, d_opacity, d_dc, d_rest
+
+
+def fused_activations(scaling, rotation, opacity, features_dc, features_rest):
+    """(scales, rotations, opacities, shs) = (exp, normalize, sigmoid, cat) of the raw parameters in one
+    kernel each way -- GaussianModel.get_scaling/get_rotation/get_opacity/get_features"""
+    return _FusedActivations.apply(scaling, rotation, opacity, features_dc, features_rest)
 
 
 # ------------------------------------------------------------------------------------------ _C

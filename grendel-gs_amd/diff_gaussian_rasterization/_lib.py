@@ -41,6 +41,8 @@ SIGNATURES = {
                                      c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "gsr_adam_step": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_double, ctypes.c_double,
                               ctypes.c_double, ctypes.c_double, c_int64, c_float, c_void_p]),
+    "gsr_activate_forward": (c_int, [c_int, c_int] + [c_void_p] * 10),
+    "gsr_activate_backward": (c_int, [c_int, c_int] + [c_void_p] * 13),
     "gsr_render_backward": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
 }

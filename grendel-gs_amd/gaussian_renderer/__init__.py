@@ -160,8 +160,13 @@ def distributed_preprocess3dgs_and_all2all_final(batched_viewpoint_cameras, pc, 
 
     if timers is not None:
         timers.start("forward_prepare_gaussians")
-    means3D, opacity, scales = pc.get_xyz, pc.get_opacity, pc.get_scaling
-    rotations, shs = pc.get_rotation, pc.get_features
+    means3D = pc.get_xyz
+    raw = [getattr(pc, n, None) for n in ("_scaling", "_rotation", "_opacity", "_features_dc", "_features_rest")]
+    if hasattr(_dgr, "fused_activations") and all(torch.is_tensor(t) and t.is_cuda for t in raw):
+        # the getters' exp / normalize / sigmoid / cat (scene/gaussian_model.py:109-129) as one HIP kernel
+        scales, rotations, opacity, shs = _dgr.fused_activations(*raw)
+    else:
+        opacity, scales, rotations, shs = pc.get_opacity, pc.get_scaling, pc.get_rotation, pc.get_features
     if timers is not None:
         timers.stop("forward_prepare_gaussians")
         timers.start("forward_preprocess_gaussians")

@@ -157,6 +157,19 @@ int gsr_l1_ssim_backward(int channels, int rows, int width, const float *image, 
 int gsr_adam_step(int64_t n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq, double lr,
                   double beta1, double beta2, double eps, int64_t step, float grad_scale, gsr_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * a19  fused parameter activations -- GaussianModel.get_scaling / get_rotation / get_opacity /
+ * get_features (scene/gaussian_model.py:109-129): scales = exp(_scaling) [N,3], rotations =
+ * normalize(_rotation) [N,4] (eps 1e-12), opacities = sigmoid(_opacity) [N,1], shs = cat(_features_dc
+ * [N,1,3], _features_rest [N,sh_rest,3]) [N,1+sh_rest,3]; and the matching backward. */
+int gsr_activate_forward(int N, int sh_rest, const float *scaling, const float *rotation, const float *opacity,
+                         const float *features_dc, const float *features_rest, float *scales, float *rotations,
+                         float *opacities, float *shs, gsr_stream_t stream);
+int gsr_activate_backward(int N, int sh_rest, const float *rotation, const float *scales, const float *opacities,
+                          const float *g_scales, const float *g_rotations, const float *g_opacities,
+                          const float *g_shs, float *d_scaling, float *d_rotation, float *d_opacity,
+                          float *d_features_dc, float *d_features_rest, gsr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

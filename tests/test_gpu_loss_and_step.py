@@ -219,3 +219,26 @@ def test_exchange_path_on_device_single_rank_rccl(device):
         utils.DEFAULT_GROUP = utils.IN_NODE_GROUP = utils.SingleGPUGroup()
         if created:
             dist.destroy_process_group()
+
+
+def test_fused_activations_match_getters(device):
+    """a19: exp / normalize / sigmoid / cat of GaussianModel's getters, forward and backward"""
+    from diff_gaussian_rasterization import fused_activations
+
+    m = S.SyntheticGaussianModel(3001, 320, 200, seed=1, device=device)
+    with torch.no_grad():
+        m._rotation[5] = 0.0  # degenerate quaternion: normalize's eps path
+    ws = [torch.rand(s, generator=torch.Generator().manual_seed(i)).to(device)
+          for i, s in enumerate([(3001, 3), (3001, 4), (3001, 1), (3001, 16, 3)])]
+    outs = fused_activations(m._scaling, m._rotation, m._opacity, m._features_dc, m._features_rest)
+    sum((o * w).sum() for o, w in zip(outs, ws)).backward()
+    got = [p.grad.clone() for p in (m._scaling, m._rotation, m._opacity, m._features_dc, m._features_rest)]
+    for p in m.parameters():
+        p.grad = None
+    refs = (m.get_scaling, m.get_rotation, m.get_opacity, m.get_features)
+    sum((o * w).sum() for o, w in zip(refs, ws)).backward()
+    want = [p.grad for p in (m._scaling, m._rotation, m._opacity, m._features_dc, m._features_rest)]
+    for o, r in zip(outs, refs):
+        assert rel_err(o, r) < 1e-6
+    for g_, w_ in zip(got, want):
+        assert rel_err(g_, w_) < 1e-5
