@@ -122,31 +122,42 @@ composite_forward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
         unsigned long long m = __ballot(e.relevant);
         GSR_STAT(0, __popcll(__ballot(have)));
         GSR_STAT(1, __popcll(m));
+        // Entries are taken UF at a time: their alphas are independent (ILP across the v_exp latency and the
+        // readlane -> VALU hazards), only the short T / colour chain is sequential, and the wave tests
+        // "everybody done?" once per group instead of draining the VALU pipe into a scalar branch per entry.
+        constexpr int UF = 4;
         while (m) {
-            const int k = __builtin_ctzll(m);
-            m &= m - 1;
-            const float gx_ = bcast(e.x, k), gy_ = bcast(e.y, k);
-            const float a2 = bcast(e.a2, k), b2 = bcast(e.b2, k), c2 = bcast(e.c2, k), o = bcast(e.o, k);
-            const float dx = gx_ - pxf, dy = gy_ - pyf;
-            const float p2 = (a2 * dx + b2 * dy) * dx + c2 * dy * dy;
-            const float alpha = fminf(0.99f, o * __builtin_amdgcn_exp2f(p2));
-            const bool take = !done && p2 <= 0.f && alpha >= ALPHA_MIN;
-            GSR_STAT(2, __any(take) ? 1 : 0);
-            GSR_STAT(3, __popcll(__ballot(take)));
-            const float test_T = T * (1.0f - alpha);
-            const bool stop = take && test_T < T_STOP;
-            done = done || stop;
-            const bool blend = take && !stop;
-            if (__any(blend)) {  // wave-uniform: colour is only broadcast when some pixel needs it
+            int kk[UF];
+            float al[UF];
+            bool ok[UF];
+#pragma unroll
+            for (int u = 0; u < UF; u++) {
+                const bool live = m != 0;  // wave-uniform
+                const int k = live ? __builtin_ctzll(m) : 0;
+                m &= m - 1;  // 0 & ~0 stays 0
+                kk[u] = k;
+                const float gx_ = bcast(e.x, k), gy_ = bcast(e.y, k);
+                const float a2 = bcast(e.a2, k), b2 = bcast(e.b2, k), c2 = bcast(e.c2, k), o = bcast(e.o, k);
+                const float dx = gx_ - pxf, dy = gy_ - pyf;
+                const float p2 = (a2 * dx + b2 * dy) * dx + c2 * dy * dy;
+                al[u] = fminf(0.99f, o * __builtin_amdgcn_exp2f(p2));
+                ok[u] = live && p2 <= 0.f && al[u] >= ALPHA_MIN;
+            }
+#pragma unroll
+            for (int u = 0; u < UF; u++) {
+                const int k = kk[u];
                 const float cr = bcast(r, k), cg = bcast(g, k), cb = bcast(b, k);
-                if (blend) {
-                    const float w = alpha * T;
-                    C0 += cr * w;
-                    C1 += cg * w;
-                    C2 += cb * w;
-                    T = test_T;
-                    last = c + k + 1;
-                }
+                const bool take = !done && ok[u];
+                const float test_T = T * (1.0f - al[u]);
+                const bool stop = take && test_T < T_STOP;
+                done = done || stop;
+                const bool blend = take && !stop;
+                const float w = blend ? al[u] * T : 0.f;
+                C0 += cr * w;
+                C1 += cg * w;
+                C2 += cb * w;
+                T = blend ? test_T : T;
+                last = blend ? c + k + 1 : last;
             }
             if (__all(done)) break;
         }
