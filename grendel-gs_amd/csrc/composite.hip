@@ -107,6 +107,7 @@ composite_forward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
     int last = 0;
     bool done = !inside;
+    __shared__ float4 slab[4][64][3];
 
     for (int c = 0; c < n; c += 64) {
         if (__all(done)) break;
@@ -122,13 +123,19 @@ composite_forward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
         unsigned long long m = __ballot(e.relevant);
         GSR_STAT(0, __popcll(__ballot(have)));
         GSR_STAT(1, __popcll(m));
-        // Entries are taken UF at a time: their alphas are independent (ILP across the v_exp latency and the
-        // readlane -> VALU hazards), only the short T / colour chain is sequential, and the wave tests
-        // "everybody done?" once per group instead of draining the VALU pipe into a scalar branch per entry.
+        // Stage the chunk in this wave's private LDS slab (lane k writes entry k) and broadcast-read it back:
+        // an LDS read with a wave-uniform address returns the entry to all 64 lanes WITHOUT spending VALU
+        // issue slots (9 v_readlane per entry before), and the VALU is what bounds this kernel.  No barrier:
+        // the slab is private to the wave and LDS operations of one wave execute in order.
+        slab[wave][lane][0] = make_float4(e.x, e.y, e.a2, e.b2);
+        slab[wave][lane][1] = make_float4(e.c2, e.o, r, g);
+        slab[wave][lane][2] = make_float4(b, 0.f, 0.f, 0.f);
+        // Entries are taken UF at a time: their alphas are independent (ILP across the LDS and v_exp latency),
+        // only the short T / colour chain is sequential, and the wave tests "everybody done?" once per group.
         constexpr int UF = 4;
         while (m) {
             int kk[UF];
-            float al[UF];
+            float al[UF], cr[UF], cg[UF], cb[UF];
             bool ok[UF];
 #pragma unroll
             for (int u = 0; u < UF; u++) {
@@ -136,28 +143,28 @@ composite_forward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
                 const int k = live ? __builtin_ctzll(m) : 0;
                 m &= m - 1;  // 0 & ~0 stays 0
                 kk[u] = k;
-                const float gx_ = bcast(e.x, k), gy_ = bcast(e.y, k);
-                const float a2 = bcast(e.a2, k), b2 = bcast(e.b2, k), c2 = bcast(e.c2, k), o = bcast(e.o, k);
-                const float dx = gx_ - pxf, dy = gy_ - pyf;
-                const float p2 = (a2 * dx + b2 * dy) * dx + c2 * dy * dy;
-                al[u] = fminf(0.99f, o * __builtin_amdgcn_exp2f(p2));
+                const float4 q0 = slab[wave][k][0], q1 = slab[wave][k][1];
+                cb[u] = slab[wave][k][2].x;
+                cr[u] = q1.z;
+                cg[u] = q1.w;
+                const float dx = q0.x - pxf, dy = q0.y - pyf;
+                const float p2 = (q0.z * dx + q0.w * dy) * dx + q1.x * dy * dy;
+                al[u] = fminf(0.99f, q1.y * __builtin_amdgcn_exp2f(p2));
                 ok[u] = live && p2 <= 0.f && al[u] >= ALPHA_MIN;
             }
 #pragma unroll
             for (int u = 0; u < UF; u++) {
-                const int k = kk[u];
-                const float cr = bcast(r, k), cg = bcast(g, k), cb = bcast(b, k);
                 const bool take = !done && ok[u];
                 const float test_T = T * (1.0f - al[u]);
                 const bool stop = take && test_T < T_STOP;
                 done = done || stop;
                 const bool blend = take && !stop;
                 const float w = blend ? al[u] * T : 0.f;
-                C0 += cr * w;
-                C1 += cg * w;
-                C2 += cb * w;
+                C0 += cr[u] * w;
+                C1 += cg[u] * w;
+                C2 += cb[u] * w;
                 T = blend ? test_T : T;
-                last = blend ? c + k + 1 : last;
+                last = blend ? c + kk[u] + 1 : last;
             }
             if (__all(done)) break;
         }
