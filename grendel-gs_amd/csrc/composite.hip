@@ -273,6 +273,7 @@ composite_backward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
     // the four waves of the tile walk the SAME chunk sequence so that their per-entry sums can be
     // combined in LDS and leave the workgroup as ONE set of atomics per (tile, entry)
     __shared__ float sacc[4][9][64];
+    __shared__ float4 slab[4][64][3];
     __shared__ int s_wmax[4];
     int wmax = last;
 #pragma unroll
@@ -305,6 +306,10 @@ composite_backward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
                 b = rgb[3 * (size_t)id + 2];
             }
             unsigned long long m = __ballot(e.relevant);
+            // wave-private LDS slab + broadcast reads instead of v_readlane (see K8): the VALU bounds this kernel
+            slab[wave][lane][0] = make_float4(e.x, e.y, e.a2, e.b2);
+            slab[wave][lane][1] = make_float4(e.c2, e.o, r, g);
+            slab[wave][lane][2] = make_float4(b, 0.f, 0.f, 0.f);
             while (m) {
                 float xs[64];
                 int ks[EB];
@@ -314,16 +319,19 @@ composite_backward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
                     bool got = false, take = false;
                     int k = 0;
                     float dx = 0.f, dy = 0.f, o = 0.f, G = 0.f, alpha = 0.f, a2 = 0.f, b2 = 0.f, c2 = 0.f;
+                    float cr = 0.f, cg = 0.f;
                     while (m) {
                         k = 63 - __builtin_clzll(m);
                         m &= ~(1ull << k);
-                        const float gx_ = bcast(e.x, k), gy_ = bcast(e.y, k);
-                        a2 = bcast(e.a2, k);
-                        b2 = bcast(e.b2, k);
-                        c2 = bcast(e.c2, k);
-                        o = bcast(e.o, k);
-                        dx = gx_ - pxf;
-                        dy = gy_ - pyf;
+                        const float4 q0 = slab[wave][k][0], q1 = slab[wave][k][1];
+                        a2 = q0.z;
+                        b2 = q0.w;
+                        c2 = q1.x;
+                        o = q1.y;
+                        cr = q1.z;
+                        cg = q1.w;
+                        dx = q0.x - pxf;
+                        dy = q0.y - pyf;
                         const float p2 = (a2 * dx + b2 * dy) * dx + c2 * dy * dy;
                         G = __builtin_amdgcn_exp2f(p2);
                         alpha = fminf(0.99f, o * G);
@@ -336,7 +344,7 @@ composite_backward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
                     ks[j] = k;
                     // branch-free contribution of this entry for this pixel (lanes that do not `take` are
                     // masked through G, dL/dG and the weight, never through a multiply by an inf/NaN)
-                    const float cr = bcast(r, k), cg = bcast(g, k), cb = bcast(b, k);
+                    const float cb = slab[wave][k][2].x;
                     const bool tk = got && take;
                     const float inv_1ma = __builtin_amdgcn_rcpf(1.f - alpha);  // 1 ulp, inside the 1e-4 budget
                     const float Tn = T * inv_1ma;                              // transmittance in front of the entry
