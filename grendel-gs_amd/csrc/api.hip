@@ -35,7 +35,7 @@ int gsr_preprocess_forward(int P, int sh_degree, int sh_coeffs, const float *mea
         !means2D || !depths || !radii || !cov3D || !conic_opacity || !rgb || !clamped)
         return GSR_EINVAL;
     return gsr_launch_preprocess_forward(P, sh_degree, sh_coeffs, means3D, scales, scale_modifier, rotations, shs,
-                                         opacities, viewmatrix, projmatrix, campos, width, height, tanfovx, tanfovy,
+                                         nullptr, opacities, viewmatrix, projmatrix, campos, width, height, tanfovx, tanfovy,
                                          means2D, depths, radii, cov3D, conic_opacity, rgb, clamped,
                                          reinterpret_cast<hipStream_t>(stream));
 }
@@ -56,10 +56,52 @@ int gsr_preprocess_backward(int P, int sh_degree, int sh_coeffs, const float *me
         !dL_dshs || !dL_dopacities)
         return GSR_EINVAL;
     return gsr_launch_preprocess_backward(P, sh_degree, sh_coeffs, means3D, scales, scale_modifier, rotations, shs,
-                                          viewmatrix, projmatrix, campos, width, height, tanfovx, tanfovy, radii,
+                                          nullptr, nullptr, viewmatrix, projmatrix, campos, width, height, tanfovx, tanfovy, radii,
                                           cov3D, clamped, dL_dmeans2D, dL_dconic_opacity, dL_drgb, dL_dmeans3D,
-                                          dL_dscales, dL_drotations, dL_dshs, dL_dopacities,
+                                          dL_dscales, dL_drotations, dL_dshs, nullptr, dL_dopacities,
                                           reinterpret_cast<hipStream_t>(stream));
+}
+
+int gsr_preprocess_forward_raw(int P, int sh_degree, int sh_coeffs, const float *xyz, const float *scaling,
+                               float scale_modifier, const float *rotation, const float *features_dc,
+                               const float *features_rest, const float *opacity, const float *viewmatrix,
+                               const float *projmatrix, const float *campos, int width, int height, float tanfovx,
+                               float tanfovy, float *means2D, float *depths, int32_t *radii, float *cov3D,
+                               float *conic_opacity, float *rgb, uint8_t *clamped, gsr_stream_t stream) {
+    if (P < 0 || sh_degree < 0 || sh_degree > 3 || sh_coeffs < 2 || sh_coeffs < (sh_degree + 1) * (sh_degree + 1) ||
+        width <= 0 || height <= 0 || !(tanfovx > 0.f) || !(tanfovy > 0.f))
+        return GSR_EINVAL;
+    if (P == 0) return 0;
+    if (!xyz || !scaling || !rotation || !features_dc || !features_rest || !opacity || !viewmatrix || !projmatrix ||
+        !campos || !means2D || !depths || !radii || !cov3D || !conic_opacity || !rgb || !clamped)
+        return GSR_EINVAL;
+    return gsr_launch_preprocess_forward(P, sh_degree, sh_coeffs, xyz, scaling, scale_modifier, rotation, features_dc,
+                                         features_rest, opacity, viewmatrix, projmatrix, campos, width, height,
+                                         tanfovx, tanfovy, means2D, depths, radii, cov3D, conic_opacity, rgb, clamped,
+                                         reinterpret_cast<hipStream_t>(stream));
+}
+
+int gsr_preprocess_backward_raw(int P, int sh_degree, int sh_coeffs, const float *xyz, const float *scaling,
+                                float scale_modifier, const float *rotation, const float *features_dc,
+                                const float *features_rest, const float *opacity, const float *viewmatrix,
+                                const float *projmatrix, const float *campos, int width, int height, float tanfovx,
+                                float tanfovy, const int32_t *radii, const float *cov3D, const uint8_t *clamped,
+                                const float *dL_dmeans2D, const float *dL_dconic_opacity, const float *dL_drgb,
+                                float *dL_dxyz, float *dL_dscaling, float *dL_drotation, float *dL_dfeatures_dc,
+                                float *dL_dfeatures_rest, float *dL_dopacity, gsr_stream_t stream) {
+    if (P < 0 || sh_degree < 0 || sh_degree > 3 || sh_coeffs < 2 || sh_coeffs < (sh_degree + 1) * (sh_degree + 1) ||
+        width <= 0 || height <= 0 || !(tanfovx > 0.f) || !(tanfovy > 0.f))
+        return GSR_EINVAL;
+    if (P == 0) return 0;
+    if (!xyz || !scaling || !rotation || !features_dc || !features_rest || !opacity || !viewmatrix || !projmatrix ||
+        !campos || !radii || !cov3D || !clamped || !dL_dmeans2D || !dL_dconic_opacity || !dL_drgb || !dL_dxyz ||
+        !dL_dscaling || !dL_drotation || !dL_dfeatures_dc || !dL_dfeatures_rest || !dL_dopacity)
+        return GSR_EINVAL;
+    return gsr_launch_preprocess_backward(P, sh_degree, sh_coeffs, xyz, scaling, scale_modifier, rotation, features_dc,
+                                          features_rest, opacity, viewmatrix, projmatrix, campos, width, height,
+                                          tanfovx, tanfovy, radii, cov3D, clamped, dL_dmeans2D, dL_dconic_opacity,
+                                          dL_drgb, dL_dxyz, dL_dscaling, dL_drotation, dL_dfeatures_dc,
+                                          dL_dfeatures_rest, dL_dopacity, reinterpret_cast<hipStream_t>(stream));
 }
 
 int gsr_get_local2j_ids_bool(int P, int width, int height, int world_size, const float *means2D,

@@ -80,18 +80,19 @@ __device__ __forceinline__ bool gsr_can_touch_box(const float2 xy, const float4 
 
 // ---- internal launchers (defined in the .hip files, called from api.hip) --------------------
 int gsr_launch_preprocess_forward(int P, int D, int M, const float *means3D, const float *scales, float scale_modifier,
-                                  const float *rotations, const float *shs, const float *opacities,
+                                  const float *rotations, const float *shs, const float *shs_rest,
+                                  const float *opacities,
                                   const float *viewmatrix, const float *projmatrix, const float *campos, int W, int H,
                                   float tanfovx, float tanfovy, float *means2D, float *depths, int32_t *radii,
                                   float *cov3D, float *conic_opacity, float *rgb, uint8_t *clamped,
                                   hipStream_t stream);
 int gsr_launch_preprocess_backward(int P, int D, int M, const float *means3D, const float *scales,
                                    float scale_modifier, const float *rotations, const float *shs,
-                                   const float *viewmatrix, const float *projmatrix, const float *campos, int W,
+                                   const float *shs_rest, const float *opacities_raw, const float *viewmatrix, const float *projmatrix, const float *campos, int W,
                                    int H, float tanfovx, float tanfovy, const int32_t *radii, const float *cov3D,
                                    const uint8_t *clamped, const float *dL_dmeans2D, const float *dL_dconic_opacity,
                                    const float *dL_drgb, float *dL_dmeans3D, float *dL_dscales, float *dL_drotations,
-                                   float *dL_dshs, float *dL_dopacities, hipStream_t stream);
+                                   float *dL_dshs, float *dL_dshs_rest, float *dL_dopacities, hipStream_t stream);
 int gsr_launch_local2j(int P, int W, int H, int ws, const float *means2D, const int32_t *radii, const int32_t *div,
                        uint8_t *out, hipStream_t stream);
 

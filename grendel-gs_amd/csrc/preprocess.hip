@@ -100,11 +100,15 @@ __device__ __forceinline__ void eval_sh(const float *__restrict__ sh, float x, f
 }
 
 // ------------------------------------------------------------------------------------------- K1
-template <int DEG>
+// RAW = true: the inputs are the RAW parameters of GaussianModel (log-scales, un-normalised quaternions,
+// opacity logits, SH split into _features_dc [N,1,3] = `shs` and _features_rest [N,M-1,3] = `shs_rest`) and the
+// getters' activations (scene/gaussian_model.py:109-129: exp, normalize, sigmoid, cat) are applied in
+// registers -- no activated copies of the 59 floats per Gaussian are written to / re-read from HBM.
+template <int DEG, bool RAW>
 __global__ void __launch_bounds__(GSR_ONE_DIM_BLOCK)
 preprocess_forward_kernel(int P, int M, const float *__restrict__ means3D, const float *__restrict__ scales,
                           float scale_modifier, const float *__restrict__ rotations, const float *__restrict__ shs,
-                          const float *__restrict__ opacities, const float *__restrict__ view,
+                          const float *__restrict__ shs_rest, const float *__restrict__ opacities, const float *__restrict__ view,
                           const float *__restrict__ proj, const float *__restrict__ campos, int W, int H,
                           float tanfovx, float tanfovy, float2 *__restrict__ means2D, float *__restrict__ depths,
                           int32_t *__restrict__ radii, float *__restrict__ cov3D, float4 *__restrict__ conic_opacity,
@@ -138,9 +142,17 @@ preprocess_forward_kernel(int P, int M, const float *__restrict__ means3D, const
 
         // Sigma = R S S R^T
         float R[3][3];
-        quat_to_R(*reinterpret_cast<const float4 *>(rotations + 4 * (size_t)i), R);
-        const float s[3] = {scale_modifier * scales[3 * i], scale_modifier * scales[3 * i + 1],
-                            scale_modifier * scales[3 * i + 2]};
+        float4 q = *reinterpret_cast<const float4 *>(rotations + 4 * (size_t)i);
+        float sc[3] = {scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]};
+        if (RAW) {
+            const float qn = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
+            q = make_float4(q.x / qn, q.y / qn, q.z / qn, q.w / qn);
+            sc[0] = expf(sc[0]);
+            sc[1] = expf(sc[1]);
+            sc[2] = expf(sc[2]);
+        }
+        quat_to_R(q, R);
+        const float s[3] = {scale_modifier * sc[0], scale_modifier * sc[1], scale_modifier * sc[2]};
         float L[3][3];
 #pragma unroll
         for (int a = 0; a < 3; a++)
@@ -183,7 +195,14 @@ preprocess_forward_kernel(int P, int M, const float *__restrict__ means3D, const
         d[2] *= inv;
         float shl[(DEG + 1) * (DEG + 1) * 3];
         const float *shp = shs + (size_t)i * M * 3;
-        if (DEG == 3 && M == 16) {
+        if (RAW) {
+            shl[0] = shs[3 * (size_t)i];
+            shl[1] = shs[3 * (size_t)i + 1];
+            shl[2] = shs[3 * (size_t)i + 2];
+            const float *rp = shs_rest + (size_t)i * (M - 1) * 3;
+#pragma unroll
+            for (int k = 3; k < (DEG + 1) * (DEG + 1) * 3; k++) shl[k] = rp[k - 3];
+        } else if (DEG == 3 && M == 16) {
             const float4 *s4 = reinterpret_cast<const float4 *>(shp);
 #pragma unroll
             for (int k = 0; k < 12; k++) {
@@ -209,7 +228,8 @@ preprocess_forward_kernel(int P, int M, const float *__restrict__ means3D, const
         depth = t[2];
         cov[0] = S[0][0]; cov[1] = S[0][1]; cov[2] = S[0][2];
         cov[3] = S[1][1]; cov[4] = S[1][2]; cov[5] = S[2][2];
-        co = make_float4(c * det_inv, -b * det_inv, a * det_inv, opacities[i]);
+        co = make_float4(c * det_inv, -b * det_inv, a * det_inv,
+                         RAW ? 1.0f / (1.0f + expf(-opacities[i])) : opacities[i]);
     } while (false);
 
     radii[i] = radius;
@@ -226,10 +246,11 @@ preprocess_forward_kernel(int P, int M, const float *__restrict__ means3D, const
 }
 
 // ------------------------------------------------------------------------------------------ K11
-template <int DEG>
+template <int DEG, bool RAW>
 __global__ void __launch_bounds__(GSR_ONE_DIM_BLOCK)
 preprocess_backward_kernel(int P, int M, const float *__restrict__ means3D, const float *__restrict__ scales,
                            float scale_modifier, const float *__restrict__ rotations, const float *__restrict__ shs,
+                           const float *__restrict__ shs_rest, const float *__restrict__ opacities_raw,
                            const float *__restrict__ view, const float *__restrict__ proj,
                            const float *__restrict__ campos, int W, int H, float tanfovx, float tanfovy,
                            const int32_t *__restrict__ radii, const float *__restrict__ cov3D,
@@ -237,12 +258,22 @@ preprocess_backward_kernel(int P, int M, const float *__restrict__ means3D, cons
                            const float4 *__restrict__ dL_dconic_opacity, const float *__restrict__ dL_drgb,
                            float *__restrict__ dL_dmeans3D, float *__restrict__ dL_dscales,
                            float4 *__restrict__ dL_drotations, float *__restrict__ dL_dshs,
-                           float *__restrict__ dL_dopacities) {
+                           float *__restrict__ dL_dshs_rest, float *__restrict__ dL_dopacities) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
     constexpr int NC = (DEG + 1) * (DEG + 1);
     float *dsh_out = dL_dshs + (size_t)i * M * 3;
 
+    if (RAW && radii[i] <= 0) {
+        dL_dmeans3D[3 * (size_t)i] = dL_dmeans3D[3 * (size_t)i + 1] = dL_dmeans3D[3 * (size_t)i + 2] = 0.f;
+        dL_dscales[3 * (size_t)i] = dL_dscales[3 * (size_t)i + 1] = dL_dscales[3 * (size_t)i + 2] = 0.f;
+        dL_drotations[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        dL_dopacities[i] = 0.f;
+        dL_dshs[3 * (size_t)i] = dL_dshs[3 * (size_t)i + 1] = dL_dshs[3 * (size_t)i + 2] = 0.f;
+        float *rp = dL_dshs_rest + (size_t)i * (M - 1) * 3;
+        for (int k = 0; k < (M - 1) * 3; k++) rp[k] = 0.f;
+        return;
+    }
     if (radii[i] <= 0) {
         dL_dmeans3D[3 * (size_t)i] = dL_dmeans3D[3 * (size_t)i + 1] = dL_dmeans3D[3 * (size_t)i + 2] = 0.f;
         dL_dscales[3 * (size_t)i] = dL_dscales[3 * (size_t)i + 1] = dL_dscales[3 * (size_t)i + 2] = 0.f;
@@ -256,7 +287,12 @@ preprocess_backward_kernel(int P, int M, const float *__restrict__ means3D, cons
     const float p[3] = {means3D[3 * (size_t)i], means3D[3 * (size_t)i + 1], means3D[3 * (size_t)i + 2]};
     const float4 gco = dL_dconic_opacity[i];
     const float gA = gco.x, gB = gco.y, gC = gco.z;
-    dL_dopacities[i] = gco.w;
+    if (RAW) {
+        const float so = 1.0f / (1.0f + expf(-opacities_raw[i]));
+        dL_dopacities[i] = gco.w * so * (1.0f - so);
+    } else {
+        dL_dopacities[i] = gco.w;
+    }
 
     // ---- conic -> cov2D -> (cov3D, t)
     float t[3];
@@ -331,7 +367,19 @@ preprocess_backward_kernel(int P, int M, const float *__restrict__ means3D, cons
 
     // ---- colour -> SH coefficients and view direction
     {
-        const float *sh = shs + (size_t)i * M * 3;
+        float sh[NC * 3];
+        if (RAW) {
+            sh[0] = shs[3 * (size_t)i];
+            sh[1] = shs[3 * (size_t)i + 1];
+            sh[2] = shs[3 * (size_t)i + 2];
+            const float *rp = shs_rest + (size_t)i * (M - 1) * 3;
+#pragma unroll
+            for (int k = 3; k < NC * 3; k++) sh[k] = rp[k - 3];
+        } else {
+            const float *sp = shs + (size_t)i * M * 3;
+#pragma unroll
+            for (int k = 0; k < NC * 3; k++) sh[k] = sp[k];
+        }
         const float dox = p[0] - cam.c[0], doy = p[1] - cam.c[1], doz = p[2] - cam.c[2];
         const float len = sqrtf(dox * dox + doy * doy + doz * doz);
         const float x = dox / len, y = doy / len, z = doz / len;
@@ -392,7 +440,15 @@ preprocess_backward_kernel(int P, int M, const float *__restrict__ means3D, cons
         dmean[0] += (ddir[0] - x * dot) / len;
         dmean[1] += (ddir[1] - y * dot) / len;
         dmean[2] += (ddir[2] - z * dot) / len;
-        if (DEG == 3 && M == 16) {
+        if (RAW) {
+            dL_dshs[3 * (size_t)i] = dsh[0];
+            dL_dshs[3 * (size_t)i + 1] = dsh[1];
+            dL_dshs[3 * (size_t)i + 2] = dsh[2];
+            float *rp = dL_dshs_rest + (size_t)i * (M - 1) * 3;
+#pragma unroll
+            for (int k = 3; k < NC * 3; k++) rp[k - 3] = dsh[k];
+            for (int k = NC * 3; k < M * 3; k++) rp[k - 3] = 0.f;
+        } else if (DEG == 3 && M == 16) {
             float4 *o4 = reinterpret_cast<float4 *>(dsh_out);
 #pragma unroll
             for (int k = 0; k < 12; k++) o4[k] = make_float4(dsh[4 * k], dsh[4 * k + 1], dsh[4 * k + 2], dsh[4 * k + 3]);
@@ -408,11 +464,21 @@ preprocess_backward_kernel(int P, int M, const float *__restrict__ means3D, cons
 
     // ---- cov3D -> scales, rotations.  Sigma = M^T M, M = S R^T
     {
-        const float4 q = *reinterpret_cast<const float4 *>(rotations + 4 * (size_t)i);
+        const float4 qraw = *reinterpret_cast<const float4 *>(rotations + 4 * (size_t)i);
+        float4 q = qraw;
+        float sc[3] = {scales[3 * (size_t)i], scales[3 * (size_t)i + 1], scales[3 * (size_t)i + 2]};
+        float qn = 1.f, qnr = 1.f;
+        if (RAW) {
+            qnr = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+            qn = fmaxf(qnr, 1e-12f);
+            q = make_float4(q.x / qn, q.y / qn, q.z / qn, q.w / qn);
+            sc[0] = expf(sc[0]);
+            sc[1] = expf(sc[1]);
+            sc[2] = expf(sc[2]);
+        }
         float R[3][3];
         quat_to_R(q, R);
-        const float s[3] = {scale_modifier * scales[3 * (size_t)i], scale_modifier * scales[3 * (size_t)i + 1],
-                            scale_modifier * scales[3 * (size_t)i + 2]};
+        const float s[3] = {scale_modifier * sc[0], scale_modifier * sc[1], scale_modifier * sc[2]};
         float Mm[3][3];
 #pragma unroll
         for (int r = 0; r < 3; r++)
@@ -430,7 +496,7 @@ preprocess_backward_kernel(int P, int M, const float *__restrict__ means3D, cons
         float dR[3][3];
 #pragma unroll
         for (int r = 0; r < 3; r++) {
-            dL_dscales[3 * (size_t)i + r] =
+            dL_dscales[3 * (size_t)i + r] = (RAW ? sc[r] : 1.f) *  // d exp(x) = exp(x) dx
                 scale_modifier * (R[0][r] * dM[r][0] + R[1][r] * dM[r][1] + R[2][r] * dM[r][2]);
 #pragma unroll
             for (int j = 0; j < 3; j++) dR[j][r] = s[r] * dM[r][j];
@@ -444,6 +510,11 @@ preprocess_backward_kernel(int P, int M, const float *__restrict__ means3D, cons
                       z * dR[2][1] - 2.f * y * dR[2][2]);
         dq.w = 2.f * (-2.f * z * dR[0][0] - r_ * dR[0][1] + x * dR[0][2] + r_ * dR[1][0] - 2.f * z * dR[1][1] +
                       y * dR[1][2] + x * dR[2][0] + y * dR[2][1]);
+        if (RAW) {  // through q = x / max(|x|, 1e-12)
+            const float dot = qnr > 1e-12f ? (q.x * dq.x + q.y * dq.y + q.z * dq.z + q.w * dq.w) : 0.f;
+            dq = make_float4((dq.x - q.x * dot) / qn, (dq.y - q.y * dot) / qn, (dq.z - q.z * dot) / qn,
+                             (dq.w - q.w * dot) / qn);
+        }
         dL_drotations[i] = dq;
     }
 }
@@ -489,37 +560,46 @@ local2j_kernel(int P, int W, int H, int ws, const float2 *__restrict__ means2D, 
     }
 
 int gsr_launch_preprocess_forward(int P, int D, int M, const float *means3D, const float *scales, float scale_modifier,
-                                  const float *rotations, const float *shs, const float *opacities,
+                                  const float *rotations, const float *shs, const float *shs_rest,
+                                  const float *opacities,
                                   const float *viewmatrix, const float *projmatrix, const float *campos, int W, int H,
                                   float tanfovx, float tanfovy, float *means2D, float *depths, int32_t *radii,
                                   float *cov3D, float *conic_opacity, float *rgb, uint8_t *clamped,
                                   hipStream_t stream) {
     if (P == 0) return 0;
     const dim3 grid(gsr_div_up(P, GSR_ONE_DIM_BLOCK)), block(GSR_ONE_DIM_BLOCK);
-    GSR_DISPATCH_DEG(D, hipLaunchKernelGGL(preprocess_forward_kernel<DEG>, grid, block, 0, stream, P, M, means3D,
-                                           scales, scale_modifier, rotations, shs, opacities, viewmatrix, projmatrix,
-                                           campos, W, H, tanfovx, tanfovy, reinterpret_cast<float2 *>(means2D), depths,
-                                           radii, cov3D, reinterpret_cast<float4 *>(conic_opacity), rgb, clamped));
+#define GSR_FWD(RAWF)                                                                                              \
+    GSR_DISPATCH_DEG(D, hipLaunchKernelGGL((preprocess_forward_kernel<DEG, RAWF>), grid, block, 0, stream, P, M,   \
+                                           means3D, scales, scale_modifier, rotations, shs, shs_rest, opacities,   \
+                                           viewmatrix, projmatrix, campos, W, H, tanfovx, tanfovy,                 \
+                                           reinterpret_cast<float2 *>(means2D), depths, radii, cov3D,              \
+                                           reinterpret_cast<float4 *>(conic_opacity), rgb, clamped))
+    if (shs_rest) { GSR_FWD(true); } else { GSR_FWD(false); }
+#undef GSR_FWD
     GSR_LAUNCH_CHECK();
     return 0;
 }
 
 int gsr_launch_preprocess_backward(int P, int D, int M, const float *means3D, const float *scales,
                                    float scale_modifier, const float *rotations, const float *shs,
-                                   const float *viewmatrix, const float *projmatrix, const float *campos, int W,
+                                   const float *shs_rest, const float *opacities_raw, const float *viewmatrix, const float *projmatrix, const float *campos, int W,
                                    int H, float tanfovx, float tanfovy, const int32_t *radii, const float *cov3D,
                                    const uint8_t *clamped, const float *dL_dmeans2D, const float *dL_dconic_opacity,
                                    const float *dL_drgb, float *dL_dmeans3D, float *dL_dscales, float *dL_drotations,
-                                   float *dL_dshs, float *dL_dopacities, hipStream_t stream) {
+                                   float *dL_dshs, float *dL_dshs_rest, float *dL_dopacities,
+                                   hipStream_t stream) {
     if (P == 0) return 0;
     const dim3 grid(gsr_div_up(P, GSR_ONE_DIM_BLOCK)), block(GSR_ONE_DIM_BLOCK);
-    GSR_DISPATCH_DEG(D, hipLaunchKernelGGL(preprocess_backward_kernel<DEG>, grid, block, 0, stream, P, M, means3D,
-                                           scales, scale_modifier, rotations, shs, viewmatrix, projmatrix, campos, W,
-                                           H, tanfovx, tanfovy, radii, cov3D, clamped,
-                                           reinterpret_cast<const float2 *>(dL_dmeans2D),
-                                           reinterpret_cast<const float4 *>(dL_dconic_opacity), dL_drgb, dL_dmeans3D,
-                                           dL_dscales, reinterpret_cast<float4 *>(dL_drotations), dL_dshs,
-                                           dL_dopacities));
+#define GSR_BWD(RAWF)                                                                                              \
+    GSR_DISPATCH_DEG(D, hipLaunchKernelGGL((preprocess_backward_kernel<DEG, RAWF>), grid, block, 0, stream, P, M,  \
+                                           means3D, scales, scale_modifier, rotations, shs, shs_rest,              \
+                                           opacities_raw, viewmatrix, projmatrix, campos, W, H, tanfovx, tanfovy,  \
+                                           radii, cov3D, clamped, reinterpret_cast<const float2 *>(dL_dmeans2D),   \
+                                           reinterpret_cast<const float4 *>(dL_dconic_opacity), dL_drgb,           \
+                                           dL_dmeans3D, dL_dscales, reinterpret_cast<float4 *>(dL_drotations),     \
+                                           dL_dshs, dL_dshs_rest, dL_dopacities))
+    if (shs_rest) { GSR_BWD(true); } else { GSR_BWD(false); }
+#undef GSR_BWD
     GSR_LAUNCH_CHECK();
     return 0;
 }

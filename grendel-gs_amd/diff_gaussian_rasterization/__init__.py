@@ -191,6 +191,71 @@ class _PreprocessGaussians(torch.autograd.Function):
         return d_means3D, d_scales, d_rot, d_shs, d_opac, None, None
 
 
+class _PreprocessGaussiansRaw(torch.autograd.Function):
+    """K1 / K11 taking GaussianModel's RAW parameters; the getters' activations run inside the kernels
+    (include/gsraster.h: gsr_preprocess_forward_raw / _backward_raw)."""
+
+    @staticmethod
+    def forward(ctx, xyz, scaling, rotation, features_dc, features_rest, opacity, raster_settings, cuda_args):
+        rs = raster_settings
+        xyz, scaling, rotation = _f32c(xyz, "xyz"), _f32c(scaling, "scaling"), _f32c(rotation, "rotation")
+        features_dc, features_rest = _f32c(features_dc, "features_dc"), _f32c(features_rest, "features_rest")
+        opacity = _f32c(opacity, "opacity")
+        P = xyz.shape[0]
+        if features_dc.shape != (P, 1, 3) or features_rest.dim() != 3 or features_rest.shape[0] != P or \
+                features_rest.shape[2] != 3 or features_rest.shape[1] < 1:
+            raise ValueError("features_dc [P,1,3] and features_rest [P,K-1,3] expected")
+        M = 1 + features_rest.shape[1]
+        dev = xyz.device
+        view, proj, campos = _f32c(rs.viewmatrix, "viewmatrix"), _f32c(rs.projmatrix, "projmatrix"), \
+            _f32c(rs.campos, "campos")
+        means2D = torch.empty((P, 2), dtype=torch.float32, device=dev)
+        depths = torch.empty((P,), dtype=torch.float32, device=dev)
+        radii = torch.empty((P,), dtype=torch.int32, device=dev)
+        cov3D = torch.empty((P, 6), dtype=torch.float32, device=dev)
+        conic_opacity = torch.empty((P, 4), dtype=torch.float32, device=dev)
+        rgb = torch.empty((P, 3), dtype=torch.float32, device=dev)
+        clamped = torch.empty((P, 3), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev), kernel_timer.range("preprocess_forward"):
+            check(lib.gsr_preprocess_forward_raw(
+                P, int(rs.sh_degree), M, _ptr(xyz), _ptr(scaling), float(rs.scale_modifier), _ptr(rotation),
+                _ptr(features_dc), _ptr(features_rest), _ptr(opacity), _ptr(view), _ptr(proj), _ptr(campos),
+                int(rs.image_width), int(rs.image_height), float(rs.tanfovx), float(rs.tanfovy), _ptr(means2D),
+                _ptr(depths), _ptr(radii), _ptr(cov3D), _ptr(conic_opacity), _ptr(rgb), _ptr(clamped), _stream()),
+                "gsr_preprocess_forward_raw")
+        ctx.raster_settings, ctx.M = rs, M
+        ctx.save_for_backward(xyz, scaling, rotation, features_dc, features_rest, opacity, view, proj, campos, radii,
+                              cov3D, clamped)
+        ctx.mark_non_differentiable(radii, depths)
+        return means2D, rgb, conic_opacity, radii, depths
+
+    @staticmethod
+    def backward(ctx, g_means2D, g_rgb, g_conic_opacity, g_radii, g_depths):
+        rs = ctx.raster_settings
+        xyz, scaling, rotation, f_dc, f_rest, opacity, view, proj, campos, radii, cov3D, clamped = ctx.saved_tensors
+        P, M = xyz.shape[0], ctx.M
+        dev = xyz.device
+
+        def z(g, cols):
+            return torch.zeros((P, cols), dtype=torch.float32, device=dev) if g is None else g.float().contiguous()
+
+        g_means2D, g_rgb, g_conic_opacity = z(g_means2D, 2), z(g_rgb, 3), z(g_conic_opacity, 4)
+        d_xyz = torch.empty((P, 3), dtype=torch.float32, device=dev)
+        d_scaling = torch.empty((P, 3), dtype=torch.float32, device=dev)
+        d_rot = torch.empty((P, 4), dtype=torch.float32, device=dev)
+        d_dc = torch.empty((P, 1, 3), dtype=torch.float32, device=dev)
+        d_rest = torch.empty((P, M - 1, 3), dtype=torch.float32, device=dev)
+        d_opac = torch.empty((P, 1), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev), kernel_timer.range("preprocess_backward"):
+            check(lib.gsr_preprocess_backward_raw(
+                P, int(rs.sh_degree), M, _ptr(xyz), _ptr(scaling), float(rs.scale_modifier), _ptr(rotation),
+                _ptr(f_dc), _ptr(f_rest), _ptr(opacity), _ptr(view), _ptr(proj), _ptr(campos), int(rs.image_width),
+                int(rs.image_height), float(rs.tanfovx), float(rs.tanfovy), _ptr(radii), _ptr(cov3D), _ptr(clamped),
+                _ptr(g_means2D), _ptr(g_conic_opacity), _ptr(g_rgb), _ptr(d_xyz), _ptr(d_scaling), _ptr(d_rot),
+                _ptr(d_dc), _ptr(d_rest), _ptr(d_opac), _stream()), "gsr_preprocess_backward_raw")
+        return d_xyz, d_scaling, d_rot, d_dc, d_rest, d_opac, None, None
+
+
 # ------------------------------------------------------------------------------- K3..K8 / K10
 def bin_gaussians(means2D, depths, radii, conic_opacity, compute_locally, width, height):
     """K3-K7: returns (point_list uint32-as-int32 [D], ranges int32 [tiles,2], D).  One host sync
@@ -330,6 +395,13 @@ class GaussianRasterizer(nn.Module):
         (pixel gradient x (W/2, H/2)), the convention densification thresholds against
         (scene/gaussian_model.py:1046-1064)."""
         return _PreprocessGaussians.apply(means3D, scales, rotations, shs, opacities, self.raster_settings, cuda_args)
+
+    def preprocess_gaussians_raw(self, xyz, scaling, rotation, features_dc, features_rest, opacity, cuda_args=None):
+        """same outputs as preprocess_gaussians, from GaussianModel's RAW parameters (_xyz, _scaling, _rotation,
+        _features_dc, _features_rest, _opacity): the getters' exp / normalize / sigmoid / cat are fused into the
+        kernels.  Extension of this build (the reference's op takes activated tensors)."""
+        return _PreprocessGaussiansRaw.apply(xyz, scaling, rotation, features_dc, features_rest, opacity,
+                                             self.raster_settings, cuda_args)
 
     def render_gaussians(self, means2D, conic_opacity, rgb, depths, radii, compute_locally,
                          extended_compute_locally=None, cuda_args=None):

@@ -160,13 +160,12 @@ def distributed_preprocess3dgs_and_all2all_final(batched_viewpoint_cameras, pc, 
 
     if timers is not None:
         timers.start("forward_prepare_gaussians")
-    means3D = pc.get_xyz
-    raw = [getattr(pc, n, None) for n in ("_scaling", "_rotation", "_opacity", "_features_dc", "_features_rest")]
-    if hasattr(_dgr, "fused_activations") and all(torch.is_tensor(t) and t.is_cuda for t in raw):
-        # the getters' exp / normalize / sigmoid / cat (scene/gaussian_model.py:109-129) as one HIP kernel
-        scales, rotations, opacity, shs = _dgr.fused_activations(*raw)
-    else:
-        opacity, scales, rotations, shs = pc.get_opacity, pc.get_scaling, pc.get_rotation, pc.get_features
+    raw = [getattr(pc, n, None) for n in ("_xyz", "_scaling", "_rotation", "_features_dc", "_features_rest", "_opacity")]
+    fused = hasattr(GaussianRasterizer, "preprocess_gaussians_raw") and all(torch.is_tensor(t) and t.is_cuda for t in raw)
+    if not fused:  # the reference's way: four stock-torch activation kernels, then the op on activated tensors
+        means3D, opacity, scales = pc.get_xyz, pc.get_opacity, pc.get_scaling
+        rotations, shs = pc.get_rotation, pc.get_features
+    # fused: exp / normalize / sigmoid / cat of the getters (scene/gaussian_model.py:109-129) happen inside K1 / K11
     if timers is not None:
         timers.stop("forward_prepare_gaussians")
         timers.start("forward_preprocess_gaussians")
@@ -189,8 +188,11 @@ def distributed_preprocess3dgs_and_all2all_final(batched_viewpoint_cameras, pc, 
             debug=pipe.debug,
         )
         rasterizer = GaussianRasterizer(raster_settings=settings)
-        means2D, rgb, conic_opacity, radii, depths = rasterizer.preprocess_gaussians(
-            means3D=means3D, scales=scales, rotations=rotations, shs=shs, opacities=opacity, cuda_args=cuda_args)
+        if fused:
+            means2D, rgb, conic_opacity, radii, depths = rasterizer.preprocess_gaussians_raw(*raw, cuda_args=cuda_args)
+        else:
+            means2D, rgb, conic_opacity, radii, depths = rasterizer.preprocess_gaussians(
+                means3D=means3D, scales=scales, rotations=rotations, shs=shs, opacities=opacity, cuda_args=cuda_args)
         if mode == "train":
             means2D.retain_grad()  # densification reads means2D.grad (scene/gaussian_model.py:1046-1052)
         rasterizers.append(rasterizer)

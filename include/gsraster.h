@@ -158,6 +158,29 @@ int gsr_adam_step(int64_t n, float *param, const float *grad, float *exp_avg, fl
                   double beta1, double beta2, double eps, int64_t step, float grad_scale, gsr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * K1 / K11 on the RAW parameters of GaussianModel (scene/gaussian_model.py:219-242): `scaling` log-scales
+ * [P,3], `rotation` un-normalised quaternions [P,4], `opacity` logits [P,1], `features_dc` [P,1,3],
+ * `features_rest` [P,sh_coeffs-1,3].  The getters' activations (scene/gaussian_model.py:109-129: exp,
+ * normalize with eps 1e-12, sigmoid, cat) are applied in registers, so the activated copies are never
+ * written to or re-read from HBM; outputs / saved tensors are those of gsr_preprocess_forward, and the
+ * backward returns gradients with respect to the raw parameters.  Used by this package's
+ * gaussian_renderer mirror; the reference-shaped entry points above remain the drop-in surface. */
+int gsr_preprocess_forward_raw(int P, int sh_degree, int sh_coeffs, const float *xyz, const float *scaling,
+                               float scale_modifier, const float *rotation, const float *features_dc,
+                               const float *features_rest, const float *opacity, const float *viewmatrix,
+                               const float *projmatrix, const float *campos, int width, int height, float tanfovx,
+                               float tanfovy, float *means2D, float *depths, int32_t *radii, float *cov3D,
+                               float *conic_opacity, float *rgb, uint8_t *clamped, gsr_stream_t stream);
+int gsr_preprocess_backward_raw(int P, int sh_degree, int sh_coeffs, const float *xyz, const float *scaling,
+                                float scale_modifier, const float *rotation, const float *features_dc,
+                                const float *features_rest, const float *opacity, const float *viewmatrix,
+                                const float *projmatrix, const float *campos, int width, int height, float tanfovx,
+                                float tanfovy, const int32_t *radii, const float *cov3D, const uint8_t *clamped,
+                                const float *dL_dmeans2D, const float *dL_dconic_opacity, const float *dL_drgb,
+                                float *dL_dxyz, float *dL_dscaling, float *dL_drotation, float *dL_dfeatures_dc,
+                                float *dL_dfeatures_rest, float *dL_dopacity, gsr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * a19  fused parameter activations -- GaussianModel.get_scaling / get_rotation / get_opacity /
  * get_features (scene/gaussian_model.py:109-129): scales = exp(_scaling) [N,3], rotations =
  * normalize(_rotation) [N,4] (eps 1e-12), opacities = sigmoid(_opacity) [N,1], shs = cat(_features_dc

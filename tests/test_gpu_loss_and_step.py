@@ -242,3 +242,36 @@ def test_fused_activations_match_getters(device):
         assert rel_err(o, r) < 1e-6
     for g_, w_ in zip(got, want):
         assert rel_err(g_, w_) < 1e-5
+
+
+@pytest.mark.parametrize("deg", [0, 2, 3])
+def test_preprocess_raw_equals_getters_then_op(device, deg):
+    """the RAW-parameter entry (activations fused into K1/K11) == getters + reference-shaped op, fwd and bwd"""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from helpers import settings_from
+
+    N, W, H = 20000, 320, 208
+    cam = S.orbit_cameras(4, W, H, device=device)[1]
+    rast = GaussianRasterizer(settings_from(cam, torch.zeros(3), sh_degree=deg))
+    gen = torch.Generator().manual_seed(3)
+    ws = [torch.rand(s, generator=gen).to(device) for s in [(N, 2), (N, 3), (N, 4)]]
+
+    def run(raw):
+        m = S.SyntheticGaussianModel(N, W, H, seed=8, device=device, scale_coef=0.01, sh_degree=deg)
+        with torch.no_grad():
+            m._rotation *= 1.7  # un-normalised quaternions
+        if raw:
+            outs = rast.preprocess_gaussians_raw(m._xyz, m._scaling, m._rotation, m._features_dc, m._features_rest,
+                                                 m._opacity, {})
+        else:
+            outs = rast.preprocess_gaussians(m.get_xyz, m.get_scaling, m.get_rotation, m.get_features, m.get_opacity, {})
+        (outs[0] * ws[0]).sum().add((outs[1] * ws[1]).sum()).add((outs[2] * ws[2]).sum()).backward()
+        return outs, [p.grad for p in (m._xyz, m._scaling, m._rotation, m._features_dc, m._features_rest, m._opacity)]
+
+    oa, ga = run(True)
+    ob, gb = run(False)
+    assert torch.equal(oa[3], ob[3])
+    for a, b in zip(oa[:3], ob[:3]):
+        assert rel_err(a, b) < 1e-6
+    for a, b in zip(ga, gb):
+        assert rel_err(a, b) < 1e-5
