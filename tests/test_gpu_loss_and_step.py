@@ -275,3 +275,58 @@ def test_preprocess_raw_equals_getters_then_op(device, deg):
         assert rel_err(a, b) < 1e-6
     for a, b in zip(ga, gb):
         assert rel_err(a, b) < 1e-5
+
+
+def test_short_training_run_reduces_loss(device):
+    """end-to-end sanity of the whole iteration (mirror + fused loss + FusedAdam): fit a perturbed copy of a
+    scene to ground-truth renders of the original for 40 iterations; the loss must drop substantially"""
+    import utils.general_utils as utils
+    from fused_optim import FusedAdam
+    from gaussian_renderer import distributed_preprocess3dgs_and_all2all_final, render_final
+    from gaussian_renderer.loss_distribution import batched_loss_computation, load_camera_from_cpu_to_all_gpu
+    from gaussian_renderer.workload_division import (DivisionStrategyHistoryFinal, finish_strategy_final,
+                                                     start_strategy_final)
+
+    N, W, H = 20000, 320, 208
+    utils.GLOBAL_RANK, utils.WORLD_SIZE = 0, 1
+    utils.DEFAULT_GROUP = utils.IN_NODE_GROUP = utils.SingleGPUGroup()
+    utils.set_args(utils.default_args(bsz=1))
+    utils.set_img_size(H, W)
+    utils.set_cur_iter(1)
+    cams = S.orbit_cameras(8, W, H, device=device)[:3]
+    bg = torch.zeros(3, device=device)
+    pipe = type("P", (), {"debug": False})()
+    teacher = S.SyntheticGaussianModel(N, W, H, seed=11, device=device, scale_coef=0.01)
+    hist = DivisionStrategyHistoryFinal(S.SyntheticDataset(cams), 1, 0)
+    with torch.no_grad():
+        for cam in cams:
+            st, _ = start_strategy_final([cam], hist)
+            pkg = distributed_preprocess3dgs_and_all2all_final([cam], teacher, pipe, bg, batched_strategies=st,
+                                                               mode="test")
+            img = render_final(pkg, st)[0][0]
+            cam.original_image_backup = (img.clamp(0, 1) * 255).round().to(torch.uint8)
+    student = S.SyntheticGaussianModel(N, W, H, seed=11, device=device, scale_coef=0.01)
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(0)
+        student._features_dc += 1.0 * torch.randn(student._features_dc.shape, generator=g).to(device)
+        student._opacity += 0.5 * torch.randn(student._opacity.shape, generator=g).to(device)
+        student._xyz += 0.01 * torch.randn(student._xyz.shape, generator=g).to(device)
+    opt = FusedAdam(student.param_groups(), lr=0.0, eps=1e-15)
+    losses = []
+    for it in range(40):
+        cam = cams[it % len(cams)]
+        utils.set_cur_iter(it + 1)
+        st, tasks = start_strategy_final([cam], hist)
+        load_camera_from_cpu_to_all_gpu([cam], st, tasks)
+        pkg = distributed_preprocess3dgs_and_all2all_final([cam], student, pipe, bg, batched_strategies=st)
+        images, masks = render_final(pkg, st)
+        stats = [ca["stats_collector"] for ca in pkg["batched_cuda_args"]]
+        loss, _ = batched_loss_computation(images, [cam], masks, st, stats)
+        loss.backward()
+        finish_strategy_final([cam], hist, st, stats)
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        losses.append(loss.item())
+    first, lastv = sum(losses[:3]) / 3, sum(losses[-3:]) / 3
+    assert all(math.isfinite(x) for x in losses)
+    assert lastv < 0.7 * first, f"loss did not drop: {first:.4f} -> {lastv:.4f}"
