@@ -519,6 +519,379 @@ preprocess_backward_kernel(int P, int M, const float *__restrict__ means3D, cons
     }
 }
 
+// ------------------------------------------------------------------------- K1 / K11, batched over cameras
+// A batch of B cameras (Grendel's --bsz B; every rank projects ITS Gaussians for ALL cameras of the batch,
+// gaussian_renderer/__init__.py:919-963) in ONE launch each way: a lane reads its Gaussian's 59 raw floats
+// once, loops over the cameras (40 floats each, wave-uniform -> scalar loads) and, in the backward, sums the
+// cameras' gradients in registers before the single store.  HBM traffic 236 + B*44 forward and
+// 236 + B*79 + 236 backward per Gaussian instead of B*(236+44) and B*552, and 2 launches instead of 2B.
+// cams[b] = { view[16], proj[16], campos[3], tanfovx, tanfovy, pad[3] }.
+constexpr int CAM_STRIDE = 40;
+
+__device__ __forceinline__ Cam load_cam_packed(const float *__restrict__ c) {
+    Cam cam;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        cam.v[i] = c[i];
+        cam.p[i] = c[16 + i];
+    }
+    cam.c[0] = c[32];
+    cam.c[1] = c[33];
+    cam.c[2] = c[34];
+    return cam;
+}
+
+template <int DEG>
+__global__ void __launch_bounds__(GSR_ONE_DIM_BLOCK)
+preprocess_forward_batched_kernel(int P, int B, int M, const float *__restrict__ xyz, const float *__restrict__ scaling,
+                                  float scale_modifier, const float *__restrict__ rotation,
+                                  const float *__restrict__ f_dc, const float *__restrict__ f_rest,
+                                  const float *__restrict__ opacity, const float *__restrict__ cams, int W, int H,
+                                  float2 *__restrict__ means2D, float *__restrict__ depths,
+                                  int32_t *__restrict__ radii, float *__restrict__ cov3D,
+                                  float4 *__restrict__ conic_opacity, float *__restrict__ rgb,
+                                  uint8_t *__restrict__ clamped) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    constexpr int NC = (DEG + 1) * (DEG + 1);
+    const int gx = (W + GSR_BLOCK_X - 1) / GSR_BLOCK_X, gy = (H + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y;
+    // ---- camera-independent part, once
+    const float p[3] = {xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2]};
+    float4 q = *reinterpret_cast<const float4 *>(rotation + 4 * (size_t)i);
+    const float qn = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
+    q = make_float4(q.x / qn, q.y / qn, q.z / qn, q.w / qn);
+    const float s[3] = {scale_modifier * expf(scaling[3 * (size_t)i]), scale_modifier * expf(scaling[3 * (size_t)i + 1]),
+                        scale_modifier * expf(scaling[3 * (size_t)i + 2])};
+    const float op = 1.0f / (1.0f + expf(-opacity[i]));
+    float R[3][3];
+    quat_to_R(q, R);
+    float L[3][3], S[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) L[a][b] = R[a][b] * s[b];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) S[a][b] = L[a][0] * L[b][0] + L[a][1] * L[b][1] + L[a][2] * L[b][2];
+    cov3D[6 * (size_t)i + 0] = S[0][0]; cov3D[6 * (size_t)i + 1] = S[0][1]; cov3D[6 * (size_t)i + 2] = S[0][2];
+    cov3D[6 * (size_t)i + 3] = S[1][1]; cov3D[6 * (size_t)i + 4] = S[1][2]; cov3D[6 * (size_t)i + 5] = S[2][2];
+    float shl[NC * 3];
+    shl[0] = f_dc[3 * (size_t)i];
+    shl[1] = f_dc[3 * (size_t)i + 1];
+    shl[2] = f_dc[3 * (size_t)i + 2];
+    {
+        const float *rp = f_rest + (size_t)i * (M - 1) * 3;
+#pragma unroll
+        for (int k = 3; k < NC * 3; k++) shl[k] = rp[k - 3];
+    }
+    // ---- per camera
+    for (int bc = 0; bc < B; bc++) {
+        const float *cp = cams + (size_t)bc * CAM_STRIDE;
+        const Cam cam = load_cam_packed(cp);
+        const float tanfovx = cp[35], tanfovy = cp[36];
+        const float fx = W / (2.0f * tanfovx), fy = H / (2.0f * tanfovy);
+        int radius = 0;
+        float2 xy = make_float2(0.f, 0.f);
+        float depth = 0.f;
+        float4 co = make_float4(0.f, 0.f, 0.f, 0.f);
+        float col[3] = {0.f, 0.f, 0.f};
+        bool cl[3] = {false, false, false};
+        float t[3];
+        t[0] = cam.v[0] * p[0] + cam.v[4] * p[1] + cam.v[8] * p[2] + cam.v[12];
+        t[1] = cam.v[1] * p[0] + cam.v[5] * p[1] + cam.v[9] * p[2] + cam.v[13];
+        t[2] = cam.v[2] * p[0] + cam.v[6] * p[1] + cam.v[10] * p[2] + cam.v[14];
+        do {
+            if (t[2] <= 0.2f) break;
+            const float phx = cam.p[0] * p[0] + cam.p[4] * p[1] + cam.p[8] * p[2] + cam.p[12];
+            const float phy = cam.p[1] * p[0] + cam.p[5] * p[1] + cam.p[9] * p[2] + cam.p[13];
+            const float phw = cam.p[3] * p[0] + cam.p[7] * p[1] + cam.p[11] * p[2] + cam.p[15];
+            const float pw = 1.0f / (phw + 0.0000001f);
+            const float pprojx = phx * pw, pprojy = phy * pw;
+            float T[2][3], tc[3];
+            bool xin, yin;
+            compute_T(t, cam.v, fx, fy, tanfovx, tanfovy, T, tc, xin, yin);
+            float ST0[3], ST1[3];
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                ST0[r] = S[r][0] * T[0][0] + S[r][1] * T[0][1] + S[r][2] * T[0][2];
+                ST1[r] = S[r][0] * T[1][0] + S[r][1] * T[1][1] + S[r][2] * T[1][2];
+            }
+            const float a = T[0][0] * ST0[0] + T[0][1] * ST0[1] + T[0][2] * ST0[2] + 0.3f;
+            const float b = T[0][0] * ST1[0] + T[0][1] * ST1[1] + T[0][2] * ST1[2];
+            const float c = T[1][0] * ST1[0] + T[1][1] * ST1[1] + T[1][2] * ST1[2] + 0.3f;
+            const float det = a * c - b * b;
+            if (det == 0.0f) break;
+            const float det_inv = 1.f / det;
+            const float mid = 0.5f * (a + c);
+            const float lam = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+            const int rad = (int)ceilf(3.f * sqrtf(lam));
+            const float px = ((pprojx + 1.0f) * W - 1.0f) * 0.5f;
+            const float py = ((pprojy + 1.0f) * H - 1.0f) * 0.5f;
+            int minx, miny, maxx, maxy;
+            gsr_get_rect(px, py, rad, gx, gy, minx, miny, maxx, maxy);
+            if ((maxx - minx) * (maxy - miny) == 0) break;
+            float d[3] = {p[0] - cam.c[0], p[1] - cam.c[1], p[2] - cam.c[2]};
+            const float inv = 1.0f / sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+            d[0] *= inv; d[1] *= inv; d[2] *= inv;
+            eval_sh<DEG>(shl, d[0], d[1], d[2], col);
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                col[k] += 0.5f;
+                cl[k] = col[k] < 0.f;
+                col[k] = fmaxf(col[k], 0.f);
+            }
+            radius = rad;
+            xy = make_float2(px, py);
+            depth = t[2];
+            co = make_float4(c * det_inv, -b * det_inv, a * det_inv, op);
+        } while (false);
+        const size_t o = (size_t)bc * P + i;
+        radii[o] = radius;
+        means2D[o] = xy;
+        depths[o] = depth;
+        conic_opacity[o] = co;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            rgb[3 * o + k] = col[k];
+            clamped[3 * o + k] = cl[k] ? 1 : 0;
+        }
+    }
+}
+
+template <int DEG>
+__global__ void __launch_bounds__(GSR_ONE_DIM_BLOCK)
+preprocess_backward_batched_kernel(int P, int B, int M, const float *__restrict__ xyz,
+                                   const float *__restrict__ scaling, float scale_modifier,
+                                   const float *__restrict__ rotation, const float *__restrict__ f_dc,
+                                   const float *__restrict__ f_rest, const float *__restrict__ opacity,
+                                   const float *__restrict__ cams, int W, int H, const int32_t *__restrict__ radii,
+                                   const float *__restrict__ cov3D, const uint8_t *__restrict__ clamped,
+                                   const float2 *__restrict__ dL_dmeans2D,
+                                   const float4 *__restrict__ dL_dconic_opacity, const float *__restrict__ dL_drgb,
+                                   float *__restrict__ dL_dxyz, float *__restrict__ dL_dscaling,
+                                   float4 *__restrict__ dL_drotation, float *__restrict__ dL_ddc,
+                                   float *__restrict__ dL_drest, float *__restrict__ dL_dopacity) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    constexpr int NC = (DEG + 1) * (DEG + 1);
+    const float p[3] = {xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2]};
+    const float *cv = cov3D + 6 * (size_t)i;
+    const float S[3][3] = {{cv[0], cv[1], cv[2]}, {cv[1], cv[3], cv[4]}, {cv[2], cv[4], cv[5]}};
+    float sh[NC * 3];
+    sh[0] = f_dc[3 * (size_t)i];
+    sh[1] = f_dc[3 * (size_t)i + 1];
+    sh[2] = f_dc[3 * (size_t)i + 2];
+    {
+        const float *rp = f_rest + (size_t)i * (M - 1) * 3;
+#pragma unroll
+        for (int k = 3; k < NC * 3; k++) sh[k] = rp[k - 3];
+    }
+    float dmean[3] = {0.f, 0.f, 0.f};
+    float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float dsh[NC * 3];
+#pragma unroll
+    for (int k = 0; k < NC * 3; k++) dsh[k] = 0.f;
+    float dop = 0.f;
+
+    for (int bc = 0; bc < B; bc++) {
+        const size_t o = (size_t)bc * P + i;
+        if (radii[o] <= 0) continue;
+        const float *cp = cams + (size_t)bc * CAM_STRIDE;
+        const Cam cam = load_cam_packed(cp);
+        const float tanfovx = cp[35], tanfovy = cp[36];
+        const float fx = W / (2.0f * tanfovx), fy = H / (2.0f * tanfovy);
+        const float4 gco = dL_dconic_opacity[o];
+        const float gA = gco.x, gB = gco.y, gC = gco.z;
+        dop += gco.w;
+        float t[3];
+        t[0] = cam.v[0] * p[0] + cam.v[4] * p[1] + cam.v[8] * p[2] + cam.v[12];
+        t[1] = cam.v[1] * p[0] + cam.v[5] * p[1] + cam.v[9] * p[2] + cam.v[13];
+        t[2] = cam.v[2] * p[0] + cam.v[6] * p[1] + cam.v[10] * p[2] + cam.v[14];
+        float T[2][3], tc[3];
+        bool xin, yin;
+        compute_T(t, cam.v, fx, fy, tanfovx, tanfovy, T, tc, xin, yin);
+        float ST0[3], ST1[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            ST0[r] = S[r][0] * T[0][0] + S[r][1] * T[0][1] + S[r][2] * T[0][2];
+            ST1[r] = S[r][0] * T[1][0] + S[r][1] * T[1][1] + S[r][2] * T[1][2];
+        }
+        const float a = T[0][0] * ST0[0] + T[0][1] * ST0[1] + T[0][2] * ST0[2] + 0.3f;
+        const float b = T[0][0] * ST1[0] + T[0][1] * ST1[1] + T[0][2] * ST1[2];
+        const float c = T[1][0] * ST1[0] + T[1][1] * ST1[1] + T[1][2] * ST1[2] + 0.3f;
+        const float denom = a * c - b * b;
+        const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+        float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
+        if (denom2inv != 0.f) {
+            dL_da = denom2inv * (-c * c * gA + b * c * gB + (denom - a * c) * gC);
+            dL_dc = denom2inv * (-a * a * gC + a * b * gB + (denom - a * c) * gA);
+            dL_db = denom2inv * (2.f * b * c * gA - (denom + 2.f * b * b) * gB + 2.f * a * b * gC);
+            dcov[0] += T[0][0] * T[0][0] * dL_da + T[0][0] * T[1][0] * dL_db + T[1][0] * T[1][0] * dL_dc;
+            dcov[3] += T[0][1] * T[0][1] * dL_da + T[0][1] * T[1][1] * dL_db + T[1][1] * T[1][1] * dL_dc;
+            dcov[5] += T[0][2] * T[0][2] * dL_da + T[0][2] * T[1][2] * dL_db + T[1][2] * T[1][2] * dL_dc;
+            dcov[1] += 2.f * T[0][0] * T[0][1] * dL_da + (T[0][0] * T[1][1] + T[0][1] * T[1][0]) * dL_db +
+                       2.f * T[1][0] * T[1][1] * dL_dc;
+            dcov[2] += 2.f * T[0][0] * T[0][2] * dL_da + (T[0][0] * T[1][2] + T[0][2] * T[1][0]) * dL_db +
+                       2.f * T[1][0] * T[1][2] * dL_dc;
+            dcov[4] += 2.f * T[0][2] * T[0][1] * dL_da + (T[0][1] * T[1][2] + T[0][2] * T[1][1]) * dL_db +
+                       2.f * T[1][1] * T[1][2] * dL_dc;
+        }
+        float dT0[3], dT1[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            dT0[k] = 2.f * ST0[k] * dL_da + ST1[k] * dL_db;
+            dT1[k] = 2.f * ST1[k] * dL_dc + ST0[k] * dL_db;
+        }
+        const float dJ00 = dT0[0] * cam.v[0] + dT0[1] * cam.v[4] + dT0[2] * cam.v[8];
+        const float dJ02 = dT0[0] * cam.v[2] + dT0[1] * cam.v[6] + dT0[2] * cam.v[10];
+        const float dJ11 = dT1[0] * cam.v[1] + dT1[1] * cam.v[5] + dT1[2] * cam.v[9];
+        const float dJ12 = dT1[0] * cam.v[2] + dT1[1] * cam.v[6] + dT1[2] * cam.v[10];
+        const float tz = 1.f / tc[2], tz2 = tz * tz, tz3 = tz2 * tz;
+        float dt[3];
+        dt[0] = (xin ? 1.f : 0.f) * (-fx * tz2 * dJ02);
+        dt[1] = (yin ? 1.f : 0.f) * (-fy * tz2 * dJ12);
+        dt[2] = -fx * tz2 * dJ00 - fy * tz2 * dJ11 + (2.f * fx * tc[0]) * tz3 * dJ02 + (2.f * fy * tc[1]) * tz3 * dJ12;
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+            dmean[k] += cam.v[k * 4 + 0] * dt[0] + cam.v[k * 4 + 1] * dt[1] + cam.v[k * 4 + 2] * dt[2];
+        {
+            const float phx = cam.p[0] * p[0] + cam.p[4] * p[1] + cam.p[8] * p[2] + cam.p[12];
+            const float phy = cam.p[1] * p[0] + cam.p[5] * p[1] + cam.p[9] * p[2] + cam.p[13];
+            const float phw = cam.p[3] * p[0] + cam.p[7] * p[1] + cam.p[11] * p[2] + cam.p[15];
+            const float mw = 1.0f / (phw + 0.0000001f);
+            const float mul1 = phx * mw * mw, mul2 = phy * mw * mw;
+            const float2 g2 = dL_dmeans2D[o];
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                dmean[k] += (cam.p[k * 4 + 0] * mw - cam.p[k * 4 + 3] * mul1) * g2.x +
+                            (cam.p[k * 4 + 1] * mw - cam.p[k * 4 + 3] * mul2) * g2.y;
+        }
+        {
+            const float dox = p[0] - cam.c[0], doy = p[1] - cam.c[1], doz = p[2] - cam.c[2];
+            const float len = sqrtf(dox * dox + doy * doy + doz * doz);
+            const float x = dox / len, y = doy / len, z = doz / len;
+            float ddir[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                const float g = clamped[3 * o + ch] ? 0.f : dL_drgb[3 * o + ch];
+                float dx = 0.f, dy = 0.f, dz = 0.f;
+                dsh[0 * 3 + ch] += SH_C0 * g;
+                if (DEG > 0) {
+                    dsh[1 * 3 + ch] += -SH_C1 * y * g;
+                    dsh[2 * 3 + ch] += SH_C1 * z * g;
+                    dsh[3 * 3 + ch] += -SH_C1 * x * g;
+                    dx = -SH_C1 * sh[3 * 3 + ch];
+                    dy = -SH_C1 * sh[1 * 3 + ch];
+                    dz = SH_C1 * sh[2 * 3 + ch];
+                    if (DEG > 1) {
+                        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                        dsh[4 * 3 + ch] += SH_C2[0] * xy * g;
+                        dsh[5 * 3 + ch] += SH_C2[1] * yz * g;
+                        dsh[6 * 3 + ch] += SH_C2[2] * (2.f * zz - xx - yy) * g;
+                        dsh[7 * 3 + ch] += SH_C2[3] * xz * g;
+                        dsh[8 * 3 + ch] += SH_C2[4] * (xx - yy) * g;
+                        dx += SH_C2[0] * y * sh[4 * 3 + ch] + SH_C2[2] * 2.f * -x * sh[6 * 3 + ch] +
+                              SH_C2[3] * z * sh[7 * 3 + ch] + SH_C2[4] * 2.f * x * sh[8 * 3 + ch];
+                        dy += SH_C2[0] * x * sh[4 * 3 + ch] + SH_C2[1] * z * sh[5 * 3 + ch] +
+                              SH_C2[2] * 2.f * -y * sh[6 * 3 + ch] + SH_C2[4] * 2.f * -y * sh[8 * 3 + ch];
+                        dz += SH_C2[1] * y * sh[5 * 3 + ch] + SH_C2[2] * 2.f * 2.f * z * sh[6 * 3 + ch] +
+                              SH_C2[3] * x * sh[7 * 3 + ch];
+                        if (DEG > 2) {
+                            dsh[9 * 3 + ch] += SH_C3[0] * y * (3.f * xx - yy) * g;
+                            dsh[10 * 3 + ch] += SH_C3[1] * xy * z * g;
+                            dsh[11 * 3 + ch] += SH_C3[2] * y * (4.f * zz - xx - yy) * g;
+                            dsh[12 * 3 + ch] += SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy) * g;
+                            dsh[13 * 3 + ch] += SH_C3[4] * x * (4.f * zz - xx - yy) * g;
+                            dsh[14 * 3 + ch] += SH_C3[5] * z * (xx - yy) * g;
+                            dsh[15 * 3 + ch] += SH_C3[6] * x * (xx - 3.f * yy) * g;
+                            dx += SH_C3[0] * sh[9 * 3 + ch] * 3.f * 2.f * xy + SH_C3[1] * sh[10 * 3 + ch] * yz +
+                                  SH_C3[2] * sh[11 * 3 + ch] * -2.f * xy + SH_C3[3] * sh[12 * 3 + ch] * -3.f * 2.f * xz +
+                                  SH_C3[4] * sh[13 * 3 + ch] * (-3.f * xx + 4.f * zz - yy) +
+                                  SH_C3[5] * sh[14 * 3 + ch] * 2.f * xz + SH_C3[6] * sh[15 * 3 + ch] * 3.f * (xx - yy);
+                            dy += SH_C3[0] * sh[9 * 3 + ch] * 3.f * (xx - yy) + SH_C3[1] * sh[10 * 3 + ch] * xz +
+                                  SH_C3[2] * sh[11 * 3 + ch] * (-3.f * yy + 4.f * zz - xx) +
+                                  SH_C3[3] * sh[12 * 3 + ch] * -3.f * 2.f * yz + SH_C3[4] * sh[13 * 3 + ch] * -2.f * xy +
+                                  SH_C3[5] * sh[14 * 3 + ch] * -2.f * yz + SH_C3[6] * sh[15 * 3 + ch] * -3.f * 2.f * xy;
+                            dz += SH_C3[1] * sh[10 * 3 + ch] * xy + SH_C3[2] * sh[11 * 3 + ch] * 4.f * 2.f * yz +
+                                  SH_C3[3] * sh[12 * 3 + ch] * 3.f * (2.f * zz - xx - yy) +
+                                  SH_C3[4] * sh[13 * 3 + ch] * 4.f * 2.f * xz + SH_C3[5] * sh[14 * 3 + ch] * (xx - yy);
+                        }
+                    }
+                }
+                ddir[0] += dx * g;
+                ddir[1] += dy * g;
+                ddir[2] += dz * g;
+            }
+            const float dot = x * ddir[0] + y * ddir[1] + z * ddir[2];
+            dmean[0] += (ddir[0] - x * dot) / len;
+            dmean[1] += (ddir[1] - y * dot) / len;
+            dmean[2] += (ddir[2] - z * dot) / len;
+        }
+    }
+    // ---- stores + the camera-independent tail (cov3D -> scale / quaternion, activations), once
+    dL_dxyz[3 * (size_t)i] = dmean[0];
+    dL_dxyz[3 * (size_t)i + 1] = dmean[1];
+    dL_dxyz[3 * (size_t)i + 2] = dmean[2];
+    dL_ddc[3 * (size_t)i] = dsh[0];
+    dL_ddc[3 * (size_t)i + 1] = dsh[1];
+    dL_ddc[3 * (size_t)i + 2] = dsh[2];
+    {
+        float *rp = dL_drest + (size_t)i * (M - 1) * 3;
+#pragma unroll
+        for (int k = 3; k < NC * 3; k++) rp[k - 3] = dsh[k];
+        for (int k = NC * 3; k < M * 3; k++) rp[k - 3] = 0.f;
+    }
+    {
+        const float so = 1.0f / (1.0f + expf(-opacity[i]));
+        dL_dopacity[i] = dop * so * (1.0f - so);
+    }
+    {
+        const float4 qraw = *reinterpret_cast<const float4 *>(rotation + 4 * (size_t)i);
+        const float qnr = sqrtf(qraw.x * qraw.x + qraw.y * qraw.y + qraw.z * qraw.z + qraw.w * qraw.w);
+        const float qn = fmaxf(qnr, 1e-12f);
+        const float4 q = make_float4(qraw.x / qn, qraw.y / qn, qraw.z / qn, qraw.w / qn);
+        const float sc[3] = {expf(scaling[3 * (size_t)i]), expf(scaling[3 * (size_t)i + 1]), expf(scaling[3 * (size_t)i + 2])};
+        float R[3][3];
+        quat_to_R(q, R);
+        const float s[3] = {scale_modifier * sc[0], scale_modifier * sc[1], scale_modifier * sc[2]};
+        float Mm[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int cc = 0; cc < 3; cc++) Mm[r][cc] = s[r] * R[cc][r];
+        const float dS[3][3] = {{dcov[0], 0.5f * dcov[1], 0.5f * dcov[2]},
+                                {0.5f * dcov[1], dcov[3], 0.5f * dcov[4]},
+                                {0.5f * dcov[2], 0.5f * dcov[4], dcov[5]}};
+        float dM[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int cc = 0; cc < 3; cc++)
+                dM[r][cc] = 2.f * (Mm[r][0] * dS[0][cc] + Mm[r][1] * dS[1][cc] + Mm[r][2] * dS[2][cc]);
+        float dR[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            dL_dscaling[3 * (size_t)i + r] =
+                sc[r] * scale_modifier * (R[0][r] * dM[r][0] + R[1][r] * dM[r][1] + R[2][r] * dM[r][2]);
+#pragma unroll
+            for (int j = 0; j < 3; j++) dR[j][r] = s[r] * dM[r][j];
+        }
+        const float r_ = q.x, x = q.y, y = q.z, z = q.w;
+        float4 dq;
+        dq.x = 2.f * (-z * dR[0][1] + y * dR[0][2] + z * dR[1][0] - x * dR[1][2] - y * dR[2][0] + x * dR[2][1]);
+        dq.y = 2.f * (y * dR[0][1] + z * dR[0][2] + y * dR[1][0] - 2.f * x * dR[1][1] - r_ * dR[1][2] + z * dR[2][0] +
+                      r_ * dR[2][1] - 2.f * x * dR[2][2]);
+        dq.z = 2.f * (-2.f * y * dR[0][0] + x * dR[0][1] + r_ * dR[0][2] + x * dR[1][0] + z * dR[1][2] - r_ * dR[2][0] +
+                      z * dR[2][1] - 2.f * y * dR[2][2]);
+        dq.w = 2.f * (-2.f * z * dR[0][0] - r_ * dR[0][1] + x * dR[0][2] + r_ * dR[1][0] - 2.f * z * dR[1][1] +
+                      y * dR[1][2] + x * dR[2][0] + y * dR[2][1]);
+        const float dot = qnr > 1e-12f ? (q.x * dq.x + q.y * dq.y + q.z * dq.z + q.w * dq.w) : 0.f;
+        dL_drotation[i] = make_float4((dq.x - q.x * dot) / qn, (dq.y - q.y * dot) / qn, (dq.z - q.z * dot) / qn,
+                                      (dq.w - q.w * dot) / qn);
+    }
+}
+
 // -------------------------------------------------------------------------------------------- K2
 __global__ void __launch_bounds__(GSR_ONE_DIM_BLOCK)
 local2j_kernel(int P, int W, int H, int ws, const float2 *__restrict__ means2D, const int32_t *__restrict__ radii,
@@ -609,6 +982,61 @@ int gsr_launch_local2j(int P, int W, int H, int ws, const float *means2D, const 
     if (P == 0) return 0;
     hipLaunchKernelGGL(local2j_kernel, dim3(gsr_div_up(P, GSR_ONE_DIM_BLOCK)), dim3(GSR_ONE_DIM_BLOCK), 0, stream, P,
                        W, H, ws, reinterpret_cast<const float2 *>(means2D), radii, div, out);
+    GSR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gsr_preprocess_forward_raw_batched(int P, int B, int sh_degree, int sh_coeffs, const float *xyz,
+                                                  const float *scaling, float scale_modifier, const float *rotation,
+                                                  const float *features_dc, const float *features_rest,
+                                                  const float *opacity, const float *cams, int width, int height,
+                                                  float *means2D, float *depths, int32_t *radii, float *cov3D,
+                                                  float *conic_opacity, float *rgb, uint8_t *clamped,
+                                                  gsr_stream_t stream) {
+    if (P < 0 || B < 1 || sh_degree < 0 || sh_degree > 3 || sh_coeffs < 2 ||
+        sh_coeffs < (sh_degree + 1) * (sh_degree + 1) || width <= 0 || height <= 0)
+        return GSR_EINVAL;
+    if (P == 0) return 0;
+    if (!xyz || !scaling || !rotation || !features_dc || !features_rest || !opacity || !cams || !means2D || !depths ||
+        !radii || !cov3D || !conic_opacity || !rgb || !clamped)
+        return GSR_EINVAL;
+    const dim3 grid(gsr_div_up(P, GSR_ONE_DIM_BLOCK)), block(GSR_ONE_DIM_BLOCK);
+    GSR_DISPATCH_DEG(sh_degree,
+                     hipLaunchKernelGGL(preprocess_forward_batched_kernel<DEG>, grid, block, 0,
+                                        reinterpret_cast<hipStream_t>(stream), P, B, sh_coeffs, xyz, scaling,
+                                        scale_modifier, rotation, features_dc, features_rest, opacity, cams, width,
+                                        height, reinterpret_cast<float2 *>(means2D), depths, radii, cov3D,
+                                        reinterpret_cast<float4 *>(conic_opacity), rgb, clamped));
+    GSR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gsr_preprocess_backward_raw_batched(int P, int B, int sh_degree, int sh_coeffs, const float *xyz,
+                                                   const float *scaling, float scale_modifier, const float *rotation,
+                                                   const float *features_dc, const float *features_rest,
+                                                   const float *opacity, const float *cams, int width, int height,
+                                                   const int32_t *radii, const float *cov3D, const uint8_t *clamped,
+                                                   const float *dL_dmeans2D, const float *dL_dconic_opacity,
+                                                   const float *dL_drgb, float *dL_dxyz, float *dL_dscaling,
+                                                   float *dL_drotation, float *dL_dfeatures_dc,
+                                                   float *dL_dfeatures_rest, float *dL_dopacity, gsr_stream_t stream) {
+    if (P < 0 || B < 1 || sh_degree < 0 || sh_degree > 3 || sh_coeffs < 2 ||
+        sh_coeffs < (sh_degree + 1) * (sh_degree + 1) || width <= 0 || height <= 0)
+        return GSR_EINVAL;
+    if (P == 0) return 0;
+    if (!xyz || !scaling || !rotation || !features_dc || !features_rest || !opacity || !cams || !radii || !cov3D ||
+        !clamped || !dL_dmeans2D || !dL_dconic_opacity || !dL_drgb || !dL_dxyz || !dL_dscaling || !dL_drotation ||
+        !dL_dfeatures_dc || !dL_dfeatures_rest || !dL_dopacity)
+        return GSR_EINVAL;
+    const dim3 grid(gsr_div_up(P, GSR_ONE_DIM_BLOCK)), block(GSR_ONE_DIM_BLOCK);
+    GSR_DISPATCH_DEG(sh_degree,
+                     hipLaunchKernelGGL(preprocess_backward_batched_kernel<DEG>, grid, block, 0,
+                                        reinterpret_cast<hipStream_t>(stream), P, B, sh_coeffs, xyz, scaling,
+                                        scale_modifier, rotation, features_dc, features_rest, opacity, cams, width,
+                                        height, radii, cov3D, clamped, reinterpret_cast<const float2 *>(dL_dmeans2D),
+                                        reinterpret_cast<const float4 *>(dL_dconic_opacity), dL_drgb, dL_dxyz,
+                                        dL_dscaling, reinterpret_cast<float4 *>(dL_drotation), dL_dfeatures_dc,
+                                        dL_dfeatures_rest, dL_dopacity));
     GSR_LAUNCH_CHECK();
     return 0;
 }

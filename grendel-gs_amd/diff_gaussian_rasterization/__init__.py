@@ -25,7 +25,8 @@ from . import _lib
 from ._lib import check, lib
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "_C", "load_image_tiles_by_pos",
-           "merge_image_tiles_by_pos", "set_timing_mode", "fused_l1_ssim_band", "fused_activations"]
+           "merge_image_tiles_by_pos", "set_timing_mode", "fused_l1_ssim_band", "fused_activations", "pack_camera",
+           "preprocess_gaussians_raw_batched"]
 
 BLOCK_X, BLOCK_Y, ONE_DIM_BLOCK_SIZE = 16, 16, 256
 
@@ -254,6 +255,92 @@ class _PreprocessGaussiansRaw(torch.autograd.Function):
                 _ptr(g_means2D), _ptr(g_conic_opacity), _ptr(g_rgb), _ptr(d_xyz), _ptr(d_scaling), _ptr(d_rot),
                 _ptr(d_dc), _ptr(d_rest), _ptr(d_opac), _stream()), "gsr_preprocess_backward_raw")
         return d_xyz, d_scaling, d_rot, d_dc, d_rest, d_opac, None, None
+
+
+def pack_camera(raster_settings):
+    """[40] float tensor { viewmatrix, projmatrix, campos, tanfovx, tanfovy, 0, 0, 0 } of one camera (device)"""
+    rs = raster_settings
+    dev = rs.viewmatrix.device
+    tail = torch.tensor([float(rs.tanfovx), float(rs.tanfovy), 0.0, 0.0, 0.0], dtype=torch.float32, device=dev)
+    return torch.cat([rs.viewmatrix.reshape(16).float(), rs.projmatrix.reshape(16).float(),
+                      rs.campos.reshape(3).float(), tail]).contiguous()
+
+
+class _PreprocessGaussiansRawBatched(torch.autograd.Function):
+    """K1 / K11 for a batch of B cameras in one launch each way (gsr_preprocess_*_raw_batched)."""
+
+    @staticmethod
+    def forward(ctx, xyz, scaling, rotation, features_dc, features_rest, opacity, cams, sh_degree, scale_modifier,
+                width, height, tanfov0):
+        xyz, scaling, rotation = _f32c(xyz, "xyz"), _f32c(scaling, "scaling"), _f32c(rotation, "rotation")
+        features_dc, features_rest = _f32c(features_dc, "features_dc"), _f32c(features_rest, "features_rest")
+        opacity, cams = _f32c(opacity, "opacity"), _f32c(cams, "cams")
+        ctx.tanfov0 = tanfov0
+        P, B = xyz.shape[0], cams.shape[0]
+        if cams.dim() != 2 or cams.shape[1] != 40:
+            raise ValueError("cams must be [B, 40]")
+        M = 1 + features_rest.shape[1]
+        dev = xyz.device
+        means2D = torch.empty((B, P, 2), dtype=torch.float32, device=dev)
+        depths = torch.empty((B, P), dtype=torch.float32, device=dev)
+        radii = torch.empty((B, P), dtype=torch.int32, device=dev)
+        cov3D = torch.empty((P, 6), dtype=torch.float32, device=dev)
+        conic_opacity = torch.empty((B, P, 4), dtype=torch.float32, device=dev)
+        rgb = torch.empty((B, P, 3), dtype=torch.float32, device=dev)
+        clamped = torch.empty((B, P, 3), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev), kernel_timer.range("preprocess_forward"):
+            check(lib.gsr_preprocess_forward_raw_batched(
+                P, B, int(sh_degree), M, _ptr(xyz), _ptr(scaling), float(scale_modifier), _ptr(rotation),
+                _ptr(features_dc), _ptr(features_rest), _ptr(opacity), _ptr(cams), int(width), int(height),
+                _ptr(means2D), _ptr(depths), _ptr(radii), _ptr(cov3D), _ptr(conic_opacity), _ptr(rgb), _ptr(clamped),
+                _stream()), "gsr_preprocess_forward_raw_batched")
+        ctx.meta = (int(sh_degree), float(scale_modifier), int(width), int(height), M)
+        ctx.save_for_backward(xyz, scaling, rotation, features_dc, features_rest, opacity, cams, radii, cov3D, clamped)
+        ctx.mark_non_differentiable(radii, depths)
+        return means2D, rgb, conic_opacity, radii, depths
+
+    @staticmethod
+    def backward(ctx, g_means2D, g_rgb, g_conic_opacity, g_radii, g_depths):
+        xyz, scaling, rotation, f_dc, f_rest, opacity, cams, radii, cov3D, clamped = ctx.saved_tensors
+        deg, smod, W, H, M = ctx.meta
+        P, B = xyz.shape[0], cams.shape[0]
+        dev = xyz.device
+
+        def z(g, cols):
+            return torch.zeros((B, P, cols), dtype=torch.float32, device=dev) if g is None else g.float().contiguous()
+
+        g_means2D, g_rgb, g_conic_opacity = z(g_means2D, 2), z(g_rgb, 3), z(g_conic_opacity, 4)
+        d_xyz = torch.empty((P, 3), dtype=torch.float32, device=dev)
+        d_scaling = torch.empty((P, 3), dtype=torch.float32, device=dev)
+        d_rot = torch.empty((P, 4), dtype=torch.float32, device=dev)
+        d_dc = torch.empty((P, 1, 3), dtype=torch.float32, device=dev)
+        d_rest = torch.empty((P, M - 1, 3), dtype=torch.float32, device=dev)
+        d_opac = torch.empty((P, 1), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev), kernel_timer.range("preprocess_backward"):
+            if B == 1 and ctx.tanfov0 is not None:
+                # single camera: the leaner one-camera kernel (no accumulators); camera fields are slices of `cams`
+                base = cams.data_ptr()
+                check(lib.gsr_preprocess_backward_raw(
+                    P, deg, M, _ptr(xyz), _ptr(scaling), smod, _ptr(rotation), _ptr(f_dc), _ptr(f_rest),
+                    _ptr(opacity), ctypes.c_void_p(base), ctypes.c_void_p(base + 64), ctypes.c_void_p(base + 128), W,
+                    H, float(ctx.tanfov0[0]), float(ctx.tanfov0[1]), _ptr(radii), _ptr(cov3D), _ptr(clamped),
+                    _ptr(g_means2D), _ptr(g_conic_opacity), _ptr(g_rgb), _ptr(d_xyz), _ptr(d_scaling), _ptr(d_rot),
+                    _ptr(d_dc), _ptr(d_rest), _ptr(d_opac), _stream()), "gsr_preprocess_backward_raw")
+            else:
+                check(lib.gsr_preprocess_backward_raw_batched(
+                    P, B, deg, M, _ptr(xyz), _ptr(scaling), smod, _ptr(rotation), _ptr(f_dc), _ptr(f_rest),
+                    _ptr(opacity), _ptr(cams), W, H, _ptr(radii), _ptr(cov3D), _ptr(clamped), _ptr(g_means2D),
+                    _ptr(g_conic_opacity), _ptr(g_rgb), _ptr(d_xyz), _ptr(d_scaling), _ptr(d_rot), _ptr(d_dc),
+                    _ptr(d_rest), _ptr(d_opac), _stream()), "gsr_preprocess_backward_raw_batched")
+        return d_xyz, d_scaling, d_rot, d_dc, d_rest, d_opac, None, None, None, None, None, None
+
+
+def preprocess_gaussians_raw_batched(xyz, scaling, rotation, features_dc, features_rest, opacity, cams, sh_degree,
+                                     scale_modifier, width, height, tanfov0=None):
+    """-> camera-major (means2D [B,P,2], rgb [B,P,3], conic_opacity [B,P,4], radii int32 [B,P], depths [B,P]) for the
+    B cameras packed in `cams` [B,40] (pack_camera); extension of this build used by the gaussian_renderer mirror."""
+    return _PreprocessGaussiansRawBatched.apply(xyz, scaling, rotation, features_dc, features_rest, opacity, cams,
+                                                sh_degree, scale_modifier, width, height, tanfov0)
 
 
 # ------------------------------------------------------------------------------- K3..K8 / K10

@@ -45,6 +45,10 @@ SIGNATURES = {
                                    [c_int, c_int, c_float, c_float] + [c_void_p] * 8),
     "gsr_preprocess_backward_raw": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_float] + [c_void_p] * 7 +
                                     [c_int, c_int, c_float, c_float] + [c_void_p] * 13),
+    "gsr_preprocess_forward_raw_batched": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float] +
+                                           [c_void_p] * 5 + [c_int, c_int] + [c_void_p] * 8),
+    "gsr_preprocess_backward_raw_batched": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float] +
+                                            [c_void_p] * 5 + [c_int, c_int] + [c_void_p] * 13),
     "gsr_activate_forward": (c_int, [c_int, c_int] + [c_void_p] * 10),
     "gsr_activate_backward": (c_int, [c_int, c_int] + [c_void_p] * 13),
     "gsr_render_backward": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -172,7 +172,7 @@ def distributed_preprocess3dgs_and_all2all_final(batched_viewpoint_cameras, pc, 
 
     rasterizers, cuda_args_list, params = [], [], []
     for camera, strategy in zip(batched_viewpoint_cameras, batched_strategies):
-        cuda_args = get_cuda_args_final(strategy, mode)
+        cuda_args_list.append(get_cuda_args_final(strategy, mode))
         settings = GaussianRasterizationSettings(
             image_height=int(camera.image_height),
             image_width=int(camera.image_width),
@@ -187,17 +187,42 @@ def distributed_preprocess3dgs_and_all2all_final(batched_viewpoint_cameras, pc, 
             prefiltered=False,
             debug=pipe.debug,
         )
-        rasterizer = GaussianRasterizer(raster_settings=settings)
-        if fused:
-            means2D, rgb, conic_opacity, radii, depths = rasterizer.preprocess_gaussians_raw(*raw, cuda_args=cuda_args)
-        else:
-            means2D, rgb, conic_opacity, radii, depths = rasterizer.preprocess_gaussians(
-                means3D=means3D, scales=scales, rotations=rotations, shs=shs, opacities=opacity, cuda_args=cuda_args)
-        if mode == "train":
-            means2D.retain_grad()  # densification reads means2D.grad (scene/gaussian_model.py:1046-1052)
-        rasterizers.append(rasterizer)
-        cuda_args_list.append(cuda_args)
-        params.append([means2D, rgb, conic_opacity, radii, depths])
+        rasterizers.append(GaussianRasterizer(raster_settings=settings))
+    same_size = len({(r.raster_settings.image_height, r.raster_settings.image_width) for r in rasterizers}) == 1
+    if fused and same_size and hasattr(_dgr, "preprocess_gaussians_raw_batched"):
+        # ONE launch for the whole batch: parameters read once, per-camera outputs camera-major
+        packed = []
+        for camera, rast in zip(batched_viewpoint_cameras, rasterizers):
+            key = (float(rast.raster_settings.tanfovx), float(rast.raster_settings.tanfovy))
+            cached = getattr(camera, "_gsr_packed", None)
+            if cached is None or cached[0] != key or cached[1].device != raw[0].device:
+                cached = (key, _dgr.pack_camera(rast.raster_settings))
+                try:
+                    camera._gsr_packed = cached  # cameras are static: packed once
+                except AttributeError:
+                    pass
+            packed.append(cached[1])
+        rs0 = rasterizers[0].raster_settings
+        m2_all, rgb_all, co_all, radii_all, depths_all = _dgr.preprocess_gaussians_raw_batched(
+            *raw, torch.stack(packed), pc.active_sh_degree, scaling_modifier, rs0.image_width, rs0.image_height,
+            tanfov0=(rs0.tanfovx, rs0.tanfovy))
+        for k in range(len(rasterizers)):
+            means2D = m2_all[k]
+            if mode == "train":
+                means2D.retain_grad()  # densification reads means2D.grad (scene/gaussian_model.py:1046-1052)
+            params.append([means2D, rgb_all[k], co_all[k], radii_all[k], depths_all[k]])
+    else:
+        for rasterizer, cuda_args in zip(rasterizers, cuda_args_list):
+            if fused:
+                means2D, rgb, conic_opacity, radii, depths = rasterizer.preprocess_gaussians_raw(
+                    *raw, cuda_args=cuda_args)
+            else:
+                means2D, rgb, conic_opacity, radii, depths = rasterizer.preprocess_gaussians(
+                    means3D=means3D, scales=scales, rotations=rotations, shs=shs, opacities=opacity,
+                    cuda_args=cuda_args)
+            if mode == "train":
+                means2D.retain_grad()  # densification reads means2D.grad (scene/gaussian_model.py:1046-1052)
+            params.append([means2D, rgb, conic_opacity, radii, depths])
     if timers is not None:
         timers.stop("forward_preprocess_gaussians")
 

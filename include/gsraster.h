@@ -180,6 +180,26 @@ int gsr_preprocess_backward_raw(int P, int sh_degree, int sh_coeffs, const float
                                 float *dL_dxyz, float *dL_dscaling, float *dL_drotation, float *dL_dfeatures_dc,
                                 float *dL_dfeatures_rest, float *dL_dopacity, gsr_stream_t stream);
 
+/* The same for a BATCH of B cameras (--bsz B: every rank projects its Gaussians for all cameras of the batch,
+ * gaussian_renderer/__init__.py:919-963) in one launch each way: a Gaussian's raw parameters are read once,
+ * the backward sums the cameras' gradients in registers.  cams [B][40] floats on the device, per camera
+ * { viewmatrix[16], projmatrix[16], campos[3], tanfovx, tanfovy, pad[3] }; outputs / incoming gradients are
+ * camera-major [B,P,...]; cov3D [P,6] is camera independent. */
+int gsr_preprocess_forward_raw_batched(int P, int B, int sh_degree, int sh_coeffs, const float *xyz,
+                                       const float *scaling, float scale_modifier, const float *rotation,
+                                       const float *features_dc, const float *features_rest, const float *opacity,
+                                       const float *cams, int width, int height, float *means2D, float *depths,
+                                       int32_t *radii, float *cov3D, float *conic_opacity, float *rgb,
+                                       uint8_t *clamped, gsr_stream_t stream);
+int gsr_preprocess_backward_raw_batched(int P, int B, int sh_degree, int sh_coeffs, const float *xyz,
+                                        const float *scaling, float scale_modifier, const float *rotation,
+                                        const float *features_dc, const float *features_rest, const float *opacity,
+                                        const float *cams, int width, int height, const int32_t *radii,
+                                        const float *cov3D, const uint8_t *clamped, const float *dL_dmeans2D,
+                                        const float *dL_dconic_opacity, const float *dL_drgb, float *dL_dxyz,
+                                        float *dL_dscaling, float *dL_drotation, float *dL_dfeatures_dc,
+                                        float *dL_dfeatures_rest, float *dL_dopacity, gsr_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * a19  fused parameter activations -- GaussianModel.get_scaling / get_rotation / get_opacity /
  * get_features (scene/gaussian_model.py:109-129): scales = exp(_scaling) [N,3], rotations =

@@ -330,3 +330,33 @@ def test_short_training_run_reduces_loss(device):
     first, lastv = sum(losses[:3]) / 3, sum(losses[-3:]) / 3
     assert all(math.isfinite(x) for x in losses)
     assert lastv < 0.7 * first, f"loss did not drop: {first:.4f} -> {lastv:.4f}"
+
+
+def test_batched_camera_preprocess_equals_per_camera(device):
+    """the one-launch-per-batch K1/K11 == B single-camera calls: outputs per camera and SUMMED gradients"""
+    import diff_gaussian_rasterization as dgr
+    from helpers import settings_from
+
+    N, W, H, B = 30000, 320, 208, 4
+    cams = S.orbit_cameras(B, W, H, device=device)
+    rasts = [dgr.GaussianRasterizer(settings_from(c, torch.zeros(3))) for c in cams]
+    gen = torch.Generator().manual_seed(1)
+    ws = [[torch.rand(s, generator=gen).to(device) for s in [(N, 2), (N, 3), (N, 4)]] for _ in range(B)]
+
+    def model():
+        m = S.SyntheticGaussianModel(N, W, H, seed=2, device=device, scale_coef=0.01)
+        return m, (m._xyz, m._scaling, m._rotation, m._features_dc, m._features_rest, m._opacity)
+
+    ma, ra = model()
+    outs_a = [r.preprocess_gaussians_raw(*ra, cuda_args={}) for r in rasts]
+    sum((o[0] * w[0]).sum() + (o[1] * w[1]).sum() + (o[2] * w[2]).sum() for o, w in zip(outs_a, ws)).backward()
+    mb, rb = model()
+    packed = torch.stack([dgr.pack_camera(r.raster_settings) for r in rasts])
+    m2, rgb, co, radii, depths = dgr.preprocess_gaussians_raw_batched(*rb, packed, 3, 1.0, W, H)
+    sum((m2[k] * ws[k][0]).sum() + (rgb[k] * ws[k][1]).sum() + (co[k] * ws[k][2]).sum() for k in range(B)).backward()
+    for k in range(B):
+        assert torch.equal(radii[k], outs_a[k][3])
+        assert torch.equal(m2[k], outs_a[k][0]) and torch.equal(depths[k], outs_a[k][4])
+        assert rel_err(rgb[k], outs_a[k][1]) < 1e-6 and rel_err(co[k], outs_a[k][2]) < 1e-6
+    for pa, pb in zip(ra, rb):
+        assert rel_err(pb.grad, pa.grad) < 1e-5
