@@ -91,7 +91,7 @@ def cpu_baseline(W, H, n_total, seconds=12.0):
         one()
         it += 1
     dt = (time.time() - t0) / it
-    return {"value": 1.0 / dt, "unit": "it/s", "cores": C.num_threads(), "kind": "port",
+    return {"value": 1.0 / dt, "unit": "images/s", "cores": C.num_threads(), "kind": "port",
             "sample": f"{n} Gaussians, {w}x{h} (1/16 of the Gaussians on a 1/16-area image), rasterizer "
                       f"fwd+bwd only (no loss/optimizer), {it} iterations, oracle/gsraster_ref.c with OpenMP"}
 
