@@ -197,3 +197,60 @@ def test_start_strategy_cut_points():
     assert division_pos_heuristic(h, 68, 2, right=True) == [0, 22, 68]  # prefix 3(i+1): first index with prefix > 68 is 22
     utils.DEFAULT_GROUP = utils.SingleGPUGroup()
     utils.WORLD_SIZE = 1
+
+
+def _gt_worker(rank, world, port, q):
+    try:
+        for p in (os.path.join(ROOT, "grendel-gs_amd"), ROOT):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                          MASTER_PORT=str(port))
+        torch.set_num_threads(1)
+        import synthetic_scene as S
+        import utils.general_utils as utils
+        from gaussian_renderer.loss_distribution import (load_camera_from_cpu_to_all_gpu,
+                                                         load_camera_from_cpu_to_all_gpu_for_eval)
+        from gaussian_renderer.workload_division import DivisionStrategyHistoryFinal, start_strategy_final
+
+        utils.init_distributed(backend="gloo")
+        W, H, bsz = 160, 112, 2
+        utils.set_img_size(H, W)
+        for storage in (False, True):
+            utils.set_args(utils.default_args(bsz=bsz, distributed_dataset_storage=storage))
+            cams = S.orbit_cameras(bsz, W, H)
+            full = [S.make_gt_image(W, H, seed=40 + k) for k in range(bsz)]
+            for k, c in enumerate(cams):
+                # distributed storage: only the first rank of the node holds the images (scene/cameras.py:60-75)
+                c.original_image_backup = full[k] if (not storage or rank == 0) else None
+            hist = DivisionStrategyHistoryFinal(S.SyntheticDataset(cams), world, rank)
+            strategies, tasks = start_strategy_final(cams, hist)
+            load_camera_from_cpu_to_all_gpu(cams, strategies, tasks)
+            for (k, l, r) in tasks[rank]:
+                y0, y1 = l * 16, min(r * 16, H)
+                assert torch.equal(cams[k].original_image, full[k][:, y0:y1, :]), (storage, k, l, r)
+            load_camera_from_cpu_to_all_gpu_for_eval(cams, strategies, tasks)
+            for k in range(bsz):
+                assert torch.equal(cams[k].original_image, full[k])
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        q.put((rank, traceback.format_exc()))
+
+
+def test_ground_truth_band_staging_local_and_distributed_storage():
+    """a15: every rank ends up with exactly the uint8 rows of the bands it renders, with local storage and with
+    rank-0-only storage + P2P band transfer (loss_distribution.py:2395-2533); eval gets full images"""
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gt_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in results:
+        assert msg == "ok", f"rank {rank}:\n{msg}"
