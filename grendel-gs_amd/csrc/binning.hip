@@ -10,8 +10,18 @@
 // A stable sort by tile id of a depth-ordered sequence is exactly the (tile, depth, arrival)
 // order of SURVEY.md A.3.  Traffic: ~64 B per Gaussian + ~40 B per pair instead of ~200 B per pair.
 //
+// At the sizes of one camera (1e6 Gaussians, 3e6 pairs) every kernel of this stage lasts 10-50 us, so
+// the stage is bound by the NUMBER of dependent launches, not by bytes.  The sort is therefore a
+// "one sweep" radix sort: the digit histograms of all passes are accumulated by the kernel that
+// PRODUCES the keys (K3 for the depth sort, K5 for the tile sort), and each pass is a single kernel
+// that obtains its workgroup's global digit offsets by decoupled look-back over the preceding
+// workgroups' per-digit counts (no histogram / scan launches between passes).  The offsets scan of
+// K4 is a single-pass look-back scan that gathers its input through the sorted order.  Workgroups
+// take their tile from a ticket counter, so a workgroup only ever waits for workgroups that are
+// already running (forward progress without co-residency assumptions).
+//
 // All primitives are hand-written for wave64: ballot-based stable multisplit inside a wave,
-// LDS per-wave digit tables, three-phase device scan.
+// LDS per-wave digit tables, LDS digit-ordered staging for coalesced stores.
 #include "common.h"
 
 namespace {
@@ -21,10 +31,52 @@ constexpr int SCAN_ITEMS = 8;
 constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;  // 2048 elements per workgroup
 
 constexpr int RADIX_THREADS = 256;
-constexpr int RADIX_ITEMS = 16;
-constexpr int RADIX_TILE = RADIX_THREADS * RADIX_ITEMS;  // 4096 elements per workgroup
 constexpr int RADIX_WAVES = RADIX_THREADS / GSR_WAVE;
 constexpr int RADIX_DIGITS = 256;
+static_assert(GSR_ONE_DIM_BLOCK == RADIX_DIGITS, "histogram tables are initialised one digit per thread");
+constexpr int RADIX_MAX_PASSES = 4;
+constexpr int RADIX_ITEMS = 16;  // 4096 pairs per workgroup (measured best of 8/12/16/24/32 at 1e6..1.4e7 pairs)
+constexpr long long RADIX_MAX_N = (1ll << 30) - 1;  // counts share a word with two flag bits
+
+// look-back state word: [31] inclusive prefix available, [30] workgroup aggregate available, [29:0] value
+constexpr uint32_t LB_PRE = 0x80000000u, LB_AGG = 0x40000000u, LB_VAL = 0x3FFFFFFFu;
+constexpr int LB_WINDOW = 4;  // independent state loads in flight per thread (look-back is short in practice)
+// 64-bit variant for the offsets scan (values up to 2^32)
+constexpr unsigned long long LB64_PRE = 2ull << 62, LB64_AGG = 1ull << 62, LB64_VAL = (1ull << 62) - 1ull;
+
+struct RadixPlan {
+    int passes;
+    int shift[RADIX_MAX_PASSES];
+    int nbits[RADIX_MAX_PASSES];
+};
+
+// split key bits [bit_lo, bit_hi) evenly over the minimum number of <= 8-bit passes (13 tile bits -> 7 + 6)
+RadixPlan radix_plan(int bit_lo, int bit_hi) {
+    RadixPlan pl{};
+    const int total = bit_hi - bit_lo;
+    pl.passes = (total + 7) / 8;
+    int shift = bit_lo;
+    for (int p = 0; p < pl.passes; p++) {
+        const int nb = (total - (shift - bit_lo) + (pl.passes - p) - 1) / (pl.passes - p);
+        pl.shift[p] = shift;
+        pl.nbits[p] = nb;
+        shift += nb;
+    }
+    return pl;
+}
+
+__device__ __forceinline__ uint32_t ld_agent(const uint32_t *p) {
+    return __hip_atomic_load(const_cast<uint32_t *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(uint32_t *p, uint32_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long ld_agent64(const unsigned long long *p) {
+    return __hip_atomic_load(const_cast<unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent64(unsigned long long *p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
     const int lane = threadIdx.x & 63;
@@ -55,109 +107,33 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *s
     return base + inc - v;
 }
 
-// ---------------------------------------------------------------- three-phase device scan (u32)
-__global__ void __launch_bounds__(SCAN_THREADS) scan_reduce_kernel(const uint32_t *__restrict__ in, long long n,
-                                                                   uint32_t *__restrict__ block_sums) {
-    __shared__ uint32_t smem[4];
-    const long long base = (long long)blockIdx.x * SCAN_TILE;
-    uint32_t s = 0;
-#pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; k++) {
-        const long long j = base + k * SCAN_THREADS + threadIdx.x;
-        if (j < n) s += in[j];
-    }
-    uint32_t tot;
-    block_exclusive_scan(s, smem, &tot);
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
-}
-
-// single workgroup: exclusive scan of block_sums[0..nb) in place, grand total to block_sums[nb]
-__global__ void __launch_bounds__(SCAN_THREADS) scan_spine_kernel(uint32_t *__restrict__ block_sums, int nb) {
-    __shared__ uint32_t smem[4];
-    uint32_t carry = 0;
-    for (int base = 0; base < nb; base += SCAN_THREADS) {
-        const int j = base + threadIdx.x;
-        const uint32_t v = j < nb ? block_sums[j] : 0u;
-        uint32_t tot;
-        const uint32_t ex = block_exclusive_scan(v, smem, &tot);
-        if (j < nb) block_sums[j] = carry + ex;
-        carry += tot;
-    }
-    if (threadIdx.x == 0) block_sums[nb] = carry;
-}
-
-__global__ void __launch_bounds__(SCAN_THREADS) scan_final_kernel(const uint32_t *__restrict__ in,
-                                                                  uint32_t *__restrict__ out, long long n,
-                                                                  const uint32_t *__restrict__ block_sums) {
-    __shared__ uint32_t smem[4];
-    // each thread owns SCAN_ITEMS CONSECUTIVE elements so that one workgroup scan suffices
-    const long long base = (long long)blockIdx.x * SCAN_TILE + (long long)threadIdx.x * SCAN_ITEMS;
-    uint32_t v[SCAN_ITEMS];
-    uint32_t s = 0;
-#pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; k++) {
-        v[k] = (base + k < n) ? in[base + k] : 0u;
-        s += v[k];
-    }
-    uint32_t tot;
-    uint32_t run = block_exclusive_scan(s, smem, &tot) + block_sums[blockIdx.x];
-#pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; k++) {
-        if (base + k < n) out[base + k] = run;
-        run += v[k];
-    }
-    // grand total lands one past the end
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[n] = block_sums[gridDim.x];
-}
-
-// single-workgroup exclusive scan for short arrays (histogram tables of the depth sort): one launch
-// instead of three.  out[n] = total.  n <= 1024 * SMALL_SCAN_ITEMS.
-constexpr int SMALL_SCAN_THREADS = 1024;
-constexpr int SMALL_SCAN_ITEMS = 64;
-__global__ void __launch_bounds__(SMALL_SCAN_THREADS) scan_small_kernel(const uint32_t *__restrict__ in,
-                                                                        uint32_t *__restrict__ out, int n) {
-    __shared__ uint32_t wsum[SMALL_SCAN_THREADS / 64];
-    const int per = (n + SMALL_SCAN_THREADS - 1) / SMALL_SCAN_THREADS;
-    const int base = threadIdx.x * per;
-    uint32_t s = 0;
-    for (int k = 0; k < per; k++) s += (base + k < n) ? in[base + k] : 0u;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t inc = wave_inclusive_scan(s);
-    if (lane == 63) wsum[wave] = inc;
-    __syncthreads();
-    uint32_t wbase = 0, tot = 0;
-    for (int w = 0; w < SMALL_SCAN_THREADS / 64; w++) {
-        const uint32_t v = wsum[w];
-        if (w < wave) wbase += v;
-        tot += v;
-    }
-    uint32_t run = wbase + inc - s;
-    for (int k = 0; k < per; k++) {
-        if (base + k < n) {
-            const uint32_t v = in[base + k];
-            out[base + k] = run;
-            run += v;
+// ------------------------------------------------------------- digit histograms of all passes at once
+// Called by the kernels that produce sort keys.  mh = LDS [passes][256]; one call per key per thread.
+// When every valid lane of the wave holds the same digit (top depth bytes, upper tile bits of one
+// splat) a single lane adds the population count instead of 64 serialised same-address LDS atomics.
+__device__ __forceinline__ void multihist_add(uint32_t (*mh)[RADIX_DIGITS], const RadixPlan &pl, uint32_t key,
+                                              bool valid) {
+    const unsigned long long vm = __ballot(valid);
+    if (vm == 0ull) return;
+    const int src = __ffsll((long long)vm) - 1;
+    const int lane = threadIdx.x & 63;
+    for (int p = 0; p < pl.passes; p++) {
+        const uint32_t d = (key >> pl.shift[p]) & ((1u << pl.nbits[p]) - 1u);
+        const uint32_t d0 = __shfl(d, src, 64);
+        if (__ballot(valid && d != d0) == 0ull) {
+            if (lane == src) atomicAdd(&mh[p][d0], (uint32_t)__popcll(vm));
+        } else if (valid) {
+            atomicAdd(&mh[p][d], 1u);
         }
     }
-    if (threadIdx.x == 0) out[n] = tot;
 }
-
-// ------------------------------------------------------------------------------ radix sort pass
-// digit = (key >> shift) & mask, mask = 2^nbits - 1, nbits <= 8
-__global__ void __launch_bounds__(RADIX_THREADS) radix_hist_kernel(const uint32_t *__restrict__ keys, long long n,
-                                                                   int shift, uint32_t mask,
-                                                                   uint32_t *__restrict__ hist, int nb) {
-    __shared__ uint32_t h[RADIX_DIGITS];
-    h[threadIdx.x] = 0;
-    __syncthreads();
-    const long long base = (long long)blockIdx.x * RADIX_TILE;
-#pragma unroll
-    for (int k = 0; k < RADIX_ITEMS; k++) {
-        const long long j = base + k * RADIX_THREADS + threadIdx.x;
-        if (j < n) atomicAdd(&h[(keys[j] >> shift) & mask], 1u);
-    }
-    __syncthreads();
-    if (threadIdx.x <= mask) hist[(size_t)threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];  // digit-major
+__device__ __forceinline__ void multihist_flush(uint32_t (*mh)[RADIX_DIGITS], const RadixPlan &pl,
+                                                uint32_t *__restrict__ ghist) {
+    for (int p = 0; p < pl.passes; p++)
+        for (int d = threadIdx.x; d < (1 << pl.nbits[p]); d += blockDim.x) {
+            const uint32_t c = mh[p][d];
+            if (c) atomicAdd(&ghist[p * RADIX_DIGITS + d], c);
+        }
 }
 
 // lanes holding the same digit (restricted to `valid` lanes)
@@ -171,44 +147,90 @@ __device__ __forceinline__ unsigned long long match_digit(uint32_t d, bool valid
     return m;
 }
 
-// One workgroup = 4096 consecutive pairs.  Stable ranks come from wave64 ballots (match_digit) plus
-// per-wave LDS cursors; the pairs are first placed in digit order INSIDE LDS and then streamed out,
-// so that each digit's run leaves the workgroup as contiguous, coalesced stores.
+// ------------------------------------------------------------------------- one radix pass, one kernel
+// Workgroup `bid` (ticket order) owns ITEMS*256 consecutive pairs.
+//   1. per-wave LDS digit counts -> workgroup count per digit, published as AGGREGATE in state[bid][d];
+//   2. thread d looks back over state[bid-1 .. ][d] (LB_WINDOW independent loads in flight), adding
+//      aggregates until it meets an inclusive PREFIX, then publishes its own inclusive prefix;
+//   3. global start of digit d = exclusive scan of the pass histogram (256 values, done by every
+//      workgroup) + look-back sum; stable ranks from wave64 ballots + per-wave LDS cursors; the pairs
+//      are placed in digit order INSIDE LDS and streamed out so that every digit's run leaves the
+//      workgroup as contiguous, coalesced stores.
+template <int ITEMS>
 __global__ void __launch_bounds__(RADIX_THREADS)
-radix_scatter_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
-                     uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, long long n, int shift,
-                     int nbits, const uint32_t *__restrict__ offsets, int nb) {
+radix_onesweep_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+                      uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, long long n, int shift,
+                      int nbits, const uint32_t *__restrict__ ghist, uint32_t *__restrict__ state,
+                      uint32_t *__restrict__ ticket) {
+    constexpr int TILE = ITEMS * RADIX_THREADS;
     __shared__ uint32_t wtab[RADIX_WAVES][RADIX_DIGITS];
     __shared__ uint32_t gbase[RADIX_DIGITS];  // global start of the digit's run minus its local start
-    __shared__ uint32_t skey[RADIX_TILE], sval[RADIX_TILE];
+    __shared__ uint32_t skey[TILE], sval[TILE];
     __shared__ uint32_t scan_tmp[4];
+    __shared__ uint32_t s_bid;
     const uint32_t mask = (1u << nbits) - 1u;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_bid = atomicAdd(ticket, 1u);
 #pragma unroll
     for (int w = 0; w < RADIX_WAVES; w++) wtab[w][threadIdx.x] = 0;
     __syncthreads();
-    // wave w owns the contiguous sub-chunk [base + w*1024, +1024), walked in 16 rounds of 64
-    const long long bbase = (long long)blockIdx.x * RADIX_TILE;
-    const long long wbase = bbase + (long long)wave * (RADIX_ITEMS * 64);
-    uint32_t key[RADIX_ITEMS];
+    const uint32_t bid = s_bid;
+    // wave w owns the contiguous sub-chunk [base + w*ITEMS*64, +ITEMS*64), walked in ITEMS rounds of 64
+    const long long bbase = (long long)bid * TILE;
+    const long long wbase = bbase + (long long)wave * (ITEMS * 64);
+    uint32_t key[ITEMS], val[ITEMS];
 #pragma unroll
-    for (int r = 0; r < RADIX_ITEMS; r++) {
+    for (int r = 0; r < ITEMS; r++) {
         const long long j = wbase + r * 64 + lane;
         key[r] = j < n ? keys_in[j] : 0xFFFFFFFFu;
+        val[r] = j < n ? vals_in[j] : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < ITEMS; r++) {
+        const long long j = wbase + r * 64 + lane;
         if (j < n) atomicAdd(&wtab[wave][(key[r] >> shift) & mask], 1u);
     }
     __syncthreads();
-    {  // thread d: per-wave counts of digit d -> local (in-workgroup) start positions
-        const int d = threadIdx.x;
+    {  // thread d: digit d
+        const uint32_t d = threadIdx.x;
+        const bool live = d <= mask;
         uint32_t cnt[RADIX_WAVES], tot = 0;
 #pragma unroll
         for (int w = 0; w < RADIX_WAVES; w++) {
             cnt[w] = wtab[w][d];
             tot += cnt[w];
         }
+        uint32_t *row = state + (size_t)bid * RADIX_DIGITS;
+        if (live) st_agent(&row[d], tot | (bid == 0 ? LB_PRE : LB_AGG));
         uint32_t all;
-        uint32_t run = block_exclusive_scan(tot, scan_tmp, &all);  // local start of digit d
-        gbase[d] = ((uint32_t)d <= mask ? offsets[(size_t)d * nb + blockIdx.x] : 0u) - run;
+        uint32_t run = block_exclusive_scan(tot, scan_tmp, &all);                         // local start of digit d
+        const uint32_t dstart = block_exclusive_scan(live ? ghist[d] : 0u, scan_tmp, &all);  // global start
+        uint32_t excl = 0;
+        if (live && bid > 0) {
+            long long j = (long long)bid - 1;
+            bool done = false;
+            while (!done) {
+                uint32_t v[LB_WINDOW];
+#pragma unroll
+                for (int k = 0; k < LB_WINDOW; k++)
+                    v[k] = (j - k >= 0) ? ld_agent(&state[(size_t)(j - k) * RADIX_DIGITS + d]) : LB_PRE;
+#pragma unroll
+                for (int k = 0; k < LB_WINDOW; k++) {
+                    if (!done) {
+                        uint32_t x = v[k];
+                        while ((x & (LB_PRE | LB_AGG)) == 0u) {
+                            __builtin_amdgcn_s_sleep(1);
+                            x = ld_agent(&state[(size_t)(j - k) * RADIX_DIGITS + d]);
+                        }
+                        excl += x & LB_VAL;
+                        done = (x & LB_PRE) != 0u;
+                    }
+                }
+                j -= LB_WINDOW;
+            }
+            st_agent(&row[d], ((excl + tot) & LB_VAL) | LB_PRE);
+        }
+        gbase[d] = dstart + excl - run;
 #pragma unroll
         for (int w = 0; w < RADIX_WAVES; w++) {
             wtab[w][d] = run;
@@ -218,7 +240,7 @@ radix_scatter_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__res
     __syncthreads();
     const unsigned long long lt = (1ull << lane) - 1ull;
 #pragma unroll
-    for (int r = 0; r < RADIX_ITEMS; r++) {
+    for (int r = 0; r < ITEMS; r++) {
         const long long j = wbase + r * 64 + lane;
         const bool valid = j < n;
         const uint32_t d = (key[r] >> shift) & mask;
@@ -232,14 +254,14 @@ radix_scatter_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__res
         __builtin_amdgcn_wave_barrier();
         if (valid) {
             skey[pos] = key[r];
-            sval[pos] = vals_in[j];
+            sval[pos] = val[r];
         }
     }
     __syncthreads();
     const long long rem = n - bbase;
-    const int count = rem < RADIX_TILE ? (int)rem : RADIX_TILE;
+    const int count = rem < TILE ? (int)rem : TILE;
 #pragma unroll
-    for (int r = 0; r < RADIX_ITEMS; r++) {
+    for (int r = 0; r < ITEMS; r++) {
         const int i = r * RADIX_THREADS + threadIdx.x;
         if (i < count) {
             const uint32_t k = skey[i];
@@ -250,72 +272,149 @@ radix_scatter_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__res
     }
 }
 
-// ---------------------------------------------------------------------------------- K3 and friends
-// Row hull of the locally computed tiles: hull[0] = first tile row with a local tile, hull[1] = one
-// past the last.  Grendel's final mode always passes whole-row bands, for which the hull IS the mask;
-// for a general mask the tiles inside the hull that are not local are emitted with a sentinel key.
-__global__ void __launch_bounds__(256) mask_hull_kernel(const uint8_t *__restrict__ mask, int gx, int gy,
-                                                        int32_t *__restrict__ hull) {
-    __shared__ int lo, hi;
-    if (threadIdx.x == 0) { lo = gy; hi = 0; }
+// ------------------------------------------------------------ K4: offsets = exclusive scan of tt[ids[.]]
+// Single pass with decoupled look-back (wave 0 inspects 64 predecessors per round).  out[n] = total.
+__global__ void __launch_bounds__(SCAN_THREADS)
+scan_gather_lookback_kernel(const uint32_t *__restrict__ src, const uint32_t *__restrict__ idx,
+                            uint32_t *__restrict__ out, long long n, unsigned long long *__restrict__ state,
+                            uint32_t *__restrict__ ticket, int nb) {
+    __shared__ uint32_t smem[4];
+    __shared__ uint32_t s_bid;
+    __shared__ unsigned long long s_excl;
+    if (threadIdx.x == 0) s_bid = atomicAdd(ticket, 1u);
     __syncthreads();
-    for (int y = threadIdx.x; y < gy; y += blockDim.x) {
-        bool any = false;
-        for (int x = 0; x < gx; x++) any = any || mask[(size_t)y * gx + x];
-        if (any) {
-            atomicMin(&lo, y);
-            atomicMax(&hi, y + 1);
+    const uint32_t bid = s_bid;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // each thread owns SCAN_ITEMS CONSECUTIVE elements so that one workgroup scan suffices
+    const long long base = (long long)bid * SCAN_TILE + (long long)threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS];
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        v[k] = (base + k < n) ? src[idx[base + k]] : 0u;
+        s += v[k];
+    }
+    uint32_t tot;
+    const uint32_t local = block_exclusive_scan(s, smem, &tot);
+    if (wave == 0) {
+        if (lane == 0) st_agent64(&state[bid], (unsigned long long)tot | (bid == 0 ? LB64_PRE : LB64_AGG));
+        unsigned long long excl = 0;
+        if (bid > 0) {
+            long long top = (long long)bid - 1;
+            while (true) {
+                const long long j = top - lane;
+                unsigned long long x = j >= 0 ? ld_agent64(&state[j]) : LB64_PRE;  // virtual zero prefix before 0
+                int fp;
+                while (true) {
+                    const unsigned long long empty = __ballot((x >> 62) == 0ull);
+                    const unsigned long long pre = __ballot((x >> 62) >= 2ull);
+                    fp = pre ? __ffsll((long long)pre) - 1 : 64;
+                    const unsigned long long need = fp >= 63 ? ~0ull : ((2ull << fp) - 1ull);
+                    if ((empty & need) == 0ull) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if ((x >> 62) == 0ull) x = ld_agent64(&state[j]);
+                }
+                unsigned long long part = lane <= fp ? (x & LB64_VAL) : 0ull;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+                excl += part;
+                if (fp < 64) break;
+                top -= 64;
+            }
+        }
+        if (lane == 0) {
+            if (bid > 0) st_agent64(&state[bid], (excl + tot) | LB64_PRE);
+            s_excl = excl;
+            if ((int)bid == nb - 1) out[n] = (uint32_t)(excl + tot);
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) { hull[0] = lo; hull[1] = hi; }
+    uint32_t run = (uint32_t)s_excl + local;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        if (base + k < n) out[base + k] = run;
+        run += v[k];
+    }
 }
 
-// K3: per Gaussian, the tile rect it can CONTRIBUTE to and the number of its tiles; depth sort keys.
+// ---------------------------------------------------------------------------------- K3 and friends
+// K3: per Gaussian, the tile rect it can CONTRIBUTE to and the number of its tiles; depth sort keys and
+// the digit histograms of the four depth-sort passes.
 // The rect is the reference's 3-sigma-radius rect intersected with the
 // bounding box of the alpha >= 1/255 ellipse (gsr_alpha_extent) and with the mask's row hull: tiles
 // dropped by the intersection cannot receive a contribution under the alpha < 1/255 rule of A.4, so
 // the image is unchanged while D (pairs to sort and to walk) shrinks.  Gaussians touching nothing get
 // key 0xFFFFFFFF (depths are > 0.2, so real keys are < 0x7F800000) and sort to the end.
+// Row hull of the locally computed tiles (computed by every workgroup from the 8-32 KB mask):
+// [first tile row with a local tile, one past the last).  Grendel's final mode always passes whole-row
+// bands, for which the hull IS the mask; for a general mask the tiles inside the hull that are not
+// local are emitted with a sentinel key.
 __global__ void __launch_bounds__(GSR_ONE_DIM_BLOCK)
 touch_count_kernel(int P, int gx, int gy, const float2 *__restrict__ means2D, const float *__restrict__ depths,
                    const int32_t *__restrict__ radii, const float4 *__restrict__ conic_opacity,
-                   const int32_t *__restrict__ hull, uint32_t *__restrict__ tt, uint32_t *__restrict__ keys,
-                   uint32_t *__restrict__ vals, uint2 *__restrict__ rects) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
-    uint32_t n = 0;
-    uint2 rect = make_uint2(0u, 0u);
-    const int rad = radii[i];
-    if (rad > 0) {
-        const float2 xy = means2D[i];
-        const float4 co = conic_opacity[i];
-        float ex, ey;
-        if (gsr_alpha_extent(co, ex, ey)) {
-            int minx, miny, maxx, maxy;
-            gsr_get_rect(xy.x, xy.y, rad, gx, gy, minx, miny, maxx, maxy);
-            // tile t covers pixel centres [16t, 16t+15]
-            minx = max(minx, (int)ceilf((xy.x - ex - (GSR_BLOCK_X - 1)) * (1.0f / GSR_BLOCK_X)));
-            maxx = min(maxx, (int)floorf((xy.x + ex) * (1.0f / GSR_BLOCK_X)) + 1);
-            miny = max(max(miny, hull[0]), (int)ceilf((xy.y - ey - (GSR_BLOCK_Y - 1)) * (1.0f / GSR_BLOCK_Y)));
-            maxy = min(min(maxy, hull[1]), (int)floorf((xy.y + ey) * (1.0f / GSR_BLOCK_Y)) + 1);
-            if (maxx > minx && maxy > miny) {
-                n = (uint32_t)((maxx - minx) * (maxy - miny));
-                rect = make_uint2((uint32_t)minx | ((uint32_t)maxx << 16), (uint32_t)miny | ((uint32_t)maxy << 16));
+                   const uint8_t *__restrict__ mask, RadixPlan plan, uint32_t *__restrict__ tt,
+                   uint32_t *__restrict__ keys, uint32_t *__restrict__ vals, uint2 *__restrict__ rects,
+                   uint32_t *__restrict__ ghist) {
+    __shared__ int s_lo, s_hi;
+    __shared__ uint32_t mh[RADIX_MAX_PASSES][RADIX_DIGITS];
+    if (threadIdx.x == 0) { s_lo = gy; s_hi = 0; }
+    for (int p = 0; p < RADIX_MAX_PASSES; p++) mh[p][threadIdx.x] = 0;
+    __syncthreads();
+    {  // every thread inspects a contiguous slice of the mask; rows are monotone in the byte index
+        const int total = gx * gy;
+        const int per = (total + GSR_ONE_DIM_BLOCK - 1) / GSR_ONE_DIM_BLOCK;
+        const int b0 = threadIdx.x * per, b1 = min(b0 + per, total);
+        int first = -1, last = -1;
+        for (int b = b0; b < b1; b++)
+            if (mask[b]) {
+                if (first < 0) first = b;
+                last = b;
             }
+        if (first >= 0) {
+            atomicMin(&s_lo, first / gx);
+            atomicMax(&s_hi, last / gx + 1);
         }
     }
-    tt[i] = n;
-    rects[i] = rect;
-    keys[i] = n ? __float_as_uint(depths[i]) : 0xFFFFFFFFu;
-    vals[i] = (uint32_t)i;
-}
-
-__global__ void __launch_bounds__(GSR_ONE_DIM_BLOCK)
-gather_u32_kernel(int n, const uint32_t *__restrict__ src, const uint32_t *__restrict__ idx,
-                  uint32_t *__restrict__ dst) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < n) dst[j] = src[idx[j]];
+    __syncthreads();
+    const int hull0 = s_lo, hull1 = s_hi;
+    for (long long base = (long long)blockIdx.x * GSR_ONE_DIM_BLOCK; base < P;
+         base += (long long)gridDim.x * GSR_ONE_DIM_BLOCK) {
+        const long long i = base + threadIdx.x;
+        const bool valid = i < P;
+        uint32_t key = 0xFFFFFFFFu;
+        if (valid) {
+            uint32_t n = 0;
+            uint2 rect = make_uint2(0u, 0u);
+            const int rad = radii[i];
+            if (rad > 0) {
+                const float2 xy = means2D[i];
+                const float4 co = conic_opacity[i];
+                float ex, ey;
+                if (gsr_alpha_extent(co, ex, ey)) {
+                    int minx, miny, maxx, maxy;
+                    gsr_get_rect(xy.x, xy.y, rad, gx, gy, minx, miny, maxx, maxy);
+                    // tile t covers pixel centres [16t, 16t+15]
+                    minx = max(minx, (int)ceilf((xy.x - ex - (GSR_BLOCK_X - 1)) * (1.0f / GSR_BLOCK_X)));
+                    maxx = min(maxx, (int)floorf((xy.x + ex) * (1.0f / GSR_BLOCK_X)) + 1);
+                    miny = max(max(miny, hull0), (int)ceilf((xy.y - ey - (GSR_BLOCK_Y - 1)) * (1.0f / GSR_BLOCK_Y)));
+                    maxy = min(min(maxy, hull1), (int)floorf((xy.y + ey) * (1.0f / GSR_BLOCK_Y)) + 1);
+                    if (maxx > minx && maxy > miny) {
+                        n = (uint32_t)((maxx - minx) * (maxy - miny));
+                        rect = make_uint2((uint32_t)minx | ((uint32_t)maxx << 16),
+                                          (uint32_t)miny | ((uint32_t)maxy << 16));
+                    }
+                }
+            }
+            if (n) key = __float_as_uint(depths[i]);
+            tt[i] = n;
+            rects[i] = rect;
+            keys[i] = key;
+            vals[i] = (uint32_t)i;
+        }
+        multihist_add(mh, plan, key, valid);
+    }
+    __syncthreads();
+    multihist_flush(mh, plan, ghist);
 }
 
 // K5: the D output pairs are cut into chunks of EMIT_CHUNK slots, one wave per chunk, so the work is
@@ -323,74 +422,102 @@ gather_u32_kernel(int n, const uint32_t *__restrict__ src, const uint32_t *__res
 // The wave finds the Gaussian that owns its first slot with a 64-ary search over the offsets (one
 // coalesced probe per round), then walks windows of 64 depth-consecutive Gaussians staged in LDS; every
 // slot locates its owner by a 6-step binary search in the window and is written with coalesced stores.
+// The digit histograms of the tile-sort passes are accumulated on the way.
 constexpr int EMIT_CHUNK = 2048;
 __global__ void __launch_bounds__(256)
 emit_pairs_kernel(int P, long long D, int gx, int tiles, const uint2 *__restrict__ rects,
                   const uint8_t *__restrict__ mask, const uint32_t *__restrict__ sorted_ids,
-                  const uint32_t *__restrict__ offsets, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+                  const uint32_t *__restrict__ offsets, RadixPlan plan, uint32_t *__restrict__ keys,
+                  uint32_t *__restrict__ vals, uint32_t *__restrict__ ghist) {
     __shared__ uint32_t s_off[4][65];
     __shared__ uint32_t s_g[4][64];
     __shared__ uint2 s_rect[4][64];
+    __shared__ uint32_t mh[RADIX_MAX_PASSES][RADIX_DIGITS];
+    for (int p = 0; p < RADIX_MAX_PASSES; p++) mh[p][threadIdx.x] = 0;
+    __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long long chunk = (long long)blockIdx.x * 4 + wave;
-    const long long sb = chunk * EMIT_CHUNK;
-    if (sb >= D) return;
-    const uint32_t s_begin = (uint32_t)sb;
-    const uint32_t s_end = (uint32_t)(sb + EMIT_CHUNK < D ? sb + EMIT_CHUNK : D);
-    // largest j in [0, P] with offsets[j] <= s_begin  (offsets is non-decreasing, offsets[P] = D > s_begin)
-    int lo = 0, hi = P;  // invariant: offsets[lo] <= s_begin < offsets[hi]
-    while (hi - lo > 1) {
-        const int step = (hi - lo + 63) / 64;
-        const int idx = min(lo + lane * step, hi);
-        const bool le = offsets[idx] <= s_begin;
-        const int c = __popcll(__ballot(le));  // probes are monotone: the first c lanes say "<="
-        const int nlo = lo + (c - 1) * step;
-        hi = min(hi, nlo + step);
-        lo = nlo;
-    }
-    int g0 = lo;
-    uint32_t s = s_begin + lane;
-    while (true) {  // one window of 64 Gaussians per iteration (wave-uniform control flow)
-        const int j = g0 + lane;
-        const uint32_t off = offsets[min(j, P)];
-        const uint32_t end = offsets[min(j + 1, P)];
-        const uint32_t g = (j < P && end > off) ? sorted_ids[j] : 0u;
-        __builtin_amdgcn_wave_barrier();
-        s_off[wave][lane] = off;
-        if (lane == 63) s_off[wave][64] = end;
-        s_g[wave][lane] = g;
-        s_rect[wave][lane] = (j < P && end > off) ? rects[g] : make_uint2(0u, 0u);
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t wend = min(__builtin_amdgcn_readlane(end, 63), s_end);
-        for (; s < wend; s += 64) {
-            int a = 0, bnd = 63;
-#pragma unroll
-            for (int it = 0; it < 6; it++) {
-                const int mid = (a + bnd + 1) >> 1;
-                if (s_off[wave][mid] <= s) a = mid; else bnd = mid - 1;
-            }
-            const uint2 r = s_rect[wave][a];
-            const uint32_t t = s - s_off[wave][a];
-            const uint32_t minx = r.x & 0xFFFFu, w = (r.x >> 16) - minx, miny = r.y & 0xFFFFu;
-            const uint32_t y = miny + t / w, x = minx + t % w;
-            const uint32_t tile = y * (uint32_t)gx + x;
-            keys[s] = mask[tile] ? tile : (uint32_t)tiles;  // non-local tile inside the hull: sentinel, sorts last
-            vals[s] = s_g[wave][a];
+    for (long long sb = ((long long)blockIdx.x * 4 + wave) * EMIT_CHUNK; sb < D;
+         sb += (long long)gridDim.x * 4 * EMIT_CHUNK) {
+        const uint32_t s_begin = (uint32_t)sb;
+        const uint32_t s_end = (uint32_t)(sb + EMIT_CHUNK < D ? sb + EMIT_CHUNK : D);
+        // largest j in [0, P] with offsets[j] <= s_begin  (offsets is non-decreasing, offsets[P] = D > s_begin)
+        int lo = 0, hi = P;  // invariant: offsets[lo] <= s_begin < offsets[hi]
+        while (hi - lo > 1) {
+            const int step = (hi - lo + 63) / 64;
+            const int idx = min(lo + lane * step, hi);
+            const bool le = offsets[idx] <= s_begin;
+            const int c = __popcll(__ballot(le));  // probes are monotone: the first c lanes say "<="
+            const int nlo = lo + (c - 1) * step;
+            hi = min(hi, nlo + step);
+            lo = nlo;
         }
-        if (wend >= s_end) break;
-        g0 += 64;
+        int g0 = lo;
+        uint32_t s = s_begin + lane;
+        while (true) {  // one window of 64 Gaussians per iteration (wave-uniform control flow)
+            const int j = g0 + lane;
+            const uint32_t off = offsets[min(j, P)];
+            const uint32_t end = offsets[min(j + 1, P)];
+            const uint32_t g = (j < P && end > off) ? sorted_ids[j] : 0u;
+            __builtin_amdgcn_wave_barrier();
+            s_off[wave][lane] = off;
+            if (lane == 63) s_off[wave][64] = end;
+            s_g[wave][lane] = g;
+            s_rect[wave][lane] = (j < P && end > off) ? rects[g] : make_uint2(0u, 0u);
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t wend = min(__builtin_amdgcn_readlane(end, 63), s_end);
+            while (__ballot(s < wend) != 0ull) {  // wave-uniform trip count (the histogram uses ballots)
+                const bool valid = s < wend;
+                uint32_t key = 0;
+                if (valid) {
+                    int a = 0, bnd = 63;
+#pragma unroll
+                    for (int it = 0; it < 6; it++) {
+                        const int mid = (a + bnd + 1) >> 1;
+                        if (s_off[wave][mid] <= s) a = mid; else bnd = mid - 1;
+                    }
+                    const uint2 r = s_rect[wave][a];
+                    const uint32_t t = s - s_off[wave][a];
+                    const uint32_t minx = r.x & 0xFFFFu, w = (r.x >> 16) - minx, miny = r.y & 0xFFFFu;
+                    const uint32_t y = miny + t / w, x = minx + t % w;
+                    const uint32_t tile = y * (uint32_t)gx + x;
+                    key = mask[tile] ? tile : (uint32_t)tiles;  // non-local tile in the hull: sentinel, sorts last
+                    keys[s] = key;
+                    vals[s] = s_g[wave][a];
+                }
+                multihist_add(mh, plan, key, valid);
+                if (valid) s += 64;
+            }
+            if (wend >= s_end) break;
+            g0 += 64;
+        }
     }
+    __syncthreads();
+    multihist_flush(mh, plan, ghist);
 }
 
-// K7
+// K7: four consecutive sorted pairs per thread
 __global__ void __launch_bounds__(GSR_ONE_DIM_BLOCK)
 tile_ranges_kernel(long long D, uint32_t tiles, const uint32_t *__restrict__ tile_of, int2 *__restrict__ ranges) {
-    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long j = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (j >= D) return;
-    const uint32_t t = tile_of[j];
-    if (t >= tiles) return;
-    if (j == 0 || tile_of[j - 1] != t) ranges[t].x = (int)j;
-    if (j == D - 1 || tile_of[j + 1] != t) ranges[t].y = (int)(j + 1);
+    uint32_t k[6];  // k[0] = predecessor, k[1..4] = own, k[5] = successor
+    k[0] = j > 0 ? tile_of[j - 1] : 0xFFFFFFFFu;
+    if (j + 4 <= D) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(tile_of + j);
+        k[1] = q.x; k[2] = q.y; k[3] = q.z; k[4] = q.w;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) k[1 + i] = j + i < D ? tile_of[j + i] : 0xFFFFFFFFu;
+    }
+    k[5] = j + 4 < D ? tile_of[j + 4] : 0xFFFFFFFFu;
+#pragma unroll
+    for (int i = 1; i <= 4; i++) {
+        if (j + i - 1 >= D) break;
+        const uint32_t t = k[i];
+        if (t >= tiles) continue;
+        if (k[i - 1] != t) ranges[t].x = (int)(j + i - 1);
+        if (k[i + 1] != t) ranges[t].y = (int)(j + i);
+    }
 }
 
 __global__ void __launch_bounds__(GSR_ONE_DIM_BLOCK)
@@ -401,62 +528,48 @@ copy_u32_kernel(long long n, const uint32_t *__restrict__ src, uint32_t *__restr
 
 inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
-}  // namespace
-
-// ----------------------------------------------------------------------------------- primitives
-size_t gsr_scan_temp_bytes(long long n) {
-    const long long nb = (n + SCAN_TILE - 1) / SCAN_TILE;
-    return align_up((size_t)(nb + 1) * sizeof(uint32_t));
+inline long long radix_blocks(long long n) {
+    const long long tile = (long long)RADIX_ITEMS * RADIX_THREADS;
+    return (n + tile - 1) / tile;
 }
 
-// out must hold n+1 words: out[i] = sum(in[0..i)), out[n] = total.  in == out is allowed.
-int gsr_exclusive_scan_u32(const uint32_t *in, uint32_t *out, long long n, void *temp, hipStream_t stream) {
-    if (n <= 0) {
-        GSR_HIP(hipMemsetAsync(out, 0, sizeof(uint32_t), stream));
-        return 0;
-    }
-    if (n <= SMALL_SCAN_THREADS) {  // one element per thread; longer arrays: the coalesced three-phase scan
-        hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(SMALL_SCAN_THREADS), 0, stream, in, out, (int)n);
-        GSR_LAUNCH_CHECK();
-        return 0;
-    }
-    const int nb = (int)((n + SCAN_TILE - 1) / SCAN_TILE);
-    uint32_t *bs = reinterpret_cast<uint32_t *>(temp);
-    hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(SCAN_THREADS), 0, stream, in, n, bs);
-    hipLaunchKernelGGL(scan_spine_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, bs, nb);
-    hipLaunchKernelGGL(scan_final_kernel, dim3(nb), dim3(SCAN_THREADS), 0, stream, in, out, n, bs);
-    GSR_LAUNCH_CHECK();
-    return 0;
+// control block of one sort (zeroed by ONE memset before the producer kernel runs):
+//   ghist[4][256] | tickets[8] | scan_state u64[scan_blocks] | radix state u32[passes][blocks][256]
+struct CtrlLayout {
+    size_t ghist, tickets, scan_state, radix_state, total;
+};
+CtrlLayout ctrl_layout(long long n, int passes, bool with_scan) {
+    CtrlLayout C;
+    size_t o = 0;
+    C.ghist = o; o += sizeof(uint32_t) * RADIX_MAX_PASSES * RADIX_DIGITS;
+    C.tickets = o; o += 256;
+    C.scan_state = o;
+    if (with_scan) o += align_up(sizeof(unsigned long long) * (size_t)((n + SCAN_TILE - 1) / SCAN_TILE + 1));
+    C.radix_state = o;
+    o += align_up(sizeof(uint32_t) * (size_t)passes * (size_t)(radix_blocks(n) + 1) * RADIX_DIGITS);
+    C.total = o;
+    return C;
 }
 
-size_t gsr_radix_temp_bytes(long long n) {
-    const long long nb = (n + RADIX_TILE - 1) / RADIX_TILE;
-    const long long nh = nb * RADIX_DIGITS;
-    return align_up((size_t)(nh + 1) * sizeof(uint32_t)) + gsr_scan_temp_bytes(nh);
-}
-
-int gsr_radix_sort_pairs(uint32_t *k0, uint32_t *v0, uint32_t *k1, uint32_t *v1, long long n, int bit_lo, int bit_hi,
-                         void *temp, int *result_in_first, hipStream_t stream, uint32_t *final_vals) {
+// stable LSD radix sort of (key,value) u32 pairs following `plan`; the pass histograms in ctrl->ghist were
+// accumulated by the producer of the keys.  Ping-pongs between (k0,v0) and (k1,v1); *result_in_first tells
+// where the sorted keys ended up; the last pass writes the values to final_vals when given.
+int radix_sort_pairs(uint32_t *k0, uint32_t *v0, uint32_t *k1, uint32_t *v1, long long n, const RadixPlan &plan,
+                     char *ctrl, const CtrlLayout &C, int *result_in_first, hipStream_t stream,
+                     uint32_t *final_vals) {
     *result_in_first = 1;
     if (n <= 0) return 0;
-    const int nb = (int)((n + RADIX_TILE - 1) / RADIX_TILE);
-    uint32_t *hist = reinterpret_cast<uint32_t *>(temp);
-    void *scan_temp = reinterpret_cast<char *>(temp) + align_up((size_t)((long long)nb * RADIX_DIGITS + 1) * sizeof(uint32_t));
-    // split the key bits evenly over the minimum number of <= 8-bit passes (13 tile bits -> 7 + 6)
-    const int total = bit_hi - bit_lo, passes = (total + 7) / 8;
+    if (n > RADIX_MAX_N) return GSR_EINVAL;
+    const int nb = (int)radix_blocks(n);
+    uint32_t *ghist = reinterpret_cast<uint32_t *>(ctrl + C.ghist);
+    uint32_t *tickets = reinterpret_cast<uint32_t *>(ctrl + C.tickets);
+    uint32_t *state = reinterpret_cast<uint32_t *>(ctrl + C.radix_state);
     uint32_t *ki = k0, *vi = v0, *ko = k1, *vo = v1;
-    int shift = bit_lo;
-    for (int p = 0; p < passes; p++) {
-        const int nbits = (total - (shift - bit_lo) + (passes - p) - 1) / (passes - p);
-        const long long nh = (long long)nb << nbits;
-        hipLaunchKernelGGL(radix_hist_kernel, dim3(nb), dim3(RADIX_THREADS), 0, stream, ki, n, shift,
-                           (1u << nbits) - 1u, hist, nb);
-        int rc = gsr_exclusive_scan_u32(hist, hist, nh, scan_temp, stream);
-        if (rc) return rc;
-        uint32_t *vdst = (p == passes - 1 && final_vals) ? final_vals : vo;  // last pass can land the values
-        hipLaunchKernelGGL(radix_scatter_kernel, dim3(nb), dim3(RADIX_THREADS), 0, stream, ki, vi, ko, vdst, n, shift,
-                           nbits, hist, nb);
-        shift += nbits;
+    for (int p = 0; p < plan.passes; p++) {
+        uint32_t *vdst = (p == plan.passes - 1 && final_vals) ? final_vals : vo;  // last pass can land the values
+        hipLaunchKernelGGL(radix_onesweep_kernel<RADIX_ITEMS>, dim3(nb), dim3(RADIX_THREADS), 0, stream, ki, vi, ko,
+                           vdst, n, plan.shift[p], plan.nbits[p], ghist + p * RADIX_DIGITS,
+                           state + (size_t)p * nb * RADIX_DIGITS, tickets + 1 + p);
         uint32_t *t = ki; ki = ko; ko = t;
         t = vi; vi = vo; vo = t;
         *result_in_first ^= 1;
@@ -465,10 +578,9 @@ int gsr_radix_sort_pairs(uint32_t *k0, uint32_t *v0, uint32_t *k1, uint32_t *v1,
     return 0;
 }
 
-// ----------------------------------------------------------------------------------- K3..K7 API
-namespace {
 struct PrepLayout {
-    size_t tt, kA, vA, kB, vB, offsets, rects, hull, temp, total;
+    size_t tt, kA, vA, kB, vB, offsets, rects, ctrl, total;
+    CtrlLayout C;
 };
 PrepLayout prep_layout(int P, int W, int H) {
     (void)W; (void)H;
@@ -482,10 +594,9 @@ PrepLayout prep_layout(int P, int W, int H) {
     L.vB = o; o += np;
     L.offsets = o; o += np;
     L.rects = o; o += align_up((size_t)(P + 1) * 8);
-    L.hull = o; o += 256;
-    L.temp = o;
-    const size_t t1 = gsr_radix_temp_bytes(P), t2 = gsr_scan_temp_bytes(P);
-    o += t1 > t2 ? t1 : t2;
+    L.ctrl = o;
+    L.C = ctrl_layout(P, 4, true);
+    o += L.C.total;
     L.total = o;
     return L;
 }
@@ -496,6 +607,7 @@ int tile_bits(int tiles) {  // bits of the largest key value, the sentinel `tile
 }
 }  // namespace
 
+// ----------------------------------------------------------------------------------- K3..K7 API
 extern "C" size_t gsr_bin_prepare_bytes(int P, int width, int height) {
     if (P < 0 || width <= 0 || height <= 0) return 0;
     return prep_layout(P, width, height).total;
@@ -509,6 +621,7 @@ extern "C" int gsr_bin_prepare(int P, int width, int height, const float *means2
     *num_rendered_host = 0;
     if (P == 0) return 0;
     if (!means2D || !depths || !radii || !conic_opacity || !compute_locally || !prep) return GSR_EINVAL;
+    if (P > RADIX_MAX_N) return GSR_EINVAL;
     const PrepLayout L = prep_layout(P, width, height);
     if (prep_bytes < L.total) return GSR_ENOSPACE;
     const int gx = (width + GSR_BLOCK_X - 1) / GSR_BLOCK_X, gy = (height + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y;
@@ -519,27 +632,30 @@ extern "C" int gsr_bin_prepare(int P, int width, int height, const float *means2
     uint32_t *kB = reinterpret_cast<uint32_t *>(base + L.kB), *vB = reinterpret_cast<uint32_t *>(base + L.vB);
     uint32_t *offsets = reinterpret_cast<uint32_t *>(base + L.offsets);
     uint2 *rects = reinterpret_cast<uint2 *>(base + L.rects);
-    int32_t *hull = reinterpret_cast<int32_t *>(base + L.hull);
-    void *temp = base + L.temp;
+    char *ctrl = base + L.ctrl;
 
-    hipLaunchKernelGGL(mask_hull_kernel, dim3(1), dim3(256), 0, stream, compute_locally, gx, gy, hull);
-    hipLaunchKernelGGL(touch_count_kernel, dim3(gsr_div_up(P, GSR_ONE_DIM_BLOCK)), dim3(GSR_ONE_DIM_BLOCK), 0, stream,
-                       P, gx, gy, reinterpret_cast<const float2 *>(means2D), depths, radii,
-                       reinterpret_cast<const float4 *>(conic_opacity), hull, tt, kA, vA, rects);
+    GSR_HIP(hipMemsetAsync(ctrl, 0, L.C.total, stream));
+    const RadixPlan plan = radix_plan(0, 32);
+    // persistent workgroups: every workgroup flushes ~800 histogram atomics, 512 of them is the measured optimum
+    const int blocks = gsr_div_up(P, GSR_ONE_DIM_BLOCK) < 512 ? gsr_div_up(P, GSR_ONE_DIM_BLOCK) : 512;
+    hipLaunchKernelGGL(touch_count_kernel, dim3(blocks), dim3(GSR_ONE_DIM_BLOCK), 0, stream, P, gx, gy,
+                       reinterpret_cast<const float2 *>(means2D), depths, radii,
+                       reinterpret_cast<const float4 *>(conic_opacity), compute_locally, plan, tt, kA, vA, rects,
+                       reinterpret_cast<uint32_t *>(ctrl + L.C.ghist));
     int in_first = 1;
-    int rc = gsr_radix_sort_pairs(kA, vA, kB, vB, P, 0, 32, temp, &in_first, stream, nullptr);
+    int rc = radix_sort_pairs(kA, vA, kB, vB, P, plan, ctrl, L.C, &in_first, stream, nullptr);
     if (rc) return rc;
-    // 4 passes -> back in (kA, vA); keep the sorted ids in vA, reuse kB for the gathered counts
+    // 4 passes -> back in (kA, vA); the sorted ids stay in vA for K5
     uint32_t *sorted_ids = in_first ? vA : vB;
     if (!in_first) {
         hipLaunchKernelGGL(copy_u32_kernel, dim3(gsr_div_up(P, GSR_ONE_DIM_BLOCK)), dim3(GSR_ONE_DIM_BLOCK), 0, stream,
                            (long long)P, vB, vA);
         sorted_ids = vA;
     }
-    hipLaunchKernelGGL(gather_u32_kernel, dim3(gsr_div_up(P, GSR_ONE_DIM_BLOCK)), dim3(GSR_ONE_DIM_BLOCK), 0, stream, P,
-                       tt, sorted_ids, kB);
-    rc = gsr_exclusive_scan_u32(kB, offsets, P, temp, stream);
-    if (rc) return rc;
+    const int nbs = gsr_div_up(P, SCAN_TILE);
+    hipLaunchKernelGGL(scan_gather_lookback_kernel, dim3(nbs), dim3(SCAN_THREADS), 0, stream, tt, sorted_ids, offsets,
+                       (long long)P, reinterpret_cast<unsigned long long *>(ctrl + L.C.scan_state),
+                       reinterpret_cast<uint32_t *>(ctrl + L.C.tickets), nbs);
     GSR_LAUNCH_CHECK();
     uint32_t total = 0;
     GSR_HIP(hipMemcpyAsync(&total, offsets + P, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
@@ -550,9 +666,10 @@ extern "C" int gsr_bin_prepare(int P, int width, int height, const float *means2
 
 namespace {
 struct SortLayout {
-    size_t kA, vA, kB, vB, temp, total;
+    size_t kA, vA, kB, vB, ctrl, total;
+    CtrlLayout C;
 };
-SortLayout sort_layout(int64_t D) {
+SortLayout sort_layout(int64_t D, int passes) {
     SortLayout L;
     size_t o = 0;
     const size_t nd = align_up((size_t)(D + 1) * 4);
@@ -560,16 +677,19 @@ SortLayout sort_layout(int64_t D) {
     L.vA = o; o += nd;
     L.kB = o; o += nd;
     L.vB = o; o += nd;
-    L.temp = o; o += gsr_radix_temp_bytes(D);
+    L.ctrl = o;
+    L.C = ctrl_layout(D, passes, false);
+    o += L.C.total;
     L.total = o;
     return L;
 }
 }  // namespace
 
 extern "C" size_t gsr_bin_sort_bytes(int P, int64_t num_rendered, int width, int height) {
-    (void)P; (void)width; (void)height;
-    if (num_rendered < 0) return 0;
-    return sort_layout(num_rendered).total;
+    (void)P;
+    if (num_rendered < 0 || width <= 0 || height <= 0) return 0;
+    const int gx = (width + GSR_BLOCK_X - 1) / GSR_BLOCK_X, gy = (height + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y;
+    return sort_layout(num_rendered, radix_plan(0, tile_bits(gx * gy)).passes).total;
 }
 
 extern "C" int gsr_bin_sort(int P, int width, int height, const uint8_t *compute_locally, const void *prep,
@@ -581,7 +701,9 @@ extern "C" int gsr_bin_sort(int P, int width, int height, const uint8_t *compute
     GSR_HIP(hipMemsetAsync(ranges, 0, sizeof(int32_t) * 2 * (size_t)gx * gy, stream));
     if (D == 0 || P == 0) return 0;
     if (!compute_locally || !prep || !scratch || !point_list) return GSR_EINVAL;
-    const SortLayout S = sort_layout(D);
+    if (D > RADIX_MAX_N) return GSR_EINVAL;
+    const RadixPlan plan = radix_plan(0, tile_bits(gx * gy));
+    const SortLayout S = sort_layout(D, plan.passes);
     if (scratch_bytes < S.total) return GSR_ENOSPACE;
     const PrepLayout L = prep_layout(P, width, height);
     const char *pbase = reinterpret_cast<const char *>(prep);
@@ -591,17 +713,20 @@ extern "C" int gsr_bin_sort(int P, int width, int height, const uint8_t *compute
     char *sbase = reinterpret_cast<char *>(scratch);
     uint32_t *kA = reinterpret_cast<uint32_t *>(sbase + S.kA), *vA = reinterpret_cast<uint32_t *>(sbase + S.vA);
     uint32_t *kB = reinterpret_cast<uint32_t *>(sbase + S.kB), *vB = reinterpret_cast<uint32_t *>(sbase + S.vB);
-    void *temp = sbase + S.temp;
+    char *ctrl = sbase + S.ctrl;
 
+    GSR_HIP(hipMemsetAsync(ctrl, 0, S.C.total, stream));
     hipLaunchKernelGGL(emit_pairs_kernel, dim3(gsr_div_up(gsr_div_up(D, EMIT_CHUNK), 4)), dim3(256), 0, stream, P,
-                       (long long)D, gx, gx * gy, rects, compute_locally, sorted_ids, offsets, kA, vA);
+                       (long long)D, gx, gx * gy, rects, compute_locally, sorted_ids, offsets, plan, kA, vA,
+                       reinterpret_cast<uint32_t *>(ctrl + S.C.ghist));
     int in_first = 1;
     // the last pass writes the Gaussian indices straight into point_list
-    int rc = gsr_radix_sort_pairs(kA, vA, kB, vB, D, 0, tile_bits(gx * gy), temp, &in_first, stream, point_list);
+    int rc = radix_sort_pairs(kA, vA, kB, vB, D, plan, ctrl, S.C, &in_first, stream, point_list);
     if (rc) return rc;
     const uint32_t *ks = in_first ? kA : kB;
-    hipLaunchKernelGGL(tile_ranges_kernel, dim3(gsr_div_up(D, GSR_ONE_DIM_BLOCK)), dim3(GSR_ONE_DIM_BLOCK), 0, stream,
-                       (long long)D, (uint32_t)(gx * gy), ks, reinterpret_cast<int2 *>(ranges));
+    hipLaunchKernelGGL(tile_ranges_kernel, dim3(gsr_div_up(gsr_div_up(D, 4), GSR_ONE_DIM_BLOCK)),
+                       dim3(GSR_ONE_DIM_BLOCK), 0, stream, (long long)D, (uint32_t)(gx * gy), ks,
+                       reinterpret_cast<int2 *>(ranges));
     GSR_LAUNCH_CHECK();
     return 0;
 }

@@ -96,15 +96,6 @@ int gsr_launch_preprocess_backward(int P, int D, int M, const float *means3D, co
 int gsr_launch_local2j(int P, int W, int H, int ws, const float *means2D, const int32_t *radii, const int32_t *div,
                        uint8_t *out, hipStream_t stream);
 
-// device-wide primitives (binning.hip)
-size_t gsr_scan_temp_bytes(long long n);
-int gsr_exclusive_scan_u32(const uint32_t *in, uint32_t *out, long long n, void *temp, hipStream_t stream);
-size_t gsr_radix_temp_bytes(long long n);
-// stable LSD radix sort of (key,value) u32 pairs on key bits [bit_lo, bit_hi); ping-pongs between
-// (k0,v0) and (k1,v1); *result_in_first tells where the sorted data ended up.
-int gsr_radix_sort_pairs(uint32_t *k0, uint32_t *v0, uint32_t *k1, uint32_t *v1, long long n, int bit_lo, int bit_hi,
-                         void *temp, int *result_in_first, hipStream_t stream, uint32_t *final_vals);
-
 int gsr_launch_composite_forward(int P, int W, int H, const int32_t *ranges, const uint32_t *point_list,
                                  const float *means2D, const float *conic_opacity, const float *rgb,
                                  const uint8_t *compute_locally, const float *bg, float *out_color, float *final_T,

@@ -1,0 +1,85 @@
+"""Time K3-K7 (gsr_bin_prepare + gsr_bin_sort) alone on the bench scene, for one or more library builds.
+Usage (GPU box): python tools/binbench.py [--lib variants/libgsraster_X.so ...] [--iters K] [--view V]
+Ablation builds may produce wrong lists; nothing downstream consumes them here."""
+import argparse
+import ctypes
+import math
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "grendel-gs_amd"), ROOT):
+    sys.path.insert(0, p)
+import torch  # noqa: E402
+
+import diff_gaussian_rasterization as dgr  # noqa: E402
+import synthetic_scene as S  # noqa: E402
+from diff_gaussian_rasterization import _lib  # noqa: E402
+
+
+def load(path):
+    lib = ctypes.CDLL(path)
+    for name in ("gsr_bin_prepare_bytes", "gsr_bin_prepare", "gsr_bin_sort_bytes", "gsr_bin_sort"):
+        res, args = _lib.SIGNATURES[name]
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--lib", action="append", default=[])
+    ap.add_argument("--gaussians", type=int, default=1_000_000)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--view", type=int, default=0)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    W, H = a.width, a.height
+    g = S.make_gaussians(a.gaussians, W, H, seed=0, device=dev)
+    cam = S.orbit_cameras(8, W, H, device=dev)[a.view]
+    rs = dgr.GaussianRasterizationSettings(H, W, math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2),
+                                           torch.zeros(3, device=dev), 1.0, cam.world_view_transform,
+                                           cam.full_proj_transform, 3, cam.camera_center, False, False)
+    with torch.no_grad():
+        m2, rgb, co, radii, depths = dgr.GaussianRasterizer(rs).preprocess_gaussians(
+            g["means3D"], g["scales"], g["rotations"], g["shs"], g["opacities"], {})
+    P = m2.shape[0]
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    mask = torch.ones(gy, gx, dtype=torch.bool, device=dev)
+    ptr = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    libs = [("production", _lib.LIB_PATH)] + [(os.path.basename(p), p) for p in a.lib]
+    for name, path in libs:
+        lib = load(path)
+        ranges = torch.empty((gx * gy, 2), dtype=torch.int32, device=dev)
+        nb = lib.gsr_bin_prepare_bytes(P, W, H)
+        prep = torch.empty(nb, dtype=torch.uint8, device=dev)
+        D = ctypes.c_int64(0)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        t_prep = t_sort = 0.0
+        for it in range(a.iters + 3):
+            ev[0].record()
+            rc = lib.gsr_bin_prepare(P, W, H, ptr(m2), ptr(depths), ptr(radii), ptr(co), ptr(mask), ptr(prep), nb,
+                                     ctypes.byref(D), stream)
+            assert rc == 0, rc
+            ev[1].record()
+            sb = lib.gsr_bin_sort_bytes(P, D.value, W, H)
+            if it == 0:
+                scratch = torch.empty(sb, dtype=torch.uint8, device=dev)
+                plist = torch.empty(D.value, dtype=torch.int32, device=dev)
+            rc = lib.gsr_bin_sort(P, W, H, ptr(mask), ptr(prep), D.value, ptr(scratch), sb, ptr(plist), ptr(ranges),
+                                  stream)
+            assert rc == 0, rc
+            ev[2].record()
+            torch.cuda.synchronize()
+            if it >= 3:
+                t_prep += ev[0].elapsed_time(ev[1])
+                t_sort += ev[1].elapsed_time(ev[2])
+        print(f"{name:40s} D={D.value:9d} prepare {t_prep / a.iters * 1e3:7.1f} us   sort {t_sort / a.iters * 1e3:7.1f} us"
+              f"   total {(t_prep + t_sort) / a.iters * 1e3:7.1f} us", flush=True)
+
+
+if __name__ == "__main__":
+    main()
