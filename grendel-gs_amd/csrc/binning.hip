@@ -24,6 +24,8 @@
 // LDS per-wave digit tables, LDS digit-ordered staging for coalesced stores.
 #include "common.h"
 
+#include <mutex>
+
 namespace {
 
 constexpr int SCAN_THREADS = 256;
@@ -35,6 +37,7 @@ constexpr int RADIX_WAVES = RADIX_THREADS / GSR_WAVE;
 constexpr int RADIX_DIGITS = 256;
 static_assert(GSR_ONE_DIM_BLOCK == RADIX_DIGITS, "histogram tables are initialised one digit per thread");
 constexpr int RADIX_MAX_PASSES = 4;
+constexpr int RADIX_REPLICAS = 8;  // histogram replicas, one per XCD
 constexpr int RADIX_ITEMS = 16;  // 4096 pairs per workgroup (measured best of 8/12/16/24/32 at 1e6..1.4e7 pairs)
 constexpr long long RADIX_MAX_N = (1ll << 30) - 1;  // counts share a word with two flag bits
 
@@ -132,7 +135,12 @@ __device__ __forceinline__ void multihist_flush(uint32_t (*mh)[RADIX_DIGITS], co
     for (int p = 0; p < pl.passes; p++)
         for (int d = threadIdx.x; d < (1 << pl.nbits[p]); d += blockDim.x) {
             const uint32_t c = mh[p][d];
-            if (c) atomicAdd(&ghist[p * RADIX_DIGITS + d], c);
+            // one histogram replica per XCD: the adds stay in that XCD's L2 (workgroup scope, no memory-side
+            // atomic); replicas become visible to the consuming kernels at the kernel boundary
+            const uint32_t xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u;  // HW_REG_XCC_ID[3:0]
+            if (c)
+                __hip_atomic_fetch_add(&ghist[(xcc * RADIX_MAX_PASSES + p) * RADIX_DIGITS + d], c, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
         }
 }
 
@@ -204,7 +212,10 @@ radix_onesweep_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__re
         if (live) st_agent(&row[d], tot | (bid == 0 ? LB_PRE : LB_AGG));
         uint32_t all;
         uint32_t run = block_exclusive_scan(tot, scan_tmp, &all);                         // local start of digit d
-        const uint32_t dstart = block_exclusive_scan(live ? ghist[d] : 0u, scan_tmp, &all);  // global start
+        uint32_t gh = 0;  // pass histogram = sum of the per-XCD replicas
+        if (live)
+            for (int x = 0; x < RADIX_REPLICAS; x++) gh += ghist[(size_t)x * RADIX_MAX_PASSES * RADIX_DIGITS + d];
+        const uint32_t dstart = block_exclusive_scan(gh, scan_tmp, &all);  // global start
         uint32_t excl = 0;
         if (live && bid > 0) {
             long long j = (long long)bid - 1;
@@ -277,7 +288,7 @@ radix_onesweep_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__re
 __global__ void __launch_bounds__(SCAN_THREADS)
 scan_gather_lookback_kernel(const uint32_t *__restrict__ src, const uint32_t *__restrict__ idx,
                             uint32_t *__restrict__ out, long long n, unsigned long long *__restrict__ state,
-                            uint32_t *__restrict__ ticket, int nb) {
+                            uint32_t *__restrict__ ticket, int nb, uint32_t *__restrict__ host_total) {
     __shared__ uint32_t smem[4];
     __shared__ uint32_t s_bid;
     __shared__ unsigned long long s_excl;
@@ -325,7 +336,10 @@ scan_gather_lookback_kernel(const uint32_t *__restrict__ src, const uint32_t *__
         if (lane == 0) {
             if (bid > 0) st_agent64(&state[bid], (excl + tot) | LB64_PRE);
             s_excl = excl;
-            if ((int)bid == nb - 1) out[n] = (uint32_t)(excl + tot);
+            if ((int)bid == nb - 1) {
+                out[n] = (uint32_t)(excl + tot);
+                *host_total = (uint32_t)(excl + tot);  // pinned host word: no copy command after the kernel
+            }
         }
     }
     __syncthreads();
@@ -541,7 +555,7 @@ struct CtrlLayout {
 CtrlLayout ctrl_layout(long long n, int passes, bool with_scan) {
     CtrlLayout C;
     size_t o = 0;
-    C.ghist = o; o += sizeof(uint32_t) * RADIX_MAX_PASSES * RADIX_DIGITS;
+    C.ghist = o; o += sizeof(uint32_t) * RADIX_REPLICAS * RADIX_MAX_PASSES * RADIX_DIGITS;
     C.tickets = o; o += 256;
     C.scan_state = o;
     if (with_scan) o += align_up(sizeof(unsigned long long) * (size_t)((n + SCAN_TILE - 1) / SCAN_TILE + 1));
@@ -600,6 +614,23 @@ PrepLayout prep_layout(int P, int W, int H) {
     L.total = o;
     return L;
 }
+// One pinned, device-mapped word per device: K4's last workgroup stores the pair count there, the host reads
+// it after the stream synchronise (no D2H copy command, no pageable staging).  The mutex is held from the
+// launch to the read, so concurrent callers on one device take turns.
+std::mutex g_total_mutex;
+uint32_t *g_total_word[64] = {};
+int total_word(uint32_t **host) {
+    int dev = 0;
+    GSR_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return GSR_EINVAL;
+    if (!g_total_word[dev]) {
+        void *p = nullptr;
+        GSR_HIP(hipHostMalloc(&p, 256, hipHostMallocDefault));
+        g_total_word[dev] = reinterpret_cast<uint32_t *>(p);
+    }
+    *host = g_total_word[dev];
+    return 0;
+}
 int tile_bits(int tiles) {  // bits of the largest key value, the sentinel `tiles`
     int b = 1;
     while ((1ll << b) <= tiles) b++;
@@ -636,7 +667,7 @@ extern "C" int gsr_bin_prepare(int P, int width, int height, const float *means2
 
     GSR_HIP(hipMemsetAsync(ctrl, 0, L.C.total, stream));
     const RadixPlan plan = radix_plan(0, 32);
-    // persistent workgroups: every workgroup flushes ~800 histogram atomics, 512 of them is the measured optimum
+    // persistent workgroups (mask hull + LDS tables are per-workgroup set-up): 512 is the measured optimum
     const int blocks = gsr_div_up(P, GSR_ONE_DIM_BLOCK) < 512 ? gsr_div_up(P, GSR_ONE_DIM_BLOCK) : 512;
     hipLaunchKernelGGL(touch_count_kernel, dim3(blocks), dim3(GSR_ONE_DIM_BLOCK), 0, stream, P, gx, gy,
                        reinterpret_cast<const float2 *>(means2D), depths, radii,
@@ -653,13 +684,16 @@ extern "C" int gsr_bin_prepare(int P, int width, int height, const float *means2
         sorted_ids = vA;
     }
     const int nbs = gsr_div_up(P, SCAN_TILE);
+    std::lock_guard<std::mutex> guard(g_total_mutex);
+    uint32_t *host_total = nullptr;
+    rc = total_word(&host_total);
+    if (rc) return rc;
     hipLaunchKernelGGL(scan_gather_lookback_kernel, dim3(nbs), dim3(SCAN_THREADS), 0, stream, tt, sorted_ids, offsets,
                        (long long)P, reinterpret_cast<unsigned long long *>(ctrl + L.C.scan_state),
-                       reinterpret_cast<uint32_t *>(ctrl + L.C.tickets), nbs);
+                       reinterpret_cast<uint32_t *>(ctrl + L.C.tickets), nbs, host_total);
     GSR_LAUNCH_CHECK();
-    uint32_t total = 0;
-    GSR_HIP(hipMemcpyAsync(&total, offsets + P, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     GSR_HIP(hipStreamSynchronize(stream));
+    const uint32_t total = *reinterpret_cast<volatile uint32_t *>(host_total);
     *num_rendered_host = (int64_t)total;
     return 0;
 }
