@@ -1,0 +1,321 @@
+// radix.h -- the one-sweep LSD radix sort of (key,value) u32 pairs shared by binning.hip (depth / tile sorts)
+// and knn.hip (Morton sort).  Include inside the translation unit; everything lives in an anonymous namespace.
+//
+// The digit histograms of ALL passes are accumulated by the kernel that produces the keys (multihist_add /
+// multihist_flush, one replica per XCD so that the adds are L2-local atomics); each pass is then one kernel
+// that gets its workgroup's global digit offsets by decoupled look-back.  Workgroups take their tile from
+// a ticket counter, so a workgroup only ever waits for workgroups that are already running.
+#pragma once
+#include "common.h"
+
+namespace {
+
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;  // 2048 elements per workgroup
+
+constexpr int RADIX_THREADS = 256;
+constexpr int RADIX_WAVES = RADIX_THREADS / GSR_WAVE;
+constexpr int RADIX_DIGITS = 256;
+static_assert(GSR_ONE_DIM_BLOCK == RADIX_DIGITS, "histogram tables are initialised one digit per thread");
+constexpr int RADIX_MAX_PASSES = 4;
+constexpr int RADIX_REPLICAS = 8;  // histogram replicas, one per XCD
+constexpr int RADIX_ITEMS = 16;  // 4096 pairs per workgroup (measured best of 8/12/16/24/32 at 1e6..1.4e7 pairs)
+constexpr long long RADIX_MAX_N = (1ll << 30) - 1;  // counts share a word with two flag bits
+
+// look-back state word: [31] inclusive prefix available, [30] workgroup aggregate available, [29:0] value
+constexpr uint32_t LB_PRE = 0x80000000u, LB_AGG = 0x40000000u, LB_VAL = 0x3FFFFFFFu;
+constexpr int LB_WINDOW = 4;  // independent state loads in flight per thread (look-back is short in practice)
+// 64-bit variant for the offsets scan (values up to 2^32)
+constexpr unsigned long long LB64_PRE = 2ull << 62, LB64_AGG = 1ull << 62, LB64_VAL = (1ull << 62) - 1ull;
+
+struct RadixPlan {
+    int passes;
+    int shift[RADIX_MAX_PASSES];
+    int nbits[RADIX_MAX_PASSES];
+};
+
+// split key bits [bit_lo, bit_hi) evenly over the minimum number of <= 8-bit passes (13 tile bits -> 7 + 6)
+RadixPlan radix_plan(int bit_lo, int bit_hi) {
+    RadixPlan pl{};
+    const int total = bit_hi - bit_lo;
+    pl.passes = (total + 7) / 8;
+    int shift = bit_lo;
+    for (int p = 0; p < pl.passes; p++) {
+        const int nb = (total - (shift - bit_lo) + (pl.passes - p) - 1) / (pl.passes - p);
+        pl.shift[p] = shift;
+        pl.nbits[p] = nb;
+        shift += nb;
+    }
+    return pl;
+}
+
+__device__ __forceinline__ uint32_t ld_agent(const uint32_t *p) {
+    return __hip_atomic_load(const_cast<uint32_t *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(uint32_t *p, uint32_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long ld_agent64(const unsigned long long *p) {
+    return __hip_atomic_load(const_cast<unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent64(unsigned long long *p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+// exclusive scan of one value per thread across a 256-thread workgroup; returns the exclusive
+// prefix, *total = workgroup sum.  `smem` holds >= 4 words.
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *smem, uint32_t *total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t inc = wave_inclusive_scan(v);
+    if (lane == 63) smem[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < SCAN_THREADS / 64; w++) {
+        const uint32_t s = smem[w];
+        if (w < wave) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+// ------------------------------------------------------------- digit histograms of all passes at once
+// Called by the kernels that produce sort keys.  mh = LDS [passes][256]; one call per key per thread.
+// When every valid lane of the wave holds the same digit (top depth bytes, upper tile bits of one
+// splat) a single lane adds the population count instead of 64 serialised same-address LDS atomics.
+__device__ __forceinline__ void multihist_add(uint32_t (*mh)[RADIX_DIGITS], const RadixPlan &pl, uint32_t key,
+                                              bool valid) {
+    const unsigned long long vm = __ballot(valid);
+    if (vm == 0ull) return;
+    const int src = __ffsll((long long)vm) - 1;
+    const int lane = threadIdx.x & 63;
+    for (int p = 0; p < pl.passes; p++) {
+        const uint32_t d = (key >> pl.shift[p]) & ((1u << pl.nbits[p]) - 1u);
+        const uint32_t d0 = __shfl(d, src, 64);
+        if (__ballot(valid && d != d0) == 0ull) {
+            if (lane == src) atomicAdd(&mh[p][d0], (uint32_t)__popcll(vm));
+        } else if (valid) {
+            atomicAdd(&mh[p][d], 1u);
+        }
+    }
+}
+__device__ __forceinline__ void multihist_flush(uint32_t (*mh)[RADIX_DIGITS], const RadixPlan &pl,
+                                                uint32_t *__restrict__ ghist) {
+    for (int p = 0; p < pl.passes; p++)
+        for (int d = threadIdx.x; d < (1 << pl.nbits[p]); d += blockDim.x) {
+            const uint32_t c = mh[p][d];
+            // one histogram replica per XCD: the adds stay in that XCD's L2 (workgroup scope, no memory-side
+            // atomic); replicas become visible to the consuming kernels at the kernel boundary
+            const uint32_t xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u;  // HW_REG_XCC_ID[3:0]
+            if (c)
+                __hip_atomic_fetch_add(&ghist[(xcc * RADIX_MAX_PASSES + p) * RADIX_DIGITS + d], c, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+}
+
+// lanes holding the same digit (restricted to `valid` lanes)
+__device__ __forceinline__ unsigned long long match_digit(uint32_t d, bool valid, int nbits) {
+    unsigned long long m = __ballot(valid);
+    for (int b = 0; b < nbits; b++) {
+        const bool bit = (d >> b) & 1;
+        const unsigned long long bm = __ballot(bit);
+        m &= bit ? bm : ~bm;
+    }
+    return m;
+}
+
+// ------------------------------------------------------------------------- one radix pass, one kernel
+// Workgroup `bid` (ticket order) owns ITEMS*256 consecutive pairs.
+//   1. per-wave LDS digit counts -> workgroup count per digit, published as AGGREGATE in state[bid][d];
+//   2. thread d looks back over state[bid-1 .. ][d] (LB_WINDOW independent loads in flight), adding
+//      aggregates until it meets an inclusive PREFIX, then publishes its own inclusive prefix;
+//   3. global start of digit d = exclusive scan of the pass histogram (256 values, done by every
+//      workgroup) + look-back sum; stable ranks from wave64 ballots + per-wave LDS cursors; the pairs
+//      are placed in digit order INSIDE LDS and streamed out so that every digit's run leaves the
+//      workgroup as contiguous, coalesced stores.
+template <int ITEMS>
+__global__ void __launch_bounds__(RADIX_THREADS)
+radix_onesweep_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+                      uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, long long n, int shift,
+                      int nbits, const uint32_t *__restrict__ ghist, uint32_t *__restrict__ state,
+                      uint32_t *__restrict__ ticket) {
+    constexpr int TILE = ITEMS * RADIX_THREADS;
+    __shared__ uint32_t wtab[RADIX_WAVES][RADIX_DIGITS];
+    __shared__ uint32_t gbase[RADIX_DIGITS];  // global start of the digit's run minus its local start
+    __shared__ uint32_t skey[TILE], sval[TILE];
+    __shared__ uint32_t scan_tmp[4];
+    __shared__ uint32_t s_bid;
+    const uint32_t mask = (1u << nbits) - 1u;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_bid = atomicAdd(ticket, 1u);
+#pragma unroll
+    for (int w = 0; w < RADIX_WAVES; w++) wtab[w][threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t bid = s_bid;
+    // wave w owns the contiguous sub-chunk [base + w*ITEMS*64, +ITEMS*64), walked in ITEMS rounds of 64
+    const long long bbase = (long long)bid * TILE;
+    const long long wbase = bbase + (long long)wave * (ITEMS * 64);
+    uint32_t key[ITEMS], val[ITEMS];
+#pragma unroll
+    for (int r = 0; r < ITEMS; r++) {
+        const long long j = wbase + r * 64 + lane;
+        key[r] = j < n ? keys_in[j] : 0xFFFFFFFFu;
+        val[r] = j < n ? vals_in[j] : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < ITEMS; r++) {
+        const long long j = wbase + r * 64 + lane;
+        if (j < n) atomicAdd(&wtab[wave][(key[r] >> shift) & mask], 1u);
+    }
+    __syncthreads();
+    {  // thread d: digit d
+        const uint32_t d = threadIdx.x;
+        const bool live = d <= mask;
+        uint32_t cnt[RADIX_WAVES], tot = 0;
+#pragma unroll
+        for (int w = 0; w < RADIX_WAVES; w++) {
+            cnt[w] = wtab[w][d];
+            tot += cnt[w];
+        }
+        uint32_t *row = state + (size_t)bid * RADIX_DIGITS;
+        if (live) st_agent(&row[d], tot | (bid == 0 ? LB_PRE : LB_AGG));
+        uint32_t all;
+        uint32_t run = block_exclusive_scan(tot, scan_tmp, &all);                         // local start of digit d
+        uint32_t gh = 0;  // pass histogram = sum of the per-XCD replicas
+        if (live)
+            for (int x = 0; x < RADIX_REPLICAS; x++) gh += ghist[(size_t)x * RADIX_MAX_PASSES * RADIX_DIGITS + d];
+        const uint32_t dstart = block_exclusive_scan(gh, scan_tmp, &all);  // global start
+        uint32_t excl = 0;
+        if (live && bid > 0) {
+            long long j = (long long)bid - 1;
+            bool done = false;
+            while (!done) {
+                uint32_t v[LB_WINDOW];
+#pragma unroll
+                for (int k = 0; k < LB_WINDOW; k++)
+                    v[k] = (j - k >= 0) ? ld_agent(&state[(size_t)(j - k) * RADIX_DIGITS + d]) : LB_PRE;
+#pragma unroll
+                for (int k = 0; k < LB_WINDOW; k++) {
+                    if (!done) {
+                        uint32_t x = v[k];
+                        while ((x & (LB_PRE | LB_AGG)) == 0u) {
+                            __builtin_amdgcn_s_sleep(1);
+                            x = ld_agent(&state[(size_t)(j - k) * RADIX_DIGITS + d]);
+                        }
+                        excl += x & LB_VAL;
+                        done = (x & LB_PRE) != 0u;
+                    }
+                }
+                j -= LB_WINDOW;
+            }
+            st_agent(&row[d], ((excl + tot) & LB_VAL) | LB_PRE);
+        }
+        gbase[d] = dstart + excl - run;
+#pragma unroll
+        for (int w = 0; w < RADIX_WAVES; w++) {
+            wtab[w][d] = run;
+            run += cnt[w];
+        }
+    }
+    __syncthreads();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int r = 0; r < ITEMS; r++) {
+        const long long j = wbase + r * 64 + lane;
+        const bool valid = j < n;
+        const uint32_t d = (key[r] >> shift) & mask;
+        const unsigned long long m = match_digit(d, valid, nbits);
+        const uint32_t rank = __popcll(m & lt);
+        volatile uint32_t *cursor = wtab[wave];
+        uint32_t pos = 0;
+        if (valid) pos = cursor[d] + rank;
+        __builtin_amdgcn_wave_barrier();
+        if (valid && rank == 0) cursor[d] = pos + (uint32_t)__popcll(m);  // group leader advances the cursor
+        __builtin_amdgcn_wave_barrier();
+        if (valid) {
+            skey[pos] = key[r];
+            sval[pos] = val[r];
+        }
+    }
+    __syncthreads();
+    const long long rem = n - bbase;
+    const int count = rem < TILE ? (int)rem : TILE;
+#pragma unroll
+    for (int r = 0; r < ITEMS; r++) {
+        const int i = r * RADIX_THREADS + threadIdx.x;
+        if (i < count) {
+            const uint32_t k = skey[i];
+            const uint32_t dst = gbase[(k >> shift) & mask] + (uint32_t)i;
+            keys_out[dst] = k;
+            vals_out[dst] = sval[i];
+        }
+    }
+}
+
+
+inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+inline long long radix_blocks(long long n) {
+    const long long tile = (long long)RADIX_ITEMS * RADIX_THREADS;
+    return (n + tile - 1) / tile;
+}
+
+// control block of one sort (zeroed by ONE memset before the producer kernel runs):
+//   ghist[4][256] | tickets[8] | scan_state u64[scan_blocks] | radix state u32[passes][blocks][256]
+struct CtrlLayout {
+    size_t ghist, tickets, scan_state, radix_state, total;
+};
+CtrlLayout ctrl_layout(long long n, int passes, bool with_scan) {
+    CtrlLayout C;
+    size_t o = 0;
+    C.ghist = o; o += sizeof(uint32_t) * RADIX_REPLICAS * RADIX_MAX_PASSES * RADIX_DIGITS;
+    C.tickets = o; o += 256;
+    C.scan_state = o;
+    if (with_scan) o += align_up(sizeof(unsigned long long) * (size_t)((n + SCAN_TILE - 1) / SCAN_TILE + 1));
+    C.radix_state = o;
+    o += align_up(sizeof(uint32_t) * (size_t)passes * (size_t)(radix_blocks(n) + 1) * RADIX_DIGITS);
+    C.total = o;
+    return C;
+}
+
+// stable LSD radix sort of (key,value) u32 pairs following `plan`; the pass histograms in ctrl->ghist were
+// accumulated by the producer of the keys.  Ping-pongs between (k0,v0) and (k1,v1); *result_in_first tells
+// where the sorted keys ended up; the last pass writes the values to final_vals when given.
+int radix_sort_pairs(uint32_t *k0, uint32_t *v0, uint32_t *k1, uint32_t *v1, long long n, const RadixPlan &plan,
+                     char *ctrl, const CtrlLayout &C, int *result_in_first, hipStream_t stream,
+                     uint32_t *final_vals) {
+    *result_in_first = 1;
+    if (n <= 0) return 0;
+    if (n > RADIX_MAX_N) return GSR_EINVAL;
+    const int nb = (int)radix_blocks(n);
+    uint32_t *ghist = reinterpret_cast<uint32_t *>(ctrl + C.ghist);
+    uint32_t *tickets = reinterpret_cast<uint32_t *>(ctrl + C.tickets);
+    uint32_t *state = reinterpret_cast<uint32_t *>(ctrl + C.radix_state);
+    uint32_t *ki = k0, *vi = v0, *ko = k1, *vo = v1;
+    for (int p = 0; p < plan.passes; p++) {
+        uint32_t *vdst = (p == plan.passes - 1 && final_vals) ? final_vals : vo;  // last pass can land the values
+        hipLaunchKernelGGL(radix_onesweep_kernel<RADIX_ITEMS>, dim3(nb), dim3(RADIX_THREADS), 0, stream, ki, vi, ko,
+                           vdst, n, plan.shift[p], plan.nbits[p], ghist + p * RADIX_DIGITS,
+                           state + (size_t)p * nb * RADIX_DIGITS, tickets + 1 + p);
+        uint32_t *t = ki; ki = ko; ko = t;
+        t = vi; vi = vo; vo = t;
+        *result_in_first ^= 1;
+    }
+    GSR_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace

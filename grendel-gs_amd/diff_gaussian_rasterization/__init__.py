@@ -26,7 +26,7 @@ from ._lib import check, lib
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "_C", "load_image_tiles_by_pos",
            "merge_image_tiles_by_pos", "set_timing_mode", "fused_l1_ssim_band", "fused_activations", "pack_camera",
-           "preprocess_gaussians_raw_batched"]
+           "preprocess_gaussians_raw_batched", "knn_mean_dist2"]
 
 BLOCK_X, BLOCK_Y, ONE_DIM_BLOCK_SIZE = 16, 16, 256
 
@@ -610,6 +610,23 @@ def fused_activations(scaling, rotation, opacity, features_dc, features_rest):
     """(scales, rotations, opacities, shs) = (exp, normalize, sigmoid, cat) of the raw parameters in one
     kernel each way -- GaussianModel.get_scaling/get_rotation/get_opacity/get_features"""
     return _FusedActivations.apply(scaling, rotation, opacity, features_dc, features_rest)
+
+
+def knn_mean_dist2(points):
+    """mean squared distance of every point to its 3 nearest other points -- what the reference obtains from
+    `simple_knn._C.distCUDA2` at scene creation (scene/gaussian_model.py:163-166).  points: fp32 [P,3] on the
+    device; returns fp32 [P]."""
+    pts = _f32c(points.detach(), "points")
+    if pts.dim() != 2 or pts.shape[1] != 3:
+        raise ValueError("points must be [P,3]")
+    P = pts.shape[0]
+    out = torch.empty(P, dtype=torch.float32, device=pts.device)
+    if P == 0:
+        return out
+    nbytes = lib.gsr_knn_workspace_bytes(P)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=pts.device)
+    check(lib.gsr_knn_mean_dist2(P, _ptr(pts), _ptr(out), _ptr(ws), nbytes, _stream()), "gsr_knn_mean_dist2")
+    return out
 
 
 # ------------------------------------------------------------------------------------------ _C

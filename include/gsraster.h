@@ -158,6 +158,17 @@ int gsr_adam_step(int64_t n, float *param, const float *grad, float *exp_avg, fl
                   double beta1, double beta2, double eps, int64_t step, float grad_scale, gsr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * N4  `simple_knn._C.distCUDA2(points)` (scene/gaussian_model.py:20,163-166; submodule
+ * https://gitlab.inria.fr/bkerbl/simple-knn, .gitmodules:1-3, absent from the reference tree):
+ * mean_dist2[i] = mean of the squared distances from point i to its 3 nearest OTHER points (only i itself is
+ * excluded, by index; coincident points count with distance 0).  Exact (Morton order + bounded boxes only
+ * prune the search).  With fewer than 4 points the mean runs over the neighbours that exist (0 for one point).
+ * points: fp32 [P,3]; workspace: gsr_knn_workspace_bytes(P) bytes of device memory, any content. */
+size_t gsr_knn_workspace_bytes(int P);
+int gsr_knn_mean_dist2(int P, const float *points, float *mean_dist2, void *workspace, size_t workspace_bytes,
+                       gsr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * K1 / K11 on the RAW parameters of GaussianModel (scene/gaussian_model.py:219-242): `scaling` log-scales
  * [P,3], `rotation` un-normalised quaternions [P,4], `opacity` logits [P,1], `features_dc` [P,1,3],
  * `features_rest` [P,sh_coeffs-1,3].  The getters' activations (scene/gaussian_model.py:109-129: exp,

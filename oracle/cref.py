@@ -17,7 +17,7 @@ _lib = None
 def build(force=False):
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(_SRC):
         subprocess.check_call(
-            ["gcc", "-O2", "-fopenmp", "-shared", "-fPIC", "-o", _SO, _SRC, "-lm"]
+            ["gcc", "-O2", "-ffp-contract=off", "-fopenmp", "-shared", "-fPIC", "-o", _SO, _SRC, "-lm"]
         )
     return _SO
 
@@ -143,3 +143,11 @@ def render_backward(means2D, conic_opacity, rgb, compute_locally, bg, W, H, poin
                                 _p(col), _p(cl), _p(bgf), _p(final_T.contiguous()), _p(n_contrib.contiguous()), _p(g),
                                 _p(d2), _p(dco), _p(drgb))
     return d2, dco, drgb
+
+
+def knn_mean_dist2(points):
+    """brute-force restatement of simple_knn._C.distCUDA2 (scene/gaussian_model.py:163-166 of the reference)"""
+    pts = _f32(points)
+    out = torch.empty(pts.shape[0], dtype=torch.float32)
+    lib().gsref_knn_mean_dist2(ctypes.c_int(pts.shape[0]), _p(pts), _p(out))
+    return out

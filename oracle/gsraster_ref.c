@@ -25,6 +25,7 @@
  * pixels are accumulated in double (the reference uses float atomics in arbitrary order,
  * so no summation order is canonical) and rounded once.
  */
+#include <float.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -608,6 +609,34 @@ void gsref_render_backward(int P, int W, int H, const int32_t *ranges, const uin
         dL_drgb[3 * i + 2] = (float)a[8];
     }
     free(acc);
+}
+
+/* ---- N4: simple_knn distCUDA2 -- exact brute force (the submodule is absent from the reference tree; its
+ * published algorithm only PRUNES an exact 3-NN search, so brute force is its arithmetic restatement).
+ * mean of the squared distances to the 3 nearest other points; only the point itself (by index) is excluded.
+ * Same degenerate-size convention as include/gsraster.h (fewer than 3 neighbours: mean of what exists). */
+void gsref_knn_mean_dist2(int P, const float *pts, float *out) {
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int i = 0; i < P; i++) {
+        float b0 = FLT_MAX, b1 = FLT_MAX, b2 = FLT_MAX;
+        const float px = pts[3 * i], py = pts[3 * i + 1], pz = pts[3 * i + 2];
+        for (int k = 0; k < P; k++) {
+            if (k == i) continue;
+            const float dx = pts[3 * k] - px, dy = pts[3 * k + 1] - py, dz = pts[3 * k + 2] - pz;
+            const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+            float d = (xx + yy) + zz;
+            if (!(d == d)) continue;
+            if (d < b0) { b2 = b1; b1 = b0; b0 = d; }
+            else if (d < b1) { b2 = b1; b1 = d; }
+            else if (d < b2) { b2 = d; }
+        }
+        float s = 0.f;
+        int n = 0;
+        if (b0 < FLT_MAX) { s += b0; n++; }
+        if (b1 < FLT_MAX) { s += b1; n++; }
+        if (b2 < FLT_MAX) { s += b2; n++; }
+        out[i] = n == 3 ? s / 3.0f : (n ? s / (float)n : 0.f);
+    }
 }
 
 int gsref_num_threads(void) {

@@ -65,10 +65,28 @@ def test_plyfile_shim_roundtrip(tmp_path):
     assert list(a["x"]) == [1.5, -2.0] and list(a["red"]) == [3, 250]
 
 
-def test_distcuda2_shim_matches_bruteforce():
+def test_distcuda2_is_the_hip_operator_and_has_no_cpu_path():
+    """simple_knn._C.distCUDA2 resolves to the library's K-NN operator; host tensors are refused loudly"""
     knn = _graft_import("simple_knn._C")
-    pts = torch.rand(500, 3, generator=torch.Generator().manual_seed(0))
-    d = torch.cdist(pts.double(), pts.double()) ** 2
-    ref = torch.sort(d, dim=1).values[:, 1:4].mean(1)
-    out = knn.distCUDA2(pts)
-    assert torch.allclose(out.double(), ref, rtol=1e-3, atol=1e-7)
+    pts = torch.rand(50, 3, generator=torch.Generator().manual_seed(0))
+    with pytest.raises(RuntimeError, match="no CPU"):
+        knn.distCUDA2(pts)
+
+
+def test_knn_oracle_matches_kdtree():
+    """pin the brute-force restatement (oracle/gsraster_ref.c) against an independent exact k-NN"""
+    from scipy.spatial import cKDTree
+
+    from oracle import cref as C
+
+    g = torch.Generator().manual_seed(1)
+    pts = torch.cat([torch.rand(3000, 3, generator=g), 0.01 * torch.randn(2000, 3, generator=g) + 0.5,
+                     torch.rand(5, 3, generator=g).repeat(3, 1)])  # uniform + a dense cluster + exact duplicates
+    out = C.knn_mean_dist2(pts)
+    d, _ = cKDTree(pts.double().numpy()).query(pts.double().numpy(), k=4)
+    ref = (d[:, 1:] ** 2).mean(1)
+    assert np.allclose(out.double().numpy(), ref, rtol=2e-4, atol=1e-9)
+    # degenerate sizes: mean over the neighbours that exist
+    assert C.knn_mean_dist2(torch.zeros(1, 3)).tolist() == [0.0]
+    two = C.knn_mean_dist2(torch.tensor([[0.0, 0, 0], [1.0, 0, 0]]))
+    assert two.tolist() == [1.0, 1.0]
