@@ -1,0 +1,273 @@
+"""N4 -- densification / redistribution of the Gaussian shard on top of the row primitives of libgsraster.so.
+
+Host-side mirror of the GaussianModel methods the reference's densification step calls
+(densification.py:5-86 -> scene/gaussian_model.py): `prune_points` (:835-852, `_prune_optimizer` :793-818),
+`densification_postfix` / `cat_tensors_to_optimizer` (:854-921), `densify_and_clone` (:972-1005),
+`densify_and_split` (:922-970), `densify_and_prune` (:1007-1044) and `redistribute_gaussians` (:1264-1329).
+Same names, arguments, semantics and optimizer-state surgery; what changes is HOW rows are moved:
+
+* the reference evaluates `tensor[mask]` once per tensor (6 parameters + 12 Adam moments + 5 statistics; each a
+  `nonzero` host sync + an index kernel) and, for redistribution, once per tensor PER DESTINATION RANK followed
+  by 18 separate all-to-alls;
+* here the selection is computed once (`group_rows`, one radix pass, one host read-back) and applied to all
+  tensors in one launch (`gather_rows`); redistribution packs every per-Gaussian tensor into one record matrix
+  and issues ONE all-to-all-v over RCCL (the reference's disabled "implementation_2", :1206-1238).
+
+Every function takes the model as its first argument, so `install(GaussianModel)` makes them the methods of the
+reference's own class (graft level B3).  The model duck type: the six raw parameters `_xyz,
+_features_dc, _features_rest, _opacity, _scaling, _rotation`, `optimizer` (one group per parameter, named
+xyz / f_dc / f_rest / opacity / scaling / rotation), the statistics `xyz_gradient_accum, denom, max_radii2D,
+sum_visible_count_in_one_batch, send_to_gpui_cnt`, `percent_dense`, and the getters.
+There is no CPU fallback: the tensors live on the gfx950 device.
+"""
+import math
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+import diff_gaussian_rasterization as dgr
+import utils.general_utils as utils
+
+_ATTR = {"xyz": "_xyz", "f_dc": "_features_dc", "f_rest": "_features_rest", "opacity": "_opacity",
+         "scaling": "_scaling", "rotation": "_rotation"}
+_STATS = ["xyz_gradient_accum", "denom", "max_radii2D", "sum_visible_count_in_one_batch", "send_to_gpui_cnt"]
+
+
+def _log(msg):
+    f = utils.get_log_file() if hasattr(utils, "get_log_file") else None
+    if f is not None:
+        f.write(msg)
+
+
+def _optimizer_slots(self):
+    """[(group, key)] for every per-Gaussian tensor the optimizer holds; key None = the parameter itself"""
+    slots = []
+    for group in self.optimizer.param_groups:
+        assert len(group["params"]) == 1
+        st = self.optimizer.state.get(group["params"][0], None)
+        if st is not None:
+            for key in ("momentum_buffer", "exp_avg", "exp_avg_sq"):
+                if key in st:
+                    slots.append((group, key))
+        slots.append((group, None))
+    return slots
+
+
+def _slot_tensor(self, group, key):
+    p = group["params"][0]
+    return p.data if key is None else self.optimizer.state[p][key]
+
+
+def _replace_optimizer_rows(self, slots, new_tensors):
+    """the optimizer-state surgery of _prune_optimizer / cat_tensors_to_optimizer / update_all_optimizer_states
+    (scene/gaussian_model.py:793-818,854-893,1175-1204): new Parameter objects, state re-keyed"""
+    new = {(id(g), k): t for (g, k), t in zip(slots, new_tensors)}
+    out = {}
+    for group in self.optimizer.param_groups:
+        old = group["params"][0]
+        st = self.optimizer.state.get(old, None)
+        if st is not None:
+            for key in ("momentum_buffer", "exp_avg", "exp_avg_sq"):
+                if key in st:
+                    st[key] = new[(id(group), key)]
+            del self.optimizer.state[old]
+        group["params"][0] = nn.Parameter(new[(id(group), None)].requires_grad_(True))
+        if st is not None:
+            self.optimizer.state[group["params"][0]] = st
+        out[group["name"]] = group["params"][0]
+    for name, attr in _ATTR.items():
+        setattr(self, attr, out[name])
+    return out
+
+
+def _live_stats(self):
+    return [n for n in _STATS if getattr(self, n, None) is not None]
+
+
+# ----------------------------------------------------------------------------------------- prune
+def prune_points(self, mask):
+    """drop the rows where `mask` is True from the 6 parameters, their Adam moments and the statistics"""
+    dest = mask.to(torch.int32).neg()  # keep -> group 0, prune -> dropped
+    order, counts = dgr.group_rows(dest, 1)
+    n = counts[0]
+    slots = _optimizer_slots(self)
+    stats = _live_stats(self)
+    srcs = [_slot_tensor(self, g, k) for g, k in slots] + [getattr(self, s) for s in stats]
+    outs = dgr.gather_rows(order, n, srcs)
+    _replace_optimizer_rows(self, slots, outs[:len(slots)])
+    for s, t in zip(stats, outs[len(slots):]):
+        setattr(self, s, t)
+
+
+# ------------------------------------------------------------------------------------- densify
+def cat_tensors_to_optimizer(self, tensors_dict):
+    slots = _optimizer_slots(self)
+    new = []
+    for g, k in slots:
+        ext = tensors_dict[g["name"]]
+        cur = _slot_tensor(self, g, k)
+        new.append(torch.cat((cur, ext if k is None else torch.zeros_like(ext)), dim=0))
+    return _replace_optimizer_rows(self, slots, new)
+
+
+def densification_postfix(self, new_xyz, new_features_dc, new_features_rest, new_opacities, new_scaling,
+                          new_rotation, new_send_to_gpui_cnt):
+    cat_tensors_to_optimizer(self, {"xyz": new_xyz, "f_dc": new_features_dc, "f_rest": new_features_rest,
+                                    "opacity": new_opacities, "scaling": new_scaling, "rotation": new_rotation})
+    n, dev = self._xyz.shape[0], self._xyz.device
+    self.xyz_gradient_accum = torch.zeros((n, 1), device=dev)
+    self.denom = torch.zeros((n, 1), device=dev)
+    self.max_radii2D = torch.zeros((n,), device=dev)
+    self.sum_visible_count_in_one_batch = torch.zeros((n,), device=dev)
+    if getattr(self, "send_to_gpui_cnt", None) is not None:
+        self.send_to_gpui_cnt = torch.cat((self.send_to_gpui_cnt, new_send_to_gpui_cnt), dim=0)
+
+
+def _selected_rows(self, selected_pts_mask, names):
+    """rows of the named attributes where the mask is True: one grouping + one gather launch"""
+    order, counts = dgr.group_rows(selected_pts_mask.to(torch.int32) - 1, 1)  # True -> 0, False -> -1
+    srcs = [getattr(self, n).data if isinstance(getattr(self, n), nn.Parameter) else getattr(self, n) for n in names]
+    return counts[0], dgr.gather_rows(order, counts[0], srcs)
+
+
+def _build_rotation(r):
+    """utils/general_utils.py:416-439 of the reference"""
+    norm = torch.sqrt(r[:, 0] * r[:, 0] + r[:, 1] * r[:, 1] + r[:, 2] * r[:, 2] + r[:, 3] * r[:, 3])
+    q = r / norm[:, None]
+    R = torch.zeros((q.size(0), 3, 3), device=r.device)
+    w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R[:, 0, 0] = 1 - 2 * (y * y + z * z)
+    R[:, 0, 1] = 2 * (x * y - w * z)
+    R[:, 0, 2] = 2 * (x * z + w * y)
+    R[:, 1, 0] = 2 * (x * y + w * z)
+    R[:, 1, 1] = 1 - 2 * (x * x + z * z)
+    R[:, 1, 2] = 2 * (y * z - w * x)
+    R[:, 2, 0] = 2 * (x * z - w * y)
+    R[:, 2, 1] = 2 * (y * z + w * x)
+    R[:, 2, 2] = 1 - 2 * (x * x + y * y)
+    return R
+
+
+def densify_and_clone(self, grads, grad_threshold, scene_extent):
+    sel = torch.norm(grads, dim=-1) >= grad_threshold
+    sel = torch.logical_and(sel, torch.max(self.get_scaling, dim=1).values <= self.percent_dense * scene_extent)
+    names = ["_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"]
+    has_cnt = getattr(self, "send_to_gpui_cnt", None) is not None
+    n, rows = _selected_rows(self, sel, names + (["send_to_gpui_cnt"] if has_cnt else []))
+    _log("Number of cloned gaussians: {}\n".format(n))
+    densification_postfix(self, *rows[:6], rows[6] if has_cnt else None)
+
+
+def densify_and_split(self, grads, grad_threshold, scene_extent, N=2):
+    n_init = self._xyz.shape[0]
+    padded_grad = torch.zeros((n_init,), device=self._xyz.device)
+    padded_grad[: grads.shape[0]] = grads.squeeze()
+    sel = padded_grad >= grad_threshold
+    sel = torch.logical_and(sel, torch.max(self.get_scaling, dim=1).values > self.percent_dense * scene_extent)
+    names = ["_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"]
+    has_cnt = getattr(self, "send_to_gpui_cnt", None) is not None
+    n, rows = _selected_rows(self, sel, names + (["send_to_gpui_cnt"] if has_cnt else []))
+    xyz, f_dc, f_rest, opacity, scaling_raw, rotation = rows[:6]
+    _log("Number of split gaussians: {}\n".format(n))
+    scaling = torch.exp(scaling_raw)  # get_scaling of the selected rows
+    stds = scaling.repeat(N, 1)
+    samples = torch.normal(mean=torch.zeros((stds.size(0), 3), device=stds.device), std=stds)
+    rots = _build_rotation(rotation).repeat(N, 1, 1)
+    new_xyz = torch.bmm(rots, samples.unsqueeze(-1)).squeeze(-1) + xyz.repeat(N, 1)
+    new_scaling = torch.log(scaling.repeat(N, 1) / (0.8 * N))
+    densification_postfix(self, new_xyz, f_dc.repeat(N, 1, 1), f_rest.repeat(N, 1, 1), opacity.repeat(N, 1),
+                          new_scaling, rotation.repeat(N, 1), rows[6].repeat(N, 1) if has_cnt else None)
+    prune_filter = torch.cat((sel, torch.zeros(N * n, device=sel.device, dtype=torch.bool)))
+    prune_points(self, prune_filter)
+
+
+def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size):
+    grads = self.xyz_gradient_accum / self.denom
+    grads[grads.isnan()] = 0.0
+    densify_and_clone(self, grads, max_grad, extent)
+    densify_and_split(self, grads, max_grad, extent)
+    prune_mask = (self.get_opacity < min_opacity).squeeze()
+    if max_screen_size:
+        big_points_vs = self.max_radii2D > max_screen_size
+        big_points_ws = self.get_scaling.max(dim=1).values > 0.1 * extent
+        prune_mask = torch.logical_or(torch.logical_or(prune_mask, big_points_vs), big_points_ws)
+    prune_points(self, prune_mask)
+
+
+# --------------------------------------------------------------------------------- redistribution
+def redistribute_rows(tensors, destination, group):
+    """send row i of every tensor to rank destination[i]: ONE packed all-to-all-v.  Returns the received
+    tensors (rows ordered by source rank, original order inside a source) and the i->j size matrix."""
+    W = group.size()
+    order, counts = dgr.group_rows(destination, W)
+    n_send = sum(counts[:W])
+    widths = [math.prod(t.shape[1:]) for t in tensors]
+    R = sum(widths)
+    dev = tensors[0].device
+    send = torch.empty((n_send, R), dtype=torch.float32, device=dev)
+    cols, c = [], 0
+    for w in widths:
+        cols.append((c, c + w))
+        c += w
+    # int32 tensors travel bit-exactly as 4-byte words of the fp32 record
+    srcs = [t.view(torch.float32) if t.dtype != torch.float32 else t for t in tensors]
+    srcs = [s.reshape(s.shape[0], -1) for s in srcs]
+    dgr.gather_rows(order, n_send, srcs, [send[:, a:b] for a, b in cols])
+    local = torch.tensor(counts[:W], dtype=torch.int32, device=dev)
+    i2j = torch.empty((W * W,), dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(i2j, local, group=group)
+    i2j = i2j.view(W, W).cpu().tolist()
+    rank = group.rank()
+    recv_splits = [i2j[i][rank] for i in range(W)]
+    recv = torch.empty((sum(recv_splits), R), dtype=torch.float32, device=dev)
+    dist.all_to_all_single(recv, send, output_split_sizes=recv_splits, input_split_sizes=counts[:W], group=group)
+    n_new = recv.shape[0]
+    outs = [torch.empty((n_new,) + tuple(t.shape[1:]), dtype=torch.float32, device=dev) for t in tensors]
+    dgr.gather_rows(None, n_new, [recv[:, a:b] for a, b in cols], [o.reshape(n_new, -1) for o in outs])
+    outs = [o.view(t.dtype) if t.dtype != torch.float32 else o for o, t in zip(outs, tensors)]
+    return outs, i2j
+
+
+def need_redistribute_gaussians(self, group):
+    """scene/gaussian_model.py:1245-1262"""
+    args = utils.get_args()
+    if group.size() == 1:
+        return False
+    if utils.get_denfify_iter() == args.redistribute_gaussians_frequency:
+        return True
+    all_n = [None for _ in range(group.size())]
+    dist.all_gather_object(all_n, self._xyz.shape[0], group=group)
+    return min(all_n) * args.redistribute_gaussians_threshold < max(all_n)
+
+
+def redistribute_gaussians(self, destination=None, group=None):
+    """random rebalancing of the shards (scene/gaussian_model.py:1264-1329); `destination` / `group` default to
+    the reference's choices (uniform random destination, the default group)"""
+    args = utils.get_args()
+    if getattr(args, "redistribute_gaussians_mode", "random_redistribute") == "no_redistribute":
+        return
+    group = group if group is not None else utils.DEFAULT_GROUP
+    if destination is None:
+        if not need_redistribute_gaussians(self, group):
+            return
+        if args.redistribute_gaussians_mode != "random_redistribute":
+            raise ValueError("Invalid redistribute_gaussians_mode: " + args.redistribute_gaussians_mode)
+        destination = torch.randint(0, group.size(), (self._xyz.shape[0],), device=self._xyz.device)
+    slots = _optimizer_slots(self)
+    outs, _ = redistribute_rows([_slot_tensor(self, g, k) for g, k in slots], destination, group)
+    _replace_optimizer_rows(self, slots, outs)
+    n, dev = self._xyz.shape[0], self._xyz.device
+    self.xyz_gradient_accum = torch.zeros((n, 1), device=dev)
+    self.denom = torch.zeros((n, 1), device=dev)
+    self.max_radii2D = torch.zeros((n,), device=dev)
+    self.sum_visible_count_in_one_batch = torch.zeros((n,), device=dev)
+    self.send_to_gpui_cnt = torch.zeros((n, group.size()), dtype=torch.int, device=dev)
+
+
+def install(cls):
+    """graft level B3: make these functions the methods of the reference's GaussianModel class"""
+    for fn in (prune_points, cat_tensors_to_optimizer, densification_postfix, densify_and_clone, densify_and_split,
+               densify_and_prune, need_redistribute_gaussians, redistribute_gaussians):
+        setattr(cls, fn.__name__, fn)
+    return cls

@@ -26,7 +26,7 @@ from ._lib import check, lib
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "_C", "load_image_tiles_by_pos",
            "merge_image_tiles_by_pos", "set_timing_mode", "fused_l1_ssim_band", "fused_activations", "pack_camera",
-           "preprocess_gaussians_raw_batched", "knn_mean_dist2"]
+           "preprocess_gaussians_raw_batched", "knn_mean_dist2", "group_rows", "gather_rows"]
 
 BLOCK_X, BLOCK_Y, ONE_DIM_BLOCK_SIZE = 16, 16, 256
 
@@ -627,6 +627,69 @@ def knn_mean_dist2(points):
     ws = torch.empty(nbytes, dtype=torch.uint8, device=pts.device)
     check(lib.gsr_knn_mean_dist2(P, _ptr(pts), _ptr(out), _ptr(ws), nbytes, _stream()), "gsr_knn_mean_dist2")
     return out
+
+
+def group_rows(dest, num_groups):
+    """stable grouping of row indices by destination: returns (order int32 [N], counts list of num_groups+1
+    python ints; the last entry counts the rows whose destination is outside [0, num_groups) = dropped).
+    One host read-back (the counts size what follows)."""
+    if not dest.is_cuda:
+        raise RuntimeError("diff_gaussian_rasterization: `dest` must live on the gfx950 device (no CPU fallback)")
+    dest = dest.to(torch.int32).contiguous()
+    N = dest.shape[0]
+    order = torch.empty(N, dtype=torch.int32, device=dest.device)
+    counts = torch.empty(num_groups + 1, dtype=torch.int64, device=dest.device)
+    nbytes = lib.gsr_group_rows_bytes(N)
+    ws = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=dest.device)
+    check(lib.gsr_group_rows(N, num_groups, _ptr(dest), _ptr(order), _ptr(counts), _ptr(ws), nbytes, _stream()),
+          "gsr_group_rows")
+    return order, counts.cpu().tolist()
+
+
+def gather_rows(order, n_out, srcs, dsts=None, row0=0):
+    """dst_k[r] = src_k[order[row0 + r]] (order None: identity) for r < n_out, all tensors in ONE launch.
+    srcs / dsts: 4-byte-element tensors whose rows are contiguous (dim 0 may be strided, e.g. a column block of a
+    record matrix); dsts=None allocates dense outputs shaped like the sources.  Returns the dsts."""
+    if dsts is None:
+        dsts = [torch.empty((n_out,) + tuple(s.shape[1:]), dtype=s.dtype, device=s.device) for s in srcs]
+    K = len(srcs)
+    if K == 0 or n_out == 0:
+        return dsts
+    if K > 32:
+        for i in range(0, K, 32):
+            gather_rows(order, n_out, srcs[i:i + 32], dsts[i:i + 32], row0)
+        return dsts
+
+    def row_layout(t, what):
+        if not t.is_cuda:
+            raise RuntimeError(f"diff_gaussian_rasterization: {what} must live on the gfx950 device (no CPU fallback)")
+        if t.element_size() != 4:
+            raise ValueError(f"{what}: 4-byte elements expected, got {t.dtype}")
+        w = 1
+        for d in t.shape[1:]:
+            w *= d
+        inner = t[0] if t.shape[0] > 0 else None
+        if inner is not None and inner.numel() > 1 and not inner.is_contiguous():
+            raise ValueError(f"{what}: rows must be contiguous")
+        return w, (t.stride(0) if t.dim() > 0 and t.shape[0] > 1 else w)
+
+    widths, ss, ds = [], [], []
+    for s_, d_ in zip(srcs, dsts):
+        w, st = row_layout(s_, "source")
+        w2, dt = row_layout(d_, "destination")
+        if w != w2 or d_.shape[0] < n_out:
+            raise ValueError("source / destination row shapes differ")
+        widths.append(w)
+        ss.append(st)
+        ds.append(dt)
+    VP = ctypes.c_void_p * K
+    order_ptr = ctypes.c_void_p(order.data_ptr() + 4 * row0) if order is not None else ctypes.c_void_p(0)
+    if order is not None and (order.dtype != torch.int32 or not order.is_contiguous()):
+        raise ValueError("order must be a contiguous int32 tensor")
+    check(lib.gsr_gather_rows(n_out, order_ptr, K, VP(*[s_.data_ptr() for s_ in srcs]),
+                              VP(*[d_.data_ptr() for d_ in dsts]), (ctypes.c_int32 * K)(*widths),
+                              (ctypes.c_int64 * K)(*ss), (ctypes.c_int64 * K)(*ds), _stream()), "gsr_gather_rows")
+    return dsts
 
 
 # ------------------------------------------------------------------------------------------ _C

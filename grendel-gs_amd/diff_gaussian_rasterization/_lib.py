@@ -41,6 +41,10 @@ SIGNATURES = {
                                      c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "gsr_knn_workspace_bytes": (c_size_t, [c_int]),
     "gsr_knn_mean_dist2": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "gsr_group_rows_bytes": (c_size_t, [c_int64]),
+    "gsr_group_rows": (c_int, [c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "gsr_gather_rows": (c_int, [c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                c_void_p]),
     "gsr_adam_step": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_double, ctypes.c_double,
                               ctypes.c_double, ctypes.c_double, c_int64, c_float, c_void_p]),
     "gsr_preprocess_forward_raw": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_float] + [c_void_p] * 7 +

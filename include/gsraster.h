@@ -169,6 +169,26 @@ int gsr_knn_mean_dist2(int P, const float *points, float *mean_dist2, void *work
                        gsr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * N4  row primitives for densification / redistribution of the Gaussian shard.  The reference selects rows
+ * with boolean indexing once PER TENSOR (and per destination rank): prune_points / _prune_optimizer
+ * scene/gaussian_model.py:775-835, densify_and_clone / densify_and_split :922-1007, all2all_gaussian_state
+ * :1073-1098.  Here the selection is computed once and applied to all tensors in one launch.
+ *
+ * gsr_group_rows: dest[i] in [0,G) = group of row i, anything else = dropped.  order[] receives the row
+ *   indices grouped by destination, original order kept inside a group (group 0, 1, ..., G-1, then the dropped
+ *   rows); counts[0..G-1] = group sizes, counts[G] = number dropped (device int64).  1 <= G <= 255.
+ * gsr_gather_rows: for every tensor k, dst_k[r, 0:width_k] = src_k[order ? order[r] : r, 0:width_k] for
+ *   r < n_out.  Rows are 4-byte words (fp32 / int32); strides are in words, so a dst may be a column block of a
+ *   wider record matrix (one all-to-all-v for all per-Gaussian state) and a src may be such a block.
+ *   srcs/dsts/widths/strides are HOST arrays of num_tensors <= 32 entries. */
+size_t gsr_group_rows_bytes(int64_t N);
+int gsr_group_rows(int64_t N, int G, const int32_t *dest, int32_t *order, int64_t *counts, void *workspace,
+                   size_t workspace_bytes, gsr_stream_t stream);
+int gsr_gather_rows(int64_t n_out, const int32_t *order, int num_tensors, const void *const *srcs, void *const *dsts,
+                    const int32_t *widths, const int64_t *src_strides, const int64_t *dst_strides,
+                    gsr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * K1 / K11 on the RAW parameters of GaussianModel (scene/gaussian_model.py:219-242): `scaling` log-scales
  * [P,3], `rotation` un-normalised quaternions [P,4], `opacity` logits [P,1], `features_dc` [P,1,3],
  * `features_rest` [P,sh_coeffs-1,3].  The getters' activations (scene/gaussian_model.py:109-129: exp,

@@ -1,0 +1,115 @@
+"""spawn-able workers shared by the CPU (gloo) and GPU (gloo, collectives staged through the host) tests of the
+redistribution path.  Test infrastructure."""
+import os
+import sys
+import traceback
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def stage_collectives_through_host():
+    """gloo's device support is not under test: device tensors take a round trip through the host"""
+    a2a, agi = dist.all_to_all_single, dist.all_gather_into_tensor
+
+    def all_to_all_single(output, input, output_split_sizes=None, input_split_sizes=None, group=None, **kw):
+        if not output.is_cuda:
+            return a2a(output, input, output_split_sizes, input_split_sizes, group=group, **kw)
+        o = torch.empty(output.shape, dtype=output.dtype)
+        a2a(o, input.detach().cpu().contiguous(), output_split_sizes, input_split_sizes, group=group)
+        output.copy_(o)
+
+    def all_gather_into_tensor(output, input, group=None, **kw):
+        if not output.is_cuda:
+            return agi(output, input, group=group, **kw)
+        o = torch.empty(output.shape, dtype=output.dtype)
+        agi(o, input.detach().cpu().contiguous(), group=group)
+        output.copy_(o)
+
+    dist.all_to_all_single = all_to_all_single
+    dist.all_gather_into_tensor = all_gather_into_tensor
+
+
+class _Shard:
+    """GaussianModel duck type whose every value encodes (global id, tensor slot, column)"""
+    SHAPES = {"xyz": (3,), "f_dc": (1, 3), "f_rest": (15, 3), "opacity": (1,), "scaling": (3,), "rotation": (4,)}
+
+    def __init__(self, gids, device):
+        import densification_ops as D
+
+        self.gids = gids
+        groups = []
+        for s, (name, shape) in enumerate(self.SHAPES.items()):
+            p = torch.nn.Parameter(self.encode(gids, 3 * s, shape).to(device))
+            setattr(self, D._ATTR[name], p)
+            groups.append({"params": [p], "lr": 0.0, "name": name})
+        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+        for s, g in enumerate(self.optimizer.param_groups):
+            p = g["params"][0]
+            self.optimizer.state[p] = {"step": torch.tensor(3.0),
+                                       "exp_avg": self.encode(gids, 3 * s + 1, p.shape[1:]).to(device),
+                                       "exp_avg_sq": self.encode(gids, 3 * s + 2, p.shape[1:]).to(device)}
+
+    @staticmethod
+    def encode(gids, slot, shape):
+        w = 1
+        for d in shape:
+            w *= d
+        v = gids[:, None].double() * 1024 + slot * 48 + torch.arange(w)[None, :].double()
+        return v.float().reshape((gids.shape[0],) + tuple(shape))
+
+
+def redistribution_worker(rank, world, port, on_gpu, q):
+    try:
+        for p in (os.path.join(ROOT, "grendel-gs_amd"), ROOT, os.path.join(ROOT, "tests")):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        os.environ.update(RANK=str(rank), LOCAL_RANK="0" if on_gpu else str(rank), WORLD_SIZE=str(world),
+                          MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        torch.set_num_threads(1)
+        import densification_ops as D
+        import diff_gaussian_rasterization as dgr
+        import utils.general_utils as utils
+
+        utils.init_distributed(backend="gloo")
+        utils.set_args(utils.default_args(redistribute_gaussians_mode="random_redistribute"))
+        if on_gpu:
+            torch.cuda.set_device(0)
+            dev = torch.device("cuda", 0)
+            stage_collectives_through_host()
+        else:  # the two HIP row primitives are played by their torch restatements (no GPU in this container)
+            from oracle import densify_oracle as O
+
+            dev = torch.device("cpu")
+            dgr.group_rows, dgr.gather_rows = O.group_rows, O.gather_rows
+        sizes = [1000 + 137 * r for r in range(world)]
+        start = sum(sizes[:rank])
+        gids = torch.arange(start, start + sizes[rank])
+        m = _Shard(gids, dev)
+        destination = ((gids * 7 + 3) % world).to(torch.int32).to(dev)
+        D.redistribute_gaussians(m, destination=destination, group=utils.DEFAULT_GROUP)
+
+        # expected content of this rank: ids with destination == rank, by source rank, original order inside
+        all_ids = torch.arange(sum(sizes))
+        mine = all_ids[((all_ids * 7 + 3) % world) == rank]
+        assert m._xyz.shape[0] == mine.shape[0]
+        for s, g in enumerate(m.optimizer.param_groups):
+            p = g["params"][0]
+            assert p is getattr(m, D._ATTR[g["name"]]) and p.requires_grad
+            st = m.optimizer.state[p]
+            assert float(st["step"]) == 3.0
+            for slot, t in ((3 * s, p.detach()), (3 * s + 1, st["exp_avg"]), (3 * s + 2, st["exp_avg_sq"])):
+                assert torch.equal(t.cpu(), _Shard.encode(mine, slot, p.shape[1:])), (g["name"], slot)
+        n = m._xyz.shape[0]
+        assert m.xyz_gradient_accum.shape == (n, 1) and m.denom.shape == (n, 1) and m.max_radii2D.shape == (n,)
+        assert m.send_to_gpui_cnt.shape == (n, world) and m.send_to_gpui_cnt.dtype == torch.int32
+        tot = torch.tensor([n])
+        dist.all_reduce(tot)
+        assert int(tot) == sum(sizes)
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        q.put((rank, traceback.format_exc()))

@@ -254,3 +254,23 @@ def test_ground_truth_band_staging_local_and_distributed_storage():
         p.join(timeout=60)
     for rank, msg in results:
         assert msg == "ok", f"rank {rank}:\n{msg}"
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_redistribute_gaussians_single_packed_all_to_all(world):
+    """N4: every parameter / Adam-moment row reaches its destination rank in ONE all-to-all-v, ordered by
+    source rank (scene/gaussian_model.py:1073-1098,1264-1329); row primitives played by their torch restatement"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from dist_workers import redistribution_worker
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=redistribution_worker, args=(r, world, port, False, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in results:
+        assert msg == "ok", f"rank {rank}:\n{msg}"

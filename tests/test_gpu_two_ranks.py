@@ -183,3 +183,27 @@ def test_partitioned_training_iteration_on_device(device, world, bsz):
                 p.kill()
     for rank, msg in results:
         assert msg == "ok", f"rank {rank}:\n{msg}"
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_redistribute_gaussians_on_device(device, world):
+    """N4 redistribution with the real row kernels (gsr_group_rows / gsr_gather_rows), ranks sharing the GPU"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from dist_workers import redistribution_worker
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=redistribution_worker, args=(r, world, port, True, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = []
+    try:
+        results = [q.get(timeout=300) for _ in procs]
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+    for rank, msg in results:
+        assert msg == "ok", f"rank {rank}:\n{msg}"
