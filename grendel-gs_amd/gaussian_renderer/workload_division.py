@@ -192,8 +192,23 @@ def _resolve_deferred_timings(st):
 def finish_strategy_final(batched_cameras, strategy_history, batched_strategies, batched_statistic_collector):
     """all-gather each rank's measured (fwd render + bwd render + 2 x fwd loss) ms per camera and turn
     it into the next per-row cost estimate (same skip rules as workload_division.py:968-978)"""
+    args = utils.get_args()
+    W = utils.DEFAULT_GROUP.size()
+    small = utils.get_img_height() <= 600 or utils.get_img_width() <= 1000
+    whole_images = args.bsz >= W and (utils.get_img_height() <= 1080 or utils.get_img_width() <= 1920)
+    frozen = (utils.get_cur_iter() <= args.adjust_strategy_warmp_iterations or W == 1 or args.no_heuristics_update
+              or whole_images or small)
+    if frozen and W > 1 and not getattr(args, "save_strategy_history", False):
+        # nobody consumes the timings (heuristics frozen, history not saved: train_internal.py:274-284): skip the
+        # event wait and the all-gather + host read-back the reference pays every iteration (:953-966), so the
+        # host keeps running ahead of the device.  The HIP event pairs are simply dropped.
+        for st in batched_statistic_collector:
+            for evkey in ("_fwd_events", "_bwd_events", "_loss_events"):
+                st.pop(evkey, None)
+        return
+
     mine = []
-    if utils.DEFAULT_GROUP.size() > 1:
+    if W > 1:
         for st in batched_statistic_collector:
             _resolve_deferred_timings(st)
     for k, strategy in enumerate(batched_strategies):
@@ -204,13 +219,7 @@ def finish_strategy_final(batched_cameras, strategy_history, batched_strategies,
         mine.append(float(st["forward_render_time"] + st["backward_render_time"] + st["forward_loss_time"] * 2))
     times = utils.our_allgather_among_cpu_processes_float_list(mine, utils.DEFAULT_GROUP)
     strategy_history.store_stats(batched_cameras, times, batched_strategies)
-
-    args = utils.get_args()
-    W = utils.DEFAULT_GROUP.size()
-    small = utils.get_img_height() <= 600 or utils.get_img_width() <= 1000
-    whole_images = args.bsz >= W and (utils.get_img_height() <= 1080 or utils.get_img_width() <= 1920)
-    if (utils.get_cur_iter() <= args.adjust_strategy_warmp_iterations or W == 1 or args.no_heuristics_update
-            or whole_images or small):
+    if frozen:
         return
 
     for k, (camera, strategy) in enumerate(zip(batched_cameras, batched_strategies)):

@@ -35,7 +35,7 @@ def default_args(**overrides):
         image_distribution=True, image_distribution_mode="final", gaussians_distribution=True,
         heuristic_decay=0.0, no_heuristics_update=False, border_divpos_coeff=1.0,
         adjust_strategy_warmp_iterations=-1, local_sampling=False, distributed_dataset_storage=False,
-        lambda_dssim=0.2, lr_scale_loss=1.0, backend="default",
+        lambda_dssim=0.2, lr_scale_loss=1.0, backend="default", save_strategy_history=False,
     )
     for k, v in overrides.items():
         setattr(a, k, v)

@@ -39,7 +39,7 @@ def _worker(rank, world, port, bsz, q):
         from oracle import torch_oracle as O
 
         utils.init_distributed(backend="gloo")
-        utils.set_args(utils.default_args(bsz=bsz))
+        utils.set_args(utils.default_args(bsz=bsz, save_strategy_history=(world == 2)))
         N, W, H = 1200, 160, 112
         utils.set_img_size(H, W)
         utils.set_cur_iter(1)
@@ -109,7 +109,10 @@ def _worker(rank, world, port, bsz, q):
         for s_ in stats:
             s_.update(forward_render_time=1.0 + rank, backward_render_time=2.0, forward_loss_time=0.5)
         finish_strategy_final(cams, hist, strategies, stats)
-        assert len(hist.history) == 1 and len(hist.history[0]["all_gpu_running_time"]) == world
+        if world == 2:
+            assert len(hist.history) == 1 and len(hist.history[0]["all_gpu_running_time"]) == world
+        else:  # timings have no consumer (heuristics frozen, history not saved): no gather, nothing logged
+            assert len(hist.history) == 0
 
         # SUM assembly of the row bands (train_internal.py:466-469)
         stack = torch.stack(images)

@@ -69,7 +69,7 @@ def _worker(rank, world, port, bsz, q):
         dev = torch.device("cuda", 0)
         utils.init_distributed(backend="gloo")
         _stage_collectives_through_host()
-        utils.set_args(utils.default_args(bsz=bsz))
+        utils.set_args(utils.default_args(bsz=bsz, save_strategy_history=(world == 2)))
         N, W, H = 6000, 208, 144
         utils.set_img_size(H, W)
         utils.set_cur_iter(1)
@@ -91,9 +91,12 @@ def _worker(rank, world, port, bsz, q):
         loss, _ = batched_loss_computation(images, cams, masks, strategies, stats)
         loss.backward()
         finish_strategy_final(cams, hist, strategies, stats)
-        assert len(hist.history) == 1 and len(hist.history[0]["all_gpu_running_time"]) == world
+        if world == 2:
+            assert len(hist.history) == 1 and len(hist.history[0]["all_gpu_running_time"]) == world
+        else:  # timings have no consumer (heuristics frozen, history not saved): no gather, nothing logged
+            assert len(hist.history) == 0
         for st, strat in zip(stats, strategies):
-            if rank not in strat.gpu_ids:
+            if rank not in strat.gpu_ids or world != 2:
                 continue
             assert isinstance(st["forward_render_time"], float) and isinstance(st["backward_render_time"], float)
 
