@@ -26,7 +26,7 @@ from ._lib import check, lib
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "_C", "load_image_tiles_by_pos",
            "merge_image_tiles_by_pos", "set_timing_mode", "fused_l1_ssim_band", "fused_activations", "pack_camera",
-           "preprocess_gaussians_raw_batched", "knn_mean_dist2", "group_rows", "gather_rows"]
+           "preprocess_gaussians_raw_batched", "knn_mean_dist2", "group_rows", "gather_rows", "exchange_need"]
 
 BLOCK_X, BLOCK_Y, ONE_DIM_BLOCK_SIZE = 16, 16, 256
 
@@ -610,6 +610,23 @@ def fused_activations(scaling, rotation, opacity, features_dc, features_rest):
     """(scales, rotations, opacities, shs) = (exp, normalize, sigmoid, cat) of the raw parameters in one
     kernel each way -- GaussianModel.get_scaling/get_rotation/get_opacity/get_features"""
     return _FusedActivations.apply(scaling, rotation, opacity, features_dc, features_rest)
+
+
+def exchange_need(means2D_all, radii_all, bands, width, height):
+    """K2 for the whole camera batch in the exchange's layout: means2D_all [B,P,2], radii_all int32 [B,P],
+    bands int32 [B,W,2] (tile rows [lo,hi) of camera k rendered by global rank g) ->
+    (need bool [W,B,P], counts int32 [W,B])."""
+    m2 = _f32c(means2D_all.detach(), "means2D_all")
+    if radii_all.dtype != torch.int32 or not radii_all.is_contiguous() or bands.dtype != torch.int32:
+        raise ValueError("radii_all / bands must be contiguous int32")
+    B, P = radii_all.shape
+    W = bands.shape[1]
+    bands = bands.to(m2.device).contiguous()
+    need = torch.empty((W, B, P), dtype=torch.bool, device=m2.device)
+    counts = torch.empty((W, B), dtype=torch.int32, device=m2.device)
+    check(lib.gsr_exchange_need(P, B, W, width, height, _ptr(m2), _ptr(radii_all), _ptr(bands), _ptr(need),
+                                _ptr(counts), _stream()), "gsr_exchange_need")
+    return need, counts
 
 
 def knn_mean_dist2(points):

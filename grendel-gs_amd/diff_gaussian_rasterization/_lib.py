@@ -39,6 +39,8 @@ SIGNATURES = {
                                     c_void_p, c_void_p]),
     "gsr_l1_ssim_backward": (c_int, [c_int, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "gsr_exchange_need": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_void_p]),
     "gsr_knn_workspace_bytes": (c_size_t, [c_int]),
     "gsr_knn_mean_dist2": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "gsr_group_rows_bytes": (c_size_t, [c_int64]),

@@ -158,6 +158,17 @@ int gsr_adam_step(int64_t n, float *param, const float *grad, float *exp_avg, fl
                   double beta1, double beta2, double eps, int64_t step, float grad_scale, gsr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * K2 for a whole camera batch, in the layout of the exchange (rows a5/a6).  The reference calls
+ * get_local2j_ids_bool once per camera and then nonzero() per (camera, band) (workload_division.py:721-744,
+ * gaussian_renderer/__init__.py:586-622).  With the camera-batched K1 the state is [B,P,.]:
+ * means2D fp32 [B,P,2], radii int32 [B,P]; bands int32 [B][W][2] = tile rows [lo,hi) of camera k rendered by
+ * GLOBAL rank g ((0,0): none); need uint8 [W][B][P] = 1 iff the Gaussian's 3-sigma tile rect (the K2 rule)
+ * meets that band -- flattened, this is the (destination, camera, Gaussian) send order of the all-to-all-v;
+ * counts int32 [W][B] = row sums of need (zeroed here).  W <= 256. */
+int gsr_exchange_need(int P, int B, int W, int width, int height, const float *means2D, const int32_t *radii,
+                      const int32_t *bands, uint8_t *need, int32_t *counts, gsr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * N4  `simple_knn._C.distCUDA2(points)` (scene/gaussian_model.py:20,163-166; submodule
  * https://gitlab.inria.fr/bkerbl/simple-knn, .gitmodules:1-3, absent from the reference tree):
  * mean_dist2[i] = mean of the squared distances from point i to its 3 nearest OTHER points (only i itself is

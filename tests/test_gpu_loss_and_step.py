@@ -215,6 +215,25 @@ def test_exchange_path_on_device_single_rank_rccl(device):
             assert rel_err(b, a) < 1e-6
         assert rel_err(model._xyz.grad, gx_a) < 1e-5
         assert rel_err(model._features_rest.grad, gf_a) < 1e-5
+
+        # the camera-batched exchange (gsr_exchange_need, packed 11-float records, regroup of two cameras) over RCCL
+        model = S.SyntheticGaussianModel(N, W, H, seed=4, device=device, scale_coef=0.012)
+        utils.DEFAULT_GROUP = utils.SingleGPUGroup()
+        pkg = gr.distributed_preprocess3dgs_and_all2all_final(cams, model, pipe, bg, batched_strategies=strategies)
+        utils.DEFAULT_GROUP = dist.group.WORLD
+        stacked = [torch.stack(pkg[f"batched_{n}_redistributed"]) for n in ("rgb", "conic_opacity", "radii", "depths")]
+        m2, rgb, co, radii, depths, sizes = gr._batched_exchange_final(
+            pkg["batched_locally_preprocessed_mean2D"], *stacked, pkg["batched_rasterizers"], strategies)
+        assert sizes[0][0][1] == int((stacked[2][1] > 0).sum().item())
+        for name, val in zip(("means2D", "rgb", "conic_opacity", "radii", "depths"), (m2, rgb, co, radii, depths)):
+            pkg[f"batched_{name}_redistributed"] = val
+        images, _ = gr.render_final(pkg, strategies)
+        sum((im * w_).sum() for im, w_ in zip(images, wgt)).backward()
+        for a, b in zip(img_a, images):
+            assert rel_err(b, a) < 1e-6
+        assert rel_err(model._xyz.grad, gx_a) < 1e-5
+        assert rel_err(model._features_rest.grad, gf_a) < 1e-5
+        assert pkg["batched_locally_preprocessed_mean2D"][1].grad is not None  # densification's input survives
     finally:
         utils.DEFAULT_GROUP = utils.IN_NODE_GROUP = utils.SingleGPUGroup()
         if created:

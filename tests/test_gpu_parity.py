@@ -11,6 +11,7 @@ import math
 import pytest
 import torch
 
+import diff_gaussian_rasterization as dgr
 import synthetic_scene as S
 from helpers import KEYS, cam_kwargs, frac_bad, oracle_c_chain, rel_err, settings_from
 
@@ -283,3 +284,26 @@ def test_saturating_stack_early_stop(device):
     assert rel_err(img, ref["image"]) < RTOL
     img.sum().backward()
     assert rel_err(gg["opacities"].grad, ref["d_opacities"]) < 5e-4
+
+
+def test_batched_exchange_need_equals_per_camera_k2(device):
+    """gsr_exchange_need (whole batch, destination-major) == K2 per camera (get_local2j_ids_bool) column by column"""
+    g = torch.Generator().manual_seed(5)
+    B, P, W, width, height = 3, 20000, 4, 640, 360
+    gy = (height + 15) // 16
+    m2 = (torch.rand(B, P, 2, generator=g) * torch.tensor([width * 1.2, height * 1.2]) - 20.0).to(device)
+    radii = torch.randint(0, 60, (B, P), generator=g, dtype=torch.int32).to(device)
+    bands = torch.zeros(B, W, 2, dtype=torch.int32)
+    parts = [[0, 5, 11, gy], [0, gy], [0, 7, gy]]  # camera k is cut into len-1 bands ...
+    owners = [[0, 1, 3], [2], [3, 0]]              # ... rendered by these global ranks
+    for k in range(B):
+        for j, r in enumerate(owners[k]):
+            bands[k, r, 0], bands[k, r, 1] = parts[k][j], parts[k][j + 1]
+    need, counts = dgr.exchange_need(m2, radii, bands, width, height)
+    assert torch.equal(counts.cpu(), need.sum(2).int().cpu())
+    for k in range(B):
+        div = torch.tensor(parts[k], dtype=torch.int32, device=device) * ((width + 15) // 16)
+        ref = dgr._C.get_local2j_ids_bool(height, width, 0, len(owners[k]), m2[k], radii[k], div, {})
+        for r in range(W):
+            want = ref[:, owners[k].index(r)] if r in owners[k] else torch.zeros(P, dtype=torch.bool, device=device)
+            assert torch.equal(need[r, k], want), (k, r)
