@@ -284,9 +284,8 @@ composite_backward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
     if (bmax == 0) return;
 
     float T = T_final;
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;      // colour accumulated BEHIND the current entry
-    float lastc0 = 0.f, lastc1 = 0.f, lastc2 = 0.f;
-    float last_alpha = 0.f;
+    float R0 = 0.f, R1 = 0.f, R2 = 0.f;  // colour accumulated BEHIND the current position
+    const float tb = T_final * bg_dot;
 
     constexpr int EB = 7;  // entries per reduction batch: 7 x 9 = 63 of the 64 butterfly slots
     const int slot_j = lane / 9, slot_v = lane - 9 * (lane / 9);
@@ -342,40 +341,41 @@ composite_backward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
                         }
                     }
                     ks[j] = k;
-                    // branch-free contribution of this entry for this pixel (lanes that do not `take` are
-                    // masked through G, dL/dG and the weight, never through a multiply by an inf/NaN)
+                    // branch-free contribution of this entry for this pixel.  A lane that does not `take` runs
+                    // the same arithmetic with alpha = 0 and G = 0: T / (1 - 0) and R + 0 * (c - R) leave its state
+                    // untouched, so only two selects are needed (never a multiply by an inf/NaN: G is SELECTED).
+                    // R = colour accumulated behind the current position, updated eagerly:
+                    // R <- alpha c + (1 - alpha) R is the reference's lazily evaluated accum_rec recurrence.
+                    if (!got) {  // wave-uniform: the chunk ran out of entries inside this batch
+#pragma unroll
+                        for (int v = 0; v < 9; v++) xs[j * 9 + v] = 0.f;
+                        continue;
+                    }
                     const float cb = slab[wave][k][2].x;
-                    const bool tk = got && take;
-                    const float inv_1ma = __builtin_amdgcn_rcpf(1.f - alpha);  // 1 ulp, inside the 1e-4 budget
-                    const float Tn = T * inv_1ma;                              // transmittance in front of the entry
-                    const float n0 = last_alpha * (lastc0 - acc0) + acc0;      // colour accumulated behind it
-                    const float n1 = last_alpha * (lastc1 - acc1) + acc1;
-                    const float n2 = last_alpha * (lastc2 - acc2) + acc2;
-                    const float dL_dalpha = ((cr - n0) * g0 + (cg - n1) * g1 + (cb - n2) * g2) * Tn -
-                                            T_final * inv_1ma * bg_dot;
-                    const float Gm = tk ? G : 0.f;
-                    const float da = tk ? dL_dalpha : 0.f;
-                    const float wm = tk ? alpha * Tn : 0.f;
-                    const float q = o * da * Gm;                 // G * dL/dG, min(0.99,.) treated as identity
+                    const float ae = take ? alpha : 0.f;
+                    const float Ge = take ? G : 0.f;
+                    const float inv_1ma = __builtin_amdgcn_rcpf(1.f - ae);  // 1 ulp, inside the 1e-4 budget
+                    const float Tn = T * inv_1ma;                           // transmittance in front of the entry
+                    const float d0 = cr - R0, d1 = cg - R1, d2 = cb - R2;
+                    const float da = (d0 * g0 + d1 * g1 + d2 * g2) * Tn - tb * inv_1ma;  // dL/dalpha
+                    const float q = o * da * Ge;  // G * dL/dG, min(0.99,.) treated as identity
                     const float qdx = q * dx, qdy = q * dy;
-                    // conic in log2 units: A = -2 a2 / log2e, B = -b2 / log2e, C = -2 c2 / log2e
-                    xs[j * 9 + 0] = (2.f * a2 * qdx + b2 * qdy) * (ddelx_dx / LOG2E);
-                    xs[j * 9 + 1] = (2.f * c2 * qdy + b2 * qdx) * (ddely_dy / LOG2E);
-                    xs[j * 9 + 2] = -0.5f * qdx * dx;
-                    xs[j * 9 + 3] = -qdx * dy;
-                    xs[j * 9 + 4] = -0.5f * qdy * dy;
-                    xs[j * 9 + 5] = Gm * da;
+                    const float wm = ae * Tn;
+                    // raw moment sums; the per-entry linear maps to dL/dmean2D and dL/dconic are applied ONCE per
+                    // (tile, entry) in the flush below instead of once per pixel here
+                    xs[j * 9 + 0] = qdx;
+                    xs[j * 9 + 1] = qdy;
+                    xs[j * 9 + 2] = qdx * dx;
+                    xs[j * 9 + 3] = qdx * dy;
+                    xs[j * 9 + 4] = qdy * dy;
+                    xs[j * 9 + 5] = Ge * da;
                     xs[j * 9 + 6] = wm * g0;
                     xs[j * 9 + 7] = wm * g1;
                     xs[j * 9 + 8] = wm * g2;
-                    T = tk ? Tn : T;
-                    acc0 = tk ? n0 : acc0;
-                    acc1 = tk ? n1 : acc1;
-                    acc2 = tk ? n2 : acc2;
-                    lastc0 = tk ? cr : lastc0;
-                    lastc1 = tk ? cg : lastc1;
-                    lastc2 = tk ? cb : lastc2;
-                    last_alpha = tk ? alpha : last_alpha;
+                    T = Tn;
+                    R0 += ae * d0;
+                    R1 += ae * d1;
+                    R2 += ae * d2;
                 }
                 xs[63] = 0.f;
                 const float total = transpose_reduce64(xs, lane);  // lane L: sum over pixels of value L
@@ -386,21 +386,39 @@ composite_backward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
             }
         }
         __syncthreads();
-        // flush: thread (part = wave, entry = lane) owns 2-3 of the 9 values of entry `lane`
+        // flush: thread (part = wave, entry = lane) owns 2-3 of the 9 moment sums of entry `lane`, maps them to
+        // gradients (S1 = sum q dx, S2 = sum q dy: dL/dmean = -(A S1 + B S2, B S1 + C S2) * (W/2, H/2);
+        // dL/d(A,B,C) = -(1/2 sum q dx^2, sum q dx dy, 1/2 sum q dy^2)) and issues one atomic per value
         if (c + lane < bmax) {
             const uint32_t id = point_list[range.x + c + lane];
             const int v0 = wave * 2, nv = wave == 3 ? 3 : 2;
-            float *dst = wave == 0 ? dL_dmeans2D + 2 * (size_t)id
-                       : wave == 1 ? dL_dconic_opacity + 4 * (size_t)id
-                       : wave == 2 ? dL_dconic_opacity + 4 * (size_t)id + 2
-                                   : dL_drgb + 3 * (size_t)id;
+            float v[3];
+            for (int j = 0; j < nv; j++)
+                v[j] = sacc[0][v0 + j][lane] + sacc[1][v0 + j][lane] + sacc[2][v0 + j][lane] + sacc[3][v0 + j][lane];
+            float *dst;
+            if (wave == 0) {
+                dst = dL_dmeans2D + 2 * (size_t)id;
+                if (v[0] != 0.f || v[1] != 0.f) {
+                    const float4 co = conic_opacity[id];
+                    const float s1 = v[0], s2 = v[1];
+                    v[0] = -(co.x * s1 + co.y * s2) * ddelx_dx;
+                    v[1] = -(co.z * s2 + co.y * s1) * ddely_dy;
+                }
+            } else if (wave == 1) {
+                dst = dL_dconic_opacity + 4 * (size_t)id;
+                v[0] *= -0.5f;
+                v[1] = -v[1];
+            } else if (wave == 2) {
+                dst = dL_dconic_opacity + 4 * (size_t)id + 2;
+                v[0] *= -0.5f;
+            } else {
+                dst = dL_drgb + 3 * (size_t)id;
+            }
             for (int j = 0; j < nv; j++) {
-                const float v = sacc[0][v0 + j][lane] + sacc[1][v0 + j][lane] + sacc[2][v0 + j][lane] +
-                                sacc[3][v0 + j][lane];
 #ifndef GSR_ABL_NOATOMIC
-                if (v != 0.f) atomicAdd(dst + j, v);
+                if (v[j] != 0.f) atomicAdd(dst + j, v[j]);
 #else
-                asm volatile("" ::"v"(v), "v"(dst));
+                asm volatile("" ::"v"(v[j]), "v"(dst));
 #endif
             }
         }

@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgsraster.so")
+LIB_PATH = os.environ.get("GSRASTER_LIB") or os.path.join(_HERE, "libgsraster.so")  # env: experiment builds only
 
 c_int, c_float, c_void_p, c_size_t, c_int64 = (ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t,
                                                 ctypes.c_int64)
