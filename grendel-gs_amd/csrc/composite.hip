@@ -459,9 +459,14 @@ int gsr_launch_composite_backward(int P, int W, int H, const int32_t *ranges, co
                                   const int32_t *n_contrib, const float *dL_dpixels, float *dL_dmeans2D,
                                   float *dL_dconic_opacity, float *dL_drgb, hipStream_t stream) {
     const int gx = (W + GSR_BLOCK_X - 1) / GSR_BLOCK_X, gy = (H + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y;
-    GSR_HIP(hipMemsetAsync(dL_dmeans2D, 0, sizeof(float) * 2 * (size_t)P, stream));
-    GSR_HIP(hipMemsetAsync(dL_dconic_opacity, 0, sizeof(float) * 4 * (size_t)P, stream));
-    GSR_HIP(hipMemsetAsync(dL_drgb, 0, sizeof(float) * 3 * (size_t)P, stream));
+    if (dL_dconic_opacity == dL_dmeans2D + 2 * (size_t)P && dL_drgb == dL_dconic_opacity + 4 * (size_t)P) {
+        // the three outputs carved out of one buffer (what the Python wrapper does): one fill instead of three
+        GSR_HIP(hipMemsetAsync(dL_dmeans2D, 0, sizeof(float) * 9 * (size_t)P, stream));
+    } else {
+        GSR_HIP(hipMemsetAsync(dL_dmeans2D, 0, sizeof(float) * 2 * (size_t)P, stream));
+        GSR_HIP(hipMemsetAsync(dL_dconic_opacity, 0, sizeof(float) * 4 * (size_t)P, stream));
+        GSR_HIP(hipMemsetAsync(dL_drgb, 0, sizeof(float) * 3 * (size_t)P, stream));
+    }
     if (P == 0) return 0;
     hipLaunchKernelGGL(composite_backward_kernel, dim3(gx * gy), dim3(256), 0, stream, W, H, gx,
                        reinterpret_cast<const int2 *>(ranges), point_list, reinterpret_cast<const float2 *>(means2D),

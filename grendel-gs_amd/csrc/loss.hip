@@ -171,6 +171,36 @@ l1_ssim_backward_kernel(int rows, int W, const float *__restrict__ image, long l
         grad_l1_sum[0] * sgn + grad_ssim_sum[0] * (c1 + 2.f * x * c2 + y * c3);
 }
 
+// one workgroup: deterministic (fixed-order) reduction of the per-workgroup partial sums, then
+//   out[0] = loss = c_l1 * S_l1 + c_ssim * S_ssim + bias,  out[1] = S_l1 * inv_n (Ll1),  out[2] = S_ssim * inv_n (ssim)
+__global__ void __launch_bounds__(256) l1_ssim_finalize_kernel(int nb, const float *__restrict__ partials, float c_l1,
+                                                                float c_ssim, float bias, float inv_n,
+                                                                float *__restrict__ out) {
+    __shared__ double red[2][4];
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < nb; i += 256) {
+        a += (double)partials[2 * i];
+        b += (double)partials[2 * i + 1];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        a += __shfl_xor(a, d, 64);
+        b += __shfl_xor(b, d, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = a;
+        red[1][threadIdx.x >> 6] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float s1 = (float)(red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        const float s2 = (float)(red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+        out[0] = c_l1 * s1 + c_ssim * s2 + bias;
+        out[1] = s1 * inv_n;
+        out[2] = s2 * inv_n;
+    }
+}
+
 }  // namespace
 
 extern "C" int gsr_l1_ssim_num_partials(int channels, int rows, int width) {
@@ -205,6 +235,15 @@ extern "C" int gsr_l1_ssim_backward(int channels, int rows, int width, const flo
     hipLaunchKernelGGL(l1_ssim_backward_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), rows, width,
                        image, (long long)image_channel_stride, gt, dm_dmu1, dm_dE11, dm_dE12, grad_l1_sum,
                        grad_ssim_sum, grad_image, (long long)grad_channel_stride);
+    GSR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gsr_l1_ssim_finalize(int num_partials, const float *partials, float c_l1, float c_ssim, float bias,
+                                    float inv_n, float *out3, gsr_stream_t stream) {
+    if (num_partials < 0 || !out3 || (num_partials > 0 && !partials)) return GSR_EINVAL;
+    hipLaunchKernelGGL(l1_ssim_finalize_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       num_partials, partials, c_l1, c_ssim, bias, inv_n, out3);
     GSR_LAUNCH_CHECK();
     return 0;
 }

@@ -25,7 +25,7 @@ from . import _lib
 from ._lib import check, lib
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "_C", "load_image_tiles_by_pos",
-           "merge_image_tiles_by_pos", "set_timing_mode", "fused_l1_ssim_band", "fused_activations", "pack_camera",
+           "merge_image_tiles_by_pos", "set_timing_mode", "fused_l1_ssim_band", "fused_band_loss", "fused_activations", "pack_camera",
            "preprocess_gaussians_raw_batched", "knn_mean_dist2", "group_rows", "gather_rows", "exchange_need"]
 
 BLOCK_X, BLOCK_Y, ONE_DIM_BLOCK_SIZE = 16, 16, 256
@@ -296,20 +296,40 @@ class _PreprocessGaussiansRawBatched(torch.autograd.Function):
                 _stream()), "gsr_preprocess_forward_raw_batched")
         ctx.meta = (int(sh_degree), float(scale_modifier), int(width), int(height), M)
         ctx.save_for_backward(xyz, scaling, rotation, features_dc, features_rest, opacity, cams, radii, cov3D, clamped)
-        ctx.mark_non_differentiable(radii, depths)
-        return means2D, rgb, conic_opacity, radii, depths
+        # per-camera outputs are separate autograd outputs (dense views of the camera-major buffers): a caller
+        # that uses camera k alone gets its gradient straight back, without the zeros + copy of a select-backward
+        outs = []
+        for k in range(B):
+            outs += [means2D[k], rgb[k], conic_opacity[k], radii[k], depths[k]]
+        ctx.mark_non_differentiable(*[o for i, o in enumerate(outs) if i % 5 >= 3])
+        return tuple(outs)
 
     @staticmethod
-    def backward(ctx, g_means2D, g_rgb, g_conic_opacity, g_radii, g_depths):
+    def backward(ctx, *grads):
         xyz, scaling, rotation, f_dc, f_rest, opacity, cams, radii, cov3D, clamped = ctx.saved_tensors
         deg, smod, W, H, M = ctx.meta
         P, B = xyz.shape[0], cams.shape[0]
         dev = xyz.device
 
-        def z(g, cols):
-            return torch.zeros((B, P, cols), dtype=torch.float32, device=dev) if g is None else g.float().contiguous()
+        def assemble(col, cols):
+            """[B,P,cols] gradient buffer of output `col` (0 means2D, 1 rgb, 2 conic_opacity) without copies when
+            there is one camera or the per-camera gradients already are the slices of one dense buffer"""
+            gs = [grads[5 * k + col] for k in range(B)]
+            if B == 1:
+                return torch.zeros((1, P, cols), dtype=torch.float32, device=dev) if gs[0] is None \
+                    else gs[0].float().contiguous()
+            if all(g is not None and g.dtype == torch.float32 and g.is_contiguous() for g in gs):
+                base, step = gs[0]._base, P * cols * 4
+                if base is not None and all(g._base is base and g.data_ptr() == gs[0].data_ptr() + k * step
+                                            for k, g in enumerate(gs)):
+                    return gs[0]  # slices of one dense [B,P,cols] block (e.g. an unbound stack gradient)
+            out = torch.zeros((B, P, cols), dtype=torch.float32, device=dev)
+            for k, g in enumerate(gs):
+                if g is not None:
+                    out[k].copy_(g)
+            return out
 
-        g_means2D, g_rgb, g_conic_opacity = z(g_means2D, 2), z(g_rgb, 3), z(g_conic_opacity, 4)
+        g_means2D, g_rgb, g_conic_opacity = assemble(0, 2), assemble(1, 3), assemble(2, 4)
         d_xyz = torch.empty((P, 3), dtype=torch.float32, device=dev)
         d_scaling = torch.empty((P, 3), dtype=torch.float32, device=dev)
         d_rot = torch.empty((P, 4), dtype=torch.float32, device=dev)
@@ -337,10 +357,12 @@ class _PreprocessGaussiansRawBatched(torch.autograd.Function):
 
 def preprocess_gaussians_raw_batched(xyz, scaling, rotation, features_dc, features_rest, opacity, cams, sh_degree,
                                      scale_modifier, width, height, tanfov0=None):
-    """-> camera-major (means2D [B,P,2], rgb [B,P,3], conic_opacity [B,P,4], radii int32 [B,P], depths [B,P]) for the
-    B cameras packed in `cams` [B,40] (pack_camera); extension of this build used by the gaussian_renderer mirror."""
-    return _PreprocessGaussiansRawBatched.apply(xyz, scaling, rotation, features_dc, features_rest, opacity, cams,
+    """-> per-camera lists (means2D [P,2], rgb [P,3], conic_opacity [P,4], radii int32 [P], depths [P]) x B for the B
+    cameras packed in `cams` [B,40] (pack_camera); entry k of each list is a dense view of a camera-major [B,P,.]
+    buffer.  Extension of this build used by the gaussian_renderer mirror."""
+    flat = _PreprocessGaussiansRawBatched.apply(xyz, scaling, rotation, features_dc, features_rest, opacity, cams,
                                                 sh_degree, scale_modifier, width, height, tanfov0)
+    return tuple([flat[5 * k + c] for k in range(cams.shape[0])] for c in range(5))
 
 
 # ------------------------------------------------------------------------------- K3..K8 / K10
@@ -431,9 +453,11 @@ class _RenderGaussians(torch.autograd.Function):
         P = means2D.shape[0]
         dev = means2D.device
         g_out = g_out.float().contiguous()
-        d_means2D = torch.empty((P, 2), dtype=torch.float32, device=dev)
-        d_conic_opacity = torch.empty((P, 4), dtype=torch.float32, device=dev)
-        d_rgb = torch.empty((P, 3), dtype=torch.float32, device=dev)
+        # one buffer, three dense views: the library zero-fills it with a single launch
+        d_all = torch.empty((9 * P,), dtype=torch.float32, device=dev)
+        d_means2D = d_all[:2 * P].view(P, 2)
+        d_conic_opacity = d_all[2 * P:6 * P].view(P, 4)
+        d_rgb = d_all[6 * P:].view(P, 3)
         timing = ctx.timing
         with torch.cuda.device(dev):
             if timing != "off":
@@ -558,6 +582,76 @@ class _FusedL1SSIMBand(torch.autograd.Function):
 def fused_l1_ssim_band(image, gt_u8, y0, y1):
     """-> (sum of |x - gt/255| , sum of the SSIM map) over rows [y0, y1) of image [C,H,W]"""
     return _FusedL1SSIMBand.apply(image, gt_u8, int(y0), int(y1))
+
+
+class _FusedBandLoss(torch.autograd.Function):
+    """loss = (1 - lambda) * Ll1 + lambda * (1 - ssim) of one rendered row band, Ll1 = sum|x - gt| / n and
+    ssim = sum(ssim_map) / n with n = H*W*3 of the FULL image (gaussian_renderer/loss_distribution.py:2567-2576,
+    2627-2629), as two launches forward (map kernel + finalize) and two backward (scalar scale + map kernel) --
+    the reference's ~30 elementwise launches around its conv2d-based maps are gone.  Returns
+    (loss, Ll1, ssim); the last two are detached (logging only)."""
+
+    _coef_cache = {}
+
+    @staticmethod
+    def forward(ctx, image, gt_u8, y0, y1, lambda_dssim, n):
+        if not image.is_cuda:
+            raise RuntimeError("fused_band_loss: device tensors required (no CPU fallback)")
+        image = image.float().contiguous()
+        C, H, W = image.shape
+        rows = y1 - y0
+        gt_u8 = gt_u8.contiguous()
+        if gt_u8.dtype != torch.uint8 or tuple(gt_u8.shape) != (C, rows, W):
+            raise ValueError(f"gt band must be uint8 [{C},{rows},{W}], got {gt_u8.dtype} {tuple(gt_u8.shape)}")
+        dev = image.device
+        need_grad = ctx.needs_input_grad[0]
+        nb = lib.gsr_l1_ssim_num_partials(C, rows, W)
+        partials = torch.empty((max(nb, 1), 2), dtype=torch.float32, device=dev)
+        maps = torch.empty((3, C, rows, W), dtype=torch.float32, device=dev) if need_grad else None
+        out3 = torch.empty((3,), dtype=torch.float32, device=dev)
+        c_l1, c_ssim = (1.0 - lambda_dssim) / n, -lambda_dssim / n
+        band_ptr = ctypes.c_void_p(image.data_ptr() + 4 * y0 * W)
+        with torch.cuda.device(dev):
+            with kernel_timer.range("l1_ssim_forward"):
+                check(lib.gsr_l1_ssim_forward(C, rows, W, band_ptr, H * W, _ptr(gt_u8), _ptr(partials),
+                                              _ptr(maps[0]) if need_grad else None,
+                                              _ptr(maps[1]) if need_grad else None,
+                                              _ptr(maps[2]) if need_grad else None, _stream()), "gsr_l1_ssim_forward")
+            check(lib.gsr_l1_ssim_finalize(nb, _ptr(partials), c_l1, c_ssim, lambda_dssim, 1.0 / n, _ptr(out3),
+                                           _stream()), "gsr_l1_ssim_finalize")
+        ctx.y0, ctx.y1, ctx.coef = y0, y1, (c_l1, c_ssim)
+        if need_grad:
+            ctx.save_for_backward(image, gt_u8, maps)
+        loss, Ll1, ssim = out3[0], out3[1], out3[2]
+        ctx.mark_non_differentiable(Ll1, ssim)
+        return loss, Ll1, ssim
+
+    @staticmethod
+    def backward(ctx, g_loss, _g1, _g2):
+        image, gt_u8, maps = ctx.saved_tensors
+        C, H, W = image.shape
+        y0, y1 = ctx.y0, ctx.y1
+        rows = y1 - y0
+        dev = image.device
+        key = (dev, ctx.coef)
+        coef = _FusedBandLoss._coef_cache.get(key)
+        if coef is None:
+            coef = _FusedBandLoss._coef_cache[key] = torch.tensor(ctx.coef, dtype=torch.float32, device=dev)
+        gvec = (coef * g_loss.float()).contiguous()  # (dL/dS_l1, dL/dS_ssim): one launch, read on the device
+        grad = torch.empty_like(image) if rows == H else torch.zeros_like(image)
+        band_ptr = ctypes.c_void_p(image.data_ptr() + 4 * y0 * W)
+        gband_ptr = ctypes.c_void_p(grad.data_ptr() + 4 * y0 * W)
+        with torch.cuda.device(dev), kernel_timer.range("l1_ssim_backward"):
+            check(lib.gsr_l1_ssim_backward(C, rows, W, band_ptr, H * W, _ptr(gt_u8), _ptr(maps[0]), _ptr(maps[1]),
+                                           _ptr(maps[2]), ctypes.c_void_p(gvec.data_ptr()),
+                                           ctypes.c_void_p(gvec.data_ptr() + 4), gband_ptr, H * W, _stream()),
+                  "gsr_l1_ssim_backward")
+        return grad, None, None, None, None, None
+
+
+def fused_band_loss(image, gt_u8, y0, y1, lambda_dssim, n):
+    """-> (loss, Ll1, ssim) of rows [y0, y1) of image [C,H,W]; n = H*W*3 of the full image"""
+    return _FusedBandLoss.apply(image, gt_u8, int(y0), int(y1), float(lambda_dssim), float(n))
 
 
 # ------------------------------------------------------------------------- a19: fused activations

@@ -39,6 +39,7 @@ SIGNATURES = {
                                     c_void_p, c_void_p]),
     "gsr_l1_ssim_backward": (c_int, [c_int, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "gsr_l1_ssim_finalize": (c_int, [c_int, c_void_p, c_float, c_float, c_float, c_float, c_void_p, c_void_p]),
     "gsr_exchange_need": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p]),
     "gsr_knn_workspace_bytes": (c_size_t, [c_int]),

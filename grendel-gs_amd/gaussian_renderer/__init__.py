@@ -199,11 +199,27 @@ class _BatchedExchange(torch.autograd.Function):
         return grads[0], grads[1], grads[2], None, None, None, None, None, None, None, None
 
 
-def _batched_exchange_final(m2_views, rgb_all, co_all, radii_all, depths_all, rasterizers, batched_strategies):
+def _camera_major(per_camera):
+    """[B,P,.] tensor of per-camera tensors: their common dense base when they are its slices and carry no
+    gradient (radii, depths), else a differentiable stack"""
+    t0 = per_camera[0]
+    base = t0._base
+    if (not t0.requires_grad and base is not None and base.is_contiguous() and base.shape[0] == len(per_camera)
+            and tuple(base.shape[1:]) == tuple(t0.shape)
+            and all(t._base is base and t.data_ptr() == base.data_ptr() + k * t0.numel() * t0.element_size()
+                    for k, t in enumerate(per_camera))):
+        return base
+    return torch.stack(list(per_camera))
+
+
+def _batched_exchange_final(m2_views, rgb_views, co_views, radii_views, depths_views, rasterizers,
+                            batched_strategies):
     """all_to_all_communication_final for the camera-batched state: same return structure, ~15 launches per
     batch instead of ~15 per camera (and no per-band nonzero)."""
     group = utils.DEFAULT_GROUP
     W, me = group.size(), group.rank()
+    rgb_all, co_all = _camera_major(rgb_views), _camera_major(co_views)
+    radii_all, depths_all = _camera_major(radii_views), _camera_major(depths_views)
     B, P = radii_all.shape
     dev = radii_all.device
     rs = rasterizers[0].raster_settings
@@ -211,7 +227,7 @@ def _batched_exchange_final(m2_views, rgb_all, co_all, radii_all, depths_all, ra
     for k, strategy in enumerate(batched_strategies):
         for j, g in enumerate(strategy.gpu_ids):
             bands[k][g] = (strategy.division_pos[j], strategy.division_pos[j + 1])
-    m2 = torch.stack(m2_views)  # keeps the per-camera means2D views in the graph (their .grad feeds densification)
+    m2 = _camera_major(m2_views)  # a stack: keeps the per-camera means2D in the graph (their .grad feeds densification)
     need, counts = _dgr.exchange_need(m2, radii_all, torch.tensor(bands, dtype=torch.int32), rs.image_width,
                                       rs.image_height)
     all_counts = torch.empty((W * W, B), dtype=torch.int32, device=dev)

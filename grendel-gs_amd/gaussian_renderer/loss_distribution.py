@@ -23,8 +23,9 @@ import utils.general_utils as utils
 
 try:  # the fused HIP loss of this package's operator module (absent when running on the reference's CUDA op)
     from diff_gaussian_rasterization import fused_l1_ssim_band as _FUSED
+    from diff_gaussian_rasterization import fused_band_loss as _FUSED_LOSS
 except ImportError:  # pragma: no cover
-    _FUSED = None
+    _FUSED = _FUSED_LOSS = None
 
 _WINDOW_CACHE = {}
 
@@ -174,22 +175,35 @@ def batched_loss_computation(batched_image, batched_cameras, batched_compute_loc
     timers = utils.get_timers()
     if timers is not None:
         timers.start("loss_computation")
-    total = 0
+    total = None
     parts = []
     for image, camera, mask, strategy, stats in zip(batched_image, batched_cameras, batched_compute_locally,
                                                     batched_strategies, batched_statistic_collector):
         if image is None:  # not rendered here
-            loss = 0
             parts.append([0.0, 0.0])
-        elif image.dim() == 0:  # scalar stand-in (< 10 Gaussians): keeps the graph, contributes nothing
+            continue
+        if image.dim() == 0:  # scalar stand-in (< 10 Gaussians): keeps the graph, contributes nothing
             loss = image * 0
             parts.append([loss, 0.0])
+        elif _FUSED_LOSS is not None and image.is_cuda:
+            # the whole band loss in one autograd node (map kernel + finalize); HIP events instead of the
+            # reference's two device syncs per camera (loss_distribution.py:2566,2578)
+            j = strategy.gpu_ids.index(utils.GLOBAL_RANK)
+            y0, y1 = get_coverage_y_min_max(strategy.division_pos[j], strategy.division_pos[j + 1])
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            loss, Ll1, ssim = _FUSED_LOSS(image, camera.original_image, y0, y1, args.lambda_dssim,
+                                          utils.get_num_pixels() * 3)
+            ev1.record()
+            stats["_loss_events"] = (ev0, ev1)
+            stats.setdefault("forward_loss_time", 0.0)
+            parts.append([Ll1, ssim])
         else:
             Ll1, ssim = final_system_loss_computation(image, camera, mask, strategy, stats)
             loss = (1.0 - args.lambda_dssim) * Ll1 + args.lambda_dssim * (1.0 - ssim)
             parts.append([Ll1, ssim])
-        total = total + loss
+        total = loss if total is None else total + loss
     assert torch.is_tensor(total) and total.dim() == 0, "The loss_sum must be a scalar tensor."
     if timers is not None:
         timers.stop("loss_computation")
-    return total * args.lr_scale_loss, parts
+    return (total if args.lr_scale_loss == 1.0 else total * args.lr_scale_loss), parts

@@ -44,6 +44,9 @@ def division_pos_heuristic(heuristic, tile_num, world_size, right=False):
     return [0] + cuts.tolist() + [tile_num]
 
 
+_MASK_CACHE = {}
+
+
 class DivisionStrategyFinal:
     """row-band partition of ONE camera among the `gpu_ids` that render a part of it"""
 
@@ -89,8 +92,15 @@ class DivisionStrategyFinal:
         rows = self._my_rows()
         if rows is None:
             return None
-        mask = torch.zeros((utils.TILE_Y, utils.TILE_X), dtype=torch.bool, device=utils.device())
-        mask[rows[0]:rows[1]] = True
+        # read-only masks, one per (band, grid, device), built once: no fill kernels in the steady state
+        key = (rows[0], rows[1], utils.TILE_Y, utils.TILE_X, str(utils.device()))
+        mask = _MASK_CACHE.get(key)
+        if mask is None:
+            if len(_MASK_CACHE) > 4096:
+                _MASK_CACHE.clear()
+            mask = torch.zeros((utils.TILE_Y, utils.TILE_X), dtype=torch.bool, device=utils.device())
+            mask[rows[0]:rows[1]] = True
+            _MASK_CACHE[key] = mask
         return mask
 
     def get_compute_locally_all(self):

@@ -147,6 +147,12 @@ int gsr_l1_ssim_backward(int channels, int rows, int width, const float *image, 
                          const uint8_t *gt, const float *dm_dmu1, const float *dm_dE11, const float *dm_dE12,
                          const float *grad_l1_sum, const float *grad_ssim_sum, float *grad_image,
                          int64_t grad_channel_stride, gsr_stream_t stream);
+/* finalize: adds the partials up (fixed order, fp64 accumulation) and forms the band's loss terms in one
+ * launch: out3[0] = c_l1 * S_l1 + c_ssim * S_ssim + bias  (batched_loss_computation's
+ * (1 - lambda) * Ll1 + lambda * (1 - ssim) with c_l1 = (1-lambda)/n, c_ssim = -lambda/n, bias = lambda;
+ * gaussian_renderer/loss_distribution.py:2627-2629), out3[1] = S_l1 * inv_n, out3[2] = S_ssim * inv_n. */
+int gsr_l1_ssim_finalize(int num_partials, const float *partials, float c_l1, float c_ssim, float bias, float inv_n,
+                         float *out3, gsr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * N3  fused Adam step for one parameter tensor of n fp32 elements (16-byte aligned, dense):
