@@ -20,8 +20,10 @@ namespace {
 __constant__ const float WIN[11] = {1.0283801239e-03f, 7.5987582095e-03f, 3.6000773311e-02f, 1.0936068743e-01f,
                                     2.1300552785e-01f, 2.6601171494e-01f, 2.1300552785e-01f, 1.0936068743e-01f,
                                     3.6000773311e-02f, 7.5987582095e-03f, 1.0283801239e-03f};
-constexpr int TS = 16;        // output tile edge
-constexpr int HS = TS + 10;   // halo tile edge
+constexpr int TW = 32, TH = 32;          // output tile of one 256-thread workgroup: 4 outputs per thread
+constexpr int HW = TW + 10, HH = TH + 10;  // halo tile
+constexpr int HSTR = TW + 8;             // row stride of the horizontal-pass results (4 rows = 32 banks apart)
+constexpr int TS = TW;                   // (partials are per workgroup: see gsr_l1_ssim_num_partials)
 constexpr float SSIM_C1 = 0.01f * 0.01f;
 constexpr float SSIM_C2 = 0.03f * 0.03f;
 
@@ -36,19 +38,22 @@ __device__ __forceinline__ float block_sum(float v, float *smem) {
     return r;
 }
 
+// Both kernels are separable 11-tap convolutions out of LDS with REGISTER sliding windows: a thread produces
+// 4 adjacent outputs from 14 loaded values (horizontal: 4 columns of a row, vertical: 4 rows of a column), i.e.
+// 3.5 LDS reads per output and map instead of 11 -- the passes are LDS-bandwidth-bound, not FMA-bound.
 __global__ void __launch_bounds__(256)
 l1_ssim_forward_kernel(int rows, int W, const float *__restrict__ image, long long img_cstride,
                        const uint8_t *__restrict__ gt, float *__restrict__ partials, float *__restrict__ M1,
                        float *__restrict__ M2, float *__restrict__ M3) {
-    __shared__ float sX[HS][HS + 1], sY[HS][HS + 1];
-    __shared__ float hor[5][HS][TS + 1];
+    __shared__ float sX[HH][HW + 1], sY[HH][HW + 1];
+    __shared__ float hor[5][HH][HSTR];
     __shared__ float red[4];
-    const int c = blockIdx.z, ox = blockIdx.x * TS, oy = blockIdx.y * TS;
+    const int c = blockIdx.z, ox = blockIdx.x * TW, oy = blockIdx.y * TH;
     const int tid = threadIdx.x;
     const float *img_c = image + (long long)c * img_cstride;
     const uint8_t *gt_c = gt + (size_t)c * rows * W;
-    for (int idx = tid; idx < HS * HS; idx += 256) {
-        const int ly = idx / HS, lx = idx % HS;
+    for (int idx = tid; idx < HH * HW; idx += 256) {
+        const int ly = idx / HW, lx = idx % HW;
         const int gy = oy + ly - 5, gx = ox + lx - 5;
         float x = 0.f, y = 0.f;
         if (gy >= 0 && gy < rows && gx >= 0 && gx < W) {
@@ -59,53 +64,72 @@ l1_ssim_forward_kernel(int rows, int W, const float *__restrict__ image, long lo
         sY[ly][lx] = y;
     }
     __syncthreads();
-    for (int idx = tid; idx < HS * TS; idx += 256) {
-        const int r = idx / TS, cx = idx % TS;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+    for (int task = tid; task < HH * (TW / 4); task += 256) {
+        const int r = task / (TW / 4), cx0 = (task % (TW / 4)) * 4;
+        float xv[14], yv[14];
 #pragma unroll
-        for (int k = 0; k < 11; k++) {
-            const float w = WIN[k], x = sX[r][cx + k], y = sY[r][cx + k];
-            a0 += w * x;
-            a1 += w * y;
-            a2 += w * x * x;
-            a3 += w * y * y;
-            a4 += w * x * y;
+        for (int i = 0; i < 14; i++) {
+            xv[i] = sX[r][cx0 + i];
+            yv[i] = sY[r][cx0 + i];
         }
-        hor[0][r][cx] = a0; hor[1][r][cx] = a1; hor[2][r][cx] = a2; hor[3][r][cx] = a3; hor[4][r][cx] = a4;
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 11; k++) {
+                const float w = WIN[k], x = xv[o + k], y = yv[o + k];
+                a0 += w * x;
+                a1 += w * y;
+                a2 += w * x * x;
+                a3 += w * y * y;
+                a4 += w * x * y;
+            }
+            hor[0][r][cx0 + o] = a0; hor[1][r][cx0 + o] = a1; hor[2][r][cx0 + o] = a2;
+            hor[3][r][cx0 + o] = a3; hor[4][r][cx0 + o] = a4;
+        }
     }
     __syncthreads();
-    const int ty = tid / TS, tx = tid % TS;
-    float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+    const int tx = tid % TW, ty0 = (tid / TW) * 4;
+    float acc[5][4];
 #pragma unroll
-    for (int k = 0; k < 11; k++) {
-        const float w = WIN[k];
-        mu1 += w * hor[0][ty + k][tx];
-        mu2 += w * hor[1][ty + k][tx];
-        e11 += w * hor[2][ty + k][tx];
-        e22 += w * hor[3][ty + k][tx];
-        e12 += w * hor[4][ty + k][tx];
+    for (int m = 0; m < 5; m++) {
+        float v[14];
+#pragma unroll
+        for (int i = 0; i < 14; i++) v[i] = hor[m][ty0 + i][tx];
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+            float a = 0.f;
+#pragma unroll
+            for (int k = 0; k < 11; k++) a += WIN[k] * v[o + k];
+            acc[m][o] = a;
+        }
     }
-    const int gy = oy + ty, gx = ox + tx;
-    const bool inside = gy < rows && gx < W;
-    float l1 = 0.f, ssim = 0.f;
-    if (inside) {
-        const float x = sX[ty + 5][tx + 5], y = sY[ty + 5][tx + 5];
-        const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
-        const float s1 = e11 - mu1_sq, s2 = e22 - mu2_sq, s12 = e12 - mu12;
-        const float A = 2.f * mu12 + SSIM_C1, B = 2.f * s12 + SSIM_C2;
-        const float Cd = mu1_sq + mu2_sq + SSIM_C1, Dd = s1 + s2 + SSIM_C2;
-        const float inv = 1.0f / (Cd * Dd);
-        ssim = A * B * inv;
-        l1 = fabsf(x - y);
-        if (M1) {
-            const size_t o = ((size_t)c * rows + gy) * W + gx;
-            M1[o] = 2.f * mu2 * (B - A) * inv - ssim * 2.f * mu1 * (Dd - Cd) * inv;
-            M2[o] = -ssim / Dd;
-            M3[o] = 2.f * A * inv;
+    const int gx = ox + tx;
+    float l1 = 0.f, ssim_sum = 0.f;
+#pragma unroll
+    for (int o = 0; o < 4; o++) {
+        const int ty = ty0 + o, gy = oy + ty;
+        if (gy < rows && gx < W) {
+            const float mu1 = acc[0][o], mu2 = acc[1][o], e11 = acc[2][o], e22 = acc[3][o], e12 = acc[4][o];
+            const float x = sX[ty + 5][tx + 5], y = sY[ty + 5][tx + 5];
+            const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+            const float s1 = e11 - mu1_sq, s2 = e22 - mu2_sq, s12 = e12 - mu12;
+            const float A = 2.f * mu12 + SSIM_C1, B = 2.f * s12 + SSIM_C2;
+            const float Cd = mu1_sq + mu2_sq + SSIM_C1, Dd = s1 + s2 + SSIM_C2;
+            const float inv = 1.0f / (Cd * Dd);
+            const float ssim = A * B * inv;
+            ssim_sum += ssim;
+            l1 += fabsf(x - y);
+            if (M1) {
+                const size_t off = ((size_t)c * rows + gy) * W + gx;
+                M1[off] = 2.f * mu2 * (B - A) * inv - ssim * 2.f * mu1 * (Dd - Cd) * inv;
+                M2[off] = -ssim / Dd;
+                M3[off] = 2.f * A * inv;
+            }
         }
     }
     const float sl1 = block_sum(l1, red);
-    const float sss = block_sum(ssim, red);
+    const float sss = block_sum(ssim_sum, red);
     if (tid == 0) {
         const size_t b = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
         partials[2 * b] = sl1;
@@ -119,13 +143,13 @@ l1_ssim_backward_kernel(int rows, int W, const float *__restrict__ image, long l
                         const float *__restrict__ M3, const float *__restrict__ grad_l1_sum,
                         const float *__restrict__ grad_ssim_sum, float *__restrict__ grad_image,
                         long long grad_cstride) {
-    __shared__ float sM[3][HS][HS + 1];
-    __shared__ float hor[3][HS][TS + 1];
-    const int c = blockIdx.z, ox = blockIdx.x * TS, oy = blockIdx.y * TS;
+    __shared__ float sM[3][HH][HW + 1];
+    __shared__ float hor[3][HH][HSTR];
+    const int c = blockIdx.z, ox = blockIdx.x * TW, oy = blockIdx.y * TH;
     const int tid = threadIdx.x;
     const size_t cbase = (size_t)c * rows * W;
-    for (int idx = tid; idx < HS * HS; idx += 256) {
-        const int ly = idx / HS, lx = idx % HS;
+    for (int idx = tid; idx < HH * HW; idx += 256) {
+        const int ly = idx / HW, lx = idx % HW;
         const int gy = oy + ly - 5, gx = ox + lx - 5;
         float a = 0.f, b = 0.f, d = 0.f;
         if (gy >= 0 && gy < rows && gx >= 0 && gx < W) {
@@ -139,36 +163,52 @@ l1_ssim_backward_kernel(int rows, int W, const float *__restrict__ image, long l
         sM[2][ly][lx] = d;
     }
     __syncthreads();
-    for (int idx = tid; idx < HS * TS; idx += 256) {
-        const int r = idx / TS, cx = idx % TS;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int task = tid; task < HH * (TW / 4); task += 256) {
+        const int r = task / (TW / 4), cx0 = (task % (TW / 4)) * 4;
 #pragma unroll
-        for (int k = 0; k < 11; k++) {
-            const float w = WIN[k];
-            a0 += w * sM[0][r][cx + k];
-            a1 += w * sM[1][r][cx + k];
-            a2 += w * sM[2][r][cx + k];
+        for (int m = 0; m < 3; m++) {
+            float v[14];
+#pragma unroll
+            for (int i = 0; i < 14; i++) v[i] = sM[m][r][cx0 + i];
+#pragma unroll
+            for (int o = 0; o < 4; o++) {
+                float a = 0.f;
+#pragma unroll
+                for (int k = 0; k < 11; k++) a += WIN[k] * v[o + k];
+                hor[m][r][cx0 + o] = a;
+            }
         }
-        hor[0][r][cx] = a0; hor[1][r][cx] = a1; hor[2][r][cx] = a2;
     }
     __syncthreads();
-    const int ty = tid / TS, tx = tid % TS;
-    const int gy = oy + ty, gx = ox + tx;
-    if (gy >= rows || gx >= W) return;
-    float c1 = 0.f, c2 = 0.f, c3 = 0.f;
+    const int tx = tid % TW, ty0 = (tid / TW) * 4;
+    float cv[3][4];
 #pragma unroll
-    for (int k = 0; k < 11; k++) {
-        const float w = WIN[k];
-        c1 += w * hor[0][ty + k][tx];
-        c2 += w * hor[1][ty + k][tx];
-        c3 += w * hor[2][ty + k][tx];
+    for (int m = 0; m < 3; m++) {
+        float v[14];
+#pragma unroll
+        for (int i = 0; i < 14; i++) v[i] = hor[m][ty0 + i][tx];
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+            float a = 0.f;
+#pragma unroll
+            for (int k = 0; k < 11; k++) a += WIN[k] * v[o + k];
+            cv[m][o] = a;
+        }
     }
-    const float x = image[(long long)c * img_cstride + (size_t)gy * W + gx];
-    const float y = (float)gt[cbase + (size_t)gy * W + gx] * (1.0f / 255.0f);
-    const float d = x - y;
-    const float sgn = (d > 0.f ? 1.f : 0.f) - (d < 0.f ? 1.f : 0.f);
-    grad_image[(long long)c * grad_cstride + (size_t)gy * W + gx] =
-        grad_l1_sum[0] * sgn + grad_ssim_sum[0] * (c1 + 2.f * x * c2 + y * c3);
+    const int gx = ox + tx;
+    if (gx >= W) return;
+    const float gl1 = grad_l1_sum[0], gss = grad_ssim_sum[0];
+#pragma unroll
+    for (int o = 0; o < 4; o++) {
+        const int gy = oy + ty0 + o;
+        if (gy >= rows) break;
+        const float x = image[(long long)c * img_cstride + (size_t)gy * W + gx];
+        const float y = (float)gt[cbase + (size_t)gy * W + gx] * (1.0f / 255.0f);
+        const float d = x - y;
+        const float sgn = (d > 0.f ? 1.f : 0.f) - (d < 0.f ? 1.f : 0.f);
+        grad_image[(long long)c * grad_cstride + (size_t)gy * W + gx] =
+            gl1 * sgn + gss * (cv[0][o] + 2.f * x * cv[1][o] + y * cv[2][o]);
+    }
 }
 
 // one workgroup: deterministic (fixed-order) reduction of the per-workgroup partial sums, then
