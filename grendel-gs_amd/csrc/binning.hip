@@ -24,6 +24,8 @@
 // LDS per-wave digit tables, LDS digit-ordered staging for coalesced stores.
 #include "common.h"
 
+#include <atomic>
+#include <chrono>
 #include <mutex>
 
 #include "radix.h"
@@ -35,7 +37,8 @@ namespace {
 __global__ void __launch_bounds__(SCAN_THREADS)
 scan_gather_lookback_kernel(const uint32_t *__restrict__ src, const uint32_t *__restrict__ idx,
                             uint32_t *__restrict__ out, long long n, unsigned long long *__restrict__ state,
-                            uint32_t *__restrict__ ticket, int nb, uint32_t *__restrict__ host_total) {
+                            uint32_t *__restrict__ ticket, int nb, uint32_t *__restrict__ host_total,
+                            uint32_t seq) {
     __shared__ uint32_t smem[4];
     __shared__ uint32_t s_bid;
     __shared__ unsigned long long s_excl;
@@ -85,7 +88,9 @@ scan_gather_lookback_kernel(const uint32_t *__restrict__ src, const uint32_t *__
             s_excl = excl;
             if ((int)bid == nb - 1) {
                 out[n] = (uint32_t)(excl + tot);
-                *host_total = (uint32_t)(excl + tot);  // pinned host word: no copy command after the kernel
+                // pinned host words: value, then (system-scope release) the call's sequence tag the host polls
+                __hip_atomic_store(host_total, (uint32_t)(excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(host_total + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
     }
@@ -309,11 +314,15 @@ PrepLayout prep_layout(int P, int W, int H) {
     L.total = o;
     return L;
 }
-// One pinned, device-mapped word per device: K4's last workgroup stores the pair count there, the host reads
-// it after the stream synchronise (no D2H copy command, no pageable staging).  The mutex is held from the
-// launch to the read, so concurrent callers on one device take turns.
+// Two pinned, device-mapped words per device: K4's last workgroup stores the pair count and then the call's
+// sequence tag; the host POLLS the tag (a few microseconds after the store lands) instead of paying a stream
+// synchronise (interrupt + wake-up, ~30-40 us measured) -- everything the host launches after this point is on
+// the critical path of the iteration.  If the tag does not show up within ~2 ms the host falls back to
+// hipStreamSynchronize (which also surfaces a faulted kernel).  The mutex is held from the launch to the read,
+// so concurrent callers on one device take turns.
 std::mutex g_total_mutex;
 uint32_t *g_total_word[64] = {};
+uint32_t g_total_seq = 0;
 int total_word(uint32_t **host) {
     int dev = 0;
     GSR_HIP(hipGetDevice(&dev));
@@ -322,9 +331,27 @@ int total_word(uint32_t **host) {
         void *p = nullptr;
         GSR_HIP(hipHostMalloc(&p, 256, hipHostMallocDefault));
         g_total_word[dev] = reinterpret_cast<uint32_t *>(p);
+        g_total_word[dev][0] = g_total_word[dev][1] = 0;
     }
     *host = g_total_word[dev];
     return 0;
+}
+int wait_total(hipStream_t stream, uint32_t *host_total, uint32_t seq, uint32_t *total) {
+    volatile uint32_t *w = host_total;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (long spins = 0;; spins++) {
+        if (w[1] == seq) {
+            std::atomic_thread_fence(std::memory_order_acquire);
+            *total = w[0];
+            return 0;
+        }
+        if ((spins & 1023) == 1023 &&
+            std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2))
+            break;
+    }
+    GSR_HIP(hipStreamSynchronize(stream));
+    *total = w[0];
+    return w[1] == seq ? 0 : GSR_EINVAL;
 }
 int tile_bits(int tiles) {  // bits of the largest key value, the sentinel `tiles`
     int b = 1;
@@ -383,12 +410,14 @@ extern "C" int gsr_bin_prepare(int P, int width, int height, const float *means2
     uint32_t *host_total = nullptr;
     rc = total_word(&host_total);
     if (rc) return rc;
+    const uint32_t seq = ++g_total_seq ? g_total_seq : ++g_total_seq;  // never 0
     hipLaunchKernelGGL(scan_gather_lookback_kernel, dim3(nbs), dim3(SCAN_THREADS), 0, stream, tt, sorted_ids, offsets,
                        (long long)P, reinterpret_cast<unsigned long long *>(ctrl + L.C.scan_state),
-                       reinterpret_cast<uint32_t *>(ctrl + L.C.tickets), nbs, host_total);
+                       reinterpret_cast<uint32_t *>(ctrl + L.C.tickets), nbs, host_total, seq);
     GSR_LAUNCH_CHECK();
-    GSR_HIP(hipStreamSynchronize(stream));
-    const uint32_t total = *reinterpret_cast<volatile uint32_t *>(host_total);
+    uint32_t total = 0;
+    rc = wait_total(stream, host_total, seq, &total);
+    if (rc) return rc;
     *num_rendered_host = (int64_t)total;
     return 0;
 }

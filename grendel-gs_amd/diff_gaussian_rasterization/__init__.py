@@ -276,6 +276,7 @@ class _PreprocessGaussiansRawBatched(torch.autograd.Function):
         features_dc, features_rest = _f32c(features_dc, "features_dc"), _f32c(features_rest, "features_rest")
         opacity, cams = _f32c(opacity, "opacity"), _f32c(cams, "cams")
         ctx.tanfov0 = tanfov0
+        ctx.set_materialize_grads(False)  # unused outputs arrive as None, not as zero-filled tensors
         P, B = xyz.shape[0], cams.shape[0]
         if cams.dim() != 2 or cams.shape[1] != 40:
             raise ValueError("cams must be [B, 40]")
@@ -393,6 +394,7 @@ def bin_gaussians(means2D, depths, radii, conic_opacity, compute_locally, width,
 class _RenderGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means2D, conic_opacity, rgb, depths, radii, compute_locally, raster_settings, cuda_args):
+        ctx.set_materialize_grads(False)
         rs = raster_settings
         means2D, conic_opacity, rgb = _f32c(means2D, "means2D"), _f32c(conic_opacity, "conic_opacity"), _f32c(rgb, "rgb")
         depths = _f32c(depths, "depths")
@@ -452,6 +454,8 @@ class _RenderGaussians(torch.autograd.Function):
         H, W = int(rs.image_height), int(rs.image_width)
         P = means2D.shape[0]
         dev = means2D.device
+        if g_out is None:
+            return None, None, None, None, None, None, None, None
         g_out = g_out.float().contiguous()
         # one buffer, three dense views: the library zero-fills it with a single launch
         d_all = torch.empty((9 * P,), dtype=torch.float32, device=dev)
@@ -597,6 +601,7 @@ class _FusedBandLoss(torch.autograd.Function):
     def forward(ctx, image, gt_u8, y0, y1, lambda_dssim, n):
         if not image.is_cuda:
             raise RuntimeError("fused_band_loss: device tensors required (no CPU fallback)")
+        ctx.set_materialize_grads(False)
         image = image.float().contiguous()
         C, H, W = image.shape
         rows = y1 - y0
@@ -628,6 +633,8 @@ class _FusedBandLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_loss, _g1, _g2):
+        if g_loss is None:
+            return None, None, None, None, None, None
         image, gt_u8, maps = ctx.saved_tensors
         C, H, W = image.shape
         y0, y1 = ctx.y0, ctx.y1
