@@ -12,7 +12,7 @@ const char *gsr_error_string(int code) {
     return "gsraster: unknown error";
 }
 
-int gsr_abi_version(void) { return 2; }
+int gsr_abi_version(void) { return 3; }
 
 int gsr_get_block_xy(int *block_x, int *block_y, int *one_dim_block) {
     if (!block_x || !block_y || !one_dim_block) return GSR_EINVAL;
@@ -45,10 +45,10 @@ int gsr_preprocess_backward(int P, int sh_degree, int sh_coeffs, const float *me
                             const float *projmatrix, const float *campos, int width, int height, float tanfovx,
                             float tanfovy, const int32_t *radii, const float *cov3D, const uint8_t *clamped,
                             const float *dL_dmeans2D, const float *dL_dconic_opacity, const float *dL_drgb,
-                            float *dL_dmeans3D, float *dL_dscales, float *dL_drotations, float *dL_dshs,
-                            float *dL_dopacities, gsr_stream_t stream) {
+                            int grad_row_stride, float *dL_dmeans3D, float *dL_dscales, float *dL_drotations,
+                            float *dL_dshs, float *dL_dopacities, gsr_stream_t stream) {
     if (P < 0 || sh_degree < 0 || sh_degree > 3 || sh_coeffs < (sh_degree + 1) * (sh_degree + 1) || width <= 0 ||
-        height <= 0 || !(tanfovx > 0.f) || !(tanfovy > 0.f))
+        height <= 0 || !(tanfovx > 0.f) || !(tanfovy > 0.f) || grad_row_stride < 0)
         return GSR_EINVAL;
     if (P == 0) return 0;
     if (!means3D || !scales || !rotations || !shs || !viewmatrix || !projmatrix || !campos || !radii || !cov3D ||
@@ -57,8 +57,8 @@ int gsr_preprocess_backward(int P, int sh_degree, int sh_coeffs, const float *me
         return GSR_EINVAL;
     return gsr_launch_preprocess_backward(P, sh_degree, sh_coeffs, means3D, scales, scale_modifier, rotations, shs,
                                           nullptr, nullptr, viewmatrix, projmatrix, campos, width, height, tanfovx, tanfovy, radii,
-                                          cov3D, clamped, dL_dmeans2D, dL_dconic_opacity, dL_drgb, dL_dmeans3D,
-                                          dL_dscales, dL_drotations, dL_dshs, nullptr, dL_dopacities,
+                                          cov3D, clamped, dL_dmeans2D, dL_dconic_opacity, dL_drgb, grad_row_stride,
+                                          dL_dmeans3D, dL_dscales, dL_drotations, dL_dshs, nullptr, dL_dopacities,
                                           reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -87,10 +87,11 @@ int gsr_preprocess_backward_raw(int P, int sh_degree, int sh_coeffs, const float
                                 const float *projmatrix, const float *campos, int width, int height, float tanfovx,
                                 float tanfovy, const int32_t *radii, const float *cov3D, const uint8_t *clamped,
                                 const float *dL_dmeans2D, const float *dL_dconic_opacity, const float *dL_drgb,
-                                float *dL_dxyz, float *dL_dscaling, float *dL_drotation, float *dL_dfeatures_dc,
-                                float *dL_dfeatures_rest, float *dL_dopacity, gsr_stream_t stream) {
+                                int grad_row_stride, float *dL_dxyz, float *dL_dscaling, float *dL_drotation,
+                                float *dL_dfeatures_dc, float *dL_dfeatures_rest, float *dL_dopacity,
+                                gsr_stream_t stream) {
     if (P < 0 || sh_degree < 0 || sh_degree > 3 || sh_coeffs < 2 || sh_coeffs < (sh_degree + 1) * (sh_degree + 1) ||
-        width <= 0 || height <= 0 || !(tanfovx > 0.f) || !(tanfovy > 0.f))
+        width <= 0 || height <= 0 || !(tanfovx > 0.f) || !(tanfovy > 0.f) || grad_row_stride < 0)
         return GSR_EINVAL;
     if (P == 0) return 0;
     if (!xyz || !scaling || !rotation || !features_dc || !features_rest || !opacity || !viewmatrix || !projmatrix ||
@@ -100,7 +101,7 @@ int gsr_preprocess_backward_raw(int P, int sh_degree, int sh_coeffs, const float
     return gsr_launch_preprocess_backward(P, sh_degree, sh_coeffs, xyz, scaling, scale_modifier, rotation, features_dc,
                                           features_rest, opacity, viewmatrix, projmatrix, campos, width, height,
                                           tanfovx, tanfovy, radii, cov3D, clamped, dL_dmeans2D, dL_dconic_opacity,
-                                          dL_drgb, dL_dxyz, dL_dscaling, dL_drotation, dL_dfeatures_dc,
+                                          dL_drgb, grad_row_stride, dL_dxyz, dL_dscaling, dL_drotation, dL_dfeatures_dc,
                                           dL_dfeatures_rest, dL_dopacity, reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -129,16 +130,15 @@ int gsr_render_forward(int P, int width, int height, const int32_t *ranges, cons
 int gsr_render_backward(int P, int width, int height, const int32_t *ranges, const uint32_t *point_list,
                         const float *means2D, const float *conic_opacity, const float *rgb,
                         const uint8_t *compute_locally, const float *bg, const float *final_T,
-                        const int32_t *n_contrib, const float *dL_dpixels, float *dL_dmeans2D,
-                        float *dL_dconic_opacity, float *dL_drgb, gsr_stream_t stream) {
+                        const int32_t *n_contrib, const float *dL_dpixels, float *dL_record, gsr_stream_t stream) {
     if (P < 0 || width <= 0 || height <= 0) return GSR_EINVAL;
     if (P == 0) return 0;
     if (!ranges || !compute_locally || !bg || !final_T || !n_contrib || !dL_dpixels || !means2D || !conic_opacity ||
-        !rgb || !dL_dmeans2D || !dL_dconic_opacity || !dL_drgb)
+        !rgb || !dL_record)
         return GSR_EINVAL;
     return gsr_launch_composite_backward(P, width, height, ranges, point_list, means2D, conic_opacity, rgb,
-                                         compute_locally, bg, final_T, n_contrib, dL_dpixels, dL_dmeans2D,
-                                         dL_dconic_opacity, dL_drgb, reinterpret_cast<hipStream_t>(stream));
+                                         compute_locally, bg, final_T, n_contrib, dL_dpixels, dL_record,
+                                         reinterpret_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -91,7 +91,7 @@ int gsr_launch_preprocess_backward(int P, int D, int M, const float *means3D, co
                                    const float *shs_rest, const float *opacities_raw, const float *viewmatrix, const float *projmatrix, const float *campos, int W,
                                    int H, float tanfovx, float tanfovy, const int32_t *radii, const float *cov3D,
                                    const uint8_t *clamped, const float *dL_dmeans2D, const float *dL_dconic_opacity,
-                                   const float *dL_drgb, float *dL_dmeans3D, float *dL_dscales, float *dL_drotations,
+                                   const float *dL_drgb, int grad_row_stride, float *dL_dmeans3D, float *dL_dscales, float *dL_drotations,
                                    float *dL_dshs, float *dL_dshs_rest, float *dL_dopacities, hipStream_t stream);
 int gsr_launch_local2j(int P, int W, int H, int ws, const float *means2D, const int32_t *radii, const int32_t *div,
                        uint8_t *out, hipStream_t stream);
@@ -103,5 +103,5 @@ int gsr_launch_composite_forward(int P, int W, int H, const int32_t *ranges, con
 int gsr_launch_composite_backward(int P, int W, int H, const int32_t *ranges, const uint32_t *point_list,
                                   const float *means2D, const float *conic_opacity, const float *rgb,
                                   const uint8_t *compute_locally, const float *bg, const float *final_T,
-                                  const int32_t *n_contrib, const float *dL_dpixels, float *dL_dmeans2D,
-                                  float *dL_dconic_opacity, float *dL_drgb, hipStream_t stream);
+                                  const int32_t *n_contrib, const float *dL_dpixels, float *dL_record,
+                                  hipStream_t stream);

@@ -246,6 +246,19 @@ preprocess_forward_kernel(int P, int M, const float *__restrict__ means3D, const
 }
 
 // ------------------------------------------------------------------------------------------ K11
+// incoming gradients: dense [P,2] / [P,4] / [P,3] (gstride == 0, vector loads) or columns of rows that are
+// `gstride` floats apart -- e.g. the [P,9] gradient record K10 accumulates into (no repacking pass in between)
+__device__ __forceinline__ float2 grad_ld2(const float *__restrict__ p, size_t i, int gstride) {
+    if (gstride == 0) return reinterpret_cast<const float2 *>(p)[i];
+    const float *q = p + (size_t)gstride * i;
+    return make_float2(q[0], q[1]);
+}
+__device__ __forceinline__ float4 grad_ld4(const float *__restrict__ p, size_t i, int gstride) {
+    if (gstride == 0) return reinterpret_cast<const float4 *>(p)[i];
+    const float *q = p + (size_t)gstride * i;
+    return make_float4(q[0], q[1], q[2], q[3]);
+}
+
 template <int DEG, bool RAW>
 __global__ void __launch_bounds__(GSR_ONE_DIM_BLOCK)
 preprocess_backward_kernel(int P, int M, const float *__restrict__ means3D, const float *__restrict__ scales,
@@ -254,8 +267,8 @@ preprocess_backward_kernel(int P, int M, const float *__restrict__ means3D, cons
                            const float *__restrict__ view, const float *__restrict__ proj,
                            const float *__restrict__ campos, int W, int H, float tanfovx, float tanfovy,
                            const int32_t *__restrict__ radii, const float *__restrict__ cov3D,
-                           const uint8_t *__restrict__ clamped, const float2 *__restrict__ dL_dmeans2D,
-                           const float4 *__restrict__ dL_dconic_opacity, const float *__restrict__ dL_drgb,
+                           const uint8_t *__restrict__ clamped, const float *__restrict__ dL_dmeans2D,
+                           const float *__restrict__ dL_dconic_opacity, const float *__restrict__ dL_drgb, int gstride,
                            float *__restrict__ dL_dmeans3D, float *__restrict__ dL_dscales,
                            float4 *__restrict__ dL_drotations, float *__restrict__ dL_dshs,
                            float *__restrict__ dL_dshs_rest, float *__restrict__ dL_dopacities) {
@@ -285,7 +298,7 @@ preprocess_backward_kernel(int P, int M, const float *__restrict__ means3D, cons
     const Cam cam = load_cam(view, proj, campos);
     const float fx = W / (2.0f * tanfovx), fy = H / (2.0f * tanfovy);
     const float p[3] = {means3D[3 * (size_t)i], means3D[3 * (size_t)i + 1], means3D[3 * (size_t)i + 2]};
-    const float4 gco = dL_dconic_opacity[i];
+    const float4 gco = grad_ld4(dL_dconic_opacity, i, gstride);
     const float gA = gco.x, gB = gco.y, gC = gco.z;
     if (RAW) {
         const float so = 1.0f / (1.0f + expf(-opacities_raw[i]));
@@ -358,7 +371,7 @@ preprocess_backward_kernel(int P, int M, const float *__restrict__ means3D, cons
         const float phw = cam.p[3] * p[0] + cam.p[7] * p[1] + cam.p[11] * p[2] + cam.p[15];
         const float mw = 1.0f / (phw + 0.0000001f);
         const float mul1 = phx * mw * mw, mul2 = phy * mw * mw;
-        const float2 g2 = dL_dmeans2D[i];
+        const float2 g2 = grad_ld2(dL_dmeans2D, i, gstride);
 #pragma unroll
         for (int k = 0; k < 3; k++)
             dmean[k] += (cam.p[k * 4 + 0] * mw - cam.p[k * 4 + 3] * mul1) * g2.x +
@@ -387,7 +400,7 @@ preprocess_backward_kernel(int P, int M, const float *__restrict__ means3D, cons
         float dsh[NC * 3];
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
-            const float g = clamped[3 * (size_t)i + ch] ? 0.f : dL_drgb[3 * (size_t)i + ch];
+            const float g = clamped[3 * (size_t)i + ch] ? 0.f : dL_drgb[(gstride ? gstride : 3) * (size_t)i + ch];
             float dx = 0.f, dy = 0.f, dz = 0.f;
             dsh[0 * 3 + ch] = SH_C0 * g;
             if (DEG > 0) {
@@ -667,8 +680,9 @@ preprocess_backward_batched_kernel(int P, int B, int M, const float *__restrict_
                                    const float *__restrict__ f_rest, const float *__restrict__ opacity,
                                    const float *__restrict__ cams, int W, int H, const int32_t *__restrict__ radii,
                                    const float *__restrict__ cov3D, const uint8_t *__restrict__ clamped,
-                                   const float2 *__restrict__ dL_dmeans2D,
-                                   const float4 *__restrict__ dL_dconic_opacity, const float *__restrict__ dL_drgb,
+                                   const float *__restrict__ dL_dmeans2D,
+                                   const float *__restrict__ dL_dconic_opacity, const float *__restrict__ dL_drgb,
+                                   int gstride,
                                    float *__restrict__ dL_dxyz, float *__restrict__ dL_dscaling,
                                    float4 *__restrict__ dL_drotation, float *__restrict__ dL_ddc,
                                    float *__restrict__ dL_drest, float *__restrict__ dL_dopacity) {
@@ -701,7 +715,7 @@ preprocess_backward_batched_kernel(int P, int B, int M, const float *__restrict_
         const Cam cam = load_cam_packed(cp);
         const float tanfovx = cp[35], tanfovy = cp[36];
         const float fx = W / (2.0f * tanfovx), fy = H / (2.0f * tanfovy);
-        const float4 gco = dL_dconic_opacity[o];
+        const float4 gco = grad_ld4(dL_dconic_opacity, o, gstride);
         const float gA = gco.x, gB = gco.y, gC = gco.z;
         dop += gco.w;
         float t[3];
@@ -761,7 +775,7 @@ preprocess_backward_batched_kernel(int P, int B, int M, const float *__restrict_
             const float phw = cam.p[3] * p[0] + cam.p[7] * p[1] + cam.p[11] * p[2] + cam.p[15];
             const float mw = 1.0f / (phw + 0.0000001f);
             const float mul1 = phx * mw * mw, mul2 = phy * mw * mw;
-            const float2 g2 = dL_dmeans2D[o];
+            const float2 g2 = grad_ld2(dL_dmeans2D, o, gstride);
 #pragma unroll
             for (int k = 0; k < 3; k++)
                 dmean[k] += (cam.p[k * 4 + 0] * mw - cam.p[k * 4 + 3] * mul1) * g2.x +
@@ -774,7 +788,7 @@ preprocess_backward_batched_kernel(int P, int B, int M, const float *__restrict_
             float ddir[3] = {0.f, 0.f, 0.f};
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) {
-                const float g = clamped[3 * o + ch] ? 0.f : dL_drgb[3 * o + ch];
+                const float g = clamped[3 * o + ch] ? 0.f : dL_drgb[(gstride ? gstride : 3) * o + ch];
                 float dx = 0.f, dy = 0.f, dz = 0.f;
                 dsh[0 * 3 + ch] += SH_C0 * g;
                 if (DEG > 0) {
@@ -958,7 +972,7 @@ int gsr_launch_preprocess_backward(int P, int D, int M, const float *means3D, co
                                    const float *shs_rest, const float *opacities_raw, const float *viewmatrix, const float *projmatrix, const float *campos, int W,
                                    int H, float tanfovx, float tanfovy, const int32_t *radii, const float *cov3D,
                                    const uint8_t *clamped, const float *dL_dmeans2D, const float *dL_dconic_opacity,
-                                   const float *dL_drgb, float *dL_dmeans3D, float *dL_dscales, float *dL_drotations,
+                                   const float *dL_drgb, int grad_row_stride, float *dL_dmeans3D, float *dL_dscales, float *dL_drotations,
                                    float *dL_dshs, float *dL_dshs_rest, float *dL_dopacities,
                                    hipStream_t stream) {
     if (P == 0) return 0;
@@ -967,8 +981,8 @@ int gsr_launch_preprocess_backward(int P, int D, int M, const float *means3D, co
     GSR_DISPATCH_DEG(D, hipLaunchKernelGGL((preprocess_backward_kernel<DEG, RAWF>), grid, block, 0, stream, P, M,  \
                                            means3D, scales, scale_modifier, rotations, shs, shs_rest,              \
                                            opacities_raw, viewmatrix, projmatrix, campos, W, H, tanfovx, tanfovy,  \
-                                           radii, cov3D, clamped, reinterpret_cast<const float2 *>(dL_dmeans2D),   \
-                                           reinterpret_cast<const float4 *>(dL_dconic_opacity), dL_drgb,           \
+                                           radii, cov3D, clamped, dL_dmeans2D, dL_dconic_opacity, dL_drgb,           \
+                                           grad_row_stride,                                                          \
                                            dL_dmeans3D, dL_dscales, reinterpret_cast<float4 *>(dL_drotations),     \
                                            dL_dshs, dL_dshs_rest, dL_dopacities))
     if (shs_rest) { GSR_BWD(true); } else { GSR_BWD(false); }
@@ -1017,7 +1031,7 @@ extern "C" int gsr_preprocess_backward_raw_batched(int P, int B, int sh_degree, 
                                                    const float *opacity, const float *cams, int width, int height,
                                                    const int32_t *radii, const float *cov3D, const uint8_t *clamped,
                                                    const float *dL_dmeans2D, const float *dL_dconic_opacity,
-                                                   const float *dL_drgb, float *dL_dxyz, float *dL_dscaling,
+                                                   const float *dL_drgb, int grad_row_stride, float *dL_dxyz, float *dL_dscaling,
                                                    float *dL_drotation, float *dL_dfeatures_dc,
                                                    float *dL_dfeatures_rest, float *dL_dopacity, gsr_stream_t stream) {
     if (P < 0 || B < 1 || sh_degree < 0 || sh_degree > 3 || sh_coeffs < 2 ||
@@ -1033,8 +1047,8 @@ extern "C" int gsr_preprocess_backward_raw_batched(int P, int B, int sh_degree, 
                      hipLaunchKernelGGL(preprocess_backward_batched_kernel<DEG>, grid, block, 0,
                                         reinterpret_cast<hipStream_t>(stream), P, B, sh_coeffs, xyz, scaling,
                                         scale_modifier, rotation, features_dc, features_rest, opacity, cams, width,
-                                        height, radii, cov3D, clamped, reinterpret_cast<const float2 *>(dL_dmeans2D),
-                                        reinterpret_cast<const float4 *>(dL_dconic_opacity), dL_drgb, dL_dxyz,
+                                        height, radii, cov3D, clamped, dL_dmeans2D, dL_dconic_opacity, dL_drgb,
+                                        grad_row_stride, dL_dxyz,
                                         dL_dscaling, reinterpret_cast<float4 *>(dL_drotation), dL_dfeatures_dc,
                                         dL_dfeatures_rest, dL_dopacity));
     GSR_LAUNCH_CHECK();

@@ -127,6 +127,22 @@ class GaussianRasterizationSettings(NamedTuple):
 
 
 # ------------------------------------------------------------------------------------ K1 / K11
+def _grad_triple(g_means2D, g_rgb, g_conic_opacity, P, dev):
+    """the three incoming gradients of a preprocess op as (means2D, rgb, conic_opacity, row stride in floats):
+    when they are column views of row-major buffers with one common row stride (K10's [P,9] record) they are passed
+    through untouched (stride > 0); otherwise dense copies / zeros (stride 0)."""
+    gs = (g_means2D, g_rgb, g_conic_opacity)
+    if all(g is not None and g.dtype == torch.float32 and g.dim() == 2 and g.shape[0] == P and
+           (P <= 1 or (g.stride(1) == 1 and g.stride(0) == gs[0].stride(0))) for g in gs) and P > 1 and \
+            gs[0].stride(0) > 4:
+        return g_means2D, g_rgb, g_conic_opacity, int(gs[0].stride(0))
+
+    def z(g, cols):
+        return torch.zeros((P, cols), dtype=torch.float32, device=dev) if g is None else g.float().contiguous()
+
+    return z(g_means2D, 2), z(g_rgb, 3), z(g_conic_opacity, 4), 0
+
+
 class _PreprocessGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, scales, rotations, shs, opacities, raster_settings, cuda_args):
@@ -169,14 +185,7 @@ class _PreprocessGaussians(torch.autograd.Function):
         P, M = means3D.shape[0], ctx.M
         dev = means3D.device
 
-        def grad_or_zero(g, cols):
-            if g is None:
-                return torch.zeros((P, cols), dtype=torch.float32, device=dev)
-            return g.float().contiguous()
-
-        g_means2D = grad_or_zero(g_means2D, 2)
-        g_rgb = grad_or_zero(g_rgb, 3)
-        g_conic_opacity = grad_or_zero(g_conic_opacity, 4)
+        g_means2D, g_rgb, g_conic_opacity, gstride = _grad_triple(g_means2D, g_rgb, g_conic_opacity, P, dev)
         d_means3D = torch.empty((P, 3), dtype=torch.float32, device=dev)
         d_scales = torch.empty((P, 3), dtype=torch.float32, device=dev)
         d_rot = torch.empty((P, 4), dtype=torch.float32, device=dev)
@@ -187,8 +196,8 @@ class _PreprocessGaussians(torch.autograd.Function):
                 P, int(rs.sh_degree), M, _ptr(means3D), _ptr(scales), float(rs.scale_modifier), _ptr(rotations),
                 _ptr(shs), _ptr(view), _ptr(proj), _ptr(campos), int(rs.image_width), int(rs.image_height),
                 float(rs.tanfovx), float(rs.tanfovy), _ptr(radii), _ptr(cov3D), _ptr(clamped), _ptr(g_means2D),
-                _ptr(g_conic_opacity), _ptr(g_rgb), _ptr(d_means3D), _ptr(d_scales), _ptr(d_rot), _ptr(d_shs),
-                _ptr(d_opac), _stream()), "gsr_preprocess_backward")
+                _ptr(g_conic_opacity), _ptr(g_rgb), gstride, _ptr(d_means3D), _ptr(d_scales), _ptr(d_rot),
+                _ptr(d_shs), _ptr(d_opac), _stream()), "gsr_preprocess_backward")
         return d_means3D, d_scales, d_rot, d_shs, d_opac, None, None
 
 
@@ -237,10 +246,7 @@ class _PreprocessGaussiansRaw(torch.autograd.Function):
         P, M = xyz.shape[0], ctx.M
         dev = xyz.device
 
-        def z(g, cols):
-            return torch.zeros((P, cols), dtype=torch.float32, device=dev) if g is None else g.float().contiguous()
-
-        g_means2D, g_rgb, g_conic_opacity = z(g_means2D, 2), z(g_rgb, 3), z(g_conic_opacity, 4)
+        g_means2D, g_rgb, g_conic_opacity, gstride = _grad_triple(g_means2D, g_rgb, g_conic_opacity, P, dev)
         d_xyz = torch.empty((P, 3), dtype=torch.float32, device=dev)
         d_scaling = torch.empty((P, 3), dtype=torch.float32, device=dev)
         d_rot = torch.empty((P, 4), dtype=torch.float32, device=dev)
@@ -252,8 +258,8 @@ class _PreprocessGaussiansRaw(torch.autograd.Function):
                 P, int(rs.sh_degree), M, _ptr(xyz), _ptr(scaling), float(rs.scale_modifier), _ptr(rotation),
                 _ptr(f_dc), _ptr(f_rest), _ptr(opacity), _ptr(view), _ptr(proj), _ptr(campos), int(rs.image_width),
                 int(rs.image_height), float(rs.tanfovx), float(rs.tanfovy), _ptr(radii), _ptr(cov3D), _ptr(clamped),
-                _ptr(g_means2D), _ptr(g_conic_opacity), _ptr(g_rgb), _ptr(d_xyz), _ptr(d_scaling), _ptr(d_rot),
-                _ptr(d_dc), _ptr(d_rest), _ptr(d_opac), _stream()), "gsr_preprocess_backward_raw")
+                _ptr(g_means2D), _ptr(g_conic_opacity), _ptr(g_rgb), gstride, _ptr(d_xyz), _ptr(d_scaling),
+                _ptr(d_rot), _ptr(d_dc), _ptr(d_rest), _ptr(d_opac), _stream()), "gsr_preprocess_backward_raw")
         return d_xyz, d_scaling, d_rot, d_dc, d_rest, d_opac, None, None
 
 
@@ -330,7 +336,10 @@ class _PreprocessGaussiansRawBatched(torch.autograd.Function):
                     out[k].copy_(g)
             return out
 
-        g_means2D, g_rgb, g_conic_opacity = assemble(0, 2), assemble(1, 3), assemble(2, 4)
+        if B == 1:  # K10's [P,9] record (or any common-stride column views) goes straight into the kernel
+            g_means2D, g_rgb, g_conic_opacity, gstride = _grad_triple(grads[0], grads[1], grads[2], P, dev)
+        else:
+            g_means2D, g_rgb, g_conic_opacity, gstride = assemble(0, 2), assemble(1, 3), assemble(2, 4), 0
         d_xyz = torch.empty((P, 3), dtype=torch.float32, device=dev)
         d_scaling = torch.empty((P, 3), dtype=torch.float32, device=dev)
         d_rot = torch.empty((P, 4), dtype=torch.float32, device=dev)
@@ -345,14 +354,14 @@ class _PreprocessGaussiansRawBatched(torch.autograd.Function):
                     P, deg, M, _ptr(xyz), _ptr(scaling), smod, _ptr(rotation), _ptr(f_dc), _ptr(f_rest),
                     _ptr(opacity), ctypes.c_void_p(base), ctypes.c_void_p(base + 64), ctypes.c_void_p(base + 128), W,
                     H, float(ctx.tanfov0[0]), float(ctx.tanfov0[1]), _ptr(radii), _ptr(cov3D), _ptr(clamped),
-                    _ptr(g_means2D), _ptr(g_conic_opacity), _ptr(g_rgb), _ptr(d_xyz), _ptr(d_scaling), _ptr(d_rot),
-                    _ptr(d_dc), _ptr(d_rest), _ptr(d_opac), _stream()), "gsr_preprocess_backward_raw")
+                    _ptr(g_means2D), _ptr(g_conic_opacity), _ptr(g_rgb), gstride, _ptr(d_xyz), _ptr(d_scaling),
+                    _ptr(d_rot), _ptr(d_dc), _ptr(d_rest), _ptr(d_opac), _stream()), "gsr_preprocess_backward_raw")
             else:
                 check(lib.gsr_preprocess_backward_raw_batched(
                     P, B, deg, M, _ptr(xyz), _ptr(scaling), smod, _ptr(rotation), _ptr(f_dc), _ptr(f_rest),
                     _ptr(opacity), _ptr(cams), W, H, _ptr(radii), _ptr(cov3D), _ptr(clamped), _ptr(g_means2D),
-                    _ptr(g_conic_opacity), _ptr(g_rgb), _ptr(d_xyz), _ptr(d_scaling), _ptr(d_rot), _ptr(d_dc),
-                    _ptr(d_rest), _ptr(d_opac), _stream()), "gsr_preprocess_backward_raw_batched")
+                    _ptr(g_conic_opacity), _ptr(g_rgb), gstride, _ptr(d_xyz), _ptr(d_scaling), _ptr(d_rot),
+                    _ptr(d_dc), _ptr(d_rest), _ptr(d_opac), _stream()), "gsr_preprocess_backward_raw_batched")
         return d_xyz, d_scaling, d_rot, d_dc, d_rest, d_opac, None, None, None, None, None, None
 
 
@@ -457,11 +466,10 @@ class _RenderGaussians(torch.autograd.Function):
         if g_out is None:
             return None, None, None, None, None, None, None, None
         g_out = g_out.float().contiguous()
-        # one buffer, three dense views: the library zero-fills it with a single launch
-        d_all = torch.empty((9 * P,), dtype=torch.float32, device=dev)
-        d_means2D = d_all[:2 * P].view(P, 2)
-        d_conic_opacity = d_all[2 * P:6 * P].view(P, 4)
-        d_rgb = d_all[6 * P:].view(P, 3)
+        # ONE [P,9] record (means2D 0:2, rgb 2:5, conic_opacity 5:9): K10 flushes a (tile, Gaussian) pair's nine sums
+        # from nine adjacent lanes into one row; K11 and the exchange read the record through its row stride
+        record = torch.empty((P, 9), dtype=torch.float32, device=dev)
+        d_means2D, d_rgb, d_conic_opacity = record[:, 0:2], record[:, 2:5], record[:, 5:9]
         timing = ctx.timing
         with torch.cuda.device(dev):
             if timing != "off":
@@ -471,8 +479,8 @@ class _RenderGaussians(torch.autograd.Function):
             with kernel_timer.range("composite_backward"):
                 check(lib.gsr_render_backward(P, W, H, _ptr(ranges), _ptr(point_list), _ptr(means2D),
                                               _ptr(conic_opacity), _ptr(rgb), _ptr(mask), _ptr(bg), _ptr(final_T),
-                                              _ptr(n_contrib), _ptr(g_out), _ptr(d_means2D), _ptr(d_conic_opacity),
-                                              _ptr(d_rgb), _stream()), "gsr_render_backward")
+                                              _ptr(n_contrib), _ptr(g_out), _ptr(record), _stream()),
+                      "gsr_render_backward")
             if timing != "off":
                 ev1.record()
         stats = ctx.cuda_args.get("stats_collector") if isinstance(ctx.cuda_args, dict) else None

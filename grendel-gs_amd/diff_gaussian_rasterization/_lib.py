@@ -21,9 +21,8 @@ SIGNATURES = {
                                        c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_void_p,
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gsr_preprocess_backward": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
-                                        c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_void_p,
-                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                        c_void_p, c_void_p, c_void_p, c_void_p]),
+                                        c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float] +
+                                [c_void_p] * 6 + [c_int] + [c_void_p] * 6),
     "gsr_get_local2j_ids_bool": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_void_p]),
     "gsr_bin_prepare_bytes": (c_size_t, [c_int, c_int, c_int]),
@@ -53,18 +52,18 @@ SIGNATURES = {
     "gsr_preprocess_forward_raw": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_float] + [c_void_p] * 7 +
                                    [c_int, c_int, c_float, c_float] + [c_void_p] * 8),
     "gsr_preprocess_backward_raw": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_float] + [c_void_p] * 7 +
-                                    [c_int, c_int, c_float, c_float] + [c_void_p] * 13),
+                                    [c_int, c_int, c_float, c_float] + [c_void_p] * 6 + [c_int] + [c_void_p] * 7),
     "gsr_preprocess_forward_raw_batched": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float] +
                                            [c_void_p] * 5 + [c_int, c_int] + [c_void_p] * 8),
     "gsr_preprocess_backward_raw_batched": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float] +
-                                            [c_void_p] * 5 + [c_int, c_int] + [c_void_p] * 13),
+                                            [c_void_p] * 5 + [c_int, c_int] + [c_void_p] * 6 + [c_int] +
+                                            [c_void_p] * 7),
     "gsr_activate_forward": (c_int, [c_int, c_int] + [c_void_p] * 10),
     "gsr_activate_backward": (c_int, [c_int, c_int] + [c_void_p] * 13),
-    "gsr_render_backward": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gsr_render_backward": (c_int, [c_int, c_int, c_int] + [c_void_p] * 12),
 }
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 def _load():

@@ -63,7 +63,10 @@ int gsr_preprocess_forward(int P, int sh_degree, int sh_coeffs, const float *mea
 /* K11 preprocess backward -- autograd backward of the call above (train_internal.py:194-196).
  * in : the forward inputs, the saved radii / cov3D / clamped, and the incoming gradients
  *      dL_dmeans2D [P,2] (NDC-scaled units, scene/gaussian_model.py:1046-1064),
- *      dL_dconic_opacity [P,4] (true partials wrt A,B,C,opacity), dL_drgb [P,3]
+ *      dL_dconic_opacity [P,4] (true partials wrt A,B,C,opacity), dL_drgb [P,3].
+ *      grad_row_stride == 0: the three are dense; > 0: each pointer addresses a column block of rows that are
+ *      grad_row_stride floats apart (e.g. columns 0, 5 and 2 of gsr_render_backward's [P,9] record, stride 9),
+ *      so K10's output feeds K11 without a repacking pass
  * out: dL_dmeans3D [P,3], dL_dscales [P,3], dL_drotations [P,4], dL_dshs [P,sh_coeffs,3],
  *      dL_dopacities [P]   (fully overwritten, zeros for culled Gaussians) */
 int gsr_preprocess_backward(int P, int sh_degree, int sh_coeffs, const float *means3D, const float *scales,
@@ -71,8 +74,8 @@ int gsr_preprocess_backward(int P, int sh_degree, int sh_coeffs, const float *me
                             const float *projmatrix, const float *campos, int width, int height, float tanfovx,
                             float tanfovy, const int32_t *radii, const float *cov3D, const uint8_t *clamped,
                             const float *dL_dmeans2D, const float *dL_dconic_opacity, const float *dL_drgb,
-                            float *dL_dmeans3D, float *dL_dscales, float *dL_drotations, float *dL_dshs,
-                            float *dL_dopacities, gsr_stream_t stream);
+                            int grad_row_stride, float *dL_dmeans3D, float *dL_dscales, float *dL_drotations,
+                            float *dL_dshs, float *dL_dopacities, gsr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K2  `_C.get_local2j_ids_bool` -- gaussian_renderer/workload_division.py:721-744.
@@ -118,13 +121,16 @@ int gsr_render_forward(int P, int width, int height, const int32_t *ranges, cons
                        int32_t *n_contrib, gsr_stream_t stream);
 
 /* K10 composite backward -- autograd backward of render_gaussians.
- * out (fully overwritten): dL_dmeans2D [P,2] (pixel gradient x (W/2, H/2)), dL_dconic_opacity [P,4],
- * dL_drgb [P,3]. */
+ * out (fully overwritten): dL_record [P,9], one row per Gaussian =
+ *   [0:2] dL_dmeans2D (pixel gradient x (W/2, H/2)), [2:5] dL_drgb, [5:9] dL_dconic_opacity
+ * -- the column order of the exchange's differentiable record (means2D, rgb, conic_opacity:
+ * gaussian_renderer/__init__.py:647-650), so that at world size > 1 the record IS the message of the mirror
+ * all-to-all.  One record instead of three arrays lets the kernel flush the 9 sums of a (tile, Gaussian) pair
+ * from 9 adjacent lanes into one 36-byte row: ~8x fewer memory-side atomic requests. */
 int gsr_render_backward(int P, int width, int height, const int32_t *ranges, const uint32_t *point_list,
                         const float *means2D, const float *conic_opacity, const float *rgb,
                         const uint8_t *compute_locally, const float *bg, const float *final_T,
-                        const int32_t *n_contrib, const float *dL_dpixels, float *dL_dmeans2D,
-                        float *dL_dconic_opacity, float *dL_drgb, gsr_stream_t stream);
+                        const int32_t *n_contrib, const float *dL_dpixels, float *dL_record, gsr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * N1  fused band-local L1 + SSIM loss -- the arithmetic of final_system_loss_computation,
@@ -225,7 +231,7 @@ int gsr_preprocess_backward_raw(int P, int sh_degree, int sh_coeffs, const float
                                 const float *projmatrix, const float *campos, int width, int height, float tanfovx,
                                 float tanfovy, const int32_t *radii, const float *cov3D, const uint8_t *clamped,
                                 const float *dL_dmeans2D, const float *dL_dconic_opacity, const float *dL_drgb,
-                                float *dL_dxyz, float *dL_dscaling, float *dL_drotation, float *dL_dfeatures_dc,
+                                int grad_row_stride, float *dL_dxyz, float *dL_dscaling, float *dL_drotation, float *dL_dfeatures_dc,
                                 float *dL_dfeatures_rest, float *dL_dopacity, gsr_stream_t stream);
 
 /* The same for a BATCH of B cameras (--bsz B: every rank projects its Gaussians for all cameras of the batch,
@@ -244,7 +250,7 @@ int gsr_preprocess_backward_raw_batched(int P, int B, int sh_degree, int sh_coef
                                         const float *features_dc, const float *features_rest, const float *opacity,
                                         const float *cams, int width, int height, const int32_t *radii,
                                         const float *cov3D, const uint8_t *clamped, const float *dL_dmeans2D,
-                                        const float *dL_dconic_opacity, const float *dL_drgb, float *dL_dxyz,
+                                        const float *dL_dconic_opacity, const float *dL_drgb, int grad_row_stride, float *dL_dxyz,
                                         float *dL_dscaling, float *dL_drotation, float *dL_dfeatures_dc,
                                         float *dL_dfeatures_rest, float *dL_dopacity, gsr_stream_t stream);
 
