@@ -260,8 +260,8 @@ __device__ __forceinline__ float4 grad_ld4(const float *__restrict__ p, size_t i
 }
 
 template <int DEG, bool RAW>
-__global__ void __launch_bounds__(GSR_ONE_DIM_BLOCK)
-preprocess_backward_kernel(int P, int M, const float *__restrict__ means3D, const float *__restrict__ scales,
+__device__ __forceinline__ void
+preprocess_backward_body(const int i, const float *__restrict__ rest_in, float *__restrict__ rest_out, int P, int M, const float *__restrict__ means3D, const float *__restrict__ scales,
                            float scale_modifier, const float *__restrict__ rotations, const float *__restrict__ shs,
                            const float *__restrict__ shs_rest, const float *__restrict__ opacities_raw,
                            const float *__restrict__ view, const float *__restrict__ proj,
@@ -272,8 +272,6 @@ preprocess_backward_kernel(int P, int M, const float *__restrict__ means3D, cons
                            float *__restrict__ dL_dmeans3D, float *__restrict__ dL_dscales,
                            float4 *__restrict__ dL_drotations, float *__restrict__ dL_dshs,
                            float *__restrict__ dL_dshs_rest, float *__restrict__ dL_dopacities) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
     constexpr int NC = (DEG + 1) * (DEG + 1);
     float *dsh_out = dL_dshs + (size_t)i * M * 3;
 
@@ -283,7 +281,7 @@ preprocess_backward_kernel(int P, int M, const float *__restrict__ means3D, cons
         dL_drotations[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         dL_dopacities[i] = 0.f;
         dL_dshs[3 * (size_t)i] = dL_dshs[3 * (size_t)i + 1] = dL_dshs[3 * (size_t)i + 2] = 0.f;
-        float *rp = dL_dshs_rest + (size_t)i * (M - 1) * 3;
+        float *rp = rest_out;
         for (int k = 0; k < (M - 1) * 3; k++) rp[k] = 0.f;
         return;
     }
@@ -385,7 +383,7 @@ preprocess_backward_kernel(int P, int M, const float *__restrict__ means3D, cons
             sh[0] = shs[3 * (size_t)i];
             sh[1] = shs[3 * (size_t)i + 1];
             sh[2] = shs[3 * (size_t)i + 2];
-            const float *rp = shs_rest + (size_t)i * (M - 1) * 3;
+            const float *rp = rest_in;
 #pragma unroll
             for (int k = 3; k < NC * 3; k++) sh[k] = rp[k - 3];
         } else {
@@ -457,7 +455,7 @@ preprocess_backward_kernel(int P, int M, const float *__restrict__ means3D, cons
             dL_dshs[3 * (size_t)i] = dsh[0];
             dL_dshs[3 * (size_t)i + 1] = dsh[1];
             dL_dshs[3 * (size_t)i + 2] = dsh[2];
-            float *rp = dL_dshs_rest + (size_t)i * (M - 1) * 3;
+            float *rp = rest_out;
 #pragma unroll
             for (int k = 3; k < NC * 3; k++) rp[k - 3] = dsh[k];
             for (int k = NC * 3; k < M * 3; k++) rp[k - 3] = 0.f;
@@ -530,6 +528,59 @@ preprocess_backward_kernel(int P, int M, const float *__restrict__ means3D, cons
         }
         dL_drotations[i] = dq;
     }
+}
+
+// K11 kernel: with the raw parameter layout and 16 SH coefficients the workgroup's 256 x 45 floats of
+// _features_rest (and of its gradient) are contiguous in HBM; per-lane rows are 180 bytes apart, so reading them
+// lane by lane touches a different cache line in every lane of every load.  They are staged through LDS with
+// coalesced 16-byte accesses instead (row stride 45 words: conflict-free), both ways.
+constexpr int REST_W = 45;  // (16 - 1) * 3
+template <int DEG, bool RAW>
+__global__ void __launch_bounds__(GSR_ONE_DIM_BLOCK)
+preprocess_backward_kernel(int P, int M, const float *__restrict__ means3D, const float *__restrict__ scales,
+                           float scale_modifier, const float *__restrict__ rotations, const float *__restrict__ shs,
+                           const float *__restrict__ shs_rest, const float *__restrict__ opacities_raw,
+                           const float *__restrict__ view, const float *__restrict__ proj,
+                           const float *__restrict__ campos, int W, int H, float tanfovx, float tanfovy,
+                           const int32_t *__restrict__ radii, const float *__restrict__ cov3D,
+                           const uint8_t *__restrict__ clamped, const float *__restrict__ dL_dmeans2D,
+                           const float *__restrict__ dL_dconic_opacity, const float *__restrict__ dL_drgb, int gstride,
+                           float *__restrict__ dL_dmeans3D, float *__restrict__ dL_dscales,
+                           float4 *__restrict__ dL_drotations, float *__restrict__ dL_dshs,
+                           float *__restrict__ dL_dshs_rest, float *__restrict__ dL_dopacities) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if constexpr (RAW) {
+        __shared__ float s_rest[GSR_ONE_DIM_BLOCK * REST_W];
+        if (M == 16) {  // block-uniform
+            const size_t row0 = (size_t)blockIdx.x * GSR_ONE_DIM_BLOCK;
+            const int nrows = (int)min((size_t)GSR_ONE_DIM_BLOCK, (size_t)P - row0);
+            const int nw = nrows * REST_W;
+            const float4 *src4 = reinterpret_cast<const float4 *>(shs_rest + row0 * REST_W);  // 46080-byte blocks
+            float4 *s4 = reinterpret_cast<float4 *>(s_rest);
+            for (int k = threadIdx.x; k < nw / 4; k += GSR_ONE_DIM_BLOCK) s4[k] = src4[k];
+            for (int k = (nw & ~3) + threadIdx.x; k < nw; k += GSR_ONE_DIM_BLOCK) s_rest[k] = shs_rest[row0 * REST_W + k];
+            __syncthreads();
+            if (i < P)
+                preprocess_backward_body<DEG, RAW>(i, s_rest + threadIdx.x * REST_W, s_rest + threadIdx.x * REST_W, P, M,
+                                                   means3D, scales, scale_modifier, rotations, shs, shs_rest,
+                                                   opacities_raw, view, proj, campos, W, H, tanfovx, tanfovy, radii,
+                                                   cov3D, clamped, dL_dmeans2D, dL_dconic_opacity, dL_drgb, gstride,
+                                                   dL_dmeans3D, dL_dscales, dL_drotations, dL_dshs, dL_dshs_rest,
+                                                   dL_dopacities);
+            __syncthreads();
+            float4 *dst4 = reinterpret_cast<float4 *>(dL_dshs_rest + row0 * REST_W);
+            for (int k = threadIdx.x; k < nw / 4; k += GSR_ONE_DIM_BLOCK) dst4[k] = s4[k];
+            for (int k = (nw & ~3) + threadIdx.x; k < nw; k += GSR_ONE_DIM_BLOCK) dL_dshs_rest[row0 * REST_W + k] = s_rest[k];
+            return;
+        }
+    }
+    if (i >= P) return;
+    preprocess_backward_body<DEG, RAW>(i, RAW ? shs_rest + (size_t)i * (M - 1) * 3 : nullptr,
+                                       RAW ? dL_dshs_rest + (size_t)i * (M - 1) * 3 : nullptr, P, M, means3D, scales,
+                                       scale_modifier, rotations, shs, shs_rest, opacities_raw, view, proj, campos, W, H,
+                                       tanfovx, tanfovy, radii, cov3D, clamped, dL_dmeans2D, dL_dconic_opacity, dL_drgb,
+                                       gstride, dL_dmeans3D, dL_dscales, dL_drotations, dL_dshs, dL_dshs_rest,
+                                       dL_dopacities);
 }
 
 // ------------------------------------------------------------------------- K1 / K11, batched over cameras
