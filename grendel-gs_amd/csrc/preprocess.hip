@@ -259,6 +259,25 @@ __device__ __forceinline__ float4 grad_ld4(const float *__restrict__ p, size_t i
     return make_float4(q[0], q[1], q[2], q[3]);
 }
 
+constexpr int REST_W = 45;  // (16 - 1) * 3 floats of _features_rest per Gaussian
+// workgroup-cooperative, coalesced copy of the block's rows of a [P, 45] array into / out of LDS
+__device__ __forceinline__ void rest_stage_in(float *__restrict__ s_rest, const float *__restrict__ g, int P) {
+    const size_t row0 = (size_t)blockIdx.x * GSR_ONE_DIM_BLOCK;
+    const int nw = (int)min((size_t)GSR_ONE_DIM_BLOCK, (size_t)P - row0) * REST_W;
+    const float4 *src4 = reinterpret_cast<const float4 *>(g + row0 * REST_W);  // 46080-byte blocks: 16-byte aligned
+    float4 *s4 = reinterpret_cast<float4 *>(s_rest);
+    for (int k = threadIdx.x; k < nw / 4; k += GSR_ONE_DIM_BLOCK) s4[k] = src4[k];
+    for (int k = (nw & ~3) + threadIdx.x; k < nw; k += GSR_ONE_DIM_BLOCK) s_rest[k] = g[row0 * REST_W + k];
+}
+__device__ __forceinline__ void rest_stage_out(const float *__restrict__ s_rest, float *__restrict__ g, int P) {
+    const size_t row0 = (size_t)blockIdx.x * GSR_ONE_DIM_BLOCK;
+    const int nw = (int)min((size_t)GSR_ONE_DIM_BLOCK, (size_t)P - row0) * REST_W;
+    float4 *dst4 = reinterpret_cast<float4 *>(g + row0 * REST_W);
+    const float4 *s4 = reinterpret_cast<const float4 *>(s_rest);
+    for (int k = threadIdx.x; k < nw / 4; k += GSR_ONE_DIM_BLOCK) dst4[k] = s4[k];
+    for (int k = (nw & ~3) + threadIdx.x; k < nw; k += GSR_ONE_DIM_BLOCK) g[row0 * REST_W + k] = s_rest[k];
+}
+
 template <int DEG, bool RAW>
 __device__ __forceinline__ void
 preprocess_backward_body(const int i, const float *__restrict__ rest_in, float *__restrict__ rest_out, int P, int M, const float *__restrict__ means3D, const float *__restrict__ scales,
@@ -534,7 +553,6 @@ preprocess_backward_body(const int i, const float *__restrict__ rest_in, float *
 // _features_rest (and of its gradient) are contiguous in HBM; per-lane rows are 180 bytes apart, so reading them
 // lane by lane touches a different cache line in every lane of every load.  They are staged through LDS with
 // coalesced 16-byte accesses instead (row stride 45 words: conflict-free), both ways.
-constexpr int REST_W = 45;  // (16 - 1) * 3
 template <int DEG, bool RAW>
 __global__ void __launch_bounds__(GSR_ONE_DIM_BLOCK)
 preprocess_backward_kernel(int P, int M, const float *__restrict__ means3D, const float *__restrict__ scales,
@@ -552,13 +570,7 @@ preprocess_backward_kernel(int P, int M, const float *__restrict__ means3D, cons
     if constexpr (RAW) {
         __shared__ float s_rest[GSR_ONE_DIM_BLOCK * REST_W];
         if (M == 16) {  // block-uniform
-            const size_t row0 = (size_t)blockIdx.x * GSR_ONE_DIM_BLOCK;
-            const int nrows = (int)min((size_t)GSR_ONE_DIM_BLOCK, (size_t)P - row0);
-            const int nw = nrows * REST_W;
-            const float4 *src4 = reinterpret_cast<const float4 *>(shs_rest + row0 * REST_W);  // 46080-byte blocks
-            float4 *s4 = reinterpret_cast<float4 *>(s_rest);
-            for (int k = threadIdx.x; k < nw / 4; k += GSR_ONE_DIM_BLOCK) s4[k] = src4[k];
-            for (int k = (nw & ~3) + threadIdx.x; k < nw; k += GSR_ONE_DIM_BLOCK) s_rest[k] = shs_rest[row0 * REST_W + k];
+            rest_stage_in(s_rest, shs_rest, P);
             __syncthreads();
             if (i < P)
                 preprocess_backward_body<DEG, RAW>(i, s_rest + threadIdx.x * REST_W, s_rest + threadIdx.x * REST_W, P, M,
@@ -568,9 +580,7 @@ preprocess_backward_kernel(int P, int M, const float *__restrict__ means3D, cons
                                                    dL_dmeans3D, dL_dscales, dL_drotations, dL_dshs, dL_dshs_rest,
                                                    dL_dopacities);
             __syncthreads();
-            float4 *dst4 = reinterpret_cast<float4 *>(dL_dshs_rest + row0 * REST_W);
-            for (int k = threadIdx.x; k < nw / 4; k += GSR_ONE_DIM_BLOCK) dst4[k] = s4[k];
-            for (int k = (nw & ~3) + threadIdx.x; k < nw; k += GSR_ONE_DIM_BLOCK) dL_dshs_rest[row0 * REST_W + k] = s_rest[k];
+            rest_stage_out(s_rest, dL_dshs_rest, P);
             return;
         }
     }
@@ -645,6 +655,8 @@ preprocess_forward_batched_kernel(int P, int B, int M, const float *__restrict__
     shl[1] = f_dc[3 * (size_t)i + 1];
     shl[2] = f_dc[3 * (size_t)i + 2];
     {
+        // (staging these 180-byte rows through LDS as K11 does was measured SLOWER here: 78 -> 96 us; the forward
+        // is light enough that the 46 KB of LDS cost more occupancy than the coalescing returns)
         const float *rp = f_rest + (size_t)i * (M - 1) * 3;
 #pragma unroll
         for (int k = 3; k < NC * 3; k++) shl[k] = rp[k - 3];
@@ -738,7 +750,13 @@ preprocess_backward_batched_kernel(int P, int B, int M, const float *__restrict_
                                    float4 *__restrict__ dL_drotation, float *__restrict__ dL_ddc,
                                    float *__restrict__ dL_drest, float *__restrict__ dL_dopacity) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
+    __shared__ float s_rest[GSR_ONE_DIM_BLOCK * REST_W];
+    const bool staged = M == 16;  // _features_rest in, its gradient out: coalesced through LDS
+    if (staged) {
+        rest_stage_in(s_rest, f_rest, P);
+        __syncthreads();
+    }
+    if (i < P) {
     constexpr int NC = (DEG + 1) * (DEG + 1);
     const float p[3] = {xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2]};
     const float *cv = cov3D + 6 * (size_t)i;
@@ -748,7 +766,7 @@ preprocess_backward_batched_kernel(int P, int B, int M, const float *__restrict_
     sh[1] = f_dc[3 * (size_t)i + 1];
     sh[2] = f_dc[3 * (size_t)i + 2];
     {
-        const float *rp = f_rest + (size_t)i * (M - 1) * 3;
+        const float *rp = staged ? s_rest + threadIdx.x * REST_W : f_rest + (size_t)i * (M - 1) * 3;
 #pragma unroll
         for (int k = 3; k < NC * 3; k++) sh[k] = rp[k - 3];
     }
@@ -902,7 +920,7 @@ preprocess_backward_batched_kernel(int P, int B, int M, const float *__restrict_
     dL_ddc[3 * (size_t)i + 1] = dsh[1];
     dL_ddc[3 * (size_t)i + 2] = dsh[2];
     {
-        float *rp = dL_drest + (size_t)i * (M - 1) * 3;
+        float *rp = staged ? s_rest + threadIdx.x * REST_W : dL_drest + (size_t)i * (M - 1) * 3;
 #pragma unroll
         for (int k = 3; k < NC * 3; k++) rp[k - 3] = dsh[k];
         for (int k = NC * 3; k < M * 3; k++) rp[k - 3] = 0.f;
@@ -954,6 +972,11 @@ preprocess_backward_batched_kernel(int P, int B, int M, const float *__restrict_
         const float dot = qnr > 1e-12f ? (q.x * dq.x + q.y * dq.y + q.z * dq.z + q.w * dq.w) : 0.f;
         dL_drotation[i] = make_float4((dq.x - q.x * dot) / qn, (dq.y - q.y * dot) / qn, (dq.z - q.z * dot) / qn,
                                       (dq.w - q.w * dot) / qn);
+    }
+    }  // i < P
+    if (staged) {
+        __syncthreads();
+        rest_stage_out(s_rest, dL_drest, P);
     }
 }
 
