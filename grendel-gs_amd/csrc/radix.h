@@ -14,13 +14,14 @@ constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_ITEMS = 8;
 constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;  // 2048 elements per workgroup
 
-constexpr int RADIX_THREADS = 256;
-constexpr int RADIX_WAVES = RADIX_THREADS / GSR_WAVE;
+constexpr int RADIX_THREADS = 256;  // block size of the key PRODUCERS (their LDS histograms: one digit per thread)
 constexpr int RADIX_DIGITS = 256;
 static_assert(GSR_ONE_DIM_BLOCK == RADIX_DIGITS, "histogram tables are initialised one digit per thread");
 constexpr int RADIX_MAX_PASSES = 4;
 constexpr int RADIX_REPLICAS = 8;  // histogram replicas, one per XCD
-constexpr int RADIX_ITEMS = 16;  // 4096 pairs per workgroup (measured best of 8/12/16/24/32 at 1e6..1.4e7 pairs)
+constexpr int RADIX_TILE = 4096;           // pairs per workgroup of a radix pass
+constexpr long long RADIX_SHORT_N = 1ll << 22;  // at most this many pairs: the 1024-thread configuration
+
 constexpr long long RADIX_MAX_N = (1ll << 30) - 1;  // counts share a word with two flag bits
 
 // look-back state word: [31] inclusive prefix available, [30] workgroup aggregate available, [29:0] value
@@ -146,23 +147,44 @@ __device__ __forceinline__ unsigned long long match_digit(uint32_t d, bool valid
 //      workgroup) + look-back sum; stable ranks from wave64 ballots + per-wave LDS cursors; the pairs
 //      are placed in digit order INSIDE LDS and streamed out so that every digit's run leaves the
 //      workgroup as contiguous, coalesced stores.
-template <int ITEMS>
-__global__ void __launch_bounds__(RADIX_THREADS)
+// the same for a workgroup of WAVES wavefronts
+template <int WAVES>
+__device__ __forceinline__ uint32_t block_exclusive_scan_n(uint32_t v, uint32_t *smem, uint32_t *total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t inc = wave_inclusive_scan(v);
+    if (lane == 63) smem[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < WAVES; w++) {
+        const uint32_t s = smem[w];
+        if (w < wave) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+template <int ITEMS, int THREADS>
+__global__ void __launch_bounds__(THREADS)
 radix_onesweep_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
                       uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, long long n, int shift,
                       int nbits, const uint32_t *__restrict__ ghist, uint32_t *__restrict__ state,
                       uint32_t *__restrict__ ticket) {
-    constexpr int TILE = ITEMS * RADIX_THREADS;
-    __shared__ uint32_t wtab[RADIX_WAVES][RADIX_DIGITS];
+    constexpr int TILE = ITEMS * THREADS;
+    constexpr int WAVES = THREADS / 64;
+    __shared__ uint32_t wtab[WAVES][RADIX_DIGITS];
     __shared__ uint32_t gbase[RADIX_DIGITS];  // global start of the digit's run minus its local start
     __shared__ uint32_t skey[TILE], sval[TILE];
-    __shared__ uint32_t scan_tmp[4];
+    __shared__ uint32_t scan_tmp[WAVES];
     __shared__ uint32_t s_bid;
     const uint32_t mask = (1u << nbits) - 1u;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_bid = atomicAdd(ticket, 1u);
 #pragma unroll
-    for (int w = 0; w < RADIX_WAVES; w++) wtab[w][threadIdx.x] = 0;
+    for (int w = 0; w < WAVES; w++)
+        if (threadIdx.x < RADIX_DIGITS) wtab[w][threadIdx.x] = 0;
     __syncthreads();
     const uint32_t bid = s_bid;
     // wave w owns the contiguous sub-chunk [base + w*ITEMS*64, +ITEMS*64), walked in ITEMS rounds of 64
@@ -182,22 +204,22 @@ radix_onesweep_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__re
     }
     __syncthreads();
     {  // thread d: digit d
-        const uint32_t d = threadIdx.x;
+        const uint32_t d = threadIdx.x;  // threads >= 256 (8-wave workgroups) only take part in the scans
         const bool live = d <= mask;
-        uint32_t cnt[RADIX_WAVES], tot = 0;
+        uint32_t cnt[WAVES], tot = 0;
 #pragma unroll
-        for (int w = 0; w < RADIX_WAVES; w++) {
-            cnt[w] = wtab[w][d];
+        for (int w = 0; w < WAVES; w++) {
+            cnt[w] = d < RADIX_DIGITS ? wtab[w][d] : 0u;
             tot += cnt[w];
         }
         uint32_t *row = state + (size_t)bid * RADIX_DIGITS;
         if (live) st_agent(&row[d], tot | (bid == 0 ? LB_PRE : LB_AGG));
         uint32_t all;
-        uint32_t run = block_exclusive_scan(tot, scan_tmp, &all);                         // local start of digit d
+        uint32_t run = block_exclusive_scan_n<WAVES>(tot, scan_tmp, &all);                         // local start of digit d
         uint32_t gh = 0;  // pass histogram = sum of the per-XCD replicas
         if (live)
             for (int x = 0; x < RADIX_REPLICAS; x++) gh += ghist[(size_t)x * RADIX_MAX_PASSES * RADIX_DIGITS + d];
-        const uint32_t dstart = block_exclusive_scan(gh, scan_tmp, &all);  // global start
+        const uint32_t dstart = block_exclusive_scan_n<WAVES>(gh, scan_tmp, &all);  // global start
         uint32_t excl = 0;
         if (live && bid > 0) {
             long long j = (long long)bid - 1;
@@ -223,11 +245,13 @@ radix_onesweep_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__re
             }
             st_agent(&row[d], ((excl + tot) & LB_VAL) | LB_PRE);
         }
-        gbase[d] = dstart + excl - run;
+        if (d < RADIX_DIGITS) {
+            gbase[d] = dstart + excl - run;
 #pragma unroll
-        for (int w = 0; w < RADIX_WAVES; w++) {
-            wtab[w][d] = run;
-            run += cnt[w];
+            for (int w = 0; w < WAVES; w++) {
+                wtab[w][d] = run;
+                run += cnt[w];
+            }
         }
     }
     __syncthreads();
@@ -255,7 +279,7 @@ radix_onesweep_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__re
     const int count = rem < TILE ? (int)rem : TILE;
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
-        const int i = r * RADIX_THREADS + threadIdx.x;
+        const int i = r * THREADS + threadIdx.x;
         if (i < count) {
             const uint32_t k = skey[i];
             const uint32_t dst = gbase[(k >> shift) & mask] + (uint32_t)i;
@@ -269,7 +293,7 @@ radix_onesweep_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__re
 inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 inline long long radix_blocks(long long n) {
-    const long long tile = (long long)RADIX_ITEMS * RADIX_THREADS;
+    const long long tile = RADIX_TILE;
     return (n + tile - 1) / tile;
 }
 
@@ -307,7 +331,15 @@ int radix_sort_pairs(uint32_t *k0, uint32_t *v0, uint32_t *k1, uint32_t *v1, lon
     uint32_t *ki = k0, *vi = v0, *ko = k1, *vo = v1;
     for (int p = 0; p < plan.passes; p++) {
         uint32_t *vdst = (p == plan.passes - 1 && final_vals) ? final_vals : vo;  // last pass can land the values
-        hipLaunchKernelGGL(radix_onesweep_kernel<RADIX_ITEMS>, dim3(nb), dim3(RADIX_THREADS), 0, stream, ki, vi, ko,
+        // 4096 pairs per workgroup either way; many small wavefront-rich workgroups hide the latency chain of the
+        // short sorts (P ~ 1e6: 1024 threads x 4 pairs), 512 x 8 is the measured optimum of the long ones
+        if (n <= RADIX_SHORT_N)
+            hipLaunchKernelGGL((radix_onesweep_kernel<RADIX_TILE / 1024, 1024>), dim3(nb), dim3(1024), 0, stream, ki, vi,
+                               ko,
+                           vdst, n, plan.shift[p], plan.nbits[p], ghist + p * RADIX_DIGITS,
+                           state + (size_t)p * nb * RADIX_DIGITS, tickets + 1 + p);
+        else
+            hipLaunchKernelGGL((radix_onesweep_kernel<RADIX_TILE / 512, 512>), dim3(nb), dim3(512), 0, stream, ki, vi, ko,
                            vdst, n, plan.shift[p], plan.nbits[p], ghist + p * RADIX_DIGITS,
                            state + (size_t)p * nb * RADIX_DIGITS, tickets + 1 + p);
         uint32_t *t = ki; ki = ko; ko = t;
