@@ -115,7 +115,8 @@ scan_gather_lookback_kernel(const uint32_t *__restrict__ src, const uint32_t *__
 // [first tile row with a local tile, one past the last).  Grendel's final mode always passes whole-row
 // bands, for which the hull IS the mask; for a general mask the tiles inside the hull that are not
 // local are emitted with a sentinel key.
-__global__ void __launch_bounds__(GSR_ONE_DIM_BLOCK)
+constexpr int TC_THREADS = 1024, TC_BLOCKS = 256;  // 16-wave persistent workgroups, one per CU (measured best)
+__global__ void __launch_bounds__(TC_THREADS)
 touch_count_kernel(int P, int gx, int gy, const float2 *__restrict__ means2D, const float *__restrict__ depths,
                    const int32_t *__restrict__ radii, const float4 *__restrict__ conic_opacity,
                    const uint8_t *__restrict__ mask, RadixPlan plan, uint32_t *__restrict__ tt,
@@ -124,11 +125,12 @@ touch_count_kernel(int P, int gx, int gy, const float2 *__restrict__ means2D, co
     __shared__ int s_lo, s_hi;
     __shared__ uint32_t mh[RADIX_MAX_PASSES][RADIX_DIGITS];
     if (threadIdx.x == 0) { s_lo = gy; s_hi = 0; }
-    for (int p = 0; p < RADIX_MAX_PASSES; p++) mh[p][threadIdx.x] = 0;
+    if (threadIdx.x < RADIX_DIGITS)
+        for (int p = 0; p < RADIX_MAX_PASSES; p++) mh[p][threadIdx.x] = 0;
     __syncthreads();
     {  // every thread inspects a contiguous slice of the mask; rows are monotone in the byte index
         const int total = gx * gy;
-        const int per = (total + GSR_ONE_DIM_BLOCK - 1) / GSR_ONE_DIM_BLOCK;
+        const int per = (total + TC_THREADS - 1) / TC_THREADS;
         const int b0 = threadIdx.x * per, b1 = min(b0 + per, total);
         int first = -1, last = -1;
         for (int b = b0; b < b1; b++)
@@ -143,8 +145,7 @@ touch_count_kernel(int P, int gx, int gy, const float2 *__restrict__ means2D, co
     }
     __syncthreads();
     const int hull0 = s_lo, hull1 = s_hi;
-    for (long long base = (long long)blockIdx.x * GSR_ONE_DIM_BLOCK; base < P;
-         base += (long long)gridDim.x * GSR_ONE_DIM_BLOCK) {
+    for (long long base = (long long)blockIdx.x * TC_THREADS; base < P; base += (long long)gridDim.x * TC_THREADS) {
         const long long i = base + threadIdx.x;
         const bool valid = i < P;
         uint32_t key = 0xFFFFFFFFu;
@@ -389,9 +390,9 @@ extern "C" int gsr_bin_prepare(int P, int width, int height, const float *means2
 
     GSR_HIP(hipMemsetAsync(ctrl, 0, L.C.total, stream));
     const RadixPlan plan = radix_plan(0, 32);
-    // persistent workgroups (mask hull + LDS tables are per-workgroup set-up): 512 is the measured optimum
-    const int blocks = gsr_div_up(P, GSR_ONE_DIM_BLOCK) < 512 ? gsr_div_up(P, GSR_ONE_DIM_BLOCK) : 512;
-    hipLaunchKernelGGL(touch_count_kernel, dim3(blocks), dim3(GSR_ONE_DIM_BLOCK), 0, stream, P, gx, gy,
+    // persistent workgroups (mask hull + LDS tables are per-workgroup set-up)
+    const int blocks = gsr_div_up(P, TC_THREADS) < TC_BLOCKS ? gsr_div_up(P, TC_THREADS) : TC_BLOCKS;
+    hipLaunchKernelGGL(touch_count_kernel, dim3(blocks), dim3(TC_THREADS), 0, stream, P, gx, gy,
                        reinterpret_cast<const float2 *>(means2D), depths, radii,
                        reinterpret_cast<const float4 *>(conic_opacity), compute_locally, plan, tt, kA, vA, rects,
                        reinterpret_cast<uint32_t *>(ctrl + L.C.ghist));
