@@ -265,9 +265,47 @@ def redistribute_gaussians(self, destination=None, group=None):
     self.send_to_gpui_cnt = torch.zeros((n, group.size()), dtype=torch.int, device=dev)
 
 
+# ----------------------------------------------------------------------- statistics / opacity reset
+def add_densification_stats(self, viewspace_point_tensor, update_filter):
+    """scene/gaussian_model.py:1046-1052: accumulate |d loss / d means2D| (the op's NDC-scaled gradient) of the
+    Gaussians visible in this view"""
+    self.xyz_gradient_accum[update_filter] += torch.norm(viewspace_point_tensor.grad[update_filter, :2], dim=-1,
+                                                         keepdim=True)
+    self.denom[update_filter] += 1
+
+
+def replace_tensor_to_optimizer(self, tensor, name):
+    """scene/gaussian_model.py:770-791: swap one parameter for a new tensor, zeroing its Adam moments"""
+    out = {}
+    for group in self.optimizer.param_groups:
+        if group["name"] != name:
+            continue
+        old = group["params"][0]
+        st = self.optimizer.state.get(old, None)
+        if st is not None:
+            for key in ("momentum_buffer", "exp_avg", "exp_avg_sq"):
+                if key in st:
+                    st[key] = torch.zeros_like(tensor)
+            del self.optimizer.state[old]
+        group["params"][0] = nn.Parameter(tensor.requires_grad_(True))
+        if st is not None:
+            self.optimizer.state[group["params"][0]] = st
+        out[name] = group["params"][0]
+    return out
+
+
+def reset_opacity(self):
+    """scene/gaussian_model.py:555-561: opacity <- min(opacity, 0.01), in logit space"""
+    _log("Resetting opacity to 0.01\n")
+    o = torch.min(self.get_opacity, torch.ones_like(self.get_opacity) * 0.01)
+    new = torch.log(o / (1 - o))
+    self._opacity = replace_tensor_to_optimizer(self, new, "opacity")["opacity"]
+
+
 def install(cls):
     """graft level B3: make these functions the methods of the reference's GaussianModel class"""
     for fn in (prune_points, cat_tensors_to_optimizer, densification_postfix, densify_and_clone, densify_and_split,
-               densify_and_prune, need_redistribute_gaussians, redistribute_gaussians):
+               densify_and_prune, need_redistribute_gaussians, redistribute_gaussians, add_densification_stats,
+               replace_tensor_to_optimizer, reset_opacity):
         setattr(cls, fn.__name__, fn)
     return cls

@@ -114,3 +114,90 @@ def test_prune_points_all_and_none(device):
         assert torch.equal(v, ref[k]), k
     D.prune_points(m, torch.ones(2000, dtype=torch.bool, device=device))
     assert all(v.shape[0] == 0 for v in _state(m).values())
+
+
+def test_training_with_densification_end_to_end(device):
+    """the whole loop the reference runs (train_internal.py:134-329 + densification.py:5-86) on the mirror: iterate,
+    accumulate the means2D-gradient statistics, densify_and_prune in between, keep training on the
+    re-keyed optimizer.  The scene grows / shrinks, nothing goes non-finite, and the loss keeps falling."""
+    import utils.general_utils as utils
+    from gaussian_renderer import distributed_preprocess3dgs_and_all2all_final, render_final
+    from gaussian_renderer.loss_distribution import batched_loss_computation, load_camera_from_cpu_to_all_gpu
+    from gaussian_renderer.workload_division import (DivisionStrategyHistoryFinal, finish_strategy_final,
+                                                     start_strategy_final)
+
+    N, W, H = 15000, 320, 208
+    utils.GLOBAL_RANK, utils.WORLD_SIZE = 0, 1
+    utils.DEFAULT_GROUP = utils.IN_NODE_GROUP = utils.SingleGPUGroup()
+    utils.set_args(utils.default_args(bsz=1))
+    utils.set_img_size(H, W)
+    utils.set_cur_iter(1)
+    cams = S.orbit_cameras(8, W, H, device=device)[:3]
+    bg = torch.zeros(3, device=device)
+    pipe = type("P", (), {"debug": False})()
+    teacher = S.SyntheticGaussianModel(N, W, H, seed=11, device=device, scale_coef=0.01)
+    hist = DivisionStrategyHistoryFinal(S.SyntheticDataset(cams), 1, 0)
+    with torch.no_grad():
+        for cam in cams:
+            st, _ = start_strategy_final([cam], hist)
+            pkg = distributed_preprocess3dgs_and_all2all_final([cam], teacher, pipe, bg, batched_strategies=st,
+                                                               mode="test")
+            cam.original_image_backup = (render_final(pkg, st)[0][0].clamp(0, 1) * 255).round().to(torch.uint8)
+    m = S.SyntheticGaussianModel(N, W, H, seed=11, device=device, scale_coef=0.01)  # the teacher, perturbed
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(0)
+        m._features_dc += 1.0 * torch.randn(m._features_dc.shape, generator=g).to(device)
+        m._opacity += 0.5 * torch.randn(m._opacity.shape, generator=g).to(device)
+        m._xyz += 0.01 * torch.randn(m._xyz.shape, generator=g).to(device)
+    m.optimizer = FusedAdam(m.param_groups(), lr=0.0, eps=1e-15)
+    m.percent_dense = 0.01
+    dev = device
+    m.xyz_gradient_accum = torch.zeros(N, 1, device=dev)
+    m.denom = torch.zeros(N, 1, device=dev)
+    m.max_radii2D = torch.zeros(N, device=dev)
+    m.sum_visible_count_in_one_batch = torch.zeros(N, device=dev)
+    m.send_to_gpui_cnt = torch.zeros(N, 1, dtype=torch.int, device=dev)
+    sizes, losses = [N], []
+    for it in range(60):
+        cam = cams[it % 3]
+        utils.set_cur_iter(it + 1)
+        st, tasks = start_strategy_final([cam], hist)
+        load_camera_from_cpu_to_all_gpu([cam], st, tasks)
+        pkg = distributed_preprocess3dgs_and_all2all_final([cam], m, pipe, bg, batched_strategies=st)
+        images, masks = render_final(pkg, st)
+        stats = [c["stats_collector"] for c in pkg["batched_cuda_args"]]
+        loss, _ = batched_loss_computation(images, [cam], masks, st, stats)
+        loss.backward()
+        finish_strategy_final([cam], hist, st, stats)
+        losses.append(loss.item())
+        with torch.no_grad():  # densification.py:13-25
+            vis = pkg["batched_locally_preprocessed_visibility_filter"][0]
+            radii = pkg["batched_locally_preprocessed_radii"][0]
+            m.max_radii2D[vis] = torch.max(m.max_radii2D[vis], radii[vis].float())
+            D.add_densification_stats(m, pkg["batched_locally_preprocessed_mean2D"][0], vis)
+        m.optimizer.step()
+        m.optimizer.zero_grad(set_to_none=True)
+        cam.original_image = None
+        if it in (19, 39):
+            with torch.no_grad():  # threshold at the 95th percentile of the accumulated statistic: ~5 % densify
+                gr = (m.xyz_gradient_accum / m.denom.clamp(min=1)).squeeze(1)
+                thr = torch.quantile(gr[m.denom.squeeze(1) > 0], 0.95).item()
+                D.densify_and_prune(m, thr, 0.005, 4.0, None)
+            sizes.append(m._xyz.shape[0])
+            for name in D._STATS:
+                assert getattr(m, name).shape[0] == m._xyz.shape[0], name
+    assert len(set(sizes)) > 1, sizes                       # the scene was actually re-sized
+    assert all(torch.isfinite(p).all() for p in m.parameters())
+    assert all(l == l for l in losses)
+    assert sum(losses[-6:]) < sum(losses[:6]), (losses[:6], losses[-6:])  # still improving after two re-sizings
+
+
+def test_reset_opacity_matches_reference_rule(device):
+    m = _model(device, n=5000)
+    before = m.get_opacity.detach().clone()
+    D.reset_opacity(m)
+    want = torch.min(before, torch.full_like(before, 0.01))
+    assert torch.allclose(m.get_opacity, want, rtol=1e-5, atol=1e-7)
+    st = m.optimizer.state[m._opacity]
+    assert float(st["exp_avg"].abs().sum()) == 0.0 and float(st["exp_avg_sq"].abs().sum()) == 0.0
+    assert m.optimizer.param_groups[3]["params"][0] is m._opacity
