@@ -94,7 +94,8 @@ int gsr_get_local2j_ids_bool(int P, int width, int height, int world_size, const
  *   rect intersected with the box around its alpha >= 1/255 ellipse: tiles outside that box get
  *   nothing under the alpha < 1/255 rule, so dropping them changes no pixel), order the
  *   Gaussians by depth (stable) and prefix-sum the counts in that order.  Writes D to
- *   *num_rendered_host AFTER synchronising `stream` (the one host sync of the render op).
+ *   *num_rendered_host once the device has produced it (the one host wait of the render op: the host polls a
+ *   pinned word the last workgroup writes, and falls back to synchronising `stream` after 2 ms).
  *   `prep` is an opaque device workspace of gsr_bin_prepare_bytes(P, width, height) bytes that must stay
  *   untouched until gsr_bin_sort returns.
  * gsr_bin_sort    : emit the D pairs in depth order and stable-sort them by tile id, giving
