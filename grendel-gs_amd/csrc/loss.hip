@@ -20,7 +20,9 @@ namespace {
 __constant__ const float WIN[11] = {1.0283801239e-03f, 7.5987582095e-03f, 3.6000773311e-02f, 1.0936068743e-01f,
                                     2.1300552785e-01f, 2.6601171494e-01f, 2.1300552785e-01f, 1.0936068743e-01f,
                                     3.6000773311e-02f, 7.5987582095e-03f, 1.0283801239e-03f};
-constexpr int TW = 32, TH = 32;          // output tile of one 256-thread workgroup: 4 outputs per thread
+constexpr int LT = 512;                  // threads per workgroup (8 waves at the same LDS: measured best of 256/512/1024)
+constexpr int VO = 1024 / LT;            // vertical outputs per thread (4 at 256 threads, 2 at 512)
+constexpr int TW = 32, TH = 32;          // output tile of one workgroup
 constexpr int HW = TW + 10, HH = TH + 10;  // halo tile
 constexpr int HSTR = TW + 8;             // row stride of the horizontal-pass results (4 rows = 32 banks apart)
 constexpr int TS = TW;                   // (partials are per workgroup: see gsr_l1_ssim_num_partials)
@@ -33,7 +35,8 @@ __device__ __forceinline__ float block_sum(float v, float *smem) {
     for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
     if (lane == 0) smem[wave] = v;
     __syncthreads();
-    const float r = smem[0] + smem[1] + smem[2] + smem[3];
+    float r = 0.f;
+    for (int w = 0; w < LT / 64; w++) r += smem[w];
     __syncthreads();
     return r;
 }
@@ -41,18 +44,18 @@ __device__ __forceinline__ float block_sum(float v, float *smem) {
 // Both kernels are separable 11-tap convolutions out of LDS with REGISTER sliding windows: a thread produces
 // 4 adjacent outputs from 14 loaded values (horizontal: 4 columns of a row, vertical: 4 rows of a column), i.e.
 // 3.5 LDS reads per output and map instead of 11 -- the passes are LDS-bandwidth-bound, not FMA-bound.
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(LT)
 l1_ssim_forward_kernel(int rows, int W, const float *__restrict__ image, long long img_cstride,
                        const uint8_t *__restrict__ gt, float *__restrict__ partials, float *__restrict__ M1,
                        float *__restrict__ M2, float *__restrict__ M3) {
     __shared__ float sX[HH][HW + 1], sY[HH][HW + 1];
     __shared__ float hor[5][HH][HSTR];
-    __shared__ float red[4];
+    __shared__ float red[LT / 64];
     const int c = blockIdx.z, ox = blockIdx.x * TW, oy = blockIdx.y * TH;
     const int tid = threadIdx.x;
     const float *img_c = image + (long long)c * img_cstride;
     const uint8_t *gt_c = gt + (size_t)c * rows * W;
-    for (int idx = tid; idx < HH * HW; idx += 256) {
+    for (int idx = tid; idx < HH * HW; idx += LT) {
         const int ly = idx / HW, lx = idx % HW;
         const int gy = oy + ly - 5, gx = ox + lx - 5;
         float x = 0.f, y = 0.f;
@@ -64,7 +67,7 @@ l1_ssim_forward_kernel(int rows, int W, const float *__restrict__ image, long lo
         sY[ly][lx] = y;
     }
     __syncthreads();
-    for (int task = tid; task < HH * (TW / 4); task += 256) {
+    for (int task = tid; task < HH * (TW / 4); task += LT) {
         const int r = task / (TW / 4), cx0 = (task % (TW / 4)) * 4;
         float xv[14], yv[14];
 #pragma unroll
@@ -89,15 +92,15 @@ l1_ssim_forward_kernel(int rows, int W, const float *__restrict__ image, long lo
         }
     }
     __syncthreads();
-    const int tx = tid % TW, ty0 = (tid / TW) * 4;
-    float acc[5][4];
+    const int tx = tid % TW, ty0 = (tid / TW) * VO;
+    float acc[5][VO];
 #pragma unroll
     for (int m = 0; m < 5; m++) {
-        float v[14];
+        float v[10 + VO];
 #pragma unroll
-        for (int i = 0; i < 14; i++) v[i] = hor[m][ty0 + i][tx];
+        for (int i = 0; i < 10 + VO; i++) v[i] = hor[m][ty0 + i][tx];
 #pragma unroll
-        for (int o = 0; o < 4; o++) {
+        for (int o = 0; o < VO; o++) {
             float a = 0.f;
 #pragma unroll
             for (int k = 0; k < 11; k++) a += WIN[k] * v[o + k];
@@ -107,7 +110,7 @@ l1_ssim_forward_kernel(int rows, int W, const float *__restrict__ image, long lo
     const int gx = ox + tx;
     float l1 = 0.f, ssim_sum = 0.f;
 #pragma unroll
-    for (int o = 0; o < 4; o++) {
+    for (int o = 0; o < VO; o++) {
         const int ty = ty0 + o, gy = oy + ty;
         if (gy < rows && gx < W) {
             const float mu1 = acc[0][o], mu2 = acc[1][o], e11 = acc[2][o], e22 = acc[3][o], e12 = acc[4][o];
@@ -137,7 +140,7 @@ l1_ssim_forward_kernel(int rows, int W, const float *__restrict__ image, long lo
     }
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(LT)
 l1_ssim_backward_kernel(int rows, int W, const float *__restrict__ image, long long img_cstride,
                         const uint8_t *__restrict__ gt, const float *__restrict__ M1, const float *__restrict__ M2,
                         const float *__restrict__ M3, const float *__restrict__ grad_l1_sum,
@@ -148,7 +151,7 @@ l1_ssim_backward_kernel(int rows, int W, const float *__restrict__ image, long l
     const int c = blockIdx.z, ox = blockIdx.x * TW, oy = blockIdx.y * TH;
     const int tid = threadIdx.x;
     const size_t cbase = (size_t)c * rows * W;
-    for (int idx = tid; idx < HH * HW; idx += 256) {
+    for (int idx = tid; idx < HH * HW; idx += LT) {
         const int ly = idx / HW, lx = idx % HW;
         const int gy = oy + ly - 5, gx = ox + lx - 5;
         float a = 0.f, b = 0.f, d = 0.f;
@@ -163,7 +166,7 @@ l1_ssim_backward_kernel(int rows, int W, const float *__restrict__ image, long l
         sM[2][ly][lx] = d;
     }
     __syncthreads();
-    for (int task = tid; task < HH * (TW / 4); task += 256) {
+    for (int task = tid; task < HH * (TW / 4); task += LT) {
         const int r = task / (TW / 4), cx0 = (task % (TW / 4)) * 4;
 #pragma unroll
         for (int m = 0; m < 3; m++) {
@@ -180,15 +183,15 @@ l1_ssim_backward_kernel(int rows, int W, const float *__restrict__ image, long l
         }
     }
     __syncthreads();
-    const int tx = tid % TW, ty0 = (tid / TW) * 4;
-    float cv[3][4];
+    const int tx = tid % TW, ty0 = (tid / TW) * VO;
+    float cv[3][VO];
 #pragma unroll
     for (int m = 0; m < 3; m++) {
-        float v[14];
+        float v[10 + VO];
 #pragma unroll
-        for (int i = 0; i < 14; i++) v[i] = hor[m][ty0 + i][tx];
+        for (int i = 0; i < 10 + VO; i++) v[i] = hor[m][ty0 + i][tx];
 #pragma unroll
-        for (int o = 0; o < 4; o++) {
+        for (int o = 0; o < VO; o++) {
             float a = 0.f;
 #pragma unroll
             for (int k = 0; k < 11; k++) a += WIN[k] * v[o + k];
@@ -199,7 +202,7 @@ l1_ssim_backward_kernel(int rows, int W, const float *__restrict__ image, long l
     if (gx >= W) return;
     const float gl1 = grad_l1_sum[0], gss = grad_ssim_sum[0];
 #pragma unroll
-    for (int o = 0; o < 4; o++) {
+    for (int o = 0; o < VO; o++) {
         const int gy = oy + ty0 + o;
         if (gy >= rows) break;
         const float x = image[(long long)c * img_cstride + (size_t)gy * W + gx];
@@ -256,7 +259,7 @@ extern "C" int gsr_l1_ssim_forward(int channels, int rows, int width, const floa
     if (!image || !gt || !partials) return GSR_EINVAL;
     if ((dm_dmu1 || dm_dE11 || dm_dE12) && !(dm_dmu1 && dm_dE11 && dm_dE12)) return GSR_EINVAL;
     const dim3 grid(gsr_div_up(width, TS), gsr_div_up(rows, TS), channels);
-    hipLaunchKernelGGL(l1_ssim_forward_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), rows, width,
+    hipLaunchKernelGGL(l1_ssim_forward_kernel, grid, dim3(LT), 0, reinterpret_cast<hipStream_t>(stream), rows, width,
                        image, (long long)image_channel_stride, gt, partials, dm_dmu1, dm_dE11, dm_dE12);
     GSR_LAUNCH_CHECK();
     return 0;
@@ -272,7 +275,7 @@ extern "C" int gsr_l1_ssim_backward(int channels, int rows, int width, const flo
     if (!image || !gt || !dm_dmu1 || !dm_dE11 || !dm_dE12 || !grad_l1_sum || !grad_ssim_sum || !grad_image)
         return GSR_EINVAL;
     const dim3 grid(gsr_div_up(width, TS), gsr_div_up(rows, TS), channels);
-    hipLaunchKernelGGL(l1_ssim_backward_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), rows, width,
+    hipLaunchKernelGGL(l1_ssim_backward_kernel, grid, dim3(LT), 0, reinterpret_cast<hipStream_t>(stream), rows, width,
                        image, (long long)image_channel_stride, gt, dm_dmu1, dm_dE11, dm_dE12, grad_l1_sum,
                        grad_ssim_sum, grad_image, (long long)grad_channel_stride);
     GSR_LAUNCH_CHECK();

@@ -17,7 +17,7 @@ def main():
     objs = []
     for u in B.UNITS:
         obj = os.path.join(B.HERE, u + ".o")
-        if u in ("binning", "composite") and defs:
+        if u in ("binning", "composite", "loss") and defs:
             obj = os.path.join(out_dir, f"{u}_{name}.o")
             subprocess.run([B._hipcc()] + B.FLAGS + defs + ["-c", os.path.join(B.HERE, u + ".hip"), "-o", obj], check=True)
         objs.append(obj)
