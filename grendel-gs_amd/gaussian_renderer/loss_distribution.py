@@ -13,7 +13,6 @@ normalised by the FULL image's pixel count, so that the per-rank partial losses 
 the full-image loss up to the band-border SSIM term.
 """
 import math
-import time
 
 import torch
 import torch.distributed as dist
@@ -21,11 +20,13 @@ import torch.nn.functional as F
 
 import utils.general_utils as utils
 
-try:  # the fused HIP loss of this package's operator module (absent when running on the reference's CUDA op)
-    from diff_gaussian_rasterization import fused_l1_ssim_band as _FUSED
-    from diff_gaussian_rasterization import fused_band_loss as _FUSED_LOSS
-except ImportError:  # pragma: no cover
-    _FUSED = _FUSED_LOSS = None
+# The fused HIP loss lives in this package's operator module.  A missing / unbuilt libgsraster.so makes this import
+# raise (no silent fallback); only an operator module WITHOUT the fused entry points (the reference's own CUDA
+# extension, when these files are dropped into the reference tree) selects the reference's torch arithmetic below.
+import diff_gaussian_rasterization as _dgr_loss
+
+_FUSED = getattr(_dgr_loss, "fused_l1_ssim_band", None)
+_FUSED_LOSS = getattr(_dgr_loss, "fused_band_loss", None)
 
 _WINDOW_CACHE = {}
 
@@ -140,30 +141,25 @@ def final_system_loss_computation(image, viewpoint_cam, compute_locally, strateg
     j = strategy.gpu_ids.index(utils.GLOBAL_RANK)
     y0, y1 = get_coverage_y_min_max(strategy.division_pos[j], strategy.division_pos[j + 1])
     n = utils.get_num_pixels() * 3
-    fused = _FUSED is not None and image.is_cuda
-    timed = image.is_cuda
-    if timed:
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record()
-    else:
-        t0 = time.time()
-    if fused:
+    if not image.is_cuda:
+        raise RuntimeError("final_system_loss_computation: the rendered band must live on the gfx950 device "
+                           "(there is no CPU path)")
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    if _FUSED is not None:
         # one HIP kernel each way (include/gsraster.h: gsr_l1_ssim_forward / _backward)
         l1_sum, ssim_sum = _FUSED(image, viewpoint_cam.original_image, y0, y1)
         Ll1, ssim = l1_sum / n, ssim_sum / n
-    else:  # host tensors (unit tests of the partition logic on CPU): plain PyTorch, same arithmetic
+    else:  # on the reference's own CUDA operator (no fused entry points): the reference's arithmetic, on the device
         band = image[:, y0:y1, :].contiguous()
         gt = torch.clamp(viewpoint_cam.original_image / 255.0, 0.0, 1.0)
         Ll1 = pixelwise_l1_with_mask(band, gt).sum() / n
         ssim = pixelwise_ssim_with_mask(band, gt).sum() / n
-    if timed:
-        ev1.record()
-        # no device sync here (the reference synchronises twice per camera, loss_distribution.py:2566,2578):
-        # finish_strategy_final resolves the event pair when -- and only when -- the balancer needs it
-        statistic_collector["_loss_events"] = (ev0, ev1)
-        statistic_collector.setdefault("forward_loss_time", 0.0)
-    else:
-        statistic_collector["forward_loss_time"] = (time.time() - t0) * 1000
+    ev1.record()
+    # no device sync here (the reference synchronises twice per camera, loss_distribution.py:2566,2578):
+    # finish_strategy_final resolves the event pair when -- and only when -- the balancer needs it
+    statistic_collector["_loss_events"] = (ev0, ev1)
+    statistic_collector.setdefault("forward_loss_time", 0.0)
     return Ll1, ssim
 
 
@@ -185,7 +181,9 @@ def batched_loss_computation(batched_image, batched_cameras, batched_compute_loc
         if image.dim() == 0:  # scalar stand-in (< 10 Gaussians): keeps the graph, contributes nothing
             loss = image * 0
             parts.append([loss, 0.0])
-        elif _FUSED_LOSS is not None and image.is_cuda:
+        elif _FUSED_LOSS is not None:
+            if not image.is_cuda:
+                raise RuntimeError("batched_loss_computation: images must live on the gfx950 device (no CPU path)")
             # the whole band loss in one autograd node (map kernel + finalize); HIP events instead of the
             # reference's two device syncs per camera (loss_distribution.py:2566,2578)
             j = strategy.gpu_ids.index(utils.GLOBAL_RANK)
