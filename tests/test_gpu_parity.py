@@ -34,6 +34,7 @@ SCENES = [
     (2000, 200, 120, 0.01, 3, 1),
     (10000, 256, 256, 0.004, 0, 0),      # BASELINE config[0] shape
     (5000, 333, 211, 0.02, 7, 2),        # non-multiple-of-16 image, big splats, long lists
+    (20000, 979, 546, 0.006, 5, 3),      # BASELINE config[3] image shape (62 x 35 tiles, ragged right / bottom edge)
 ]
 
 
