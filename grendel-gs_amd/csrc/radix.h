@@ -166,41 +166,45 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_n(uint32_t v, uint32_t 
     return base + inc - v;
 }
 
+// LDS of one radix pass workgroup
 template <int ITEMS, int THREADS>
-__global__ void __launch_bounds__(THREADS)
-radix_onesweep_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
-                      uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, long long n, int shift,
-                      int nbits, const uint32_t *__restrict__ ghist, uint32_t *__restrict__ state,
-                      uint32_t *__restrict__ ticket) {
+struct OnesweepSmem {
+    uint32_t wtab[THREADS / 64][RADIX_DIGITS];
+    uint32_t gbase[RADIX_DIGITS];  // global start of the digit's run minus its local start
+    uint32_t skey[ITEMS * THREADS], sval[ITEMS * THREADS];
+    uint32_t scan_tmp[THREADS / 64];
+    uint32_t bid;
+};
+
+// ticket of this workgroup (its tile index) + cleared per-wave digit tables; ends with a barrier
+template <int ITEMS, int THREADS>
+__device__ __forceinline__ uint32_t onesweep_begin(OnesweepSmem<ITEMS, THREADS> &sm, uint32_t *__restrict__ ticket) {
+    if (threadIdx.x == 0) sm.bid = atomicAdd(ticket, 1u);
+#pragma unroll
+    for (int w = 0; w < THREADS / 64; w++)
+        if (threadIdx.x < RADIX_DIGITS) sm.wtab[w][threadIdx.x] = 0;
+    __syncthreads();
+    return sm.bid;
+}
+
+// steps 1-3 above for the ITEMS pairs per thread held in registers: pair r of a lane is element
+// bid * TILE + wave * ITEMS * 64 + r * 64 + lane of the pass input
+template <int ITEMS, int THREADS>
+__device__ __forceinline__ void onesweep_scatter(OnesweepSmem<ITEMS, THREADS> &sm, const uint32_t (&key)[ITEMS],
+                                                 const uint32_t (&val)[ITEMS], uint32_t bid, long long n, int shift,
+                                                 int nbits, const uint32_t *__restrict__ ghist,
+                                                 uint32_t *__restrict__ state, uint32_t *__restrict__ keys_out,
+                                                 uint32_t *__restrict__ vals_out) {
     constexpr int TILE = ITEMS * THREADS;
     constexpr int WAVES = THREADS / 64;
-    __shared__ uint32_t wtab[WAVES][RADIX_DIGITS];
-    __shared__ uint32_t gbase[RADIX_DIGITS];  // global start of the digit's run minus its local start
-    __shared__ uint32_t skey[TILE], sval[TILE];
-    __shared__ uint32_t scan_tmp[WAVES];
-    __shared__ uint32_t s_bid;
     const uint32_t mask = (1u << nbits) - 1u;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_bid = atomicAdd(ticket, 1u);
-#pragma unroll
-    for (int w = 0; w < WAVES; w++)
-        if (threadIdx.x < RADIX_DIGITS) wtab[w][threadIdx.x] = 0;
-    __syncthreads();
-    const uint32_t bid = s_bid;
-    // wave w owns the contiguous sub-chunk [base + w*ITEMS*64, +ITEMS*64), walked in ITEMS rounds of 64
     const long long bbase = (long long)bid * TILE;
     const long long wbase = bbase + (long long)wave * (ITEMS * 64);
-    uint32_t key[ITEMS], val[ITEMS];
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
         const long long j = wbase + r * 64 + lane;
-        key[r] = j < n ? keys_in[j] : 0xFFFFFFFFu;
-        val[r] = j < n ? vals_in[j] : 0u;
-    }
-#pragma unroll
-    for (int r = 0; r < ITEMS; r++) {
-        const long long j = wbase + r * 64 + lane;
-        if (j < n) atomicAdd(&wtab[wave][(key[r] >> shift) & mask], 1u);
+        if (j < n) atomicAdd(&sm.wtab[wave][(key[r] >> shift) & mask], 1u);
     }
     __syncthreads();
     {  // thread d: digit d
@@ -209,17 +213,17 @@ radix_onesweep_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__re
         uint32_t cnt[WAVES], tot = 0;
 #pragma unroll
         for (int w = 0; w < WAVES; w++) {
-            cnt[w] = d < RADIX_DIGITS ? wtab[w][d] : 0u;
+            cnt[w] = d < RADIX_DIGITS ? sm.wtab[w][d] : 0u;
             tot += cnt[w];
         }
         uint32_t *row = state + (size_t)bid * RADIX_DIGITS;
         if (live) st_agent(&row[d], tot | (bid == 0 ? LB_PRE : LB_AGG));
         uint32_t all;
-        uint32_t run = block_exclusive_scan_n<WAVES>(tot, scan_tmp, &all);                         // local start of digit d
+        uint32_t run = block_exclusive_scan_n<WAVES>(tot, sm.scan_tmp, &all);  // local start of digit d
         uint32_t gh = 0;  // pass histogram = sum of the per-XCD replicas
         if (live)
             for (int x = 0; x < RADIX_REPLICAS; x++) gh += ghist[(size_t)x * RADIX_MAX_PASSES * RADIX_DIGITS + d];
-        const uint32_t dstart = block_exclusive_scan_n<WAVES>(gh, scan_tmp, &all);  // global start
+        const uint32_t dstart = block_exclusive_scan_n<WAVES>(gh, sm.scan_tmp, &all);  // global start
         uint32_t excl = 0;
         if (live && bid > 0) {
             long long j = (long long)bid - 1;
@@ -246,10 +250,10 @@ radix_onesweep_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__re
             st_agent(&row[d], ((excl + tot) & LB_VAL) | LB_PRE);
         }
         if (d < RADIX_DIGITS) {
-            gbase[d] = dstart + excl - run;
+            sm.gbase[d] = dstart + excl - run;
 #pragma unroll
             for (int w = 0; w < WAVES; w++) {
-                wtab[w][d] = run;
+                sm.wtab[w][d] = run;
                 run += cnt[w];
             }
         }
@@ -263,15 +267,15 @@ radix_onesweep_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__re
         const uint32_t d = (key[r] >> shift) & mask;
         const unsigned long long m = match_digit(d, valid, nbits);
         const uint32_t rank = __popcll(m & lt);
-        volatile uint32_t *cursor = wtab[wave];
+        volatile uint32_t *cursor = sm.wtab[wave];
         uint32_t pos = 0;
         if (valid) pos = cursor[d] + rank;
         __builtin_amdgcn_wave_barrier();
         if (valid && rank == 0) cursor[d] = pos + (uint32_t)__popcll(m);  // group leader advances the cursor
         __builtin_amdgcn_wave_barrier();
         if (valid) {
-            skey[pos] = key[r];
-            sval[pos] = val[r];
+            sm.skey[pos] = key[r];
+            sm.sval[pos] = val[r];
         }
     }
     __syncthreads();
@@ -281,12 +285,33 @@ radix_onesweep_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__re
     for (int r = 0; r < ITEMS; r++) {
         const int i = r * THREADS + threadIdx.x;
         if (i < count) {
-            const uint32_t k = skey[i];
-            const uint32_t dst = gbase[(k >> shift) & mask] + (uint32_t)i;
+            const uint32_t k = sm.skey[i];
+            const uint32_t dst = sm.gbase[(k >> shift) & mask] + (uint32_t)i;
             keys_out[dst] = k;
-            vals_out[dst] = sval[i];
+            vals_out[dst] = sm.sval[i];
         }
     }
+}
+
+template <int ITEMS, int THREADS>
+__global__ void __launch_bounds__(THREADS)
+radix_onesweep_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+                      uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, long long n, int shift,
+                      int nbits, const uint32_t *__restrict__ ghist, uint32_t *__restrict__ state,
+                      uint32_t *__restrict__ ticket) {
+    __shared__ OnesweepSmem<ITEMS, THREADS> sm;
+    const uint32_t bid = onesweep_begin(sm, ticket);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // wave w owns the contiguous sub-chunk [base + w*ITEMS*64, +ITEMS*64), walked in ITEMS rounds of 64
+    const long long wbase = (long long)bid * (ITEMS * THREADS) + (long long)wave * (ITEMS * 64);
+    uint32_t key[ITEMS], val[ITEMS];
+#pragma unroll
+    for (int r = 0; r < ITEMS; r++) {
+        const long long j = wbase + r * 64 + lane;
+        key[r] = j < n ? keys_in[j] : 0xFFFFFFFFu;
+        val[r] = j < n ? vals_in[j] : 0u;
+    }
+    onesweep_scatter(sm, key, val, bid, n, shift, nbits, ghist, state, keys_out, vals_out);
 }
 
 
