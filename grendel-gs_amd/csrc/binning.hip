@@ -26,6 +26,8 @@
 
 #include <atomic>
 #include <chrono>
+#include <cstdlib>
+#include <cstring>
 #include <mutex>
 
 #include "radix.h"
@@ -121,9 +123,15 @@ touch_count_kernel(int P, int gx, int gy, const float2 *__restrict__ means2D, co
                    const int32_t *__restrict__ radii, const float4 *__restrict__ conic_opacity,
                    const uint8_t *__restrict__ mask, RadixPlan plan, uint32_t *__restrict__ tt,
                    uint32_t *__restrict__ keys, uint32_t *__restrict__ vals, uint2 *__restrict__ rects,
-                   uint32_t *__restrict__ ghist) {
+                   uint32_t *__restrict__ ghist, uint32_t *__restrict__ tile_hist) {
     __shared__ int s_lo, s_hi;
     __shared__ uint32_t mh[RADIX_MAX_PASSES][RADIX_DIGITS];
+    // digit histograms of the TILE sort (keys (y, x): pass 0 = column, pass 1 = row), known here without looking at
+    // a single pair: a rect of w x h tiles adds h to every column digit in [minx, maxx) and w to every row digit in
+    // [miny, maxy) -- two +/- entries in a difference array each, prefix-summed once per workgroup
+    __shared__ int32_t dxy[2][RADIX_DIGITS + 1];
+    __shared__ uint32_t tc_scan[TC_THREADS / 64];
+    if (threadIdx.x <= RADIX_DIGITS) dxy[0][threadIdx.x] = dxy[1][threadIdx.x] = 0;
     if (threadIdx.x == 0) { s_lo = gy; s_hi = 0; }
     if (threadIdx.x < RADIX_DIGITS)
         for (int p = 0; p < RADIX_MAX_PASSES; p++) mh[p][threadIdx.x] = 0;
@@ -169,6 +177,12 @@ touch_count_kernel(int P, int gx, int gy, const float2 *__restrict__ means2D, co
                         n = (uint32_t)((maxx - minx) * (maxy - miny));
                         rect = make_uint2((uint32_t)minx | ((uint32_t)maxx << 16),
                                           (uint32_t)miny | ((uint32_t)maxy << 16));
+                        if (tile_hist) {
+                            atomicAdd(&dxy[0][minx], maxy - miny);
+                            atomicAdd(&dxy[0][maxx], miny - maxy);
+                            atomicAdd(&dxy[1][miny], maxx - minx);
+                            atomicAdd(&dxy[1][maxy], minx - maxx);
+                        }
                     }
                 }
             }
@@ -182,6 +196,17 @@ touch_count_kernel(int P, int gx, int gy, const float2 *__restrict__ means2D, co
     }
     __syncthreads();
     multihist_flush(mh, plan, ghist);
+    if (tile_hist) {  // kernel-uniform
+        const uint32_t xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u;  // HW_REG_XCC_ID[3:0]
+        for (int p = 0; p < 2; p++) {
+            const uint32_t v = threadIdx.x < RADIX_DIGITS ? (uint32_t)dxy[p][threadIdx.x] : 0u;
+            uint32_t all;
+            const uint32_t c = block_exclusive_scan_n<TC_THREADS / 64>(v, tc_scan, &all) + v;  // inclusive: the count
+            if (threadIdx.x < RADIX_DIGITS && c)
+                __hip_atomic_fetch_add(&tile_hist[(xcc * RADIX_MAX_PASSES + p) * RADIX_DIGITS + threadIdx.x], c,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
 }
 
 // K5: the D output pairs are cut into chunks of EMIT_CHUNK slots, one wave per chunk, so the work is
@@ -262,6 +287,119 @@ emit_pairs_kernel(int P, long long D, int gx, int tiles, const uint2 *__restrict
     multihist_flush(mh, plan, ghist);
 }
 
+// K5 + first pass of K6 in one kernel (frames of <= 256 x 256 tiles).  The tile sort uses keys (row << xbits | column):
+// pass 0 sorts by column, pass 1 by row, and both digit histograms are already known (K3).  So the pairs need not
+// be written unsorted and read back: the workgroup that owns slots [4096 b, 4096 b + 4096) of the emission order
+// decodes them into registers (owner search as in emit_pairs_kernel, one window of 64 depth-consecutive Gaussians
+// at a time) and runs the pass-0 scatter on them directly.  All tiles of the rect are emitted, computed locally
+// or not: K7 leaves the ranges of tiles that are not computed locally empty, and K8 / K10 never look at them.
+template <int ITEMS, int THREADS>
+__global__ void __launch_bounds__(THREADS)
+emit_scatter_kernel(int P, long long D, int xbits, const uint2 *__restrict__ rects,
+                    const uint32_t *__restrict__ sorted_ids, const uint32_t *__restrict__ offsets,
+                    const uint32_t *__restrict__ ghist, uint32_t *__restrict__ state, uint32_t *__restrict__ ticket,
+                    uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out) {
+    constexpr int WAVES = THREADS / 64;
+    __shared__ OnesweepSmem<ITEMS, THREADS> sm;
+    __shared__ uint32_t s_off[WAVES][65];
+    __shared__ uint32_t s_g[WAVES][64];
+    __shared__ uint2 s_rect[WAVES][64];
+    const uint32_t bid = onesweep_begin(sm, ticket);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long wbase = (long long)bid * (ITEMS * THREADS) + (long long)wave * (ITEMS * 64);
+    uint32_t key[ITEMS], val[ITEMS];
+#pragma unroll
+    for (int r = 0; r < ITEMS; r++) { key[r] = 0xFFFFFFFFu; val[r] = 0u; }
+    if (wbase < D) {  // wave-uniform
+        const uint32_t s_begin = (uint32_t)wbase;
+        // largest j in [0, P] with offsets[j] <= s_begin  (offsets is non-decreasing, offsets[P] = D > s_begin)
+        int lo = 0, hi = P;
+        while (hi - lo > 1) {
+            const int step = (hi - lo + 63) / 64;
+            const int idx = min(lo + lane * step, hi);
+            const bool le = offsets[idx] <= s_begin;
+            const int c = __popcll(__ballot(le));
+            const int nlo = lo + (c - 1) * step;
+            hi = min(hi, nlo + step);
+            lo = nlo;
+        }
+        int g0 = lo;
+        uint32_t wend = 0;  // first slot NOT covered by the window staged in LDS (0: nothing staged yet)
+        bool have_window = false;
+#pragma unroll
+        for (int r = 0; r < ITEMS; r++) {
+            const long long sj = wbase + r * 64 + lane;
+            const uint32_t s = (uint32_t)sj;
+            bool pending = sj < D;
+            while (__ballot(pending) != 0ull) {  // at most a few windows per round of 64 slots
+                if (!have_window || __ballot(pending && s >= wend) == __ballot(pending)) {
+                    // every pending slot lies beyond the staged window: stage the next 64 Gaussians
+                    if (have_window) g0 += 64;
+                    const int j = g0 + lane;
+                    const uint32_t off = offsets[min(j, P)];
+                    const uint32_t end = offsets[min(j + 1, P)];
+                    const uint32_t g = (j < P && end > off) ? sorted_ids[j] : 0u;
+                    __builtin_amdgcn_wave_barrier();
+                    s_off[wave][lane] = off;
+                    if (lane == 63) s_off[wave][64] = end;
+                    s_g[wave][lane] = g;
+                    s_rect[wave][lane] = (j < P && end > off) ? rects[g] : make_uint2(0u, 0u);
+                    __builtin_amdgcn_wave_barrier();
+                    wend = __builtin_amdgcn_readlane(end, 63);
+                    have_window = true;
+                }
+                if (pending && s < wend) {
+                    int a = 0, bnd = 63;
+#pragma unroll
+                    for (int it = 0; it < 6; it++) {
+                        const int mid = (a + bnd + 1) >> 1;
+                        if (s_off[wave][mid] <= s) a = mid; else bnd = mid - 1;
+                    }
+                    const uint2 rc = s_rect[wave][a];
+                    const uint32_t t = s - s_off[wave][a];
+                    const uint32_t minx = rc.x & 0xFFFFu, w = (rc.x >> 16) - minx, miny = rc.y & 0xFFFFu;
+                    const uint32_t q = t / w;
+                    key[r] = ((miny + q) << xbits) | (minx + (t - q * w));
+                    val[r] = s_g[wave][a];
+                    pending = false;
+                }
+            }
+        }
+    }
+    onesweep_scatter(sm, key, val, bid, D, 0, xbits, ghist, state, keys_out, vals_out);
+}
+
+// K7 for (row << xbits | column) keys: four consecutive sorted pairs per thread; tiles that are not computed
+// locally keep the empty range
+__global__ void __launch_bounds__(GSR_ONE_DIM_BLOCK)
+tile_ranges_yx_kernel(long long D, int gx, int xbits, const uint32_t *__restrict__ keys,
+                      const uint8_t *__restrict__ mask, int2 *__restrict__ ranges) {
+    const long long j = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (j >= D) return;
+    uint32_t k[6];  // k[0] = predecessor, k[1..4] = own, k[5] = successor
+    k[0] = j > 0 ? keys[j - 1] : 0xFFFFFFFFu;
+    if (j + 4 <= D) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(keys + j);
+        k[1] = q.x; k[2] = q.y; k[3] = q.z; k[4] = q.w;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) k[1 + i] = j + i < D ? keys[j + i] : 0xFFFFFFFFu;
+    }
+    k[5] = j + 4 < D ? keys[j + 4] : 0xFFFFFFFFu;
+    const uint32_t xmask = (1u << xbits) - 1u;
+#pragma unroll
+    for (int i = 1; i <= 4; i++) {
+        if (j + i - 1 >= D) break;
+        const uint32_t kk = k[i];
+        if (k[i - 1] != kk || k[i + 1] != kk) {
+            const uint32_t t = (kk >> xbits) * (uint32_t)gx + (kk & xmask);
+            if (!mask[t]) continue;
+            if (k[i - 1] != kk) ranges[t].x = (int)(j + i - 1);
+            if (k[i + 1] != kk) ranges[t].y = (int)(j + i);
+        }
+    }
+}
+
 // K7: four consecutive sorted pairs per thread
 __global__ void __launch_bounds__(GSR_ONE_DIM_BLOCK)
 tile_ranges_kernel(long long D, uint32_t tiles, const uint32_t *__restrict__ tile_of, int2 *__restrict__ ranges) {
@@ -294,7 +432,7 @@ copy_u32_kernel(long long n, const uint32_t *__restrict__ src, uint32_t *__restr
 }
 
 struct PrepLayout {
-    size_t tt, kA, vA, kB, vB, offsets, rects, ctrl, total;
+    size_t tt, kA, vA, kB, vB, offsets, rects, thist, ctrl, total;
     CtrlLayout C;
 };
 PrepLayout prep_layout(int P, int W, int H) {
@@ -309,6 +447,7 @@ PrepLayout prep_layout(int P, int W, int H) {
     L.vB = o; o += np;
     L.offsets = o; o += np;
     L.rects = o; o += align_up((size_t)(P + 1) * 8);
+    L.thist = o; o += align_up(sizeof(uint32_t) * RADIX_REPLICAS * RADIX_MAX_PASSES * RADIX_DIGITS);  // zeroed with ctrl
     L.ctrl = o;
     L.C = ctrl_layout(P, 4, true);
     o += L.C.total;
@@ -354,6 +493,18 @@ int wait_total(hipStream_t stream, uint32_t *host_total, uint32_t seq, uint32_t 
     *total = w[0];
     return w[1] == seq ? 0 : GSR_EINVAL;
 }
+// (row, column) keys + fused emission (emit_scatter_kernel): frames of <= 256 x 256 tiles; GSR_BINNING=generic
+// forces the tile-id path (kept for larger frames) for A/B measurements and tests
+bool yx_path(int gx, int gy) {
+    const char *e = getenv("GSR_BINNING");
+    if (e && strcmp(e, "generic") == 0) return false;
+    return gx <= RADIX_DIGITS && gy <= RADIX_DIGITS;
+}
+int bits_for(int n) {  // bits needed for the values 0 .. n-1 (at least 1)
+    int b = 1;
+    while ((1 << b) < n) b++;
+    return b;
+}
 int tile_bits(int tiles) {  // bits of the largest key value, the sentinel `tiles`
     int b = 1;
     while ((1ll << b) <= tiles) b++;
@@ -388,14 +539,15 @@ extern "C" int gsr_bin_prepare(int P, int width, int height, const float *means2
     uint2 *rects = reinterpret_cast<uint2 *>(base + L.rects);
     char *ctrl = base + L.ctrl;
 
-    GSR_HIP(hipMemsetAsync(ctrl, 0, L.C.total, stream));
+    GSR_HIP(hipMemsetAsync(base + L.thist, 0, (L.ctrl - L.thist) + L.C.total, stream));
     const RadixPlan plan = radix_plan(0, 32);
+    uint32_t *tile_hist = yx_path(gx, gy) ? reinterpret_cast<uint32_t *>(base + L.thist) : nullptr;
     // persistent workgroups (mask hull + LDS tables are per-workgroup set-up)
     const int blocks = gsr_div_up(P, TC_THREADS) < TC_BLOCKS ? gsr_div_up(P, TC_THREADS) : TC_BLOCKS;
     hipLaunchKernelGGL(touch_count_kernel, dim3(blocks), dim3(TC_THREADS), 0, stream, P, gx, gy,
                        reinterpret_cast<const float2 *>(means2D), depths, radii,
                        reinterpret_cast<const float4 *>(conic_opacity), compute_locally, plan, tt, kA, vA, rects,
-                       reinterpret_cast<uint32_t *>(ctrl + L.C.ghist));
+                       reinterpret_cast<uint32_t *>(ctrl + L.C.ghist), tile_hist);
     int in_first = 1;
     int rc = radix_sort_pairs(kA, vA, kB, vB, P, plan, ctrl, L.C, &in_first, stream, nullptr);
     if (rc) return rc;
@@ -448,7 +600,8 @@ extern "C" size_t gsr_bin_sort_bytes(int P, int64_t num_rendered, int width, int
     (void)P;
     if (num_rendered < 0 || width <= 0 || height <= 0) return 0;
     const int gx = (width + GSR_BLOCK_X - 1) / GSR_BLOCK_X, gy = (height + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y;
-    return sort_layout(num_rendered, radix_plan(0, tile_bits(gx * gy)).passes).total;
+    const int passes = radix_plan(0, tile_bits(gx * gy)).passes;
+    return sort_layout(num_rendered, passes < 2 ? 2 : passes).total;  // the (row, column) path always runs 2 passes
 }
 
 extern "C" int gsr_bin_sort(int P, int width, int height, const uint8_t *compute_locally, const void *prep,
@@ -462,7 +615,7 @@ extern "C" int gsr_bin_sort(int P, int width, int height, const uint8_t *compute
     if (!compute_locally || !prep || !scratch || !point_list) return GSR_EINVAL;
     if (D > RADIX_MAX_N) return GSR_EINVAL;
     const RadixPlan plan = radix_plan(0, tile_bits(gx * gy));
-    const SortLayout S = sort_layout(D, plan.passes);
+    const SortLayout S = sort_layout(D, plan.passes < 2 ? 2 : plan.passes);
     if (scratch_bytes < S.total) return GSR_ENOSPACE;
     const PrepLayout L = prep_layout(P, width, height);
     const char *pbase = reinterpret_cast<const char *>(prep);
@@ -475,6 +628,24 @@ extern "C" int gsr_bin_sort(int P, int width, int height, const uint8_t *compute
     char *ctrl = sbase + S.ctrl;
 
     GSR_HIP(hipMemsetAsync(ctrl, 0, S.C.total, stream));
+    if (yx_path(gx, gy)) {
+        const int xbits = bits_for(gx), ybits = bits_for(gy);
+        const uint32_t *thist = reinterpret_cast<const uint32_t *>(pbase + L.thist);
+        const int nb = (int)radix_blocks(D);
+        uint32_t *tickets = reinterpret_cast<uint32_t *>(ctrl + S.C.tickets);
+        uint32_t *state = reinterpret_cast<uint32_t *>(ctrl + S.C.radix_state);
+        // pass 0 (column digit) fused with the emission: pairs land in (kB, vB); pass 1 (row digit) -> (kA, point_list)
+        hipLaunchKernelGGL((emit_scatter_kernel<RADIX_TILE / 512, 512>), dim3(nb), dim3(512), 0, stream, P, (long long)D,
+                           xbits, rects, sorted_ids, offsets, thist, state, tickets + 1, kB, vB);
+        hipLaunchKernelGGL((radix_onesweep_kernel<RADIX_TILE / 512, 512>), dim3(nb), dim3(512), 0, stream, kB, vB, kA,
+                           point_list, (long long)D, xbits, ybits, thist + RADIX_DIGITS,
+                           state + (size_t)nb * RADIX_DIGITS, tickets + 2);
+        hipLaunchKernelGGL(tile_ranges_yx_kernel, dim3(gsr_div_up(gsr_div_up(D, 4), GSR_ONE_DIM_BLOCK)),
+                           dim3(GSR_ONE_DIM_BLOCK), 0, stream, (long long)D, gx, xbits, kA, compute_locally,
+                           reinterpret_cast<int2 *>(ranges));
+        GSR_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(emit_pairs_kernel, dim3(gsr_div_up(gsr_div_up(D, EMIT_CHUNK), 4)), dim3(256), 0, stream, P,
                        (long long)D, gx, gx * gy, rects, compute_locally, sorted_ids, offsets, plan, kA, vA,
                        reinterpret_cast<uint32_t *>(ctrl + S.C.ghist));
