@@ -6,19 +6,22 @@
 // produced with far less HBM traffic by splitting the key:
 //   1. stable radix sort of the P Gaussians by depth bits (4 x 8-bit passes over P pairs);
 //   2. emit the D pairs in that depth order, (ty, tx)-major inside a Gaussian;
-//   3. stable radix sort of the D pairs by tile id only (ceil(log2(tiles)/8) = 2 passes at 1080p/4K).
-// A stable sort by tile id of a depth-ordered sequence is exactly the (tile, depth, arrival)
-// order of SURVEY.md A.3.  Traffic: ~64 B per Gaussian + ~40 B per pair instead of ~200 B per pair.
+//   3. stable radix sort of the D pairs by tile only: keys (row << xbits | column), pass 0 by column, pass 1 by row
+//      (frames of <= 256 x 256 tiles; larger frames sort tile ids in ceil(log2(tiles)/8) passes).
+// A stable sort by tile of a depth-ordered sequence is exactly the (tile, depth, arrival)
+// order of SURVEY.md A.3.  Traffic: ~64 B per Gaussian + ~32 B per pair instead of ~200 B per pair.
 //
-// At the sizes of one camera (1e6 Gaussians, 3e6 pairs) every kernel of this stage lasts 10-50 us, so
-// the stage is bound by the NUMBER of dependent launches, not by bytes.  The sort is therefore a
-// "one sweep" radix sort: the digit histograms of all passes are accumulated by the kernel that
-// PRODUCES the keys (K3 for the depth sort, K5 for the tile sort), and each pass is a single kernel
-// that obtains its workgroup's global digit offsets by decoupled look-back over the preceding
-// workgroups' per-digit counts (no histogram / scan launches between passes).  The offsets scan of
-// K4 is a single-pass look-back scan that gathers its input through the sorted order.  Workgroups
-// take their tile from a ticket counter, so a workgroup only ever waits for workgroups that are
-// already running (forward progress without co-residency assumptions).
+// At the sizes of one camera (1e6 Gaussians, 1e7 pairs) every kernel of this stage lasts 10-70 us, so
+// the stage is bound by the NUMBER of dependent launches as much as by bytes.  The sort is therefore a
+// "one sweep" radix sort: the digit histograms of all passes are known BEFORE the keys are sorted -- the depth
+// histograms are accumulated by K3 while it writes the keys, and the tile-sort histograms follow from the rects
+// alone (a w x h rect adds h to every column digit it spans and w to every row digit) -- and each pass is a single
+// kernel that obtains its workgroup's global digit offsets by decoupled look-back over the preceding
+// workgroups' per-digit counts (no histogram / scan launches between passes).  Step 2 is fused into the first
+// pass of step 3 (emit_scatter_kernel): the pairs are decoded into registers and scattered, never stored
+// unsorted.  The offsets scan of K4 is a single-pass look-back scan that gathers its input through the sorted
+// order.  Workgroups take their tile from a ticket counter, so a workgroup only ever waits for workgroups that
+// are already running (forward progress without co-residency assumptions).
 //
 // All primitives are hand-written for wave64: ballot-based stable multisplit inside a wave,
 // LDS per-wave digit tables, LDS digit-ordered staging for coalesced stores.
