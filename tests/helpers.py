@@ -28,6 +28,24 @@ def frac_bad(a, b, rtol=1e-3, atol=1e-5):
     return bad.double().mean().item()
 
 
+def elem_excess(a, b, rtol=1e-4, atol_rms=1e-5, q=0.99):
+    """element-wise tolerance test of SURVEY.md 8(c)'s fidelity ladder ("norm-wise AND p99 element-wise"):
+    the q-quantile over the non-zero reference entries of |a-b| / (rtol*|b| + atol), atol = atol_rms * rms(b).
+    <= 1 means: at least a fraction q of the entries satisfy |a-b| <= rtol*|b| + atol.
+    Measured fp32-noise bound (oracle/gsraster_ref.c in fp32 against the fp64 autograd oracle, same scenes):
+    p99 <= 0.30, p99.9 <= 0.92 for every gradient tensor with atol_rms = 1e-5 -- so a HIP result that passes
+    with value <= 1 is inside ~3x the rounding noise of a plain fp32 CPU implementation."""
+    a, b = a.detach().double().cpu().reshape(-1), b.detach().double().cpu().reshape(-1)
+    nz = b != 0
+    if int(nz.sum()) == 0:
+        return float((a - b).abs().max()) if a.numel() else 0.0
+    rms = b[nz].pow(2).mean().sqrt()
+    ratio = (a - b).abs()[nz] / (rtol * b[nz].abs() + atol_rms * rms)
+    if ratio.numel() > 2_000_000:  # torch.quantile input limit: subsample deterministically
+        ratio = ratio[:: ratio.numel() // 2_000_000 + 1]
+    return float(torch.quantile(ratio, q))
+
+
 def settings_from(cam, bg, sh_degree=3, device="cuda"):
     from diff_gaussian_rasterization import GaussianRasterizationSettings
 
@@ -51,3 +69,56 @@ def oracle_c_chain(g, cam, bg, mask, wgt, sh_degree=3):
     return dict(means2D=m2, rgb=rgb, conic_opacity=co, radii=radii, depths=depths, cov3D=cov3D, clamped=clamped,
                 point_list=pl, ranges=ranges, image=img, final_T=fT, n_contrib=nc, d_means2D=d2, d_conic_opacity=dco,
                 d_rgb=drgb, d_means3D=dm, d_scales=ds, d_rotations=dr, d_shs=dsh, d_opacities=do)
+
+
+# ---------------------------------------------------------------------------- frozen rasterizer goldens
+GOLDEN_DIR = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "golden")
+GOLDEN_SCENES = ["single", "two_overlap", "rand10k_256", "behind_camera", "low_opacity", "saturating", "border_band0",
+                 "border_band1", "sh0", "sh1", "sh2", "sh3", "white_bg", "black_bg", "rows1080"]
+
+
+def golden_weight(H, W):
+    """dL/dimage of the golden scenes (analytic, float64) -- the same formula as tests/golden/make_raster_golden.py"""
+    y, x = torch.meshgrid(torch.arange(H, dtype=torch.float64), torch.arange(W, dtype=torch.float64), indexing="ij")
+    return torch.stack([0.5 + 0.5 * torch.sin(0.37 * x + 0.91 * y + 1.3 * c) for c in range(3)])
+
+
+def load_golden(name):
+    """-> dict(g = the five input tensors (float32), kw = camera kwargs of the oracles, bg, mask (bool [gy,gx]), W, H,
+    sh_degree, out = dict of the frozen float64-oracle results (float32 / int32 tensors))"""
+    import numpy as np
+
+    z = np.load(__import__("os").path.join(GOLDEN_DIR, f"raster_{name}.npz"))
+    W, H, deg = int(z["W"]), int(z["H"]), int(z["sh_degree"])
+    if "regen" in z.files:
+        n, w, h, seed = [int(v) for v in z["regen"]]
+        g = S.make_gaussians(n, w, h, seed=seed, scale_coef=float(z["regen_scale_coef"]))
+    else:
+        g = {k: torch.from_numpy(z["in_" + k]) for k in KEYS}
+    chk = torch.tensor([float(g[k].double().sum()) for k in KEYS] + [float(g[k].double().abs().sum()) for k in KEYS],
+                       dtype=torch.float64)
+    want = torch.from_numpy(z["input_checksum"])
+    assert torch.allclose(chk, want, rtol=1e-12, atol=1e-12), f"golden {name}: inputs are not the frozen ones"
+    kw = dict(viewmatrix=torch.from_numpy(z["viewmatrix"]), projmatrix=torch.from_numpy(z["projmatrix"]),
+              campos=torch.from_numpy(z["campos"]), W=W, H=H, tanfovx=float(z["tanfovx"]), tanfovy=float(z["tanfovy"]),
+              sh_degree=deg)
+    out = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("out_")}
+    return dict(name=name, g=g, kw=kw, bg=torch.from_numpy(z["bg"]), mask=torch.from_numpy(z["mask"]), W=W, H=H,
+                sh_degree=deg, out=out)
+
+
+def c_chain_kw(g, kw, bg, mask, wgt):
+    """oracle_c_chain for explicit camera kwargs (the goldens carry matrices, not camera objects)"""
+    W, H = kw["W"], kw["H"]
+    m2, rgb, co, radii, depths, cov3D, clamped = C.preprocess_forward(*[g[k] for k in KEYS], **kw)
+    pl, ranges, tt = C.bin_and_sort(m2, radii, depths, mask, W, H)
+    img, fT, nc = C.render_forward(m2, co, rgb, mask, bg, W, H, pl, ranges)
+    d2, dco, drgb = C.render_backward(m2, co, rgb, mask, bg, W, H, pl, ranges, fT, nc, wgt)
+    dm, ds, dr, dsh, do = C.preprocess_backward(g["means3D"], g["scales"], g["rotations"], g["shs"], radii, cov3D,
+                                                clamped, d2, dco, drgb, **kw)
+    return dict(means2D=m2, rgb=rgb, conic_opacity=co, radii=radii, depths=depths, image=img, final_T=fT, n_contrib=nc,
+                d_means2D=d2, d_conic_opacity=dco, d_rgb=drgb, d_means3D=dm, d_scales=ds, d_rotations=dr, d_shs=dsh,
+                d_opacities=do)
+
+
+GOLDEN_GRADS = ["d_means2D", "d_means3D", "d_scales", "d_rotations", "d_shs", "d_opacities"]

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 import synthetic_scene as S
-from helpers import KEYS, cam_kwargs, oracle_c_chain, rel_err, settings_from
+from helpers import KEYS, cam_kwargs, elem_excess, oracle_c_chain, rel_err, settings_from
 
 pytestmark = pytest.mark.gpu
 
@@ -40,6 +40,42 @@ def test_config1_1M_1080p_matches_c_oracle(device):
     for k, rk in [("means3D", "d_means3D"), ("scales", "d_scales"), ("rotations", "d_rotations"), ("shs", "d_shs"),
                   ("opacities", "d_opacities")]:
         assert rel_err(gg[k].grad, ref[rk]) < 1e-4, k
+        assert elem_excess(gg[k].grad, ref[rk]) <= 1.0, f"{k}: p99 element-wise"
+
+
+@pytest.mark.parametrize("N,W,H,band,deg", [
+    (1_500_000, 1920, 1080, (17, 34), 3),   # BASELINE configs[2] per-rank shape: 6 M / 4 GPUs, a quarter-image band
+    (5_000_000, 3840, 2160, (51, 68), 3),   # BASELINE configs[4] per-rank shape: 40 M / 8 GPUs at 4K, an eighth band
+    (1_500_000, 1920, 1080, (51, 68), 1),   # the ragged last band (row 67 is half a tile), SH degree 1
+])
+def test_per_rank_band_shapes_match_c_oracle(device, N, W, H, band, deg):
+    """what ONE rank of the multi-GPU configs computes -- its Gaussian shard projected, one row band rendered,
+    backward -- against the C restatement on the box's host cores (the image outside the band is exactly 0)"""
+    from diff_gaussian_rasterization import GaussianRasterizer
+
+    g = S.make_gaussians(N, W, H, seed=21, sh_rest_sigma=0.1 if deg == 3 else 0.4)
+    cam = S.orbit_cameras(8, W, H)[0]
+    bg = torch.tensor([0.2, 0.1, 0.3])
+    gy, gx = (H + 15) // 16, (W + 15) // 16
+    mask = torch.zeros(gy, gx, dtype=torch.bool)
+    mask[band[0]:band[1]] = True
+    wgt = torch.rand(3, H, W, generator=torch.Generator().manual_seed(3))
+    ref = oracle_c_chain(g, cam, bg, mask, wgt, sh_degree=deg)
+    rast = GaussianRasterizer(settings_from(cam, bg, sh_degree=deg))
+    gg = {k: v.to(device).requires_grad_(True) for k, v in g.items()}
+    img, radii = _chain(rast, gg, mask.to(device), wgt.to(device))
+    assert (radii.cpu() != ref["radii"]).sum().item() <= N // 100000
+    y0, y1 = band[0] * 16, min(band[1] * 16, H)
+    assert float(img[:, :y0].abs().sum()) == 0.0 and float(img[:, y1:].abs().sum()) == 0.0
+    assert rel_err(img, ref["image"]) < 1e-4
+    bad = ((img.cpu() - ref["image"]).abs() > 1e-3).float().mean().item()
+    assert bad < 1e-4, f"{bad:.2e} of the pixels differ by more than 1e-3 (threshold flips)"
+    for k, rk in [("means3D", "d_means3D"), ("scales", "d_scales"), ("rotations", "d_rotations"), ("shs", "d_shs"),
+                  ("opacities", "d_opacities")]:
+        e, x = rel_err(gg[k].grad, ref[rk]), elem_excess(gg[k].grad, ref[rk])
+        print(f"[band {N} {W}x{H} rows {band}] {k}: rel {e:.1e}, p99 excess {x:.2f}")
+        assert e < 1e-4, k
+        assert x <= 1.0, f"{k}: p99 element-wise"
 
 
 @pytest.mark.parametrize("N,W,H", [(1_000_000, 1920, 1080), (1_500_000, 3840, 2160)])
@@ -76,10 +112,17 @@ def test_fullsize_band_union_and_permutation(device, N, W, H):
     # order): ~N^2 / 4e7 tied pairs among N random fp32 depths, a few of which overlap on screen
     perm = torch.randperm(N, generator=torch.Generator().manual_seed(5))
     imgp, grp = run([(0, gy)], perm)
-    assert rel_err(imgp, img1) < 1e-3
     inv = torch.empty_like(perm)
     inv[perm] = torch.arange(N)
-    assert rel_err(grp["means3D"][inv.to(device)], gr1["means3D"]) < 1e-2
+    # NOT a rounding tolerance: a permutation changes which of two exactly depth-tied Gaussians is in front (ties are
+    # broken by index, like the reference's arrival order), i.e. it renders a slightly different scene.  The bound is
+    # the measured effect of those tie swaps (printed), with the count of tied pairs reported beside it.
+    d = torch.sort(g["means3D"][:, 2]).values
+    ties = int((d[1:] == d[:-1]).sum())
+    e_img, e_g = rel_err(imgp, img1), rel_err(grp["means3D"][inv.to(device)], gr1["means3D"])
+    print(f"[permutation {N} {W}x{H}] {ties} exact depth ties; image rel {e_img:.1e}, d_means3D rel {e_g:.1e}")
+    assert e_img < 1e-3
+    assert e_g < 1e-2
 
 
 def test_backward_is_linear_in_incoming_gradient(device):

@@ -1,0 +1,96 @@
+"""-m gpu: the HIP path (through the operator surface, i.e. the C-ABI) against the FROZEN rasterizer golden vectors
+tests/golden/raster_*.npz -- the float64 autograd oracle's results on SURVEY.md 8(c)'s list of scenes (N = 1, 2
+overlapping, 10k; behind the camera; opacity < 1/255; saturating stack; border straddler on two bands; SH degree 0..3;
+white / black background; 1080 rows).  Bars (north_star: 1e-4 relative fp32):
+  * radii: equal except where ceil() sits on an integer in fp32 (<= N/5000 entries);
+  * image and every gradient tensor: norm-wise <= 1e-4 AND p99 element-wise (helpers.elem_excess <= 1:
+    |a-b| <= 1e-4 |b| + 1e-5 rms(b) for 99 % of the non-zero entries)."""
+import pytest
+import torch
+
+from helpers import GOLDEN_GRADS, GOLDEN_SCENES, KEYS, elem_excess, frac_bad, golden_weight, load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _hip_chain(gd, device):
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+
+    kw = gd["kw"]
+    rs = GaussianRasterizationSettings(
+        image_height=gd["H"], image_width=gd["W"], tanfovx=kw["tanfovx"], tanfovy=kw["tanfovy"], bg=gd["bg"].to(device),
+        scale_modifier=1.0, viewmatrix=kw["viewmatrix"].to(device), projmatrix=kw["projmatrix"].to(device),
+        sh_degree=gd["sh_degree"], campos=kw["campos"].to(device), prefiltered=False, debug=False)
+    rast = GaussianRasterizer(rs)
+    gg = {k: v.to(device).requires_grad_(True) for k, v in gd["g"].items()}
+    m2, rgb, co, radii, depths = rast.preprocess_gaussians(*[gg[k] for k in KEYS], {})
+    m2.retain_grad()
+    img, _, _, nc = rast.render_gaussians(m2, co, rgb, depths, radii, gd["mask"].to(device), None,
+                                          {"stats_collector": {}})
+    (img * golden_weight(gd["H"], gd["W"]).float().to(device)).sum().backward()
+    out = dict(image=img, means2D=m2, rgb=rgb, conic_opacity=co, radii=radii, depths=depths, n_contrib=nc,
+               d_means2D=m2.grad)
+    for k in KEYS:
+        out["d_" + k] = gg[k].grad
+    return {k: v.detach().cpu() for k, v in out.items()}
+
+
+@pytest.mark.parametrize("name", GOLDEN_SCENES)
+def test_hip_matches_frozen_golden(device, name):
+    gd = load_golden(name)
+    ref = gd["out"]
+    got = _hip_chain(gd, device)
+    N = gd["g"]["means3D"].shape[0]
+    assert int((got["radii"] != ref["radii"]).sum()) <= N // 5000, "radii"
+    same = got["radii"] == ref["radii"]
+    for k, tol in (("means2D", 2e-6), ("depths", 2e-6), ("conic_opacity", 1e-5), ("rgb", 1e-5)):
+        assert rel_err(got[k][same], ref[k][same]) < tol, k
+    report = [f"image {rel_err(got['image'], ref['image']):.1e}"]
+    assert rel_err(got["image"], ref["image"]) < 1e-4
+    assert frac_bad(got["image"], ref["image"], rtol=1e-3, atol=1e-4) < 2e-4
+    pm = gd["mask"].repeat_interleave(16, 0).repeat_interleave(16, 1)[: gd["H"], : gd["W"]]
+    assert float(got["image"][:, ~pm].abs().sum()) == 0.0, "non-local pixels are exactly 0"
+    for k in GOLDEN_GRADS:
+        e, x = rel_err(got[k], ref[k]), elem_excess(got[k], ref[k])
+        report.append(f"{k} {e:.1e}/p99 {x:.2f}")
+        assert e < 1e-4, f"{k}: norm-wise {e}"
+        assert x <= 1.0, f"{k}: p99 element-wise excess {x}"
+    print(f"[golden {name}] " + "  ".join(report))
+
+
+def test_det_zero_cull_matches_fp32_restatement(device):
+    """`det == 0` cull: needle-shaped giant splats whose fp32 cov2D determinant cancels to
+    exactly 0.  A float64 oracle keeps them (the cull is an artefact of fp32 arithmetic), so this is pinned on the
+    plain-C fp32 restatement instead: bit-identical radii (both are compiled without FP contraction)."""
+    import math
+
+    import synthetic_scene as S
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from helpers import cam_kwargs, settings_from
+    from oracle import cref as C
+    from oracle import torch_oracle as O
+
+    W, H, n = 64, 48, 2000
+    cam = S.SyntheticCamera(0, W, H)
+    gen = torch.Generator().manual_seed(3)
+    g = S.make_gaussians(n, W, H, seed=1, scale_coef=0.02)
+    s = 10 ** (torch.rand(n, generator=gen) * 2.0 + 2.0)
+    g["scales"] = torch.stack([s, torch.full((n,), 0.01), torch.full((n,), 0.01)], 1)
+    ang = torch.rand(n, generator=gen) * math.pi
+    g["rotations"] = torch.stack([torch.cos(ang / 2), torch.zeros(n), torch.zeros(n), torch.sin(ang / 2)], 1)
+    kw = cam_kwargs(cam)
+    ref = C.preprocess_forward(*[g[k] for k in KEYS], **kw)
+    r64 = O.preprocess(*[g[k].double() for k in KEYS], **kw)[3]
+    det0 = (ref[3] == 0) & (r64 > 0)
+    assert int(det0.sum()) > 100, "the scene must contain fp32 det == 0 culls"
+    rast = GaussianRasterizer(settings_from(cam, torch.zeros(3)))
+    gg = {k: v.to(device).requires_grad_(True) for k, v in g.items()}
+    m2, rgb, co, radii, depths = rast.preprocess_gaussians(*[gg[k] for k in KEYS], {})
+    assert torch.equal(radii.cpu(), ref[3]), "radii incl. the det == 0 culls are bit-identical to the fp32 restatement"
+    assert float(co[det0.to(device)].abs().sum()) == 0.0 and float(m2[det0.to(device)].abs().sum()) == 0.0
+    img, _, _, _ = rast.render_gaussians(m2, co, rgb, depths, radii, None, None, {})
+    img.sum().backward()
+    assert torch.isfinite(img).all()
+    for k in KEYS:
+        assert torch.isfinite(gg[k].grad).all(), k
+        assert float(gg[k].grad[det0.to(device)].abs().sum()) == 0.0, f"culled Gaussians receive no gradient ({k})"

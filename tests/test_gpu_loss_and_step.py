@@ -116,7 +116,9 @@ def test_training_iteration_through_mirror_matches_oracle(device):
         d_means += C.preprocess_backward(g["means3D"], g["scales"], g["rotations"], g["shs"], radii, cov3D, clamped,
                                          d2, dco, drgb, **kw)[0].double()
     assert abs(loss.item() - total) < 1e-4 * abs(total)
-    assert rel_err(model._xyz.grad, d_means) < 2e-4
+    e = rel_err(model._xyz.grad, d_means)
+    print(f"[mirror iteration] d_xyz rel {e:.2e}")
+    assert e < 1e-4
 
 
 def test_fused_adam_matches_torch_adam(device):
@@ -263,7 +265,7 @@ def test_fused_activations_match_getters(device):
         assert rel_err(g_, w_) < 1e-5
 
 
-@pytest.mark.parametrize("deg", [0, 2, 3])
+@pytest.mark.parametrize("deg", [0, 1, 2, 3])
 def test_preprocess_raw_equals_getters_then_op(device, deg):
     """the RAW-parameter entry (activations fused into K1/K11) == getters + reference-shaped op, fwd and bwd"""
     from diff_gaussian_rasterization import GaussianRasterizer
@@ -351,14 +353,15 @@ def test_short_training_run_reduces_loss(device):
     assert lastv < 0.7 * first, f"loss did not drop: {first:.4f} -> {lastv:.4f}"
 
 
-def test_batched_camera_preprocess_equals_per_camera(device):
+@pytest.mark.parametrize("deg", [3, 0, 1, 2])
+def test_batched_camera_preprocess_equals_per_camera(device, deg):
     """the one-launch-per-batch K1/K11 == B single-camera calls: outputs per camera and SUMMED gradients"""
     import diff_gaussian_rasterization as dgr
     from helpers import settings_from
 
     N, W, H, B = 30000, 320, 208, 4
     cams = S.orbit_cameras(B, W, H, device=device)
-    rasts = [dgr.GaussianRasterizer(settings_from(c, torch.zeros(3))) for c in cams]
+    rasts = [dgr.GaussianRasterizer(settings_from(c, torch.zeros(3), sh_degree=deg)) for c in cams]
     gen = torch.Generator().manual_seed(1)
     ws = [[torch.rand(s, generator=gen).to(device) for s in [(N, 2), (N, 3), (N, 4)]] for _ in range(B)]
 
@@ -371,7 +374,7 @@ def test_batched_camera_preprocess_equals_per_camera(device):
     sum((o[0] * w[0]).sum() + (o[1] * w[1]).sum() + (o[2] * w[2]).sum() for o, w in zip(outs_a, ws)).backward()
     mb, rb = model()
     packed = torch.stack([dgr.pack_camera(r.raster_settings) for r in rasts])
-    m2, rgb, co, radii, depths = dgr.preprocess_gaussians_raw_batched(*rb, packed, 3, 1.0, W, H)
+    m2, rgb, co, radii, depths = dgr.preprocess_gaussians_raw_batched(*rb, packed, deg, 1.0, W, H)
     sum((m2[k] * ws[k][0]).sum() + (rgb[k] * ws[k][1]).sum() + (co[k] * ws[k][2]).sum() for k in range(B)).backward()
     for k in range(B):
         assert torch.equal(radii[k], outs_a[k][3])

@@ -13,7 +13,7 @@ import torch
 
 import diff_gaussian_rasterization as dgr
 import synthetic_scene as S
-from helpers import KEYS, cam_kwargs, frac_bad, oracle_c_chain, rel_err, settings_from
+from helpers import KEYS, cam_kwargs, elem_excess, frac_bad, oracle_c_chain, rel_err, settings_from
 
 pytestmark = pytest.mark.gpu
 
@@ -40,7 +40,7 @@ SCENES = [
 
 
 @pytest.mark.parametrize("N,W,H,sc,seed,ci", SCENES)
-@pytest.mark.parametrize("sh_degree", [0, 3])
+@pytest.mark.parametrize("sh_degree", [0, 1, 2, 3])  # training walks 0 -> 1 -> 2 -> 3 (scene/gaussian_model.py:136)
 def test_preprocess_forward_matches_c_oracle(device, N, W, H, sc, seed, ci, sh_degree):
     from diff_gaussian_rasterization import GaussianRasterizer
     from oracle import cref as C
@@ -112,12 +112,13 @@ def test_binning_is_ordered_subsequence_of_reference_lists(device, N, W, H, sc, 
 
 
 @pytest.mark.parametrize("N,W,H,sc,seed,ci", SCENES)
-@pytest.mark.parametrize("bgv", [0.0, 0.7])
-def test_full_chain_matches_c_oracle(device, N, W, H, sc, seed, ci, bgv):
-    """preprocess -> render -> backward through the operator surface vs the C restatement"""
+@pytest.mark.parametrize("bgv,sh_degree", [(0.0, 3), (0.7, 3), (0.0, 0), (0.7, 1), (0.0, 2)])
+def test_full_chain_matches_c_oracle(device, N, W, H, sc, seed, ci, bgv, sh_degree):
+    """preprocess -> render -> backward through the operator surface vs the C restatement: norm-wise AND p99
+    element-wise on every gradient tensor, for every SH degree"""
     from diff_gaussian_rasterization import GaussianRasterizer
 
-    g = S.make_gaussians(N, W, H, seed=seed, scale_coef=sc)
+    g = S.make_gaussians(N, W, H, seed=seed, scale_coef=sc, sh_rest_sigma=0.1 if sh_degree == 3 else 0.4)
     cam = S.orbit_cameras(4, W, H)[ci]
     bg = torch.tensor([bgv, bgv * 0.5, 1.0 - bgv])
     mask = _full_mask(cam)
@@ -125,9 +126,9 @@ def test_full_chain_matches_c_oracle(device, N, W, H, sc, seed, ci, bgv):
         mask[0:2, :] = False
     gen = torch.Generator().manual_seed(11)
     wgt = torch.rand(3, H, W, generator=gen)
-    ref = oracle_c_chain(g, cam, bg, mask, wgt)
+    ref = oracle_c_chain(g, cam, bg, mask, wgt, sh_degree=sh_degree)
 
-    rast = GaussianRasterizer(settings_from(cam, bg))
+    rast = GaussianRasterizer(settings_from(cam, bg, sh_degree=sh_degree))
     gg = {k: v.to(device).requires_grad_(True) for k, v in g.items()}
     cuda_args = {"stats_collector": {}}
     m2, rgb, co, radii, depths = rast.preprocess_gaussians(gg["means3D"], gg["scales"], gg["rotations"], gg["shs"],
@@ -144,17 +145,25 @@ def test_full_chain_matches_c_oracle(device, N, W, H, sc, seed, ci, bgv):
     assert frac_bad(img, ref["image"], rtol=1e-3, atol=1e-4) < 2e-4
     assert n_contrib.shape == (H, W) and n_contrib.dtype == torch.int32  # positions in the (culled) HIP lists
     (img * wgt.to(device)).sum().backward()
-    assert rel_err(rgb.grad, ref["d_rgb"]) < RTOL
-    assert rel_err(co.grad, ref["d_conic_opacity"]) < RTOL
-    assert rel_err(m2.grad, ref["d_means2D"]) < RTOL
-    for k, rk in [("means3D", "d_means3D"), ("scales", "d_scales"), ("rotations", "d_rotations"), ("shs", "d_shs"),
-                  ("opacities", "d_opacities")]:
-        assert rel_err(gg[k].grad, ref[rk]) < RTOL, k
+    worst = 0.0
+    for name, got, want in [("d_rgb", rgb.grad, ref["d_rgb"]), ("d_conic_opacity", co.grad, ref["d_conic_opacity"]),
+                            ("d_means2D", m2.grad, ref["d_means2D"])] + \
+            [(rk, gg[k].grad, ref[rk]) for k, rk in [("means3D", "d_means3D"), ("scales", "d_scales"),
+                                                     ("rotations", "d_rotations"), ("shs", "d_shs"),
+                                                     ("opacities", "d_opacities")]]:
+        assert rel_err(got, want) < RTOL, name
+        x = elem_excess(got, want)
+        worst = max(worst, x)
+        assert x <= 1.0, f"{name}: p99 element-wise excess {x:.2f} (|a-b| <= 1e-4 |b| + 1e-5 rms)"
+    used = (sh_degree + 1) ** 2
+    assert float(gg["shs"].grad[:, used:].abs().sum()) == 0.0, "coefficients above the active degree get no gradient"
+    print(f"[full chain N={N} {W}x{H} deg={sh_degree}] worst p99 element-wise excess {worst:.2f}")
     st = cuda_args["stats_collector"]
     assert isinstance(st["forward_render_time"], float) and isinstance(st["backward_render_time"], float)
 
 
-def test_small_chain_matches_fp64_autograd_oracle(device):
+@pytest.mark.parametrize("sh_degree", [3, 1])
+def test_small_chain_matches_fp64_autograd_oracle(device, sh_degree):
     """the arbiter: float64 autograd oracle (independent backward derivation)"""
     from diff_gaussian_rasterization import GaussianRasterizer
     from oracle import torch_oracle as O
@@ -167,12 +176,12 @@ def test_small_chain_matches_fp64_autograd_oracle(device):
     gen = torch.Generator().manual_seed(2)
     wgt = torch.rand(3, H, W, generator=gen)
     ins = {k: v.double().clone().requires_grad_(True) for k, v in g.items()}
-    kw = cam_kwargs(cam)
+    kw = cam_kwargs(cam, sh_degree)
     m2o, rgbo, coo, radiio, deptho = O.preprocess(*[ins[k] for k in KEYS], **kw)
     imgo, _, _ = O.render(m2o, coo, rgbo, deptho, radiio, mask, bg=bg, W=W, H=H)
     (imgo * wgt.double()).sum().backward()
 
-    rast = GaussianRasterizer(settings_from(cam, bg))
+    rast = GaussianRasterizer(settings_from(cam, bg, sh_degree=sh_degree))
     gg = {k: v.to(device).requires_grad_(True) for k, v in g.items()}
     m2, rgb, co, radii, depths = rast.preprocess_gaussians(*[gg[k] for k in KEYS], {})
     img, _, _, _ = rast.render_gaussians(m2, co, rgb, depths, radii, mask.to(device), None, {})
@@ -180,6 +189,7 @@ def test_small_chain_matches_fp64_autograd_oracle(device):
     assert rel_err(img, imgo) < RTOL
     for k in KEYS:
         assert rel_err(gg[k].grad, ins[k].grad) < RTOL, k
+        assert elem_excess(gg[k].grad, ins[k].grad) <= 1.0, f"{k}: p99 element-wise"
 
 
 def test_local2j_matches_oracle(device):
@@ -230,6 +240,7 @@ def test_partition_union_equals_single(device):
         assert torch.equal(imgw, img1), "forward composite is tile-independent: bitwise equal"
         for k in KEYS:
             assert rel_err(grw[k], gr1[k]) < RTOL, k
+            assert elem_excess(grw[k], gr1[k]) <= 1.0, f"{k}: p99 element-wise (only the atomic-add order differs)"
 
 
 def test_degenerate_inputs(device):
@@ -285,7 +296,15 @@ def test_saturating_stack_early_stop(device):
     assert int(nc.max()) <= n and int(nc.max()) < int(ref["n_contrib"].max()) + 1
     assert rel_err(img, ref["image"]) < RTOL
     img.sum().backward()
-    assert rel_err(gg["opacities"].grad, ref["d_opacities"]) < 5e-4
+    # In this scene every pixel of the stack stops at the T < 1e-4 rule.  A pixel whose T lands within an ulp of 1e-4
+    # may stop one entry earlier / later than in the restatement (v_exp_f32 vs libm expf): a discrete change of one
+    # blended entry on that pixel, not rounding noise.  Measured (printed): <= 1e-4 norm-wise still holds.
+    e = rel_err(gg["opacities"].grad, ref["d_opacities"])
+    flips = int((nc.cpu() != ref["n_contrib"]).sum())
+    print(f"[saturating] d_opacities rel {e:.2e}, n_contrib differs on {flips} of {W * H} pixels")
+    assert e < RTOL
+    for k, rk in [("means3D", "d_means3D"), ("scales", "d_scales"), ("shs", "d_shs")]:
+        assert rel_err(gg[k].grad, ref[rk]) < RTOL, k
 
 
 def test_batched_exchange_need_equals_per_camera_k2(device):

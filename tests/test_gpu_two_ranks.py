@@ -109,7 +109,7 @@ def _worker(rank, world, port, bsz, q):
         tot = loss.detach().cpu().double().reshape(1).clone()
         dist.all_reduce(tot)
         chunk = (N + world - 1) // world
-        names = ["_xyz", "_features_dc", "_opacity", "_scaling", "_rotation"]
+        names = ["_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"]
         gathered = {}
         for nm in names:
             gten = getattr(model, nm).grad
@@ -160,7 +160,8 @@ def _worker(rank, world, port, bsz, q):
             assert abs(tot.item() - total) < 1e-4 * abs(total), (tot.item(), total)
             for nm in names:
                 e = rel_err(gathered[nm], leaves[nm].grad)
-                assert e < 3e-4, f"{nm}: gradient through the partitioned iteration differs, rel {e}"
+                print(f"[{world} ranks, bsz {bsz}] {nm}: rel {e:.2e}", flush=True)
+                assert e < 1e-4, f"{nm}: gradient through the partitioned iteration differs, rel {e}"
         dist.barrier()
         dist.destroy_process_group()
         q.put((rank, "ok"))
