@@ -183,6 +183,14 @@ def densify_and_split(self, grads, grad_threshold, scene_extent, N=2):
 
 
 def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size):
+    args = utils.get_args()
+    if not getattr(args, "gaussians_distribution", True) and utils.DEFAULT_GROUP.size() > 1:
+        # replicated storage (scene/gaussian_model.py:1006-1016): every rank saw only its own pixels, so the replicas
+        # agree on the statistics first -- otherwise they would clone / split / prune different sets and diverge
+        group = getattr(utils, "DP_GROUP", None) or utils.DEFAULT_GROUP
+        dist.all_reduce(self.max_radii2D, op=dist.ReduceOp.MAX, group=group)
+        dist.all_reduce(self.xyz_gradient_accum, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(self.denom, op=dist.ReduceOp.SUM, group=group)
     grads = self.xyz_gradient_accum / self.denom
     grads[grads.isnan()] = 0.0
     densify_and_clone(self, grads, max_grad, extent)

@@ -8,6 +8,7 @@ From-scratch mirror of the live (`*_final`) surface of the reference's gaussian_
   all_to_all_communication_final                    gaussian_renderer/__init__.py:542-698
   distributed_preprocess3dgs_and_all2all_final      gaussian_renderer/__init__.py:878-1037
   render_final                                      gaussian_renderer/__init__.py:1217-1291
+  render / preprocess3dgs_and_all2all (legacy)      gaussian_renderer/__init__.py:410-507
   gsplat_* twins                                    third-party backend, source absent -> raise
 
 Same inputs, same returned dict keys / list shapes, same ordering of received Gaussians (source-rank
@@ -320,7 +321,11 @@ def distributed_preprocess3dgs_and_all2all_final(batched_viewpoint_cameras, pc, 
         # ONE launch for the whole batch: parameters read once, per-camera outputs camera-major
         packed = []
         for camera, rast in zip(batched_viewpoint_cameras, rasterizers):
-            key = (float(rast.raster_settings.tanfovx), float(rast.raster_settings.tanfovy))
+            # the packed record is valid as long as the camera's tensors are the same objects with the same contents:
+            # data_ptr + in-place version counter of each matrix (pose refinement / test-time edits repack)
+            rs_k = rast.raster_settings
+            key = (float(rs_k.tanfovx), float(rs_k.tanfovy)) + tuple(
+                (t.data_ptr(), t._version) for t in (rs_k.viewmatrix, rs_k.projmatrix, rs_k.campos))
             cached = getattr(camera, "_gsr_packed", None)
             if cached is None or cached[0] != key or cached[1].device != raw[0].device:
                 cached = (key, _dgr.pack_camera(rast.raster_settings))
@@ -426,3 +431,65 @@ def _no_gsplat(*a, **k):
 
 gsplat_distributed_preprocess3dgs_and_all2all_final = _no_gsplat
 gsplat_render_final = _no_gsplat
+
+
+# ------------------------------------------------------------------ legacy single-camera surface
+def _local_camera_index(batched_strategies):
+    """the camera this rank renders: the reference indexes the batch with utils.DP_GROUP.rank()
+    (gaussian_renderer/__init__.py:414-415); DP_GROUP is never assigned there, so fall back to the first
+    camera whose strategy lists this rank"""
+    dp = getattr(utils, "DP_GROUP", None)
+    if dp is not None:
+        return dp.rank()
+    for k, strategy in enumerate(batched_strategies):
+        if utils.GLOBAL_RANK in strategy.gpu_ids:
+            return k
+    return 0
+
+
+def preprocess3dgs_and_all2all(batched_cameras, gaussians, pipe_args, background, batched_strategies, mode):
+    """legacy entry point (gaussian_renderer/__init__.py:410-455): the package `render()` below consumes -- one
+    local camera, keys `rasterizer`, `cuda_args`, `*_for_render` -- built from the live `final` path."""
+    pkg = distributed_preprocess3dgs_and_all2all_final(batched_cameras, gaussians, pipe_args, background,
+                                                       batched_strategies=batched_strategies, mode=mode)
+    k = _local_camera_index(batched_strategies)
+    out = {
+        "batched_locally_preprocessed_mean2D": pkg["batched_locally_preprocessed_mean2D"],
+        "batched_locally_preprocessed_radii": pkg["batched_locally_preprocessed_radii"],
+        "rasterizer": pkg["batched_rasterizers"][k],
+        "cuda_args": pkg["batched_cuda_args"][k],
+        "means2D_for_render": pkg["batched_means2D_redistributed"][k],
+        "rgb_for_render": pkg["batched_rgb_redistributed"][k],
+        "conic_opacity_for_render": pkg["batched_conic_opacity_redistributed"][k],
+        "radii_for_render": pkg["batched_radii_redistributed"][k],
+        "depths_for_render": pkg["batched_depths_redistributed"][k],
+        "i2j_send_size": pkg["gpui_to_gpuj_imgk_size"],
+    }
+    if mode != "test":
+        out["batched_locally_preprocessed_visibility_filter"] = pkg["batched_locally_preprocessed_visibility_filter"]
+    return out
+
+
+def render(screenspace_pkg, strategy=None):
+    """legacy `gaussian_renderer.render()` (gaussian_renderer/__init__.py:458-507; named by north_star): one camera,
+    -> (rendered_image, compute_locally).  Same scalar stand-in rule (< 1000 received Gaussians) and the same
+    stats_collector keys as the reference's function."""
+    timers = utils.get_timers()
+    compute_locally = strategy.get_compute_locally()
+    extended = strategy.get_extended_compute_locally()
+    if timers is not None:
+        timers.start("forward_render_gaussians")
+    pkg = screenspace_pkg
+    if pkg["means2D_for_render"].shape[0] < 1000:
+        image = pkg["means2D_for_render"].sum() + pkg["conic_opacity_for_render"].sum() + pkg["rgb_for_render"].sum()
+        st = pkg["cuda_args"]["stats_collector"]
+        st["forward_render_time"] = st["backward_render_time"] = 0.0
+        st["forward_loss_time"] = st["backward_loss_time"] = 0.0
+        return image, compute_locally
+    image, _, _, _ = pkg["rasterizer"].render_gaussians(
+        means2D=pkg["means2D_for_render"], conic_opacity=pkg["conic_opacity_for_render"], rgb=pkg["rgb_for_render"],
+        depths=pkg["depths_for_render"], radii=pkg["radii_for_render"], compute_locally=compute_locally,
+        extended_compute_locally=extended, cuda_args=pkg["cuda_args"])
+    if timers is not None:
+        timers.stop("forward_render_gaussians")
+    return image, compute_locally

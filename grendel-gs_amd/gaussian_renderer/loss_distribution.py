@@ -31,6 +31,12 @@ _FUSED_LOSS = getattr(_dgr_loss, "fused_band_loss", None)
 _WINDOW_CACHE = {}
 
 
+def _device():
+    """the current HIP device.  Deliberately NOT a helper of `utils`: when these files are grafted over the
+    reference's (INTEGRATION.md level B2) `utils` is the reference's own module, which has no such function."""
+    return torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+
+
 def get_coverage_y_min(tile_row_l):
     return tile_row_l * utils.BLOCK_Y
 
@@ -54,7 +60,7 @@ def load_camera_from_cpu_to_all_gpu(batched_cameras, batched_strategies, gpuid2t
     renders.  With `distributed_dataset_storage` only the first rank of a node holds the images and
     sends the other ranks their bands over xGMI (batched isend/irecv)."""
     args = utils.get_args()
-    dev = utils.device()
+    dev = _device()
     me = utils.GLOBAL_RANK
     if not args.distributed_dataset_storage or args.local_sampling or utils.DEFAULT_GROUP.size() == 1:
         for (k, l, r) in gpuid2tasks[me]:
@@ -88,10 +94,22 @@ def load_camera_from_cpu_to_all_gpu(batched_cameras, batched_strategies, gpuid2t
 def load_camera_from_cpu_to_all_gpu_for_eval(batched_cameras, batched_strategies, gpuid2tasks):
     """evaluation wants the FULL ground-truth image on every rank (PSNR after the image all-reduce)."""
     args = utils.get_args()
-    dev = utils.device()
+    dev = _device()
     if not args.distributed_dataset_storage or utils.DEFAULT_GROUP.size() == 1:
         for camera in batched_cameras:
             camera.original_image = camera.original_image_backup.to(dev)
+        return
+    if args.local_sampling:
+        # every camera of the batch is held by the rank that sampled it: idx // (bsz / world) (loss_distribution.py:
+        # 2339-2365 of the reference scatters from that rank; a broadcast moves the same bytes)
+        per_gpu = max(args.bsz // utils.WORLD_SIZE, 1)
+        for idx, camera in enumerate(batched_cameras):
+            owner = idx // per_gpu
+            if camera.original_image_backup is not None:
+                camera.original_image = camera.original_image_backup.to(dev)
+            else:
+                camera.original_image = torch.empty((3, utils.IMG_H, utils.IMG_W), dtype=torch.uint8, device=dev)
+            dist.broadcast(camera.original_image, src=owner, group=utils.IN_NODE_GROUP)
         return
     root = utils.get_first_rank_on_cur_node()
     for camera in batched_cameras:

@@ -47,6 +47,11 @@ def division_pos_heuristic(heuristic, tile_num, world_size, right=False):
 _MASK_CACHE = {}
 
 
+def _device():
+    """the current HIP device (not a `utils` helper: under graft level B2 `utils` is the reference's module)"""
+    return torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+
+
 class DivisionStrategyFinal:
     """row-band partition of ONE camera among the `gpu_ids` that render a part of it"""
 
@@ -93,12 +98,12 @@ class DivisionStrategyFinal:
         if rows is None:
             return None
         # read-only masks, one per (band, grid, device), built once: no fill kernels in the steady state
-        key = (rows[0], rows[1], utils.TILE_Y, utils.TILE_X, str(utils.device()))
+        key = (rows[0], rows[1], utils.TILE_Y, utils.TILE_X, str(_device()))
         mask = _MASK_CACHE.get(key)
         if mask is None:
             if len(_MASK_CACHE) > 4096:
                 _MASK_CACHE.clear()
-            mask = torch.zeros((utils.TILE_Y, utils.TILE_X), dtype=torch.bool, device=utils.device())
+            mask = torch.zeros((utils.TILE_Y, utils.TILE_X), dtype=torch.bool, device=_device())
             mask[rows[0]:rows[1]] = True
             _MASK_CACHE[key] = mask
         return mask
@@ -106,7 +111,7 @@ class DivisionStrategyFinal:
     def get_compute_locally_all(self):
         if self._my_rows() is None:
             return None
-        return torch.ones((utils.TILE_Y, utils.TILE_X), dtype=torch.bool, device=utils.device())
+        return torch.ones((utils.TILE_Y, utils.TILE_X), dtype=torch.bool, device=_device())
 
     def get_extended_compute_locally(self):
         return None
@@ -227,7 +232,10 @@ def finish_strategy_final(batched_cameras, strategy_history, batched_strategies,
             continue
         st = batched_statistic_collector[k]
         mine.append(float(st["forward_render_time"] + st["backward_render_time"] + st["forward_loss_time"] * 2))
-    times = utils.our_allgather_among_cpu_processes_float_list(mine, utils.DEFAULT_GROUP)
+    if W == 1:
+        times = [list(mine)]  # nothing to gather: no device round trip (the reference's helper syncs the device here)
+    else:
+        times = utils.our_allgather_among_cpu_processes_float_list(mine, utils.DEFAULT_GROUP)
     strategy_history.store_stats(batched_cameras, times, batched_strategies)
     if frozen:
         return

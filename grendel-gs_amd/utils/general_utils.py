@@ -18,9 +18,12 @@ CUR_ITER = 0
 GLOBAL_RANK = 0
 LOCAL_RANK = 0
 WORLD_SIZE = 1
+DP_GROUP = None
+MP_GROUP = None
 DEFAULT_GROUP = None
 IN_NODE_GROUP = None
 TIMERS = None
+DENSIFY_ITER = 0
 
 BLOCK_X, BLOCK_Y = 16, 16
 ONE_DIM_BLOCK_SIZE = 256
@@ -36,6 +39,8 @@ def default_args(**overrides):
         heuristic_decay=0.0, no_heuristics_update=False, border_divpos_coeff=1.0,
         adjust_strategy_warmp_iterations=-1, local_sampling=False, distributed_dataset_storage=False,
         lambda_dssim=0.2, lr_scale_loss=1.0, backend="default", save_strategy_history=False,
+        redistribute_gaussians_mode="random_redistribute", redistribute_gaussians_frequency=10,
+        redistribute_gaussians_threshold=1.1, sync_grad_mode="dense",  # arguments/__init__.py:148-156
     )
     for k, v in overrides.items():
         setattr(a, k, v)
@@ -104,6 +109,15 @@ def get_img_height():
 
 def get_num_pixels():
     return IMG_H * IMG_W
+
+
+def get_denfify_iter():  # (sic) utils/general_utils.py:116
+    return DENSIFY_ITER
+
+
+def inc_densify_iter():
+    global DENSIFY_ITER
+    DENSIFY_ITER += 1
 
 
 def check_initial_gpu_memory_usage(prefix):

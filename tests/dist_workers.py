@@ -108,6 +108,24 @@ def redistribution_worker(rank, world, port, on_gpu, q):
         tot = torch.tensor([n])
         dist.all_reduce(tot)
         assert int(tot) == sum(sizes)
+
+        # the reference's own call form, no arguments (densification.py:78-84): destination drawn uniformly at random
+        # when the trigger fires -- here the densification counter hits redistribute_gaussians_frequency
+        assert not D.need_redistribute_gaussians(m, utils.DEFAULT_GROUP) or world > 1
+        utils.DENSIFY_ITER = utils.get_args().redistribute_gaussians_frequency
+        assert D.need_redistribute_gaussians(m, utils.DEFAULT_GROUP)
+        torch.manual_seed(100 + rank)
+        D.redistribute_gaussians(m)
+        ids_now = (m._xyz.detach().cpu()[:, 0].double() / 1024).round().long()  # column 0 of slot 0 encodes the id
+        for s, g in enumerate(m.optimizer.param_groups):
+            p = g["params"][0]
+            st = m.optimizer.state[p]
+            for slot, t in ((3 * s, p.detach()), (3 * s + 1, st["exp_avg"]), (3 * s + 2, st["exp_avg_sq"])):
+                assert torch.equal(t.cpu(), _Shard.encode(ids_now, slot, p.shape[1:])), (g["name"], slot)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, ids_now.tolist())
+        assert sorted(i for part in gathered for i in part) == list(range(sum(sizes))), "every Gaussian exactly once"
+        utils.DENSIFY_ITER = 0
         dist.barrier()
         dist.destroy_process_group()
         q.put((rank, "ok"))

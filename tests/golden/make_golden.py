@@ -112,5 +112,34 @@ def main():
     print("wrote", path, {k: v.shape for k, v in out.items()})
 
 
+def write_reference_utils_names():
+    """names defined at module level by the reference's utils/general_utils.py (functions, classes, globals): the
+    B2 graft keeps that module, so the mirror may only touch these (tests/test_b1_graft_cpu.py)"""
+    import ast
+    import os
+
+    src = open("/root/reference/utils/general_utils.py").read()
+    names = set()
+    for node in ast.parse(src).body:
+        if isinstance(node, (ast.FunctionDef, ast.ClassDef)):
+            names.add(node.name)
+        elif isinstance(node, ast.Assign):
+            for t in node.targets:
+                for n in ast.walk(t):
+                    if isinstance(n, ast.Name):
+                        names.add(n.id)
+        elif isinstance(node, ast.FunctionDef):
+            names.add(node.name)
+    # globals created by `global X` assignments inside functions (IMG_H, TILE_X, ...)
+    for node in ast.walk(ast.parse(src)):
+        if isinstance(node, ast.Global):
+            names.update(node.names)
+    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_utils_names.txt")
+    open(out, "w").write("\n".join(sorted(names)) + "\n")
+    print("wrote", out, len(names), "names")
+
+
 if __name__ == "__main__":
-    main()
+    if "--names-only" not in sys.argv:
+        main()
+    write_reference_utils_names()

@@ -90,3 +90,67 @@ def test_knn_oracle_matches_kdtree():
     assert C.knn_mean_dist2(torch.zeros(1, 3)).tolist() == [0.0]
     two = C.knn_mean_dist2(torch.tensor([[0.0, 0, 0], [1.0, 0, 0]]))
     assert two.tolist() == [1.0, 1.0]
+
+
+# ------------------------------------------------------------------------------- level B2
+MIRROR = os.path.join(ROOT, "grendel-gs_amd", "gaussian_renderer")
+MIRROR_FILES = ["__init__.py", "workload_division.py", "loss_distribution.py"]
+
+
+def _utils_names_used_by_the_mirror():
+    import ast
+
+    names = set()
+    for f in MIRROR_FILES:
+        tree = ast.parse(open(os.path.join(MIRROR, f)).read())
+        for node in ast.walk(tree):
+            if isinstance(node, ast.Attribute) and isinstance(node.value, ast.Name) and node.value.id == "utils":
+                names.add(node.attr)
+    names.discard("general_utils")
+    return sorted(names)
+
+
+def test_mirror_only_uses_names_the_reference_utils_module_has():
+    """graft level B2 keeps the reference's utils/: every `utils.X` the three mirror files touch must exist there.
+    The list of the reference's names travels as a golden (tests/golden/reference_utils_names.txt, written by
+    tests/golden/make_golden.py from the reference's utils/general_utils.py) so this also runs without the tree."""
+    have = set(open(os.path.join(ROOT, "tests", "golden", "reference_utils_names.txt")).read().split())
+    missing = [n for n in _utils_names_used_by_the_mirror() if n not in have]
+    assert not missing, f"mirror uses utils names the reference's utils/general_utils.py does not define: {missing}"
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "gaussian_renderer")), reason="reference tree not present")
+def test_b2_graft_mirror_runs_on_the_reference_utils(tmp_path):
+    """the three mirror files dropped over the reference's (a symlinked package that shadows it) with the REFERENCE's
+    utils/: import, partition a batch, build the band mask, stage the ground-truth bands (world size 1, CPU tensors)"""
+    os.symlink(MIRROR, str(tmp_path / "gaussian_renderer"))
+    code = (
+        "import sys, types, torch\n"
+        "import utils.general_utils as u\n"
+        "assert u.__file__.startswith(%r), u.__file__\n"
+        "assert not hasattr(u, 'device'), 'the reference utils has no device() helper'\n"
+        "import gaussian_renderer as g, gaussian_renderer.workload_division as w, gaussian_renderer.loss_distribution as l\n"
+        "assert g.__file__.startswith(%r), g.__file__\n"
+        "a = types.SimpleNamespace(bsz=2, local_sampling=False, border_divpos_coeff=1.0, distributed_dataset_storage=False,\n"
+        "    adjust_strategy_warmp_iterations=-1, no_heuristics_update=False, heuristic_decay=0.0, save_strategy_history=False,\n"
+        "    gaussians_distribution=True, image_distribution=True, log_interval=250, log_folder='/tmp/x', zhx_debug=False,\n"
+        "    zhx_time=False, lambda_dssim=0.2, lr_scale_loss=1.0)\n"
+        "u.set_args(a); u.set_block_size(16, 16, 256); u.set_img_size(144, 208); u.set_cur_iter(1); u.init_distributed(a)\n"
+        "u.GLOBAL_RANK = 0\n"
+        "cams = [types.SimpleNamespace(uid=k, image_height=144, image_width=208,\n"
+        "        original_image_backup=torch.full((3, 144, 208), k, dtype=torch.uint8), original_image=None) for k in range(2)]\n"
+        "hist = w.DivisionStrategyHistoryFinal(types.SimpleNamespace(cameras=cams), 1, 0)\n"
+        "st, tasks = w.start_strategy_final(cams, hist)\n"
+        "assert tasks == [[(0, 0, 9), (1, 0, 9)]], tasks\n"
+        "m = st[0].get_compute_locally(); assert m.shape == (9, 13) and bool(m.all())\n"
+        "l.load_camera_from_cpu_to_all_gpu(cams, st, tasks)\n"
+        "assert cams[1].original_image.shape == (3, 144, 208) and int(cams[1].original_image[0, 0, 0]) == 1\n"
+        "l.load_camera_from_cpu_to_all_gpu_for_eval(cams, st, tasks)\n"
+        "ca = g.get_cuda_args_final(st[0], 'train'); assert ca['mp_world_size'] == '1' and ca['stats_collector'] == {}\n"
+        "stats = [{'forward_render_time': 1.0, 'backward_render_time': 2.0, 'forward_loss_time': 0.5} for _ in cams]\n"
+        "w.finish_strategy_final(cams, hist, st, stats)\n"
+        "assert hist.history[0]['all_gpu_running_time'] == [8.0]\n"
+        "print('ok')\n" % (REF, str(tmp_path)))
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([str(tmp_path), REF, GRAFT]))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout + r.stderr)[-3000:]

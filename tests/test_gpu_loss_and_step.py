@@ -382,3 +382,39 @@ def test_batched_camera_preprocess_equals_per_camera(device, deg):
         assert rel_err(rgb[k], outs_a[k][1]) < 1e-6 and rel_err(co[k], outs_a[k][2]) < 1e-6
     for pa, pb in zip(ra, rb):
         assert rel_err(pb.grad, pa.grad) < 1e-5
+
+
+def test_legacy_render_equals_render_final(device):
+    """`gaussian_renderer.render()` (the legacy single-camera surface north_star names) == render_final, W = 1"""
+    import gaussian_renderer as gr
+    import utils.general_utils as utils
+    from gaussian_renderer.workload_division import DivisionStrategyHistoryFinal, start_strategy_final
+
+    N, W, H = 5000, 240, 160
+    utils.GLOBAL_RANK, utils.WORLD_SIZE = 0, 1
+    utils.DEFAULT_GROUP = utils.IN_NODE_GROUP = utils.SingleGPUGroup()
+    utils.set_args(utils.default_args(bsz=1))
+    utils.set_img_size(H, W)
+    utils.set_cur_iter(1)
+    cams = S.orbit_cameras(2, W, H, device=device)[:1]
+    bg = torch.tensor([0.1, 0.2, 0.3], device=device)
+    pipe = type("P", (), {"debug": False})()
+    wgt = torch.rand(3, H, W, generator=torch.Generator().manual_seed(0)).to(device)
+    grads = []
+    images = []
+    for legacy in (False, True):
+        model = S.SyntheticGaussianModel(N, W, H, seed=4, device=device, scale_coef=0.012)
+        hist = DivisionStrategyHistoryFinal(S.SyntheticDataset(cams), 1, 0)
+        strategies, _ = start_strategy_final(cams, hist)
+        if legacy:
+            pkg = gr.preprocess3dgs_and_all2all(cams, model, pipe, bg, strategies, "train")
+            img, mask = gr.render(pkg, strategies[0])
+            assert mask.shape == (utils.TILE_Y, utils.TILE_X) and "batched_locally_preprocessed_visibility_filter" in pkg
+        else:
+            pkg = gr.distributed_preprocess3dgs_and_all2all_final(cams, model, pipe, bg, batched_strategies=strategies)
+            img = gr.render_final(pkg, strategies)[0][0]
+        (img * wgt).sum().backward()
+        images.append(img.detach())
+        grads.append(model._xyz.grad.clone())
+    assert torch.equal(images[0], images[1])
+    assert rel_err(grads[1], grads[0]) < 1e-6
