@@ -2,29 +2,39 @@
 
     python bench.py --gpus N --steps K --warmup W           (N = 1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W        (N > 1, one rank per GPU)
+           --master-port P bench.py --gpus N --steps K --warmup W        (N > 1, one rank per GPU over RCCL)
 
 A STEP is one training iteration of the hot path on one batch of synthetic cameras, through the
 reference's own call sequence (train_internal.py:134-329): start_strategy_final -> GT staging ->
 distributed_preprocess3dgs_and_all2all_final (activations + K1 per camera + the sparse exchange)
 -> render_final (K3-K8) -> batched_loss_computation (band-local L1 + SSIM) -> backward (K10, mirror
 exchange, K11, activation backward) -> finish_strategy_final -> grad /= bsz -> Adam step -> zero_grad.
-Nothing is skipped or cached inside the timed region.
+Nothing is skipped or cached inside the timed region.  Inputs (parameters, cameras, uint8 ground-truth
+images) are resident in HBM before the timed region.
 
-Workload (BASELINE.json configs[1], SURVEY.md §8(d) "C2"): a synthetic scene of 1,000,000 Gaussians
-("Mip360-bicycle sized"), 1920x1080 cameras, SH degree 3, fp32.  At N GPUs the scene is sharded over
-the ranks (contiguous shards) and the batch holds N cameras (bsz = N, Grendel's batched pixel
-partition), so per-GPU work is constant: "weak" scaling, value = images / second of the whole job.
-Inputs (parameters, cameras, uint8 ground-truth images) are resident in HBM before the timed region.
+Workloads (`--workload`, default `auto`):
+  c1   BASELINE.json configs[1]: 1,000,000 Gaussians, 1920x1080, SH 3, bsz 1, ONE GPU.      <- auto at N = 1
+  c2   configs[2] shape: 6,000,000 Gaussians sharded over the N ranks, 1920x1080, bsz 1: ONE image split into N
+       row bands (Grendel's pixel partition), dynamic load balancing on.                      <- auto at N > 1
+  c4   configs[4] shape: 40,000,000 Gaussians sharded over N ranks, 3840x2160, bsz 1, image split N ways
+       (reported beside c2 in `extra_workloads` at N > 1 unless --no-extra).
+  weak bsz = N cameras per step on the c1 scene sharded N ways (every rank renders a whole image).
+At N > 1 the total work of c2 / c4 does not depend on N ("scaling": "strong"); every line also carries
+`same_workload_1gpu` -- the SAME scene and camera on one GPU, measured in the same run on rank 0's device -- and
+`speedup_vs_1gpu`, which is the pixel-partition scaling north_star asks about.
 
 One JSON line is printed by rank 0; besides the contract fields it carries
-  roofline     : HBM roofline of the dominant HIP kernel, from HIP events recorded inside the timed
-                 steps on the kernels' stream (algorithmic bytes per launch are SURVEY.md §8(d)'s
-                 formulas, restated in DESIGN.md);
+  kernels      : every HIP kernel group of the step with HIP-event time (recorded on the launch stream inside the
+                 timed steps) and the algorithmic bytes OF THE SAME LAUNCHES (each launch's own N / P / D / Px);
+  roofline     : the dominant kernel against the 8 TB/s HBM peak; `traffic` (PMC HBM bytes per launch) and `valu`
+                 (SQ counters) come from profiles/r02_pmc.json, which tools/pmc_collect.py derives from rocprofv3
+                 --pmc passes over THIS command -- used only while its source hash matches the kernels being run;
+  timing       : median / p10 / p90 ms per step over `--repeats` timed regions (value = the first region);
   cpu_baseline : oracle/gsraster_ref.c (the plain-C "port") timed on this box's host cores on a
                  bounded sample of the same workload (rank 0, N = 1 only).
 """
 import argparse
+import hashlib
 import json
 import math
 import os
@@ -41,24 +51,50 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+SIMDS, CLOCK_HZ, VALU_CYCLES = 1024, 2.4e9, 2  # 256 CUs x 4 SIMD-32; a wave64 VALU instruction issues in 2 cycles
+
+WORKLOADS = {
+    # name: (gaussians_total, width, height, bsz or None = world, description)
+    "c1": (1_000_000, 1920, 1080, 1, "BASELINE configs[1]: Mip360-bicycle-sized scene on one GPU"),
+    "c2": (6_000_000, 1920, 1080, 1, "BASELINE configs[2] shape: one 1080p image split into row bands over the ranks"),
+    "c4": (40_000_000, 3840, 2160, 1, "BASELINE configs[4] shape: one 4K image split into row bands over the ranks"),
+    "weak": (1_000_000, 1920, 1080, None, "bsz = N whole images per step on the configs[1] scene sharded N ways"),
+}
 
 
-def algorithmic_bytes(kernel, N, P, D, Px, tiles, sh_coeffs=16):
-    """SURVEY.md §8(d) per-launch algorithmic HBM bytes (stated again in DESIGN.md)"""
-    in_per_g = 44 + 12 * sh_coeffs  # xyz 12 + scale 12 + rot 16 + opacity 4 + SH
-    if kernel == "preprocess_forward":
-        return N * (in_per_g + 44)
+def algorithmic_bytes(kernel, m):
+    """SURVEY.md 8(d) algorithmic HBM bytes of ONE launch from that launch's own sizes (restated in DESIGN.md 6)"""
+    coeffs = m.get("M", 16)
+    in_g = 44 + 12 * coeffs  # xyz 12 + scale 12 + rot 16 + opacity 4 + SH 12/coefficient = 236 at 16
+    if kernel == "preprocess_forward":  # batched launch: parameters read once, 44 B of outputs per camera
+        return m["N"] * (in_g + 44 * m.get("B", 1))
     if kernel == "preprocess_backward":
-        return N * (in_per_g + 44 + 36 + in_per_g)
-    if kernel == "binning":
-        key_bits = max(1, math.ceil(math.log2(max(tiles, 2))))
-        passes = math.ceil(key_bits / 8)
-        return P * (8 + 4 + 4) + P * 4 * 16 + D * 12 + D * 16 * passes + D * 8
+        return m["N"] * (in_g + (44 + 36) * m.get("B", 1) + in_g)
+    if kernel == "binning":  # the reference's algorithm: 64-bit (tile | depth) keys, LSD passes of 8 bits
+        key_bits = 32 + max(1, math.ceil(math.log2(max(m["tiles"], 2))))
+        return m["P"] * 16 + m["D"] * 12 + m["D"] * 24 * math.ceil(key_bits / 8) + m["D"] * 8
     if kernel == "composite_forward":
-        return 40 * D + 20 * Px
+        return 40 * m["D"] + 20 * m["Px"]
     if kernel == "composite_backward":
-        return 76 * D + 20 * Px
+        return 76 * m["D"] + 20 * m["Px"]
+    if kernel == "l1_ssim_forward":   # image 12 + uint8 GT 3 + three derivative maps 36 per pixel
+        return 51 * m["Px"]
+    if kernel == "l1_ssim_backward":  # maps 36 + image 12 + GT 3 + gradient 12
+        return 63 * m["Px"]
+    if kernel == "adam":              # p, m, v read + written, g read: 28 B per element
+        return 28 * m["numel"]
     return 0
+
+
+def source_hash():
+    """sha256 over the kernel sources: profiles/r02_pmc.json is only quoted for the build it was measured on"""
+    h = hashlib.sha256()
+    d = os.path.join(PKG, "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def cpu_baseline(W, H, n_total, seconds=12.0):
@@ -96,44 +132,62 @@ def cpu_baseline(W, H, n_total, seconds=12.0):
                       f"fwd+bwd only (no loss/optimizer), {it} iterations, oracle/gsraster_ref.c with OpenMP"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--gaussians", type=int, default=1_000_000)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--views", type=int, default=8, help="distinct synthetic cameras to cycle through")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--render-steps", type=int, default=20, help="forward-only views/sec leg (untimed by driver)")
-    a = ap.parse_args()
+class _SingleRankView:
+    """run the W = 1 path inside a W > 1 process (the same-workload single-GPU leg): the process-global state the
+    mirror reads is switched to a one-rank view and restored afterwards"""
 
+    def __init__(self, utils):
+        self.u = utils
+
+    def __enter__(self):
+        u = self.u
+        self.saved = (u.GLOBAL_RANK, u.WORLD_SIZE, u.DEFAULT_GROUP, u.IN_NODE_GROUP)
+        u.GLOBAL_RANK, u.WORLD_SIZE = 0, 1
+        u.DEFAULT_GROUP = u.IN_NODE_GROUP = u.SingleGPUGroup()
+
+    def __exit__(self, *exc):
+        u = self.u
+        u.GLOBAL_RANK, u.WORLD_SIZE, u.DEFAULT_GROUP, u.IN_NODE_GROUP = self.saved
+
+
+def percentile(xs, q):
+    xs = sorted(xs)
+    k = (len(xs) - 1) * q
+    lo, hi = int(math.floor(k)), int(math.ceil(k))
+    return xs[lo] + (xs[hi] - xs[lo]) * (k - lo)
+
+
+def run_workload(a, name, world, rank, dev, steps, warmup, repeats, render_steps, single_view=False,
+                 collect_kernels=True):
+    """-> dict of measurements of one workload on the current process group view (world ranks)"""
+    import diff_gaussian_rasterization as dgr
     import synthetic_scene as S
     import utils.general_utils as utils
-
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-    local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    utils.init_distributed(backend="nccl" if world > 1 else None)
-    rank = utils.GLOBAL_RANK
-    bsz = max(1, world)
-    utils.set_args(utils.default_args(bsz=bsz))
-    utils.set_img_size(a.height, a.width)
-    utils.set_cur_iter(1)
-
-    import diff_gaussian_rasterization as dgr
+    from fused_optim import FusedAdam
     from gaussian_renderer import distributed_preprocess3dgs_and_all2all_final, render_final
     from gaussian_renderer.loss_distribution import batched_loss_computation, load_camera_from_cpu_to_all_gpu
     from gaussian_renderer.workload_division import (DivisionStrategyHistoryFinal, finish_strategy_final,
                                                      start_strategy_final)
 
-    W, H = a.width, a.height
-    model = S.SyntheticGaussianModel(a.gaussians, W, H, seed=0, rank=rank, world_size=world, device=dev)
+    n_total, W, H, bsz, desc = WORKLOADS[name]
+    n_total = a.gaussians or n_total
+    W, H = a.width or W, a.height or H
+    bsz = a.bsz or (bsz if bsz is not None else max(1, world))
+    real_world = int(os.environ.get("WORLD_SIZE", 1))
+    utils.set_args(utils.default_args(bsz=bsz))
+    utils.set_img_size(H, W)
+    utils.set_cur_iter(1)
+
+    if name == "c1" and not a.device_scene:  # the headline scene: SURVEY.md 8(d) generator on the host, seed 0
+        model = S.SyntheticGaussianModel(n_total, W, H, seed=0, rank=rank, world_size=world, device=dev,
+                                         opacity_logit_mean=a.opacity_logit_mean, opacity_logit_std=a.opacity_logit_std)
+        scene = "host generator, seed 0"
+    else:  # large / sharded scenes are drawn on the device; shard r of R is a pure function of (seed, r, R)
+        shards = range(real_world) if single_view else None
+        model = S.SyntheticGaussianModel(n_total, W, H, seed=0, rank=rank, world_size=real_world if single_view else world,
+                                         device=dev, on_device=True, shards=shards,
+                                         opacity_logit_mean=a.opacity_logit_mean, opacity_logit_std=a.opacity_logit_std)
+        scene = "device generator, seed 0, shard = f(seed, rank, world)"
     n_views = max(a.views, bsz)
     cameras = S.orbit_cameras(n_views, W, H, device=dev)
     for k, cam in enumerate(cameras):
@@ -141,11 +195,8 @@ def main():
     history = DivisionStrategyHistoryFinal(S.SyntheticDataset(cameras), world, rank)
     bg = torch.zeros(3, dtype=torch.float32, device=dev)
     pipe = type("Pipe", (), {"debug": False})()
-    from fused_optim import FusedAdam
-
     opt = FusedAdam(model.param_groups(), lr=0.0, eps=1e-15)  # scene/gaussian_model.py:292 settings
-
-    state = {"it": 0}
+    state = {"it": 0, "sizes": None}
 
     def batch():
         s = (state["it"] * bsz) % n_views
@@ -168,6 +219,8 @@ def main():
         opt.zero_grad(set_to_none=True)
         for cam in cams:
             cam.original_image = None
+        state["sizes"] = pkg["gpui_to_gpuj_imgk_size"]
+        state["bands"] = [(s.gpu_ids, s.division_pos) for s in strategies]
 
     def render_step():
         with torch.no_grad():
@@ -183,10 +236,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(fn, steps):
+    def timed(fn, n):
         fence()
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for _ in range(n):
             fn()
         fence()
         dt = time.perf_counter() - t0
@@ -196,77 +249,226 @@ def main():
             dt = t.item()
         return dt
 
-    for _ in range(a.warmup):
+    for _ in range(warmup):
         train_step()
     dgr.kernel_timer.reset()
-    dgr.kernel_timer.enabled = True
-    dt = timed(train_step, a.steps)
+    dgr.kernel_timer.enabled = collect_kernels
+    dt = timed(train_step, steps)  # THE timed region of the contract: exactly `steps` steps between two fences
     dgr.kernel_timer.enabled = False
     torch.cuda.synchronize()
-    ksum = dgr.kernel_timer.summary_ms()
-    D = int(getattr(dgr._RenderGaussians, "last_num_rendered", 0) or 0)
+    launches = dgr.kernel_timer.launches() if collect_kernels else {}
+    dgr.kernel_timer.reset()
+    extra = [timed(train_step, steps) for _ in range(max(repeats - 1, 0))]
+    per_step = [1e3 * x / steps for x in [dt] + extra]
 
-    # forward-only leg: rendered views / second (second half of BASELINE.json's metric)
-    for _ in range(3):
-        render_step()
-    dt_r = timed(render_step, a.render_steps)
+    out = {"name": name, "desc": desc, "gaussians_total": n_total, "gaussians_this_rank": int(model._xyz.shape[0]),
+           "image": [W, H], "bsz": bsz, "world": world, "scene": scene, "dt": dt, "steps": steps,
+           "ms_per_step": 1e3 * dt / steps, "images_per_s": bsz * steps / dt,
+           "timing": {"repeats": len(per_step), "ms_per_step_median": round(percentile(per_step, 0.5), 4),
+                      "ms_per_step_p10": round(percentile(per_step, 0.1), 4),
+                      "ms_per_step_p90": round(percentile(per_step, 0.9), 4),
+                      "ms_per_step_all": [round(x, 4) for x in per_step]}}
+    if render_steps > 0:
+        for _ in range(3):
+            render_step()
+        dt_r = timed(render_step, render_steps)
+        out["rendered_views_per_sec"] = bsz * render_steps / dt_r
+
+    # ---- per-kernel: time and algorithmic bytes of the SAME launches
+    kern = {}
+    px_cache = {}
+    for kname, recs in launches.items():
+        tot_ms, tot_b, D_sum = 0.0, 0, 0
+        for ms, meta in recs:
+            m = dict(meta)
+            if "mask" in m:
+                key = (m["mask"].data_ptr(), m["W"], m["H"])
+                if key not in px_cache:
+                    px_cache[key] = dgr.local_pixels(m["mask"], m["W"], m["H"])
+                m["Px"] = px_cache[key]
+            tot_ms += ms
+            tot_b += algorithmic_bytes(kname, m)
+            D_sum += m.get("D", 0) or 0
+        n = len(recs)
+        kern[kname] = {"launches": n, "avg_ms": round(tot_ms / n, 5), "algo_MB": round(tot_b / n / 1e6, 3),
+                       "GBps": round(tot_b / (tot_ms * 1e-3) / 1e9, 1) if tot_ms > 0 and tot_b else None}
+        if kern[kname]["GBps"]:
+            kern[kname]["frac_hbm_peak"] = round(kern[kname]["GBps"] / HBM_PEAK_GBS, 4)
+        if D_sum:
+            kern[kname]["mean_pairs_D"] = D_sum // n
+    out["kernels"] = kern
+    if world > 1 and state["sizes"] is not None:
+        sizes = state["sizes"]  # sizes[i][j][k]: rows rank i sends to rank j for camera k (last step)
+        rows = [[sum(sizes[i][j]) for j in range(world)] for i in range(world)]
+        out["exchange"] = {
+            "rows_sent_per_rank": [sum(r) - r[i] for i, r in enumerate(rows)],
+            "bytes_fwd_per_rank": [44 * (sum(r) - r[i]) for i, r in enumerate(rows)],  # 11 floats per row
+            "bytes_bwd_per_rank": [36 * (sum(r) - r[i]) for i, r in enumerate(rows)],  # 9 gradient floats back
+            "rows_kept_local_per_rank": [rows[i][i] for i in range(world)],
+            "bands_last_step": [[list(g), list(d)] for g, d in state.get("bands", [])],
+            "note": "last step; all-to-all-v over xGMI, rank i -> rank j peer copies; local rows do not leave the GPU"}
+    del model, opt, cameras, history
+    torch.cuda.empty_cache()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps; value = the first one")
+    ap.add_argument("--workload", default="auto", choices=["auto"] + list(WORKLOADS))
+    ap.add_argument("--gaussians", type=int, default=0, help="override the workload's Gaussian count")
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--bsz", type=int, default=0, help="cameras per step (default: the workload's; independent of --gpus)")
+    ap.add_argument("--views", type=int, default=8, help="distinct synthetic cameras to cycle through")
+    ap.add_argument("--opacity-logit-mean", type=float, default=0.0, help="SURVEY 8(d) generator: N(0, 2^2)")
+    ap.add_argument("--opacity-logit-std", type=float, default=2.0)
+    ap.add_argument("--device-scene", action="store_true", help="draw the c1 scene on the device as well")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="N > 1: skip the second workload (c4)")
+    ap.add_argument("--no-1gpu-leg", action="store_true", help="N > 1: skip the same-workload single-GPU leg")
+    ap.add_argument("--render-steps", type=int, default=20, help="forward-only views/sec leg (untimed by driver)")
+    ap.add_argument("--pmc-calib", action="store_true", help="also run a 256 MiB streaming multiply (PMC calibration)")
+    a = ap.parse_args()
+
+    import utils.general_utils as utils
+
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != a.gpus and world == 1 and a.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if local_rank >= torch.cuda.device_count():  # several ranks sharing one device (tools/, tests): not a bench mode
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    utils.init_distributed(backend="nccl" if world > 1 else None)
+    rank = utils.GLOBAL_RANK
+
+    name = a.workload if a.workload != "auto" else ("c1" if world == 1 else "c2")
+    main_res = run_workload(a, name, world, rank, dev, a.steps, a.warmup, a.repeats, a.render_steps)
+
+    def same_workload_1gpu(wname):
+        """the same scene + camera on ONE GPU (rank 0's device); the other ranks wait at the barrier"""
+        res = None
+        if rank == 0:
+            with _SingleRankView(utils):
+                res = run_workload(a, wname, 1, 0, dev, min(a.steps, 10), min(a.warmup, 3), 1, 0, single_view=True,
+                                   collect_kernels=False)
+        dist.barrier()
+        return res
+
+    extras = []
+    one_gpu = None
+    if world > 1:
+        if not a.no_1gpu_leg:
+            one_gpu = same_workload_1gpu(name)
+        if a.workload == "auto" and not a.no_extra:
+            ex = run_workload(a, "c4", world, rank, dev, max(a.steps // 3, 5), min(a.warmup, 3), 1, 0,
+                              collect_kernels=False)
+            ex1 = None if a.no_1gpu_leg else same_workload_1gpu("c4")
+            extras.append((ex, ex1))
+
+    if a.pmc_calib:
+        x = torch.rand(64 * 1024 * 1024, device=dev)  # 256 MiB
+        y = torch.empty_like(x)
+        for _ in range(3):
+            torch.mul(x, 2.0, out=y)  # vectorised elementwise kernel: 256 MiB read (16 B/lane) + 256 MiB written
+        torch.cuda.synchronize()
 
     if rank != 0:
         return
-    value = bsz * a.steps / dt
-    tiles = ((W + 15) // 16) * ((H + 15) // 16)
-    N_local = model._xyz.shape[0]
-    Px = W * H  # at bsz = world every rank renders about one full image per step
-    P_render = N_local if world == 1 else None
-    kern = {}
-    for name, (cnt, ms) in ksum.items():
-        nbytes = algorithmic_bytes(name, N_local, P_render or N_local, D, Px, tiles)
-        kern[name] = {"launches": cnt, "avg_ms": round(ms, 4), "algo_MB": round(nbytes / 1e6, 2),
-                      "GBps": round(nbytes / (ms * 1e-3) / 1e9, 1) if ms > 0 else None}
-    hip = {k: v for k, v in kern.items()}
-    dom = max(hip, key=lambda k: hip[k]["avg_ms"] * hip[k]["launches"]) if hip else None
+
+    def brief(res, res1):
+        d = {"workload": f"{res['name']}: {res['desc']}", "gaussians_total": res["gaussians_total"],
+             "image": res["image"], "bsz": res["bsz"], "value": round(res["images_per_s"], 3), "unit": "images/s",
+             "ms_per_step": round(res["ms_per_step"], 4), "steps": res["steps"], "timing": res["timing"]}
+        if "exchange" in res:
+            d["exchange"] = res["exchange"]
+        if res1 is not None:
+            d["same_workload_1gpu"] = {"value": round(res1["images_per_s"], 3), "unit": "images/s",
+                                       "ms_per_step": round(res1["ms_per_step"], 4), "steps": res1["steps"],
+                                       "note": "same scene and camera on ONE GPU, measured in this run on rank 0"}
+            d["speedup_vs_1gpu"] = round(res["images_per_s"] / res1["images_per_s"], 3)
+        return d
+
+    kern = main_res["kernels"]
+    dom = max(kern, key=lambda k: kern[k]["avg_ms"] * kern[k]["launches"]) if kern else None
     roofline = None
     if dom:
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tp):
+        src = source_hash()
+        pmc, pmc_note = None, "profiles/r02_pmc.json absent"
+        pp = os.path.join(ROOT, "profiles", "r02_pmc.json")
+        if os.path.exists(pp):
             try:
-                traffic = json.load(open(tp)).get(dom, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        ach = hip[dom]["GBps"]
+                blob = json.load(open(pp))
+                if blob.get("source_hash") == src:
+                    pmc, pmc_note = blob, blob.get("command", "")
+                else:
+                    pmc_note = (f"profiles/r02_pmc.json was measured on source hash {blob.get('source_hash')}, this "
+                                f"build is {src}: not quoted")
+            except Exception as e:  # noqa: BLE001
+                pmc_note = f"unreadable: {e}"
+        ach = kern[dom]["GBps"]
+        pk = (pmc or {}).get("kernels", {}).get(dom, {})
+        valu = None
+        if pk.get("SQ_INSTS_VALU"):
+            # issue-slot view: wave64 VALU instructions x 2 cycles over (1024 SIMDs x kernel duration x 2.4 GHz)
+            valu = {"insts_per_launch": pk["SQ_INSTS_VALU"], "active_cycles_per_launch": pk.get("SQ_ACTIVE_INST_VALU"),
+                    "busy_cycles_per_launch": pk.get("SQ_BUSY_CYCLES"), "profiled_avg_ms": pk.get("avg_ms"),
+                    "frac": round(pk["SQ_INSTS_VALU"] * VALU_CYCLES / (SIMDS * CLOCK_HZ * pk["avg_ms"] * 1e-3), 4)
+                    if pk.get("avg_ms") else None,
+                    "peak": "1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md)"}
         roofline = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4) if ach else None, "traffic": traffic,
-                    "avg_ms": hip[dom]["avg_ms"], "algorithmic_bytes": int(hip[dom]["algo_MB"] * 1e6),
-                    "note": "composite kernels are VALU/exp-bound by construction (DESIGN.md); the HBM "
-                            "fraction is reported because north_star fixes HBM as the yardstick"}
+                    "frac": round(ach / HBM_PEAK_GBS, 4) if ach else None,
+                    "traffic": pk.get("hbm_bytes_per_launch"),
+                    "traffic_frac": round(pk["hbm_bytes_per_launch"] / (pk["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                    if pk.get("hbm_bytes_per_launch") and pk.get("avg_ms") else None,
+                    "avg_ms": kern[dom]["avg_ms"], "algorithmic_bytes": int(kern[dom]["algo_MB"] * 1e6),
+                    "valu": valu, "pmc_source": pmc_note, "source_hash": src,
+                    "note": "achieved = algorithmic bytes of the timed launches / their HIP-event time; the composite "
+                            "kernels stop early on saturated pixels, so they MOVE fewer bytes than the formula "
+                            "credits (traffic_frac is the measured-bytes fraction) and are bound by VALU issue "
+                            "(valu.frac), see DESIGN.md"}
+    n_total, W, H = main_res["gaussians_total"], main_res["image"][0], main_res["image"][1]
     out = {
         "metric": "training iters/sec (fwd+bwd)",
-        "value": round(value, 3),
+        "value": round(main_res["images_per_s"], 3),
         "unit": "images/s",
         "n_gpus": world,
         "steps": a.steps,
         "warmup": a.warmup,
-        "ms_per_step": round(dt / a.steps * 1e3, 3),
+        "ms_per_step": round(main_res["ms_per_step"], 3),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "weak" if (name == "weak" or world == 1) else "strong",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": f"synthetic Mip360-bicycle-sized scene: {a.gaussians} Gaussians total, SH degree 3, "
-                               f"{W}x{H} cameras, full train iteration (activations, preprocess, exchange, render, "
+        "config": {"workload": f"{name}: {main_res['desc']}; {n_total} Gaussians total, SH degree 3, {W}x{H}, "
+                               f"bsz {main_res['bsz']}, full train iteration (activations, preprocess, exchange, render, "
                                f"L1+SSIM loss, backward, Adam)",
-                   "gaussians_total": a.gaussians, "gaussians_per_gpu": N_local, "image": [W, H],
-                   "bsz": bsz, "parallelism": f"pixel-partition x{world}, Gaussian-sharded x{world}",
-                   "num_rendered_pairs_D": D, "seed": 0},
-        "rendered_views_per_sec": round(bsz * a.render_steps / dt_r, 3),
+                   "gaussians_total": n_total, "gaussians_per_gpu": main_res["gaussians_this_rank"], "image": [W, H],
+                   "bsz": main_res["bsz"],
+                   "parallelism": f"pixel-partition x{world} (row bands), Gaussian-sharded x{world}",
+                   "scene": main_res["scene"], "opacity_logit": [a.opacity_logit_mean, a.opacity_logit_std], "seed": 0},
+        "timing": main_res["timing"],
+        "rendered_views_per_sec": round(main_res.get("rendered_views_per_sec", 0.0), 3),
         "kernels": kern,
         "roofline": roofline,
         "reference_published": {"a100_bicycle_1gpu_images_per_s": 16.6, "note": "README.md:342 of the reference; "
                                 "other hardware, real data at 1237x822 -- not comparable, hence vs_baseline null"},
     }
+    if "exchange" in main_res:
+        out["exchange"] = main_res["exchange"]
+    if one_gpu is not None:
+        b = brief(main_res, one_gpu)
+        out["same_workload_1gpu"], out["speedup_vs_1gpu"] = b["same_workload_1gpu"], b["speedup_vs_1gpu"]
+    if extras:
+        out["extra_workloads"] = [brief(ex, ex1) for ex, ex1 in extras]
     if world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(W, H, a.gaussians)
+        out["cpu_baseline"] = cpu_baseline(W, H, n_total)
     print(json.dumps(out), flush=True)
 
 

@@ -59,39 +59,57 @@ def _timing_mode():
 
 class _KernelTimer:
     """optional HIP-event brackets around each C-ABI call (bench.py's `roofline` leg): events are
-    recorded on the stream the kernels are launched on and resolved by the caller after a sync."""
+    recorded on the stream the kernels are launched on and resolved by the caller after a sync.  Every record
+    carries the launch's own sizes (N, P, D, Px, ...), so that bytes and time describe the SAME launches."""
 
     def __init__(self):
         self.enabled = False
         self.records = {}
 
     class _Range:
-        def __init__(self, owner, name):
-            self.owner, self.name = owner, name
+        def __init__(self, owner, name, meta):
+            self.owner, self.name, self.meta = owner, name, meta
 
         def __enter__(self):
             if self.owner.enabled:
                 self.e0 = torch.cuda.Event(enable_timing=True)
                 self.e1 = torch.cuda.Event(enable_timing=True)
                 self.e0.record()
+            return self
 
         def __exit__(self, *exc):
             if self.owner.enabled:
                 self.e1.record()
-                self.owner.records.setdefault(self.name, []).append((self.e0, self.e1))
+                self.owner.records.setdefault(self.name, []).append((self.e0, self.e1, self.meta))
 
-    def range(self, name):
-        return _KernelTimer._Range(self, name)
+    def range(self, name, **meta):
+        return _KernelTimer._Range(self, name, meta)
 
     def reset(self):
         self.records = {}
 
     def summary_ms(self):
         """name -> (launches, mean ms); call after torch.cuda.synchronize()"""
-        return {k: (len(v), sum(a.elapsed_time(b) for a, b in v) / len(v)) for k, v in self.records.items() if v}
+        return {k: (len(v), sum(r[0].elapsed_time(r[1]) for r in v) / len(v)) for k, v in self.records.items() if v}
+
+    def launches(self):
+        """name -> list of (ms, meta dict) per launch; call after torch.cuda.synchronize()"""
+        return {k: [(r[0].elapsed_time(r[1]), r[2]) for r in v] for k, v in self.records.items() if v}
 
 
 kernel_timer = _KernelTimer()
+
+
+def local_pixels(mask, W, H):
+    """number of image pixels inside the tiles marked in `mask` (uint8/bool [TILE_Y*TILE_X]); host-syncing helper for
+    bench bookkeeping, called after the timed region"""
+    gx, gy = (W + BLOCK_X - 1) // BLOCK_X, (H + BLOCK_Y - 1) // BLOCK_Y
+    m = mask.reshape(gy, gx).to(torch.int64).cpu()
+    hh = torch.full((gy,), BLOCK_Y, dtype=torch.int64)
+    hh[-1] = H - (gy - 1) * BLOCK_Y
+    ww = torch.full((gx,), BLOCK_X, dtype=torch.int64)
+    ww[-1] = W - (gx - 1) * BLOCK_X
+    return int((m * hh[:, None] * ww[None, :]).sum())
 
 
 def _ptr(t):
@@ -166,7 +184,7 @@ class _PreprocessGaussians(torch.autograd.Function):
         conic_opacity = torch.empty((P, 4), dtype=torch.float32, device=dev)
         rgb = torch.empty((P, 3), dtype=torch.float32, device=dev)
         clamped = torch.empty((P, 3), dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev), kernel_timer.range("preprocess_forward"):
+        with torch.cuda.device(dev), kernel_timer.range("preprocess_forward", N=P, B=1, M=M):
             check(lib.gsr_preprocess_forward(
                 P, int(rs.sh_degree), M, _ptr(means3D), _ptr(scales), float(rs.scale_modifier), _ptr(rotations),
                 _ptr(shs), _ptr(opacities), _ptr(view), _ptr(proj), _ptr(campos), int(rs.image_width),
@@ -191,7 +209,7 @@ class _PreprocessGaussians(torch.autograd.Function):
         d_rot = torch.empty((P, 4), dtype=torch.float32, device=dev)
         d_shs = torch.empty((P, M, 3), dtype=torch.float32, device=dev)
         d_opac = torch.empty((P, 1), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev), kernel_timer.range("preprocess_backward"):
+        with torch.cuda.device(dev), kernel_timer.range("preprocess_backward", N=P, B=1, M=M):
             check(lib.gsr_preprocess_backward(
                 P, int(rs.sh_degree), M, _ptr(means3D), _ptr(scales), float(rs.scale_modifier), _ptr(rotations),
                 _ptr(shs), _ptr(view), _ptr(proj), _ptr(campos), int(rs.image_width), int(rs.image_height),
@@ -226,7 +244,7 @@ class _PreprocessGaussiansRaw(torch.autograd.Function):
         conic_opacity = torch.empty((P, 4), dtype=torch.float32, device=dev)
         rgb = torch.empty((P, 3), dtype=torch.float32, device=dev)
         clamped = torch.empty((P, 3), dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev), kernel_timer.range("preprocess_forward"):
+        with torch.cuda.device(dev), kernel_timer.range("preprocess_forward", N=P, B=1, M=M):
             check(lib.gsr_preprocess_forward_raw(
                 P, int(rs.sh_degree), M, _ptr(xyz), _ptr(scaling), float(rs.scale_modifier), _ptr(rotation),
                 _ptr(features_dc), _ptr(features_rest), _ptr(opacity), _ptr(view), _ptr(proj), _ptr(campos),
@@ -253,7 +271,7 @@ class _PreprocessGaussiansRaw(torch.autograd.Function):
         d_dc = torch.empty((P, 1, 3), dtype=torch.float32, device=dev)
         d_rest = torch.empty((P, M - 1, 3), dtype=torch.float32, device=dev)
         d_opac = torch.empty((P, 1), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev), kernel_timer.range("preprocess_backward"):
+        with torch.cuda.device(dev), kernel_timer.range("preprocess_backward", N=P, B=1, M=M):
             check(lib.gsr_preprocess_backward_raw(
                 P, int(rs.sh_degree), M, _ptr(xyz), _ptr(scaling), float(rs.scale_modifier), _ptr(rotation),
                 _ptr(f_dc), _ptr(f_rest), _ptr(opacity), _ptr(view), _ptr(proj), _ptr(campos), int(rs.image_width),
@@ -295,7 +313,7 @@ class _PreprocessGaussiansRawBatched(torch.autograd.Function):
         conic_opacity = torch.empty((B, P, 4), dtype=torch.float32, device=dev)
         rgb = torch.empty((B, P, 3), dtype=torch.float32, device=dev)
         clamped = torch.empty((B, P, 3), dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev), kernel_timer.range("preprocess_forward"):
+        with torch.cuda.device(dev), kernel_timer.range("preprocess_forward", N=P, B=B, M=M):
             check(lib.gsr_preprocess_forward_raw_batched(
                 P, B, int(sh_degree), M, _ptr(xyz), _ptr(scaling), float(scale_modifier), _ptr(rotation),
                 _ptr(features_dc), _ptr(features_rest), _ptr(opacity), _ptr(cams), int(width), int(height),
@@ -346,7 +364,7 @@ class _PreprocessGaussiansRawBatched(torch.autograd.Function):
         d_dc = torch.empty((P, 1, 3), dtype=torch.float32, device=dev)
         d_rest = torch.empty((P, M - 1, 3), dtype=torch.float32, device=dev)
         d_opac = torch.empty((P, 1), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev), kernel_timer.range("preprocess_backward"):
+        with torch.cuda.device(dev), kernel_timer.range("preprocess_backward", N=P, B=B, M=M):
             if B == 1 and ctx.tanfov0 is not None:
                 # single camera: the leaner one-camera kernel (no accumulators); camera fields are slices of `cams`
                 base = cams.data_ptr()
@@ -429,12 +447,15 @@ class _RenderGaussians(torch.autograd.Function):
                 ev0 = torch.cuda.Event(enable_timing=True)
                 ev1 = torch.cuda.Event(enable_timing=True)
                 ev0.record()
-            with kernel_timer.range("binning"):
+            with kernel_timer.range("binning", P=P, tiles=gx * gy) as kt:
                 point_list, ranges, D = bin_gaussians(means2D, depths, radii, conic_opacity, mask, W, H)
+                kt.meta["D"] = D
             out = torch.empty((3, H, W), dtype=torch.float32, device=dev)
             final_T = torch.empty((H, W), dtype=torch.float32, device=dev)
             n_contrib = torch.empty((H, W), dtype=torch.int32, device=dev)
-            with kernel_timer.range("composite_forward"):
+            # bench bookkeeping: the launch's local pixel count is derived from the mask AFTER the run (no sync here)
+            ctx.px_meta = dict(mask=mask, W=W, H=H) if kernel_timer.enabled else {}
+            with kernel_timer.range("composite_forward", P=P, D=D, **ctx.px_meta):
                 check(lib.gsr_render_forward(P, W, H, _ptr(ranges), _ptr(point_list), _ptr(means2D),
                                              _ptr(conic_opacity), _ptr(rgb), _ptr(mask), _ptr(bg), _ptr(out),
                                              _ptr(final_T), _ptr(n_contrib), _stream()), "gsr_render_forward")
@@ -476,7 +497,7 @@ class _RenderGaussians(torch.autograd.Function):
                 ev0 = torch.cuda.Event(enable_timing=True)
                 ev1 = torch.cuda.Event(enable_timing=True)
                 ev0.record()
-            with kernel_timer.range("composite_backward"):
+            with kernel_timer.range("composite_backward", P=P, D=ctx.num_rendered, **ctx.px_meta):
                 check(lib.gsr_render_backward(P, W, H, _ptr(ranges), _ptr(point_list), _ptr(means2D),
                                               _ptr(conic_opacity), _ptr(rgb), _ptr(mask), _ptr(bg), _ptr(final_T),
                                               _ptr(n_contrib), _ptr(g_out), _ptr(record), _stream()),
@@ -562,7 +583,7 @@ class _FusedL1SSIMBand(torch.autograd.Function):
         partials = torch.empty((max(nb, 1), 2), dtype=torch.float32, device=dev)
         maps = torch.empty((3, C, rows, W), dtype=torch.float32, device=dev) if need_grad else None
         band_ptr = ctypes.c_void_p(image.data_ptr() + 4 * y0 * W)
-        with torch.cuda.device(dev), kernel_timer.range("l1_ssim_forward"):
+        with torch.cuda.device(dev), kernel_timer.range("l1_ssim_forward", Px=rows * W):
             check(lib.gsr_l1_ssim_forward(C, rows, W, band_ptr, H * W, _ptr(gt_u8), _ptr(partials),
                                           _ptr(maps[0]) if need_grad else None, _ptr(maps[1]) if need_grad else None,
                                           _ptr(maps[2]) if need_grad else None, _stream()), "gsr_l1_ssim_forward")
@@ -584,7 +605,7 @@ class _FusedL1SSIMBand(torch.autograd.Function):
         grad = torch.empty_like(image) if rows == H else torch.zeros_like(image)
         band_ptr = ctypes.c_void_p(image.data_ptr() + 4 * y0 * W)
         gband_ptr = ctypes.c_void_p(grad.data_ptr() + 4 * y0 * W)
-        with torch.cuda.device(dev), kernel_timer.range("l1_ssim_backward"):
+        with torch.cuda.device(dev), kernel_timer.range("l1_ssim_backward", Px=rows * W):
             check(lib.gsr_l1_ssim_backward(C, rows, W, band_ptr, H * W, _ptr(gt_u8), _ptr(maps[0]), _ptr(maps[1]),
                                            _ptr(maps[2]), _ptr(g_l1), _ptr(g_ssim), gband_ptr, H * W, _stream()),
                   "gsr_l1_ssim_backward")
@@ -625,7 +646,7 @@ class _FusedBandLoss(torch.autograd.Function):
         c_l1, c_ssim = (1.0 - lambda_dssim) / n, -lambda_dssim / n
         band_ptr = ctypes.c_void_p(image.data_ptr() + 4 * y0 * W)
         with torch.cuda.device(dev):
-            with kernel_timer.range("l1_ssim_forward"):
+            with kernel_timer.range("l1_ssim_forward", Px=rows * W):
                 check(lib.gsr_l1_ssim_forward(C, rows, W, band_ptr, H * W, _ptr(gt_u8), _ptr(partials),
                                               _ptr(maps[0]) if need_grad else None,
                                               _ptr(maps[1]) if need_grad else None,
@@ -656,7 +677,7 @@ class _FusedBandLoss(torch.autograd.Function):
         grad = torch.empty_like(image) if rows == H else torch.zeros_like(image)
         band_ptr = ctypes.c_void_p(image.data_ptr() + 4 * y0 * W)
         gband_ptr = ctypes.c_void_p(grad.data_ptr() + 4 * y0 * W)
-        with torch.cuda.device(dev), kernel_timer.range("l1_ssim_backward"):
+        with torch.cuda.device(dev), kernel_timer.range("l1_ssim_backward", Px=rows * W):
             check(lib.gsr_l1_ssim_backward(C, rows, W, band_ptr, H * W, _ptr(gt_u8), _ptr(maps[0]), _ptr(maps[1]),
                                            _ptr(maps[2]), ctypes.c_void_p(gvec.data_ptr()),
                                            ctypes.c_void_p(gvec.data_ptr() + 4), gband_ptr, H * W, _stream()),

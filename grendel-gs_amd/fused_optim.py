@@ -10,7 +10,7 @@ import ctypes
 
 import torch
 
-from diff_gaussian_rasterization import _lib
+from diff_gaussian_rasterization import _lib, kernel_timer
 
 
 class FusedAdam(torch.optim.Optimizer):
@@ -41,7 +41,7 @@ class FusedAdam(torch.optim.Optimizer):
                 if not (p.is_contiguous() and g.is_contiguous() and p.dtype == torch.float32 and
                         g.dtype == torch.float32):
                     raise RuntimeError("FusedAdam: dense fp32 parameters and gradients expected")
-                with torch.cuda.device(p.device):
+                with torch.cuda.device(p.device), kernel_timer.range("adam", numel=p.numel()):
                     _lib.check(_lib.lib.gsr_adam_step(
                         p.numel(), ctypes.c_void_p(p.data_ptr()), ctypes.c_void_p(g.data_ptr()),
                         ctypes.c_void_p(st["exp_avg"].data_ptr()), ctypes.c_void_p(st["exp_avg_sq"].data_ptr()),

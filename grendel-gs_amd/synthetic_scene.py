@@ -55,12 +55,14 @@ class SyntheticCamera:
         return self
 
 
-def make_gaussians(n, width, height, seed=0, fx=None, device="cpu", sh_rest_sigma=0.1, scale_coef=0.004):
+def make_gaussians(n, width, height, seed=0, fx=None, device="cpu", sh_rest_sigma=0.1, scale_coef=0.004,
+                   opacity_logit_mean=0.0, opacity_logit_std=2.0):
     """Activated Gaussian attributes in view space of the identity camera (R=I, T=0).
 
     z ~ U(2,10); x,y ~ U(-1.15,1.15) * z * tanfov (about 13 % outside the frustum, exercising the
     cull); log-scale ~ N(log(scale_coef*z), 0.5^2) per axis; unit quaternions from N(0,1)^4;
-    opacity = sigmoid(N(0,2^2)); SH dc ~ U(-1,1)/0.28209, rest ~ N(0, 0.1^2)."""
+    opacity = sigmoid(N(opacity_logit_mean, opacity_logit_std^2)) (N(0, 2^2); the knob exists for the
+    low-opacity sensitivity run); SH dc ~ U(-1,1)/0.28209, rest ~ N(0, 0.1^2)."""
     g = torch.Generator(device="cpu")
     g.manual_seed(seed)
     fx = 0.9 * width if fx is None else fx
@@ -74,7 +76,7 @@ def make_gaussians(n, width, height, seed=0, fx=None, device="cpu", sh_rest_sigm
     scales = torch.exp(log_s)
     q = torch.randn(n, 4, generator=g)
     rotations = q / q.norm(dim=1, keepdim=True)
-    opacities = torch.sigmoid(2.0 * torch.randn(n, 1, generator=g))
+    opacities = torch.sigmoid(opacity_logit_mean + opacity_logit_std * torch.randn(n, 1, generator=g))
     dc = (torch.rand(n, 1, 3, generator=g) * 2.0 - 1.0) / 0.28209479177387814
     rest = sh_rest_sigma * torch.randn(n, 15, 3, generator=g)
     shs = torch.cat([dc, rest], dim=1).contiguous()
@@ -117,14 +119,19 @@ class SyntheticGaussianModel(torch.nn.Module):
     (scene/gaussian_model.py:181-194)."""
 
     def __init__(self, n_total, width, height, seed=0, sh_degree=3, rank=0, world_size=1, device="cpu",
-                 scale_coef=0.004):
+                 scale_coef=0.004, opacity_logit_mean=0.0, opacity_logit_std=2.0, on_device=False, shards=None):
         super().__init__()
-        g = make_gaussians(n_total, width, height, seed=seed, scale_coef=scale_coef)
+        self.active_sh_degree = sh_degree
+        self.max_sh_degree = 3
+        if on_device:
+            self._init_on_device(n_total, width, height, seed, rank, world_size, device, scale_coef,
+                                 opacity_logit_mean, opacity_logit_std, shards)
+            return
+        g = make_gaussians(n_total, width, height, seed=seed, scale_coef=scale_coef,
+                           opacity_logit_mean=opacity_logit_mean, opacity_logit_std=opacity_logit_std)
         chunk = (n_total + world_size - 1) // world_size
         l, r = rank * chunk, min((rank + 1) * chunk, n_total)
         sl = slice(l, r)
-        self.active_sh_degree = sh_degree
-        self.max_sh_degree = 3
         P = torch.nn.Parameter
         op = g["opacities"][sl].clamp(1e-6, 1 - 1e-6)
         self._xyz = P(g["means3D"][sl].clone().to(device))
@@ -133,6 +140,42 @@ class SyntheticGaussianModel(torch.nn.Module):
         self._scaling = P(torch.log(g["scales"][sl]).to(device))
         self._rotation = P(g["rotations"][sl].clone().to(device))
         self._opacity = P(torch.log(op / (1 - op)).to(device))
+
+    def _init_on_device(self, n_total, width, height, seed, rank, world_size, device, scale_coef, op_mean, op_std,
+                        shards):
+        """the same distributions generated ON the device, shard by shard (the multi-GPU bench scenes hold up to 40 M
+        Gaussians: 9.4 GB of parameters are not drawn on the host and copied).  Shard r of W is a pure function of
+        (seed, r, W): a rank builds its own; the single-GPU run of the same workload concatenates shards 0..W-1."""
+        chunk = (n_total + world_size - 1) // world_size
+        shards = [rank] if shards is None else list(shards)
+        parts = {k: [] for k in ("xyz", "dc", "rest", "scaling", "rotation", "opacity")}
+        fx = 0.9 * width
+        tanx, tany = width / (2.0 * fx), height / (2.0 * fx)
+        for r in shards:
+            n = min((r + 1) * chunk, n_total) - r * chunk
+            g = torch.Generator(device=device)
+            g.manual_seed(seed * 100003 + r * 1009 + world_size)
+
+            def U(*shape):
+                return torch.rand(*shape, generator=g, device=device)
+
+            def Nrm(*shape):
+                return torch.randn(*shape, generator=g, device=device)
+
+            z = U(n) * 8.0 + 2.0
+            x = (U(n) * 2.3 - 1.15) * z * tanx
+            y = (U(n) * 2.3 - 1.15) * z * tany
+            parts["xyz"].append(torch.stack([x, y, z], dim=1))
+            parts["scaling"].append(torch.log(scale_coef * z)[:, None] + 0.5 * Nrm(n, 3))
+            q = Nrm(n, 4)
+            parts["rotation"].append(q / q.norm(dim=1, keepdim=True))
+            parts["opacity"].append((op_mean + op_std * Nrm(n, 1)).clamp(-13.8, 13.8))  # logit of [1e-6, 1 - 1e-6]
+            parts["dc"].append((U(n, 1, 3) * 2.0 - 1.0) / 0.28209479177387814)
+            parts["rest"].append(0.1 * Nrm(n, 15, 3))
+        P = torch.nn.Parameter
+        cat = {k: (v[0] if len(v) == 1 else torch.cat(v, 0)).contiguous() for k, v in parts.items()}
+        self._xyz, self._features_dc, self._features_rest = P(cat["xyz"]), P(cat["dc"]), P(cat["rest"])
+        self._scaling, self._rotation, self._opacity = P(cat["scaling"]), P(cat["rotation"]), P(cat["opacity"])
 
     @property
     def get_xyz(self):

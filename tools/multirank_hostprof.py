@@ -38,7 +38,8 @@ def worker(rank, world, port, profile, gaussians, size):
     orig = utils.init_distributed
     utils.init_distributed = lambda *a, **k: orig(backend="gloo")
     sys.argv = ["bench.py", "--gpus", str(world), "--steps", "100", "--warmup", "10", "--no-cpu-baseline",
-                "--gaussians", str(gaussians), "--width", str(size), "--height", str(size), "--render-steps", "1"]
+                "--gaussians", str(gaussians), "--width", str(size), "--height", str(size), "--render-steps", "1",
+                "--repeats", "1", "--no-extra"] + (["--workload", os.environ["GSR_WORKLOAD"]] if "GSR_WORKLOAD" in os.environ else [])
     import bench
 
     if profile and rank == 0:
