@@ -58,23 +58,26 @@ __device__ __forceinline__ bool gsr_alpha_extent(const float4 co, float &ex, flo
 // quadratic form over the box is <= 2 tau.  The centre inside the box gives 0; otherwise the minimum
 // lies on the boundary and is the smallest of the four edges' 1-D minima (vertex clamped to the edge).
 // Tolerance: 2 tau is inflated by 0.2 % + 0.01 (alpha error < 1 % of 1/255) -- only ever keeps more.
-__device__ __forceinline__ float gsr_edge_min_q(float a, float b, float c, float u, float v0, float v1) {
-    // min over v in [v0,v1] of a u^2 + 2 b u v + c v^2   (c > 0)
-    const float vs = fminf(v1, fmaxf(v0, -b * u / c));
+__device__ __forceinline__ float gsr_edge_min_q(float a, float b, float c, float rc, float u, float v0, float v1) {
+    // min over v in [v0,v1] of a u^2 + 2 b u v + c v^2   (c > 0, rc ~ 1 / c: the vertex only has to be NEAR the
+    // minimiser -- the form is flat there -- so a 1-ulp reciprocal replaces four IEEE divisions per entry)
+    const float vs = fminf(v1, fmaxf(v0, -b * u * rc));
     return a * u * u + (2.0f * b * u + c * vs) * vs;
 }
 __device__ __forceinline__ bool gsr_can_touch_box(const float2 xy, const float4 co, float x0, float y0, float x1,
                                                   float y1) {
     if (!(co.w >= 1.0f / 255.0f)) return false;
-    const float lim = 2.0f * __logf(255.0f * co.w) * 1.002f + 0.01f;
+    // 2 ln(255 o) via the hardware log2 (v_log_f32; 255 o >= 1, no denormal path needed)
+    const float lim = (2.0f * 0.6931471805599453f) * __builtin_amdgcn_logf(255.0f * co.w) * 1.002f + 0.01f;
     // box in coordinates relative to the centre: d = pixel - centre (sign irrelevant for the form)
     const float l = x0 - xy.x, r = x1 - xy.x, t = y0 - xy.y, bt = y1 - xy.y;
     if (l <= 0.f && r >= 0.f && t <= 0.f && bt >= 0.f) return true;
     if (!(co.x > 0.f && co.z > 0.f)) return true;  // not a proper conic: do not cull
-    float q = gsr_edge_min_q(co.x, co.y, co.z, l, t, bt);           // edge x = x0
-    q = fminf(q, gsr_edge_min_q(co.x, co.y, co.z, r, t, bt));       // edge x = x1
-    q = fminf(q, gsr_edge_min_q(co.z, co.y, co.x, t, l, r));        // edge y = y0
-    q = fminf(q, gsr_edge_min_q(co.z, co.y, co.x, bt, l, r));       // edge y = y1
+    const float rcz = __builtin_amdgcn_rcpf(co.z), rcx = __builtin_amdgcn_rcpf(co.x);
+    float q = gsr_edge_min_q(co.x, co.y, co.z, rcz, l, t, bt);           // edge x = x0
+    q = fminf(q, gsr_edge_min_q(co.x, co.y, co.z, rcz, r, t, bt));       // edge x = x1
+    q = fminf(q, gsr_edge_min_q(co.z, co.y, co.x, rcx, t, l, r));        // edge y = y0
+    q = fminf(q, gsr_edge_min_q(co.z, co.y, co.x, rcx, bt, l, r));       // edge y = y1
     return !(q > lim);  // NaN -> keep
 }
 

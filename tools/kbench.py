@@ -23,10 +23,13 @@ def main():
     ap.add_argument("--view", type=int, default=0)
     ap.add_argument("--scale-coef", type=float, default=0.004)
     ap.add_argument("--calib", action="store_true", help="also run a 256 MiB device copy (PMC byte calibration)")
+    ap.add_argument("--opacity-logit-mean", type=float, default=0.0)
+    ap.add_argument("--opacity-logit-std", type=float, default=2.0)
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     W, H = a.width, a.height
-    g = S.make_gaussians(a.gaussians, W, H, seed=0, scale_coef=a.scale_coef, device=dev)
+    g = S.make_gaussians(a.gaussians, W, H, seed=0, scale_coef=a.scale_coef, device=dev,
+                         opacity_logit_mean=a.opacity_logit_mean, opacity_logit_std=a.opacity_logit_std)
     cam = S.orbit_cameras(8, W, H, device=dev)[a.view]
     rs = dgr.GaussianRasterizationSettings(H, W, math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2),
                                            torch.zeros(3, device=dev), 1.0, cam.world_view_transform,
