@@ -47,7 +47,106 @@ adam_kernel(long long n, float *__restrict__ param, const float *__restrict__ gr
     }
 }
 
+// All parameter tensors of the model in ONE launch (six launches of 50 us each otherwise: the per-launch tails and
+// the ~2 us boundaries between them are ~8 % of the optimizer).  Blocks are assigned to tensors by a prefix table.
+constexpr int ADAM_MAX_TENSORS = 16;
+struct AdamBatch {
+    float *param[ADAM_MAX_TENSORS];
+    const float *grad[ADAM_MAX_TENSORS];
+    float *m[ADAM_MAX_TENSORS];
+    float *v[ADAM_MAX_TENSORS];
+    long long n[ADAM_MAX_TENSORS];
+    int block0[ADAM_MAX_TENSORS + 1];  // first block of each tensor
+    float lr_c[ADAM_MAX_TENSORS], b1[ADAM_MAX_TENSORS], b2[ADAM_MAX_TENSORS], omb1[ADAM_MAX_TENSORS],
+        omb2[ADAM_MAX_TENSORS], inv_sqrt_bc2[ADAM_MAX_TENSORS], eps[ADAM_MAX_TENSORS];
+    int count;
+};
+constexpr int ADAM_ELEMS_PER_BLOCK = 256 * 4 * 4;  // 256 threads x 4 float4 each
+
+__global__ void __launch_bounds__(256) adam_multi_kernel(AdamBatch a, float grad_scale) {
+    int t = 0;
+    while (t + 1 < a.count && (int)blockIdx.x >= a.block0[t + 1]) t++;  // <= 16 uniform compares
+    const long long n = a.n[t];
+    float *__restrict__ param = a.param[t];
+    const float *__restrict__ grad = a.grad[t];
+    float *__restrict__ em = a.m[t];
+    float *__restrict__ ev = a.v[t];
+    const float lr_c = a.lr_c[t], b1 = a.b1[t], b2 = a.b2[t], omb1 = a.omb1[t], omb2 = a.omb2[t],
+                inv_sqrt_bc2 = a.inv_sqrt_bc2[t], eps = a.eps[t];
+    const long long base = (long long)((int)blockIdx.x - a.block0[t]) * ADAM_ELEMS_PER_BLOCK;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const long long i4 = base + ((long long)r * 256 + threadIdx.x) * 4;
+        if (i4 + 3 < n) {
+            float4 p = *reinterpret_cast<float4 *>(param + i4);
+            float4 g = *reinterpret_cast<const float4 *>(grad + i4);
+            float4 m = *reinterpret_cast<float4 *>(em + i4);
+            float4 v = *reinterpret_cast<float4 *>(ev + i4);
+            adam1<float>(p.x, g.x * grad_scale, m.x, v.x, lr_c, b1, b2, omb1, omb2, inv_sqrt_bc2, eps);
+            adam1<float>(p.y, g.y * grad_scale, m.y, v.y, lr_c, b1, b2, omb1, omb2, inv_sqrt_bc2, eps);
+            adam1<float>(p.z, g.z * grad_scale, m.z, v.z, lr_c, b1, b2, omb1, omb2, inv_sqrt_bc2, eps);
+            adam1<float>(p.w, g.w * grad_scale, m.w, v.w, lr_c, b1, b2, omb1, omb2, inv_sqrt_bc2, eps);
+            *reinterpret_cast<float4 *>(param + i4) = p;
+            *reinterpret_cast<float4 *>(em + i4) = m;
+            *reinterpret_cast<float4 *>(ev + i4) = v;
+        } else {
+            for (long long i = i4; i < n && i < i4 + 4; i++) {
+                float p = param[i], m = em[i], v = ev[i];
+                adam1<float>(p, grad[i] * grad_scale, m, v, lr_c, b1, b2, omb1, omb2, inv_sqrt_bc2, eps);
+                param[i] = p;
+                em[i] = m;
+                ev[i] = v;
+            }
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int gsr_adam_step_multi(int num_tensors, const int64_t *numels, float *const *params,
+                                   const float *const *grads, float *const *exp_avgs, float *const *exp_avg_sqs,
+                                   const double *lrs, const double *beta1s, const double *beta2s, const double *epss,
+                                   const int64_t *steps, float grad_scale, gsr_stream_t stream) {
+    if (num_tensors < 0 || num_tensors > ADAM_MAX_TENSORS) return GSR_EINVAL;
+    if (num_tensors == 0) return 0;
+    if (!numels || !params || !grads || !exp_avgs || !exp_avg_sqs || !lrs || !beta1s || !beta2s || !epss || !steps)
+        return GSR_EINVAL;
+    AdamBatch a{};
+    int blocks = 0, k = 0;
+    for (int t = 0; t < num_tensors; t++) {
+        if (numels[t] < 0 || steps[t] < 1) return GSR_EINVAL;
+        if (numels[t] == 0) continue;
+        if (!params[t] || !grads[t] || !exp_avgs[t] || !exp_avg_sqs[t]) return GSR_EINVAL;
+        if (((uintptr_t)params[t] | (uintptr_t)grads[t] | (uintptr_t)exp_avgs[t] | (uintptr_t)exp_avg_sqs[t]) & 15)
+            return GSR_EINVAL;
+        const double bc1 = 1.0 - pow(beta1s[t], (double)steps[t]);
+        const double bc2 = 1.0 - pow(beta2s[t], (double)steps[t]);
+        a.param[k] = params[t];
+        a.grad[k] = grads[t];
+        a.m[k] = exp_avgs[t];
+        a.v[k] = exp_avg_sqs[t];
+        a.n[k] = numels[t];
+        a.block0[k] = blocks;
+        a.lr_c[k] = (float)(lrs[t] / bc1);
+        a.b1[k] = (float)beta1s[t];
+        a.b2[k] = (float)beta2s[t];
+        a.omb1[k] = (float)(1.0 - beta1s[t]);
+        a.omb2[k] = (float)(1.0 - beta2s[t]);
+        a.inv_sqrt_bc2[k] = (float)(1.0 / sqrt(bc2));
+        a.eps[k] = (float)epss[t];
+        const long long nb = (numels[t] + ADAM_ELEMS_PER_BLOCK - 1) / ADAM_ELEMS_PER_BLOCK;
+        if (blocks + nb > 0x7fffffffLL) return GSR_EINVAL;
+        blocks += (int)nb;
+        k++;
+    }
+    if (k == 0) return 0;
+    a.block0[k] = blocks;
+    a.count = k;
+    hipLaunchKernelGGL(adam_multi_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a,
+                       grad_scale);
+    GSR_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int gsr_adam_step(int64_t n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq, double lr,
                              double beta1, double beta2, double eps, int64_t step, float grad_scale,

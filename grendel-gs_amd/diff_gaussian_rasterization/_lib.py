@@ -49,6 +49,7 @@ SIGNATURES = {
                                 c_void_p]),
     "gsr_adam_step": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_double, ctypes.c_double,
                               ctypes.c_double, ctypes.c_double, c_int64, c_float, c_void_p]),
+    "gsr_adam_step_multi": (c_int, [c_int] + [c_void_p] * 10 + [c_float, c_void_p]),
     "gsr_preprocess_forward_raw": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_float] + [c_void_p] * 7 +
                                    [c_int, c_int, c_float, c_float] + [c_void_p] * 8),
     "gsr_preprocess_backward_raw": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_float] + [c_void_p] * 7 +

@@ -1,6 +1,6 @@
 """FusedAdam -- host-side mirror of the optimizer the reference builds at scene/gaussian_model.py:292
 (`torch.optim.Adam(l, lr=0.0, eps=1e-15)`, one param group per attribute with its own lr / betas), running
-the dense Adam update as ONE HIP kernel per parameter tensor (include/gsraster.h: gsr_adam_step) with the
+the dense Adam update of ALL parameter tensors as ONE HIP kernel launch (include/gsraster.h: gsr_adam_step_multi) with the
 batch-size gradient scaling of train_internal.py:319-324 folded in.
 
 State layout (`state[p]["step" | "exp_avg" | "exp_avg_sq"]`) is the stock optimizer's, so
@@ -19,11 +19,13 @@ class FusedAdam(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None, grad_scale=1.0):
-        """`grad_scale` multiplies every gradient before the update (1 / bsz in the reference's loop)"""
+        """`grad_scale` multiplies every gradient before the update (1 / bsz in the reference's loop).  All parameter
+        tensors that have a gradient are updated by ONE kernel launch (gsr_adam_step_multi)."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        batch = []
         for group in self.param_groups:
             b1, b2 = group["betas"]
             for p in group["params"]:
@@ -41,10 +43,20 @@ class FusedAdam(torch.optim.Optimizer):
                 if not (p.is_contiguous() and g.is_contiguous() and p.dtype == torch.float32 and
                         g.dtype == torch.float32):
                     raise RuntimeError("FusedAdam: dense fp32 parameters and gradients expected")
-                with torch.cuda.device(p.device), kernel_timer.range("adam", numel=p.numel()):
-                    _lib.check(_lib.lib.gsr_adam_step(
-                        p.numel(), ctypes.c_void_p(p.data_ptr()), ctypes.c_void_p(g.data_ptr()),
-                        ctypes.c_void_p(st["exp_avg"].data_ptr()), ctypes.c_void_p(st["exp_avg_sq"].data_ptr()),
-                        float(group["lr"]), float(b1), float(b2), float(group["eps"]), int(st["step"].item()),
-                        float(grad_scale), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "gsr_adam_step")
+                batch.append((p, g, st, float(group["lr"]), float(b1), float(b2), float(group["eps"])))
+        for i in range(0, len(batch), 16):
+            part = batch[i:i + 16]
+            K = len(part)
+            VP, D, I64 = ctypes.c_void_p * K, ctypes.c_double * K, ctypes.c_int64 * K
+            dev = part[0][0].device
+            if any(b[0].device != dev for b in part):
+                raise RuntimeError("FusedAdam: all parameters of one step must live on one device")
+            with torch.cuda.device(dev), kernel_timer.range("adam", numel=sum(b[0].numel() for b in part)):
+                _lib.check(_lib.lib.gsr_adam_step_multi(
+                    K, I64(*[b[0].numel() for b in part]), VP(*[b[0].data_ptr() for b in part]),
+                    VP(*[b[1].data_ptr() for b in part]), VP(*[b[2]["exp_avg"].data_ptr() for b in part]),
+                    VP(*[b[2]["exp_avg_sq"].data_ptr() for b in part]), D(*[b[3] for b in part]),
+                    D(*[b[4] for b in part]), D(*[b[5] for b in part]), D(*[b[6] for b in part]),
+                    I64(*[int(b[2]["step"].item()) for b in part]), float(grad_scale),
+                    ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "gsr_adam_step_multi")
         return loss

@@ -170,6 +170,15 @@ int gsr_l1_ssim_finalize(int num_partials, const float *partials, float c_l1, fl
 int gsr_adam_step(int64_t n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq, double lr,
                   double beta1, double beta2, double eps, int64_t step, float grad_scale, gsr_stream_t stream);
 
+/* The same update for up to 16 parameter tensors in ONE launch (the reference's optimizer walks its six param
+ * groups, scene/gaussian_model.py:244-292: xyz, f_dc, f_rest, opacity, scaling, rotation): arrays of length
+ * num_tensors with each tensor's element count, pointers and its group's hyper-parameters / step count.
+ * Tensors with 0 elements are skipped. */
+int gsr_adam_step_multi(int num_tensors, const int64_t *numels, float *const *params, const float *const *grads,
+                        float *const *exp_avgs, float *const *exp_avg_sqs, const double *lrs, const double *beta1s,
+                        const double *beta2s, const double *epss, const int64_t *steps, float grad_scale,
+                        gsr_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * K2 for a whole camera batch, in the layout of the exchange (rows a5/a6).  The reference calls
  * get_local2j_ids_bool once per camera and then nonzero() per (camera, band) (workload_division.py:721-744,
