@@ -56,7 +56,9 @@ struct GatherArgs {
     int64_t src_stride[GATHER_MAX_TENSORS], dst_stride[GATHER_MAX_TENSORS];  // in words
 };
 
-// blockIdx.y = tensor; one thread per 4-byte word of the selected rows
+// blockIdx.y = tensor; one thread per 4-byte word of the selected rows.  SCATTER: dst[order[r]] = src[r] instead of
+// dst[r] = src[order[r]] (the inverse of a gather with the same order: N2 writes the reduced compact rows back)
+template <bool SCATTER>
 __global__ void __launch_bounds__(256)
 gather_rows_kernel(long long n_out, const int32_t *__restrict__ order, GatherArgs a) {
     const int k = blockIdx.y;
@@ -70,7 +72,8 @@ gather_rows_kernel(long long n_out, const int32_t *__restrict__ order, GatherArg
         const long long r = e / w;
         const int c = (int)(e - r * w);
         const long long sr = order ? (long long)order[r] : r;
-        dst[r * ds + c] = src[sr * ss + c];
+        if (SCATTER) dst[sr * ds + c] = src[r * ss + c];
+        else dst[r * ds + c] = src[sr * ss + c];
     }
 }
 
@@ -128,10 +131,10 @@ extern "C" int gsr_group_rows(int64_t N, int G, const int32_t *dest, int32_t *or
     return 0;
 }
 
-extern "C" int gsr_gather_rows(int64_t n_out, const int32_t *order, int num_tensors, const void *const *srcs,
-                               void *const *dsts, const int32_t *widths, const int64_t *src_strides,
-                               const int64_t *dst_strides, gsr_stream_t stream_) {
-    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+namespace {
+int launch_rows(bool scatter, int64_t n_out, const int32_t *order, int num_tensors, const void *const *srcs,
+                void *const *dsts, const int32_t *widths, const int64_t *src_strides, const int64_t *dst_strides,
+                hipStream_t stream) {
     if (n_out < 0 || num_tensors < 0 || num_tensors > GATHER_MAX_TENSORS) return GSR_EINVAL;
     if (n_out == 0 || num_tensors == 0) return 0;
     if (!srcs || !dsts || !widths || !src_strides || !dst_strides) return GSR_EINVAL;
@@ -148,8 +151,28 @@ extern "C" int gsr_gather_rows(int64_t n_out, const int32_t *order, int num_tens
     }
     long long blocks = (n_out * widest + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)blocks, (unsigned)num_tensors), dim3(256), 0, stream,
-                       (long long)n_out, order, a);
+    if (scatter)
+        hipLaunchKernelGGL(gather_rows_kernel<true>, dim3((unsigned)blocks, (unsigned)num_tensors), dim3(256), 0, stream,
+                           (long long)n_out, order, a);
+    else
+        hipLaunchKernelGGL(gather_rows_kernel<false>, dim3((unsigned)blocks, (unsigned)num_tensors), dim3(256), 0,
+                           stream, (long long)n_out, order, a);
     GSR_LAUNCH_CHECK();
     return 0;
+}
+}  // namespace
+
+extern "C" int gsr_gather_rows(int64_t n_out, const int32_t *order, int num_tensors, const void *const *srcs,
+                               void *const *dsts, const int32_t *widths, const int64_t *src_strides,
+                               const int64_t *dst_strides, gsr_stream_t stream_) {
+    return launch_rows(false, n_out, order, num_tensors, srcs, dsts, widths, src_strides, dst_strides,
+                       reinterpret_cast<hipStream_t>(stream_));
+}
+
+extern "C" int gsr_scatter_rows(int64_t n_in, const int32_t *order, int num_tensors, const void *const *srcs,
+                                void *const *dsts, const int32_t *widths, const int64_t *src_strides,
+                                const int64_t *dst_strides, gsr_stream_t stream_) {
+    if (n_in > 0 && !order) return GSR_EINVAL;
+    return launch_rows(true, n_in, order, num_tensors, srcs, dsts, widths, src_strides, dst_strides,
+                       reinterpret_cast<hipStream_t>(stream_));
 }

@@ -9,6 +9,18 @@
 //                       (destination, camera, Gaussian) order the all-to-all-v needs, and counts per
 //                       (destination, camera);
 //   the 11-float records are then packed / unpacked by gsr_gather_rows (compact.hip), one launch each.
+// The fused path used by the mirror does not materialise the need mask at all:
+//   gsr_exchange_count : the same K2 test, counted per (destination, camera) and per 1024-Gaussian chunk;
+//   gsr_exchange_pack  : (after the ONE host read-back that sizes the message) every wave recomputes the test for its
+//                        chunk, ranks the hits with ballots -- the order is (destination, camera, local index), the
+//                        order the reference produces -- and writes the 11-float records (means2D 2, rgb 3,
+//                        conic_opacity 4, radius bits, depth) straight into the all-to-all send buffer, plus the row
+//                        index list the backward needs;
+//   gsr_scatter_add_rows: the mirror step of the backward: gradient rows coming back from the peers are added into
+//                        the owners' rows (a Gaussian needed by two bands receives two contributions), 9 adjacent
+//                        lanes per row like K10's flush.
+// These replace nonzero_static + two index kernels + a gather launch in the forward and three zero fills + three
+// index_add_ launches in the backward.
 #include "common.h"
 
 namespace {
@@ -45,7 +57,185 @@ exchange_need_kernel(int P, int B, int W, int gx, int gy, const float2 *__restri
     __syncthreads();
     if ((int)threadIdx.x < W && s_cnt[threadIdx.x]) atomicAdd(&counts[(size_t)threadIdx.x * B + k], s_cnt[threadIdx.x]);
 }
+constexpr int XCHUNK = 1024;  // Gaussians per wave-chunk: 16 rounds of 64 lanes
+
+// rows [miny, maxy) of the 3-sigma tile rect of Gaussian r (the K2 rule); false when it touches nothing
+__device__ __forceinline__ bool rect_rows(const float2 *__restrict__ means2D, const int32_t *__restrict__ radii, size_t r,
+                                          int gx, int gy, int &miny, int &maxy) {
+    const int rad = radii[r];
+    if (rad <= 0) return false;
+    const float2 xy = means2D[r];
+    int minx, maxx;
+    gsr_get_rect(xy.x, xy.y, rad, gx, gy, minx, miny, maxx, maxy);
+    return maxx > minx && maxy > miny;
+}
+
+// grid (chunks, cameras), 256 threads = 4 waves, one chunk per wave
+__global__ void __launch_bounds__(256)
+exchange_count_kernel(int P, int B, int W, int k0, int gx, int gy, int nchunk, const float2 *__restrict__ means2D,
+                      const int32_t *__restrict__ radii, const int32_t *__restrict__ bands,
+                      int32_t *__restrict__ chunkcnt, int32_t *__restrict__ counts) {
+    __shared__ int32_t s_cnt[4][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kk = blockIdx.y, k = k0 + kk;  // kk: camera within the launch, k: camera of the batch
+    const int chunk = blockIdx.x * 4 + wave;
+    for (int g = lane; g < W; g += 64) s_cnt[wave][g] = 0;
+    __builtin_amdgcn_wave_barrier();
+    if (chunk < nchunk) {
+        for (int r = 0; r < XCHUNK / 64; r++) {
+            const int i = chunk * XCHUNK + r * 64 + lane;
+            int miny = 0, maxy = 0;
+            const bool ok = i < P && rect_rows(means2D, radii, (size_t)k * P + i, gx, gy, miny, maxy);
+            for (int g = 0; g < W; g++) {
+                const int lo = bands[((size_t)k * W + g) * 2], hi = bands[((size_t)k * W + g) * 2 + 1];  // uniform
+                const unsigned long long m = __ballot(ok && hi > lo && max(lo, miny) < min(hi, maxy));
+                if (lane == 0 && m) s_cnt[wave][g] += (int32_t)__popcll(m);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int g = lane; g < W; g += 64) {
+            const int32_t c = s_cnt[wave][g];
+            chunkcnt[((size_t)g * B + kk) * nchunk + chunk] = c;
+            if (c) atomicAdd(&counts[(size_t)g * B + kk], c);
+        }
+    }
+}
+
+struct SegOffsets {
+    int32_t off[512];  // first message row of segment (destination g, camera kk) = off[g * B + kk]
+};
+
+__global__ void __launch_bounds__(256)
+exchange_pack_kernel(int P, int B, int W, int k0, int cntB, int cnt0, int gx, int gy, int nchunk,
+                     const float2 *__restrict__ means2D,
+                     const float *__restrict__ rgb, const float4 *__restrict__ conic_opacity,
+                     const int32_t *__restrict__ radii, const float *__restrict__ depths,
+                     const int32_t *__restrict__ bands, const int32_t *__restrict__ chunkcnt, SegOffsets seg,
+                     float *__restrict__ msg, int32_t *__restrict__ send_idx) {
+    __shared__ int32_t s_base[4][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kk = blockIdx.y, k = k0 + kk;
+    const int chunk = blockIdx.x * 4 + wave;
+    if (chunk >= nchunk) return;  // wave-uniform; no workgroup barrier below
+    // first row of this chunk in each segment: segment start + the counts of the chunks before it
+    for (int g = 0; g < W; g++) {
+        const int32_t *cc = chunkcnt + ((size_t)g * cntB + (cnt0 + kk)) * nchunk;  // layout of the count launch
+        int32_t part = 0;
+        for (int c = lane; c < chunk; c += 64) part += cc[c];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+        if (lane == 0) s_base[wave][g] = seg.off[g * B + kk] + part;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int r = 0; r < XCHUNK / 64; r++) {
+        const int i = chunk * XCHUNK + r * 64 + lane;
+        const size_t row = (size_t)k * P + i;
+        int miny = 0, maxy = 0;
+        const bool ok = i < P && rect_rows(means2D, radii, row, gx, gy, miny, maxy);
+        if (__ballot(ok) == 0ull) continue;
+        float rec[11];
+        if (ok) {
+            const float2 xy = means2D[row];
+            const float4 co = conic_opacity[row];
+            rec[0] = xy.x; rec[1] = xy.y;
+            rec[2] = rgb[3 * row]; rec[3] = rgb[3 * row + 1]; rec[4] = rgb[3 * row + 2];
+            rec[5] = co.x; rec[6] = co.y; rec[7] = co.z; rec[8] = co.w;
+            rec[9] = __int_as_float(radii[row]);
+            rec[10] = depths[row];
+        }
+        for (int g = 0; g < W; g++) {
+            const int lo = bands[((size_t)k * W + g) * 2], hi = bands[((size_t)k * W + g) * 2 + 1];  // uniform
+            const bool hit = ok && hi > lo && max(lo, miny) < min(hi, maxy);
+            const unsigned long long m = __ballot(hit);
+            if (m == 0ull) continue;
+            const int32_t base = s_base[wave][g];
+            if (hit) {
+                const size_t pos = (size_t)base + __popcll(m & lt);
+                float *dst = msg + pos * 11;
+#pragma unroll
+                for (int c = 0; c < 11; c++) dst[c] = rec[c];
+                send_idx[pos] = (int32_t)(kk * P + i);  // row of the [cameras of this launch, P] state
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) s_base[wave][g] = base + (int32_t)__popcll(m);
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+// dst[idx[r]][0:9] += src[r][0:9]; 9 adjacent lanes per row
+__global__ void __launch_bounds__(256)
+scatter_add_rows_kernel(long long n, const int32_t *__restrict__ idx, const float *__restrict__ src,
+                        float *__restrict__ dst) {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n * 9;
+         e += (long long)gridDim.x * blockDim.x) {
+        const long long r = e / 9;
+        const int c = (int)(e - r * 9);
+        const float v = src[e];
+        if (v != 0.f) atomicAdd(dst + (size_t)idx[r] * 9 + c, v);
+    }
+}
 }  // namespace
+
+extern "C" size_t gsr_exchange_chunks(int P) { return P <= 0 ? 0 : (size_t)gsr_div_up(P, XCHUNK); }
+
+extern "C" int gsr_exchange_count(int P, int B_total, int k0, int B, int W, int width, int height,
+                                  const float *means2D, const int32_t *radii, const int32_t *bands,
+                                  int32_t *chunkcnt, int32_t *counts, gsr_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (P < 0 || B < 1 || B > 65535 || k0 < 0 || k0 + B > B_total || W < 1 || W > 256 || W * B > 512 ||
+        width <= 0 || height <= 0 || !counts)
+        return GSR_EINVAL;
+    GSR_HIP(hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)W * B, stream));
+    if (P == 0) return 0;
+    if (!means2D || !radii || !bands || !chunkcnt) return GSR_EINVAL;
+    const int gx = (width + GSR_BLOCK_X - 1) / GSR_BLOCK_X, gy = (height + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y;
+    const int nchunk = gsr_div_up(P, XCHUNK);
+    hipLaunchKernelGGL(exchange_count_kernel, dim3(gsr_div_up(nchunk, 4), B), dim3(256), 0, stream, P, B, W, k0, gx, gy,
+                       nchunk, reinterpret_cast<const float2 *>(means2D), radii, bands, chunkcnt, counts);
+    GSR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gsr_exchange_pack(int P, int B_total, int k0, int B, int W, int width, int height, int count_cameras,
+                                 int count_first, const float *means2D, const float *rgb, const float *conic_opacity,
+                                 const int32_t *radii, const float *depths, const int32_t *bands,
+                                 const int32_t *chunkcnt, const int32_t *segment_offsets, int64_t n_send, float *msg,
+                                 int32_t *send_idx, gsr_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (P < 0 || B < 1 || B > 65535 || k0 < 0 || k0 + B > B_total || W < 1 || W > 256 || W * B > 512 ||
+        width <= 0 || height <= 0 || n_send < 0 || !segment_offsets || count_cameras < B || count_first < 0 ||
+        k0 < count_first || k0 - count_first + B > count_cameras)
+        return GSR_EINVAL;
+    if (P == 0 || n_send == 0) return 0;
+    if (!means2D || !rgb || !conic_opacity || !radii || !depths || !bands || !chunkcnt || !msg || !send_idx)
+        return GSR_EINVAL;
+    SegOffsets seg;
+    for (int i = 0; i < W * B; i++) seg.off[i] = segment_offsets[i];
+    const int gx = (width + GSR_BLOCK_X - 1) / GSR_BLOCK_X, gy = (height + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y;
+    const int nchunk = gsr_div_up(P, XCHUNK);
+    hipLaunchKernelGGL(exchange_pack_kernel, dim3(gsr_div_up(nchunk, 4), B), dim3(256), 0, stream, P, B, W, k0,
+                       count_cameras, k0 - count_first, gx, gy, nchunk, reinterpret_cast<const float2 *>(means2D), rgb,
+                       reinterpret_cast<const float4 *>(conic_opacity), radii, depths, bands, chunkcnt, seg, msg,
+                       send_idx);
+    GSR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gsr_scatter_add_rows(int64_t n, const int32_t *idx, const float *src, float *dst,
+                                    gsr_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (n < 0) return GSR_EINVAL;
+    if (n == 0) return 0;
+    if (!idx || !src || !dst) return GSR_EINVAL;
+    long long blocks = (n * 9 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (long long)n, idx, src,
+                       dst);
+    GSR_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int gsr_exchange_need(int P, int B, int W, int width, int height, const float *means2D,
                                  const int32_t *radii, const int32_t *bands, uint8_t *need, int32_t *counts,

@@ -26,7 +26,8 @@ from ._lib import check, lib
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "_C", "load_image_tiles_by_pos",
            "merge_image_tiles_by_pos", "set_timing_mode", "fused_l1_ssim_band", "fused_band_loss", "fused_activations", "pack_camera",
-           "preprocess_gaussians_raw_batched", "knn_mean_dist2", "group_rows", "gather_rows", "exchange_need"]
+           "preprocess_gaussians_raw_batched", "knn_mean_dist2", "group_rows", "gather_rows", "exchange_need",
+           "exchange_count", "exchange_pack", "scatter_add_rows", "scatter_rows", "local_pixels"]
 
 BLOCK_X, BLOCK_Y, ONE_DIM_BLOCK_SIZE = 16, 16, 256
 
@@ -290,6 +291,25 @@ def pack_camera(raster_settings):
                       rs.campos.reshape(3).float(), tail]).contiguous()
 
 
+def _batched_record(grads, B, P):
+    """the [B*P, 9] fp32 record whose column blocks 0:2 / 2:5 / 5:9 of rows [kP, (k+1)P) ARE the gradients of camera
+    k's means2D / rgb / conic_opacity, or None"""
+    g0 = grads[0]
+    if g0 is None or g0._base is None:
+        return None
+    base = g0._base
+    if base.dtype != torch.float32 or not base.is_contiguous() or base.numel() != B * P * 9:
+        return None
+    p0 = base.data_ptr()
+    for k in range(B):
+        for col, (off, cols) in enumerate(((0, 2), (2, 3), (5, 4))):
+            g = grads[5 * k + col]
+            if g is None or g._base is not base or tuple(g.shape) != (P, cols) or g.stride() != (9, 1) or \
+                    g.data_ptr() != p0 + 4 * (k * P * 9 + off):
+                return None
+    return base.view(B * P, 9)
+
+
 class _PreprocessGaussiansRawBatched(torch.autograd.Function):
     """K1 / K11 for a batch of B cameras in one launch each way (gsr_preprocess_*_raw_batched)."""
 
@@ -357,7 +377,11 @@ class _PreprocessGaussiansRawBatched(torch.autograd.Function):
         if B == 1:  # K10's [P,9] record (or any common-stride column views) goes straight into the kernel
             g_means2D, g_rgb, g_conic_opacity, gstride = _grad_triple(grads[0], grads[1], grads[2], P, dev)
         else:
-            g_means2D, g_rgb, g_conic_opacity, gstride = assemble(0, 2), assemble(1, 3), assemble(2, 4), 0
+            rec = _batched_record(grads, B, P)
+            if rec is not None:  # column views of ONE [B,P,9] record (the exchange's backward): read through the stride
+                g_means2D, g_rgb, g_conic_opacity, gstride = rec[:, 0:2], rec[:, 2:5], rec[:, 5:9], 9
+            else:
+                g_means2D, g_rgb, g_conic_opacity, gstride = assemble(0, 2), assemble(1, 3), assemble(2, 4), 0
         d_xyz = torch.empty((P, 3), dtype=torch.float32, device=dev)
         d_scaling = torch.empty((P, 3), dtype=torch.float32, device=dev)
         d_rot = torch.empty((P, 4), dtype=torch.float32, device=dev)
@@ -420,7 +444,10 @@ def bin_gaussians(means2D, depths, radii, conic_opacity, compute_locally, width,
 
 class _RenderGaussians(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, means2D, conic_opacity, rgb, depths, radii, compute_locally, raster_settings, cuda_args):
+    def forward(ctx, means2D, conic_opacity, rgb, depths, radii, compute_locally, raster_settings, cuda_args,
+                token=None):
+        # `token`: an optional 1-element tensor that only ties this node into the caller's autograd graph (the mirror
+        # chains its per-camera exchanges through it so that every rank runs their backward collectives in one order)
         ctx.set_materialize_grads(False)
         rs = raster_settings
         means2D, conic_opacity, rgb = _f32c(means2D, "means2D"), _f32c(conic_opacity, "conic_opacity"), _f32c(rgb, "rgb")
@@ -485,7 +512,7 @@ class _RenderGaussians(torch.autograd.Function):
         P = means2D.shape[0]
         dev = means2D.device
         if g_out is None:
-            return None, None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None, None
         g_out = g_out.float().contiguous()
         # ONE [P,9] record (means2D 0:2, rgb 2:5, conic_opacity 5:9): K10 flushes a (tile, Gaussian) pair's nine sums
         # from nine adjacent lanes into one row; K11 and the exchange read the record through its row stride
@@ -523,7 +550,7 @@ class _RenderGaussians(torch.autograd.Function):
                     _last_backward_ms = float(pend[0].elapsed_time(pend[1]))
                 _RenderGaussians._pending = (ev0, ev1)
                 stats["backward_render_time"] = float(_last_backward_ms)
-        return d_means2D, d_conic_opacity, d_rgb, None, None, None, None, None
+        return d_means2D, d_conic_opacity, d_rgb, None, None, None, None, None, None
 
 
 class GaussianRasterizer(nn.Module):
@@ -556,8 +583,9 @@ class GaussianRasterizer(nn.Module):
         if cuda_args is None:
             cuda_args = {}
         fn = _RenderGaussians
+        token = cuda_args.get("_exchange_token") if isinstance(cuda_args, dict) else None
         image, n_contrib = fn.apply(means2D, conic_opacity, rgb, depths, radii, compute_locally,
-                                    self.raster_settings, cuda_args)
+                                    self.raster_settings, cuda_args, token)
         return image, getattr(fn, "last_num_rendered", None), None, n_contrib
 
 
@@ -759,6 +787,61 @@ def exchange_need(means2D_all, radii_all, bands, width, height):
     return need, counts
 
 
+def exchange_count(means2D_all, radii_all, bands, k0, nb, width, height):
+    """K2 counted, not materialised: for the cameras [k0, k0 + nb) of the camera-major state (means2D_all fp32 [B,P,2],
+    radii_all int32 [B,P]; bands int32 [B,W,2] on the device) -> (chunkcnt int32 [W * nb, chunks], counts int32 [W, nb])"""
+    m2 = _f32c(means2D_all.detach(), "means2D_all")
+    if radii_all.dtype != torch.int32 or not radii_all.is_contiguous() or bands.dtype != torch.int32 or \
+            not bands.is_cuda or not bands.is_contiguous():
+        raise ValueError("radii_all / bands must be contiguous int32 device tensors")
+    B, P = radii_all.shape
+    W = bands.shape[1]
+    nchunk = lib.gsr_exchange_chunks(P)
+    chunkcnt = torch.empty((W * nb, max(nchunk, 1)), dtype=torch.int32, device=m2.device)
+    counts = torch.empty((W, nb), dtype=torch.int32, device=m2.device)
+    with torch.cuda.device(m2.device):
+        check(lib.gsr_exchange_count(P, B, k0, nb, W, width, height, _ptr(m2), _ptr(radii_all), _ptr(bands),
+                                     _ptr(chunkcnt), _ptr(counts), _stream()), "gsr_exchange_count")
+    return chunkcnt, counts
+
+
+def exchange_pack(means2D_all, rgb_all, co_all, radii_all, depths_all, bands, chunkcnt, segment_offsets, n_send, k0, nb,
+                  width, height, count_cameras=None, count_first=None):
+    """-> (msg fp32 [n_send, 11], send_idx int32 [n_send]): the records of the cameras [k0, k0 + nb) in
+    (destination, camera, local index) order; segment_offsets: python ints [W * nb] (first row of each segment);
+    chunkcnt: what exchange_count returned for the camera range [count_first, count_first + count_cameras) (default:
+    the same range)"""
+    B, P = radii_all.shape
+    W = bands.shape[1]
+    dev = radii_all.device
+    msg = torch.empty((n_send, 11), dtype=torch.float32, device=dev)
+    send_idx = torch.empty((n_send,), dtype=torch.int32, device=dev)
+    if len(segment_offsets) != W * nb:
+        raise ValueError("segment_offsets must have W * nb entries")
+    seg = (ctypes.c_int32 * (W * nb))(*segment_offsets)
+    with torch.cuda.device(dev):
+        check(lib.gsr_exchange_pack(P, B, k0, nb, W, width, height, nb if count_cameras is None else count_cameras,
+                                    k0 if count_first is None else count_first, _ptr(means2D_all), _ptr(rgb_all), _ptr(co_all),
+                                    _ptr(radii_all), _ptr(depths_all), _ptr(bands), _ptr(chunkcnt), seg, n_send,
+                                    _ptr(msg), _ptr(send_idx), _stream()), "gsr_exchange_pack")
+    return msg, send_idx
+
+
+def scatter_add_rows(idx, src, n_rows, dst=None):
+    """-> dst fp32 [n_rows, 9] with dst[idx[r]] += src[r] (rows of 9 floats; duplicates in idx accumulate); `dst`:
+    an existing contiguous [n_rows, 9] view to add into (default: a fresh zero tensor)"""
+    src = _f32c(src, "src")
+    if src.dim() != 2 or src.shape[1] != 9 or idx.dtype != torch.int32 or not idx.is_contiguous():
+        raise ValueError("src must be [n, 9] fp32 and idx contiguous int32")
+    if dst is None:
+        dst = torch.zeros((n_rows, 9), dtype=torch.float32, device=src.device)
+    elif tuple(dst.shape) != (n_rows, 9) or dst.dtype != torch.float32 or not dst.is_contiguous():
+        raise ValueError("dst must be a contiguous fp32 [n_rows, 9] tensor")
+    with torch.cuda.device(src.device):
+        check(lib.gsr_scatter_add_rows(src.shape[0], _ptr(idx), _ptr(src), _ptr(dst), _stream()), "gsr_scatter_add_rows")
+    return dst
+
+
 def knn_mean_dist2(points):
     """mean squared distance of every point to its 3 nearest other points -- what the reference obtains from
     `simple_knn._C.distCUDA2` at scene creation (scene/gaussian_model.py:163-166).  points: fp32 [P,3] on the
@@ -793,7 +876,12 @@ def group_rows(dest, num_groups):
     return order, counts.cpu().tolist()
 
 
-def gather_rows(order, n_out, srcs, dsts=None, row0=0):
+def scatter_rows(order, n_in, srcs, dsts, row0=0):
+    """dst_k[order[row0 + r]] = src_k[r] for r < n_in, all tensors in ONE launch (the inverse of gather_rows)"""
+    return gather_rows(order, n_in, srcs, dsts, row0, _scatter=True)
+
+
+def gather_rows(order, n_out, srcs, dsts=None, row0=0, _scatter=False):
     """dst_k[r] = src_k[order[row0 + r]] (order None: identity) for r < n_out, all tensors in ONE launch.
     srcs / dsts: 4-byte-element tensors whose rows are contiguous (dim 0 may be strided, e.g. a column block of a
     record matrix); dsts=None allocates dense outputs shaped like the sources.  Returns the dsts."""
@@ -804,7 +892,7 @@ def gather_rows(order, n_out, srcs, dsts=None, row0=0):
         return dsts
     if K > 32:
         for i in range(0, K, 32):
-            gather_rows(order, n_out, srcs[i:i + 32], dsts[i:i + 32], row0)
+            gather_rows(order, n_out, srcs[i:i + 32], dsts[i:i + 32], row0, _scatter)
         return dsts
 
     def row_layout(t, what):
@@ -824,7 +912,7 @@ def gather_rows(order, n_out, srcs, dsts=None, row0=0):
     for s_, d_ in zip(srcs, dsts):
         w, st = row_layout(s_, "source")
         w2, dt = row_layout(d_, "destination")
-        if w != w2 or d_.shape[0] < n_out:
+        if w != w2 or (s_ if _scatter else d_).shape[0] < n_out:
             raise ValueError("source / destination row shapes differ")
         widths.append(w)
         ss.append(st)
@@ -833,9 +921,9 @@ def gather_rows(order, n_out, srcs, dsts=None, row0=0):
     order_ptr = ctypes.c_void_p(order.data_ptr() + 4 * row0) if order is not None else ctypes.c_void_p(0)
     if order is not None and (order.dtype != torch.int32 or not order.is_contiguous()):
         raise ValueError("order must be a contiguous int32 tensor")
-    check(lib.gsr_gather_rows(n_out, order_ptr, K, VP(*[s_.data_ptr() for s_ in srcs]),
-                              VP(*[d_.data_ptr() for d_ in dsts]), (ctypes.c_int32 * K)(*widths),
-                              (ctypes.c_int64 * K)(*ss), (ctypes.c_int64 * K)(*ds), _stream()), "gsr_gather_rows")
+    fn, what = (lib.gsr_scatter_rows, "gsr_scatter_rows") if _scatter else (lib.gsr_gather_rows, "gsr_gather_rows")
+    check(fn(n_out, order_ptr, K, VP(*[s_.data_ptr() for s_ in srcs]), VP(*[d_.data_ptr() for d_ in dsts]),
+             (ctypes.c_int32 * K)(*widths), (ctypes.c_int64 * K)(*ss), (ctypes.c_int64 * K)(*ds), _stream()), what)
     return dsts
 
 

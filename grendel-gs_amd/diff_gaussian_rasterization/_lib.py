@@ -41,12 +41,18 @@ SIGNATURES = {
     "gsr_l1_ssim_finalize": (c_int, [c_int, c_void_p, c_float, c_float, c_float, c_float, c_void_p, c_void_p]),
     "gsr_exchange_need": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p]),
+    "gsr_exchange_chunks": (c_size_t, [c_int]),
+    "gsr_exchange_count": (c_int, [c_int] * 7 + [c_void_p] * 6),
+    "gsr_exchange_pack": (c_int, [c_int] * 9 + [c_void_p] * 8 + [c_int64, c_void_p, c_void_p, c_void_p]),
+    "gsr_scatter_add_rows": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gsr_knn_workspace_bytes": (c_size_t, [c_int]),
     "gsr_knn_mean_dist2": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "gsr_group_rows_bytes": (c_size_t, [c_int64]),
     "gsr_group_rows": (c_int, [c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "gsr_gather_rows": (c_int, [c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                 c_void_p]),
+    "gsr_scatter_rows": (c_int, [c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_void_p]),
     "gsr_adam_step": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_double, ctypes.c_double,
                               ctypes.c_double, ctypes.c_double, c_int64, c_float, c_void_p]),
     "gsr_adam_step_multi": (c_int, [c_int] + [c_void_p] * 10 + [c_float, c_void_p]),
@@ -64,7 +70,7 @@ SIGNATURES = {
     "gsr_render_backward": (c_int, [c_int, c_int, c_int] + [c_void_p] * 12),
 }
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 def _load():

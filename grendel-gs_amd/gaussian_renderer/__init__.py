@@ -150,40 +150,103 @@ def all_to_all_communication_final(batched_rasterizers, batched_screenspace_para
     return out[0], out[1], out[2], out[3], out[4], sizes
 
 
-class _BatchedExchange(torch.autograd.Function):
-    """the exchange on the camera-batched state ([B,P,.] arrays of the batched K1): 11-float records
-    (means2D 2, rgb 3, conic_opacity 4, radii bits 1, depth 1) packed by ONE gather launch, ONE all-to-all-v, ONE
-    unpack launch.  Returns dense camera-major arrays of what this rank renders.  backward: grads packed (1 launch),
-    mirror all-to-all-v, scatter-add into the senders' rows (a Gaussian needed by two bands gets two
-    contributions)."""
+# ---- the fused exchange of the camera-batched state -------------------------------------------------------------
+# switches (parity tests flip them): pipeline the per-camera exchanges on a side HIP stream; use the fused kernels
+_EXCHANGE_OPTIONS = {"overlap": True}
+_SIDE_STREAMS = {}
+_BANDS_CACHE = {}
+
+
+def set_exchange_overlap(enabled):
+    """camera k's all-to-all (pack, RCCL, unpack -- and its mirror in the backward) on a side HIP stream, so that it
+    runs beside camera k-1's K3-K8 in the forward and beside camera k+1's K10 in the backward (north_star); off: one
+    exchange for the whole batch on the current stream"""
+    _EXCHANGE_OPTIONS["overlap"] = bool(enabled)
+
+
+def _side_stream(dev):
+    key = (dev.type, dev.index)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _SIDE_STREAMS[key]
+
+
+def _bands_tensor(batched_strategies, W, dev):
+    """int32 [B, W, 2] tile rows [lo, hi) of camera k rendered by global rank g, on the device; cached per partition
+    (static strategies -- bsz >= W, frozen heuristics -- hit the cache every step: no host-to-device copy)"""
+    key = (dev.index, W) + tuple((tuple(s.gpu_ids), tuple(s.division_pos)) for s in batched_strategies)
+    t = _BANDS_CACHE.get(key)
+    if t is None:
+        if len(_BANDS_CACHE) > 512:
+            _BANDS_CACHE.clear()
+        bands = [[(0, 0)] * W for _ in batched_strategies]
+        for k, strategy in enumerate(batched_strategies):
+            for j, g in enumerate(strategy.gpu_ids):
+                bands[k][g] = (strategy.division_pos[j], strategy.division_pos[j + 1])
+        t = _BANDS_CACHE[key] = torch.tensor(bands, dtype=torch.int32).to(dev)
+    return t
+
+
+def _camera_major_base(per_camera):
+    """the dense [B,P,.] buffer whose slices the per-camera tensors are (the batched K1 allocates them that way), or a
+    stacked copy"""
+    t0 = per_camera[0]
+    base = t0._base
+    if (base is not None and base.is_contiguous() and base.shape[0] == len(per_camera)
+            and tuple(base.shape[1:]) == tuple(t0.shape)
+            and all(t._base is base and t.data_ptr() == base.data_ptr() + k * t0.numel() * t0.element_size()
+                    for k, t in enumerate(per_camera))):
+        return base.detach()
+    return torch.stack([t.detach() for t in per_camera]).contiguous()
+
+
+class _ExchangeGroup(torch.autograd.Function):
+    """the exchange of the cameras [k0, k0 + nb) of a batch: pack (gsr_exchange_pack: 11-float records in
+    (destination, camera, local index) order, straight into the send buffer), ONE all-to-all-v, unpack.  Runs on the
+    stream that is current when it is called -- autograd runs the backward (gradient rows back through the mirror
+    all-to-all-v, gsr_scatter_add_rows into the owners' rows) on the same stream.  Differentiable inputs: the per-camera
+    means2D / rgb / conic_opacity views (their gradients come back as column views of one [nb*P, 9] record that the
+    batched K11 reads through its row stride)."""
 
     @staticmethod
-    def forward(ctx, m2, rgb, co, radii, depths, send_idx, send_splits, recv_splits, perm, inv_perm, group):
-        B, P = radii.shape
-        BP, n_send, n_recv = B * P, send_idx.shape[0], sum(recv_splits)
-        dev = m2.device
-        msg = torch.empty((n_send, N_DIFF + 2), dtype=torch.float32, device=dev)
-        _dgr.gather_rows(send_idx, n_send,
-                         [m2.detach().reshape(BP, 2), rgb.detach().reshape(BP, 3), co.detach().reshape(BP, 4),
-                          radii.reshape(BP, 1).view(torch.float32), depths.detach().reshape(BP, 1)],
-                         [msg[:, 0:2], msg[:, 2:5], msg[:, 5:9], msg[:, 9:10], msg[:, 10:11]])
-        recv = torch.empty((n_recv, N_DIFF + 2), dtype=torch.float32, device=dev)
+    def forward(ctx, meta, bases, token, *views):
+        (k0, nb, P, width, height, seg_off, send_splits, recv_splits, perm, inv_perm, group, chunkcnt, cnt_B, bands,
+         consumer_stream, holder) = meta
+        m2_all, rgb_all, co_all, radii_all, depths_all = bases
+        dev = radii_all.device
+        n_send, n_recv = sum(send_splits), sum(recv_splits)
+        cur = torch.cuda.current_stream() if dev.type == "cuda" else None
+        msg, send_idx = _dgr.exchange_pack(m2_all, rgb_all, co_all, radii_all, depths_all, bands, chunkcnt, seg_off,
+                                           n_send, k0, nb, width, height, count_cameras=cnt_B, count_first=0)
+        recv = torch.empty((n_recv, N_DIFF + N_AUX), dtype=msg.dtype, device=dev)
         dist.all_to_all_single(recv, msg, output_split_sizes=recv_splits, input_split_sizes=send_splits, group=group)
-        outs = [torch.empty((n_recv, w), dtype=torch.float32, device=dev) for w in (2, 3, 4, 1, 1)]
+        outs = [torch.empty((n_recv, w), dtype=msg.dtype, device=dev) for w in (2, 3, 4, 1, 1)]
         _dgr.gather_rows(perm, n_recv, [recv[:, 0:2], recv[:, 2:5], recv[:, 5:9], recv[:, 9:10], recv[:, 10:11]], outs)
-        ctx.group, ctx.send_splits, ctx.recv_splits, ctx.shape = group, send_splits, recv_splits, (B, P)
+        if consumer_stream is not None and consumer_stream != cur:
+            for t in outs:
+                t.record_stream(consumer_stream)  # allocated on the side stream, consumed by the renderer's stream
+            for t in bases:
+                t.record_stream(cur)
+        ctx.meta = (k0, nb, P, cnt_B, send_splits, recv_splits, group, consumer_stream, holder)
         ctx.save_for_backward(send_idx, inv_perm if inv_perm is not None else send_idx[:0])
         ctx.has_perm = inv_perm is not None
-        r_radii, r_depths = outs[3].view(torch.int32).reshape(n_recv), outs[4].reshape(n_recv)
+        r_radii = (outs[3].view(torch.int32) if outs[3].dtype == torch.float32 else outs[3].to(torch.int32)).reshape(n_recv)
+        r_depths = outs[4].reshape(n_recv)
         ctx.mark_non_differentiable(r_radii, r_depths)
-        return outs[0], outs[1], outs[2], r_radii, r_depths
+        # the token chains the per-camera exchanges of a batch: camera k's node consumes camera k-1's token, the last
+        # one is handed to a render op, so every rank's backward runs the mirror collectives of ALL cameras (also of
+        # those it renders no part of) and in the same order, camera B-1 first
+        token_out = torch.empty((1,), dtype=outs[0].dtype, device=dev) if token is not None else None
+        return outs[0], outs[1], outs[2], r_radii, r_depths, token_out
 
     @staticmethod
-    def backward(ctx, g_m2, g_rgb, g_co, _gr, _gd):
+    def backward(ctx, g_m2, g_rgb, g_co, _gr, _gd, _gtoken):
         send_idx, inv_perm = ctx.saved_tensors
-        B, P = ctx.shape
-        n_recv, n_send = sum(ctx.recv_splits), sum(ctx.send_splits)
+        k0, nb, P, B, send_splits, recv_splits, group, consumer_stream, holder = ctx.meta
+        n_recv, n_send = sum(recv_splits), sum(send_splits)
         dev = send_idx.device
+        cur = torch.cuda.current_stream() if dev.type == "cuda" else None
+        fdt = next((g.dtype for g in (g_m2, g_rgb, g_co) if g is not None), torch.float32)  # fp32 (fp64 in CPU tests)
         g_recv = None
         if not ctx.has_perm and all(g is not None and g.dtype == torch.float32 for g in (g_m2, g_rgb, g_co)):
             base = g_m2._base
@@ -192,88 +255,105 @@ class _BatchedExchange(torch.autograd.Function):
                     and g_rgb.data_ptr() == base.data_ptr() + 8 and g_co.data_ptr() == base.data_ptr() + 20):
                 g_recv = base  # K10's gradient record has the message's column order: it IS the message
         if g_recv is None:
-            gs = [g if g is not None else torch.zeros((n_recv, w), dtype=torch.float32, device=dev)
+            gs = [g if g is not None else torch.zeros((n_recv, w), dtype=fdt, device=dev)
                   for g, w in ((g_m2, 2), (g_rgb, 3), (g_co, 4))]
-            gs = [g if (g.dtype == torch.float32 and (g.shape[0] <= 1 or g.stride(1) == 1)) else g.float().contiguous()
+            gs = [g if (g.dtype == fdt and (g.shape[0] <= 1 or g.stride(1) == 1)) else g.to(fdt).contiguous()
                   for g in gs]
-            g_recv = torch.empty((n_recv, N_DIFF), dtype=torch.float32, device=dev)
+            g_recv = torch.empty((n_recv, N_DIFF), dtype=fdt, device=dev)
             _dgr.gather_rows(inv_perm if ctx.has_perm else None, n_recv, gs,
                              [g_recv[:, 0:2], g_recv[:, 2:5], g_recv[:, 5:9]])
-        back = torch.empty((n_send, N_DIFF), dtype=torch.float32, device=dev)
-        dist.all_to_all_single(back, g_recv, output_split_sizes=ctx.send_splits, input_split_sizes=ctx.recv_splits,
-                               group=ctx.group)
+        if consumer_stream is not None and consumer_stream != cur:
+            g_recv.record_stream(cur)  # produced by K10 on the renderer's stream, read here on the side stream
+        back = torch.empty((n_send, N_DIFF), dtype=fdt, device=dev)
+        dist.all_to_all_single(back, g_recv, output_split_sizes=send_splits, input_split_sizes=recv_splits, group=group)
+        # ONE [B*P, 9] record for the whole batch (the exchanges of its cameras add into their own row blocks); the
+        # gradients that go back are its column views, which the batched K11 reads through the row stride
+        if holder.get("rec") is None:
+            holder["rec"] = torch.zeros((B * P, N_DIFF), dtype=fdt, device=dev)
+            if consumer_stream is not None and consumer_stream != cur:
+                holder["rec"].record_stream(consumer_stream)
+        rec = holder["rec"][k0 * P:(k0 + nb) * P]
+        _dgr.scatter_add_rows(send_idx, back, nb * P, dst=rec)
         grads = []
         for a, b in ((0, 2), (2, 5), (5, 9)):
-            g = torch.zeros((B * P, b - a), dtype=torch.float32, device=dev)
-            g.index_add_(0, send_idx, back[:, a:b])
-            grads.append(g.view(B, P, b - a))
-        return grads[0], grads[1], grads[2], None, None, None, None, None, None, None, None
-
-
-def _camera_major(per_camera):
-    """[B,P,.] tensor of per-camera tensors: their common dense base when they are its slices and carry no
-    gradient (radii, depths), else a differentiable stack"""
-    t0 = per_camera[0]
-    base = t0._base
-    if (not t0.requires_grad and base is not None and base.is_contiguous() and base.shape[0] == len(per_camera)
-            and tuple(base.shape[1:]) == tuple(t0.shape)
-            and all(t._base is base and t.data_ptr() == base.data_ptr() + k * t0.numel() * t0.element_size()
-                    for k, t in enumerate(per_camera))):
-        return base
-    return torch.stack(list(per_camera))
+            grads += [rec[k * P:(k + 1) * P, a:b] for k in range(nb)]
+        return (None, None, None) + tuple(grads)
 
 
 def _batched_exchange_final(m2_views, rgb_views, co_views, radii_views, depths_views, rasterizers,
                             batched_strategies):
-    """all_to_all_communication_final for the camera-batched state: same return structure, ~15 launches per
-    batch instead of ~15 per camera (and no per-band nonzero)."""
+    """all_to_all_communication_final for the camera-batched state: same return structure (+ the per-camera events a
+    consumer on another stream must wait for, None without overlap).  Host cost per batch: one count launch, one size
+    all-gather + the one read-back, then per exchange one pack launch, one all-to-all-v and one unpack launch."""
     group = utils.DEFAULT_GROUP
     W, me = group.size(), group.rank()
-    rgb_all, co_all = _camera_major(rgb_views), _camera_major(co_views)
-    radii_all, depths_all = _camera_major(radii_views), _camera_major(depths_views)
-    B, P = radii_all.shape
+    B = len(radii_views)
+    bases = [_camera_major_base(v) for v in (m2_views, rgb_views, co_views, radii_views, depths_views)]
+    radii_all = bases[3]
+    P = radii_all.shape[1]
     dev = radii_all.device
     rs = rasterizers[0].raster_settings
-    bands = [[(0, 0)] * W for _ in range(B)]
-    for k, strategy in enumerate(batched_strategies):
-        for j, g in enumerate(strategy.gpu_ids):
-            bands[k][g] = (strategy.division_pos[j], strategy.division_pos[j + 1])
-    m2 = _camera_major(m2_views)  # a stack: keeps the per-camera means2D in the graph (their .grad feeds densification)
-    need, counts = _dgr.exchange_need(m2, radii_all, torch.tensor(bands, dtype=torch.int32), rs.image_width,
-                                      rs.image_height)
+    width, height = int(rs.image_width), int(rs.image_height)
+    bands = _bands_tensor(batched_strategies, W, dev)
+    chunkcnt, counts = _dgr.exchange_count(bases[0], radii_all, bands, 0, B, width, height)
     all_counts = torch.empty((W * W, B), dtype=torch.int32, device=dev)
     dist.all_gather_into_tensor(all_counts, counts, group=group)
     sizes = all_counts.view(W, W, B).cpu().tolist()  # the one host read-back of the exchange; sizes[i][j][k]
-    send_splits = [sum(sizes[me][j]) for j in range(W)]
-    recv_splits = [sum(sizes[i][me]) for i in range(W)]
-    flat = torch.nonzero_static(need.view(-1), size=sum(send_splits)).squeeze(1)
-    send_idx = (flat % (B * P)).to(torch.int32)  # (g, k, i) -> row k * P + i of the [B*P, .] state
 
-    # received rows are (source, camera)-major; the renderer wants camera-major with the source order kept
-    per_cam = [sum(sizes[i][me][k] for i in range(W)) for k in range(B)]
-    perm = inv_perm = None
-    if sum(1 for n in per_cam if n) > 1:
-        off, o = {}, 0
-        for i in range(W):
-            for k in range(B):
-                off[(i, k)] = o
-                o += sizes[i][me][k]
-        order = torch.cat([torch.arange(off[(i, k)], off[(i, k)] + sizes[i][me][k], dtype=torch.int32)
-                           for k in range(B) for i in range(W)])
-        inv = torch.empty_like(order)
-        inv[order.long()] = torch.arange(order.numel(), dtype=torch.int32)
-        perm, inv_perm = order.to(dev), inv.to(dev)
-    r_m2, r_rgb, r_co, r_radii, r_depths = _BatchedExchange.apply(
-        m2, rgb_all, co_all, radii_all, depths_all, send_idx, send_splits, recv_splits, perm, inv_perm, group)
-    out = ([], [], [], [], [])
-    start = 0
-    for k in range(B):
-        n = per_cam[k]
-        whole = n == r_radii.shape[0]
-        for c, t in enumerate((r_m2, r_rgb, r_co, r_radii, r_depths)):
-            out[c].append(t if whole else t[start:start + n])
-        start += n
-    return out[0], out[1], out[2], out[3], out[4], sizes
+    pipelined = _EXCHANGE_OPTIONS["overlap"] and B > 1   # one exchange per camera ...
+    overlap = pipelined and dev.type == "cuda"            # ... on the side stream
+    groups = [(k, 1) for k in range(B)] if pipelined else [(0, B)]
+    cur = torch.cuda.current_stream() if dev.type == "cuda" else None
+    side = _side_stream(dev) if overlap else None
+    if overlap:
+        side.wait_stream(cur)  # K1's outputs and the counts are ready
+    out = ([None] * B, [None] * B, [None] * B, [None] * B, [None] * B)
+    events = [None] * B
+    holder = {"rec": None}  # the backward's shared [B*P, 9] gradient record
+    token = torch.zeros((1,), dtype=bases[0].dtype, device=dev, requires_grad=True) if pipelined else None
+    for (k0, nb) in groups:
+        cams = range(k0, k0 + nb)
+        send_splits = [sum(sizes[me][j][k] for k in cams) for j in range(W)]
+        recv_splits = [sum(sizes[i][me][k] for k in cams) for i in range(W)]
+        seg_off, o = [0] * (W * nb), 0
+        for g in range(W):
+            for kk, k in enumerate(cams):
+                seg_off[g * nb + kk] = o
+                o += sizes[me][g][k]
+        # received rows are (source, camera)-major; the renderer wants camera-major with the source order kept
+        per_cam = [sum(sizes[i][me][k] for i in range(W)) for k in cams]
+        perm = inv_perm = None
+        if sum(1 for n in per_cam if n) > 1:
+            off, o = {}, 0
+            for i in range(W):
+                for k in cams:
+                    off[(i, k)] = o
+                    o += sizes[i][me][k]
+            order = torch.cat([torch.arange(off[(i, k)], off[(i, k)] + sizes[i][me][k], dtype=torch.int32)
+                               for k in cams for i in range(W)])
+            inv = torch.empty_like(order)
+            inv[order.long()] = torch.arange(order.numel(), dtype=torch.int32)
+            perm, inv_perm = order.to(dev), inv.to(dev)
+        meta = (k0, nb, P, width, height, seg_off, send_splits, recv_splits, perm, inv_perm, group, chunkcnt, B, bands,
+                cur if overlap else None, holder)
+        views = [m2_views[k] for k in cams] + [rgb_views[k] for k in cams] + [co_views[k] for k in cams]
+        if overlap:
+            with torch.cuda.stream(side):
+                r = _ExchangeGroup.apply(meta, bases, token, *views)
+                ev = torch.cuda.Event()
+                ev.record(side)
+        else:
+            r, ev = _ExchangeGroup.apply(meta, bases, token, *views), None
+        token = r[5]
+        start = 0
+        for kk, k in enumerate(cams):
+            n = per_cam[kk]
+            whole = n == r[3].shape[0]
+            for c in range(5):
+                out[c][k] = r[c] if whole else r[c][start:start + n]
+            events[k] = ev
+            start += n
+    return out[0], out[1], out[2], out[3], out[4], sizes, (events, token)
 
 
 def distributed_preprocess3dgs_and_all2all_final(batched_viewpoint_cameras, pc, pipe, bg_color, scaling_modifier=1.0,
@@ -372,9 +452,14 @@ def distributed_preprocess3dgs_and_all2all_final(batched_viewpoint_cameras, pc, 
     else:
         if timers is not None:
             timers.start("forward_all_to_all_communication")
-        if batched_state is not None and hasattr(_dgr, "exchange_need"):
-            *redistributed, sizes = _batched_exchange_final([p[0] for p in params], *batched_state, rasterizers,
-                                                            batched_strategies)
+        if batched_state is not None and hasattr(_dgr, "exchange_pack") and utils.DEFAULT_GROUP.size() * len(params) <= 512:
+            *redistributed, sizes, (events, token) = _batched_exchange_final(
+                [p[0] for p in params], *batched_state, rasterizers, batched_strategies)
+            pkg["_exchange_events"] = events
+            if token is not None:  # anchor of the exchange chain: the render op of the LAST camera this rank renders
+                mine = [k for k, st in enumerate(batched_strategies) if utils.GLOBAL_RANK in st.gpu_ids]
+                if mine:
+                    cuda_args_list[mine[-1]]["_exchange_token"] = token
         else:
             *redistributed, sizes = all_to_all_communication_final(rasterizers, params, cuda_args_list,
                                                                    batched_strategies)
@@ -402,6 +487,9 @@ def render_final(batched_screenspace_pkg, batched_strategies, tile_size=16):
         compute_locally = strategy.get_compute_locally()
         extended = strategy.get_extended_compute_locally()
         cuda_args = pkg["batched_cuda_args"][k]
+        ev = pkg.get("_exchange_events", None)
+        if ev is not None and ev[k] is not None:
+            torch.cuda.current_stream().wait_event(ev[k])  # camera k's exchange ran on the side stream
         means2D = pkg["batched_means2D_redistributed"][k]
         rgb = pkg["batched_rgb_redistributed"][k]
         conic_opacity = pkg["batched_conic_opacity_redistributed"][k]
@@ -409,6 +497,8 @@ def render_final(batched_screenspace_pkg, batched_strategies, tile_size=16):
             timers.start("forward_render_gaussians")
         if means2D.shape[0] < 10:
             image = means2D.sum() + conic_opacity.sum() + rgb.sum()
+            if cuda_args.get("_exchange_token") is not None:
+                image = image + 0.0 * cuda_args["_exchange_token"].sum()
             st = cuda_args["stats_collector"]
             st["forward_render_time"] = st["backward_render_time"] = st["forward_loss_time"] = 0.0
         else:

@@ -15,6 +15,8 @@ north_star names it, with the fused sparse variant the reference left unimplemen
 import torch
 import torch.distributed as dist
 
+import diff_gaussian_rasterization as _dgr  # the row primitives of the HIP library (no CPU fallback)
+
 PARAMS = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")
 
 
@@ -58,17 +60,27 @@ def sync_gradients_sparsely(gaussians, group):
 
 
 def sync_gradients_fused_sparsely(gaussians, group):
-    """one mask all-reduce + one compact [nnz, 59] all-reduce for all six parameters"""
+    """one mask all-reduce + one compact [nnz, 59] all-reduce for all six parameters.  The row selection is computed
+    ONCE on the device (gsr_group_rows: touched rows first, stable), ONE launch packs the touched rows of the six
+    gradient tensors into the column blocks of the compact buffer (gsr_gather_rows), ONE launch writes the reduced
+    rows back (gsr_scatter_rows); the reference's per-tensor variant (scene/gaussian_model.py:1350-1391) runs a
+    boolean-index gather, an all-reduce and a masked write per tensor."""
     with torch.no_grad():
         mask = touched_rows_mask(gaussians, group)
-        idx = mask.nonzero().squeeze(1)  # one host sync: the row count sizes the message (same on all ranks)
         grads = _grads(gaussians)
         n = grads[0].shape[0]
         widths = [g.numel() // max(n, 1) for g in grads]
-        compact = torch.cat([g.reshape(n, -1).index_select(0, idx) for g in grads], dim=1).contiguous()
+        order, counts = _dgr.group_rows((~mask).to(torch.int32), 1)  # group 0 = touched rows; one host read-back:
+        nnz = counts[0]                                              # the message size, the same on every rank
+        compact = torch.empty((nnz, sum(widths)), dtype=torch.float32, device=grads[0].device)
+        cols, c = [], 0
+        for w in widths:
+            cols.append(compact[:, c:c + w])
+            c += w
+        flat = [g.reshape(n, -1) for g in grads]
+        _dgr.gather_rows(order, nnz, flat, cols)
         dist.all_reduce(compact, op=dist.ReduceOp.SUM, group=group)
-        for g, part in zip(grads, torch.split(compact, widths, dim=1)):
-            g.reshape(n, -1).index_copy_(0, idx, part)
+        _dgr.scatter_rows(order, nnz, cols, flat)
     return mask
 
 

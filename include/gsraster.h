@@ -191,6 +191,33 @@ int gsr_exchange_need(int P, int B, int W, int width, int height, const float *m
                       const int32_t *bands, uint8_t *need, int32_t *counts, gsr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * The exchange without the mask (rows a5/a6; what the mirror's _batched_exchange_final calls).  The reference's
+ * all_to_all_communication_final (gaussian_renderer/__init__.py:542-698) runs K2, then nonzero() per (camera, band),
+ * index_select + cat per destination; its autograd backward is an index_put with accumulate.  Here, for the cameras
+ * [k0, k0 + B) of a batch of B_total whose state is camera-major ([B_total,P,.] arrays):
+ *   gsr_exchange_count : counts int32 [W][B] (zeroed here) = number of Gaussians rank g needs of camera k0 + kk, and
+ *       chunkcnt int32 [W * B][gsr_exchange_chunks(P)] = the same per 1024-Gaussian chunk (a workspace for pack);
+ *   gsr_exchange_pack  : after the caller has turned the counts of all ranks into the layout of its send buffer --
+ *       segment_offsets[g * B + kk] (HOST array, W * B <= 512 entries) = first row of the (destination g, camera
+ *       k0 + kk) segment -- writes the 11-float records (means2D 2, rgb 3, conic_opacity 4, radius bits, depth) into
+ *       msg fp32 [n_send][11] in (destination, camera, local index) order and send_idx int32 [n_send] = kk * P + i,
+ *       the row each record came from; chunkcnt is what gsr_exchange_count wrote for the camera range
+ *       [count_first, count_first + count_cameras) (which must contain [k0, k0 + B): one count launch for the batch,
+ *       one pack launch per camera when the exchanges are pipelined);
+ *   gsr_scatter_add_rows : dst[idx[r]][0:9] += src[r][0:9] -- the backward's mirror step on the gradient rows the
+ *       peers send back (dst fp32 [rows][9], zeroed by the caller; a Gaussian needed by two bands is added twice). */
+size_t gsr_exchange_chunks(int P);
+int gsr_exchange_count(int P, int B_total, int k0, int B, int W, int width, int height, const float *means2D,
+                       const int32_t *radii, const int32_t *bands, int32_t *chunkcnt, int32_t *counts,
+                       gsr_stream_t stream);
+int gsr_exchange_pack(int P, int B_total, int k0, int B, int W, int width, int height, int count_cameras,
+                      int count_first, const float *means2D,
+                      const float *rgb, const float *conic_opacity, const int32_t *radii, const float *depths,
+                      const int32_t *bands, const int32_t *chunkcnt, const int32_t *segment_offsets, int64_t n_send,
+                      float *msg, int32_t *send_idx, gsr_stream_t stream);
+int gsr_scatter_add_rows(int64_t n, const int32_t *idx, const float *src, float *dst, gsr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * N4  `simple_knn._C.distCUDA2(points)` (scene/gaussian_model.py:20,163-166; submodule
  * https://gitlab.inria.fr/bkerbl/simple-knn, .gitmodules:1-3, absent from the reference tree):
  * mean_dist2[i] = mean of the squared distances from point i to its 3 nearest OTHER points (only i itself is
@@ -220,6 +247,13 @@ int gsr_group_rows(int64_t N, int G, const int32_t *dest, int32_t *order, int64_
 int gsr_gather_rows(int64_t n_out, const int32_t *order, int num_tensors, const void *const *srcs, void *const *dsts,
                     const int32_t *widths, const int64_t *src_strides, const int64_t *dst_strides,
                     gsr_stream_t stream);
+/* gsr_scatter_rows: the inverse, dst_k[order[r], 0:width_k] = src_k[r, 0:width_k] for r < n_in (rows not named in
+ * order[0:n_in] keep their contents).  N2 (scene/gaussian_model.py:1350-1391, the sparse gradient sync of the
+ * replicated-storage mode) packs the touched rows of the six gradient tensors into ONE compact [nnz,59] buffer with
+ * gsr_gather_rows, all-reduces it, and writes the sums back with this call. */
+int gsr_scatter_rows(int64_t n_in, const int32_t *order, int num_tensors, const void *const *srcs, void *const *dsts,
+                     const int32_t *widths, const int64_t *src_strides, const int64_t *dst_strides,
+                     gsr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K1 / K11 on the RAW parameters of GaussianModel (scene/gaussian_model.py:219-242): `scaling` log-scales

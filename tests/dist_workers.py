@@ -131,3 +131,64 @@ def redistribution_worker(rank, world, port, on_gpu, q):
         q.put((rank, "ok"))
     except Exception:  # noqa: BLE001
         q.put((rank, traceback.format_exc()))
+
+
+def grad_sync_worker(rank, world, port, q):
+    """N2 on the device: ranks share cuda:0, talk over gloo (all_reduce staged through the host by this worker); the
+    fused sparse sync (gsr_group_rows / gsr_gather_rows / gsr_scatter_rows + ONE compact all-reduce) must give the
+    dense sum of the ranks' gradients, and untouched rows must stay bit-identical"""
+    try:
+        for p in (os.path.join(ROOT, "grendel-gs_amd"), ROOT, os.path.join(ROOT, "tests")):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                          MASTER_PORT=str(port))
+        import grad_sync as gs
+
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        ar = dist.all_reduce
+
+        def all_reduce(t, op=dist.ReduceOp.SUM, group=None, **kw):
+            if not t.is_cuda:
+                return ar(t, op=op, group=group, **kw)
+            c = t.cpu()
+            ar(c, op=op, group=group)
+            t.copy_(c)
+
+        dist.all_reduce = all_reduce
+        N = 200_003
+        shapes = {"_xyz": (N, 3), "_features_dc": (N, 1, 3), "_features_rest": (N, 15, 3), "_opacity": (N, 1),
+                  "_scaling": (N, 3), "_rotation": (N, 4)}
+
+        def make(r, device):
+            g = torch.Generator().manual_seed(100 + r)
+            vis = torch.rand(N, generator=g) < 0.15
+            m = type("G", (), {})()
+            for name, shp in shapes.items():
+                gr = torch.randn(shp, generator=g)
+                gr[~vis] = 0
+                p = torch.zeros(shp, device=device)
+                p.grad = gr.to(device)
+                setattr(m, name, p)
+            return m, vis
+
+        expect = {n: sum(getattr(make(r, "cpu")[0], n).grad for r in range(world)) for n in shapes}
+        union = torch.zeros(N, dtype=torch.bool)
+        for r in range(world):
+            union |= make(r, "cpu")[1]
+        for mode in ("fused_sparse", "sparse", "fused_dense"):
+            m, _ = make(rank, dev)
+            out = gs.sync_gradients_for_replicated_3dgs_storage(m, dist.group.WORLD, mode, gaussians_distribution=False)
+            for n in shapes:
+                got = getattr(m, n).grad.cpu()
+                assert torch.allclose(got, expect[n], atol=1e-6), (mode, n)
+                assert float(got[~union].abs().sum()) == 0.0, (mode, n)
+            if mode.endswith("sparse"):
+                assert torch.equal(out.cpu(), union), mode
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        q.put((rank, traceback.format_exc()))

@@ -67,7 +67,6 @@ def _worker(rank, world, port, bsz, q):
         full = S.make_gaussians(N, W, H, seed=7, scale_coef=0.015)
         chunk = (N + world - 1) // world
         sl = slice(rank * chunk, min((rank + 1) * chunk, N))
-        mine = {k: v[sl].double().clone().requires_grad_(True) for k, v in full.items()}
         keys = ["means3D", "scales", "rotations", "shs", "opacities"]
         bg = torch.tensor([0.2, 0.3, 0.4], dtype=torch.float64)
         gen = torch.Generator().manual_seed(3)
@@ -82,29 +81,69 @@ def _worker(rank, world, port, bsz, q):
             def __init__(self):
                 self.raster_settings = type("RS", (), {"image_height": H, "image_width": W})()
 
-        params, cargs = [], []
-        for cam, st in zip(cams, strategies):
-            m2, rgb, co, radii, depths = O.preprocess(*[mine[k] for k in keys], **cam_kw(cam))
-            params.append([m2, rgb, co, radii, depths])
-            cargs.append(get_cuda_args_final(st, "train"))
-        m2s, rgbs, cos, radiis, depthss, sizes = all_to_all_communication_final([R() for _ in cams], params, cargs,
-                                                                                strategies)
-        assert len(sizes) == world and len(sizes[0]) == world and len(sizes[0][0]) == bsz
-        loss = torch.zeros((), dtype=torch.float64)
-        images = []
-        for k, st in enumerate(strategies):
-            img = torch.zeros(3, H, W, dtype=torch.float64)
-            if rank in st.gpu_ids:
-                mask = st.get_compute_locally()
-                assert m2s[k].shape[0] == sum(sizes[i][rank][k] for i in range(world))
-                if m2s[k].shape[0] > 0:
-                    img, _, _ = O.render(m2s[k], cos[k], rgbs[k], depthss[k], radiis[k], mask, bg=bg, W=W, H=H)
-                loss = loss + (img * wgts[k]).sum()
+        # the device side of the fused exchange (HIP kernels, no GPU here) is played by its torch restatement
+        import gaussian_renderer as gr
+        from oracle import densify_oracle as DO
+        from oracle import exchange_oracle as XO
+
+        dgr.exchange_count, dgr.exchange_pack, dgr.scatter_add_rows = XO.exchange_count, XO.exchange_pack, XO.scatter_add_rows
+        dgr.gather_rows = DO.gather_rows
+
+        def one_pass(mode):
+            """mode: 'reference' = all_to_all_communication_final (the reference-shaped per-camera path),
+            'batched' = _batched_exchange_final as ONE exchange, 'pipelined' = one exchange per camera"""
+            mine = {k: v[sl].double().clone().requires_grad_(True) for k, v in full.items()}
+            params, cargs = [], []
+            for cam, st in zip(cams, strategies):
+                m2, rgb, co, radii, depths = O.preprocess(*[mine[k] for k in keys], **cam_kw(cam))
+                m2.retain_grad()
+                params.append([m2, rgb, co, radii, depths])
+                cargs.append(get_cuda_args_final(st, "train"))
+            if mode == "reference":
+                m2s, rgbs, cos, radiis, depthss, sizes = all_to_all_communication_final([R() for _ in cams], params, cargs,
+                                                                                        strategies)
             else:
-                assert m2s[k].shape[0] == 0
-            images.append(img.detach())
-        loss = loss + 0.0 * sum(p[0].sum() for p in params)  # keep the graph alive on idle ranks
-        loss.backward()
+                gr.set_exchange_overlap(mode == "pipelined")
+                m2s, rgbs, cos, radiis, depthss, sizes, (events, token) = gr._batched_exchange_final(
+                    *[[p[c] for p in params] for c in range(5)], [R() for _ in cams], strategies)
+                assert all(e is None for e in events)  # no side stream on the CPU
+                assert (token is not None) == (mode == "pipelined" and bsz > 1)
+            assert len(sizes) == world and len(sizes[0]) == world and len(sizes[0][0]) == bsz
+            loss = torch.zeros((), dtype=torch.float64)
+            images = []
+            for k, st in enumerate(strategies):
+                img = torch.zeros(3, H, W, dtype=torch.float64)
+                if rank in st.gpu_ids:
+                    mask = st.get_compute_locally()
+                    assert m2s[k].shape[0] == sum(sizes[i][rank][k] for i in range(world))
+                    if m2s[k].shape[0] > 0:
+                        img, _, _ = O.render(m2s[k], cos[k], rgbs[k], depthss[k], radiis[k], mask, bg=bg, W=W, H=H)
+                    loss = loss + (img * wgts[k]).sum()
+                else:
+                    assert m2s[k].shape[0] == 0
+                images.append(img.detach())
+            loss = loss + 0.0 * sum(p[0].sum() for p in params)  # keep the graph alive on idle ranks
+            if mode != "reference" and token is not None:
+                loss = loss + 0.0 * token.sum()  # what the render op of the last local camera does in the product
+            loss.backward()
+            grads = [mine[k].grad if mine[k].grad is not None else torch.zeros_like(mine[k]) for k in keys]
+            m2_grads = [p[0].grad for p in params]  # densification's input survives the exchange
+            received = [(m2s[k].detach(), radiis[k].clone(), depthss[k].detach()) for k in range(bsz)]
+            return images, grads, cargs, m2_grads, received, sizes
+
+        images, grads, cargs, m2g_ref, recv_ref, sizes_ref = one_pass("reference")
+        for mode in ("batched", "pipelined"):
+            im2, gr2, _, m2g, recv2, sizes2 = one_pass(mode)
+            assert sizes2 == sizes_ref, mode
+            for k in range(bsz):
+                assert torch.equal(recv2[k][1], recv_ref[k][1]), f"{mode}: radii / row order of camera {k}"
+                assert torch.equal(recv2[k][0], recv_ref[k][0]) and torch.equal(recv2[k][2], recv_ref[k][2]), mode
+                assert torch.equal(im2[k], images[k]), mode
+                assert (m2g[k] is None) == (m2g_ref[k] is None)
+                if m2g[k] is not None:
+                    assert torch.allclose(m2g[k], m2g_ref[k], rtol=1e-12, atol=1e-14), mode
+            for a, b in zip(gr2, grads):
+                assert torch.allclose(a, b, rtol=1e-11, atol=1e-13), f"{mode}: gradients differ from the reference-shaped path"
         stats = [c["stats_collector"] for c in cargs]
         for s_ in stats:
             s_.update(forward_render_time=1.0 + rank, backward_render_time=2.0, forward_loss_time=0.5)
@@ -118,7 +157,6 @@ def _worker(rank, world, port, bsz, q):
         stack = torch.stack(images)
         dist.all_reduce(stack)
         # single-process reference on rank 0
-        grads = [mine[k].grad if mine[k].grad is not None else torch.zeros_like(mine[k]) for k in keys]
         gathered = []
         for gtensor in grads:
             lst = [torch.zeros((min((r + 1) * chunk, N) - r * chunk,) + tuple(gtensor.shape[1:]), dtype=torch.float64)

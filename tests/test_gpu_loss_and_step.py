@@ -223,10 +223,13 @@ def test_exchange_path_on_device_single_rank_rccl(device):
         utils.DEFAULT_GROUP = utils.SingleGPUGroup()
         pkg = gr.distributed_preprocess3dgs_and_all2all_final(cams, model, pipe, bg, batched_strategies=strategies)
         utils.DEFAULT_GROUP = dist.group.WORLD
-        stacked = [torch.stack(pkg[f"batched_{n}_redistributed"]) for n in ("rgb", "conic_opacity", "radii", "depths")]
-        m2, rgb, co, radii, depths, sizes = gr._batched_exchange_final(
-            pkg["batched_locally_preprocessed_mean2D"], *stacked, pkg["batched_rasterizers"], strategies)
-        assert sizes[0][0][1] == int((stacked[2][1] > 0).sum().item())
+        lists = [pkg[f"batched_{n}_redistributed"] for n in ("rgb", "conic_opacity", "radii", "depths")]
+        m2, rgb, co, radii, depths, sizes, (events, token) = gr._batched_exchange_final(
+            pkg["batched_locally_preprocessed_mean2D"], *lists, pkg["batched_rasterizers"], strategies)
+        pkg["_exchange_events"] = events
+        if token is not None:
+            pkg["batched_cuda_args"][-1]["_exchange_token"] = token
+        assert sizes[0][0][1] == int((lists[2][1] > 0).sum().item())
         for name, val in zip(("means2D", "rgb", "conic_opacity", "radii", "depths"), (m2, rgb, co, radii, depths)):
             pkg[f"batched_{name}_redistributed"] = val
         images, _ = gr.render_final(pkg, strategies)

@@ -211,3 +211,27 @@ def test_redistribute_gaussians_on_device(device, world):
                 p.kill()
     for rank, msg in results:
         assert msg == "ok", f"rank {rank}:\n{msg}"
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_replicated_gradient_sync_on_device(device, world):
+    """N2 with the real row kernels: fused sparse sync == dense sum, ranks sharing the GPU"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from dist_workers import grad_sync_worker
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=grad_sync_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = []
+    try:
+        results = [q.get(timeout=300) for _ in procs]
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+    for rank, msg in results:
+        assert msg == "ok", f"rank {rank}:\n{msg}"

@@ -25,6 +25,13 @@ def _worker(rank, world, port, q):
         sys.path.insert(0, os.path.join(ROOT, "grendel-gs_amd"))
         os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         torch.set_num_threads(1)
+        sys.path.insert(0, ROOT)
+        import diff_gaussian_rasterization as dgr
+        from oracle import densify_oracle as DO
+
+        # the HIP row primitives need a GPU: their torch restatements play them in this host-logic test
+        dgr.group_rows, dgr.gather_rows = DO.group_rows, DO.gather_rows
+        dgr.scatter_rows = lambda order, n, srcs, dsts, row0=0: [d.__setitem__(order[row0:row0 + n].long(), s_[:n]) for s_, d in zip(srcs, dsts)]
         import grad_sync as gs
 
         dist.init_process_group("gloo", rank=rank, world_size=world)
