@@ -354,9 +354,13 @@ def main():
         """the same scene + camera on ONE GPU (rank 0's device); the other ranks wait at the barrier"""
         res = None
         if rank == 0:
-            with _SingleRankView(utils):
-                res = run_workload(a, wname, 1, 0, dev, min(a.steps, 10), min(a.warmup, 3), 1, 0, single_view=True,
-                                   collect_kernels=False)
+            try:
+                with _SingleRankView(utils):
+                    res = run_workload(a, wname, 1, 0, dev, min(a.steps, 10), min(a.warmup, 3), 1, 0, single_view=True,
+                                       collect_kernels=False)
+            except Exception as e:  # noqa: BLE001  (the other ranks wait at the barrier below: never leave them there)
+                res = {"error": f"{type(e).__name__}: {e}"}
+                torch.cuda.empty_cache()
         dist.barrier()
         return res
 
@@ -387,7 +391,9 @@ def main():
              "ms_per_step": round(res["ms_per_step"], 4), "steps": res["steps"], "timing": res["timing"]}
         if "exchange" in res:
             d["exchange"] = res["exchange"]
-        if res1 is not None:
+        if res1 is not None and "error" in res1:
+            d["same_workload_1gpu"] = res1
+        elif res1 is not None:
             d["same_workload_1gpu"] = {"value": round(res1["images_per_s"], 3), "unit": "images/s",
                                        "ms_per_step": round(res1["ms_per_step"], 4), "steps": res1["steps"],
                                        "note": "same scene and camera on ONE GPU, measured in this run on rank 0"}
@@ -464,7 +470,7 @@ def main():
         out["exchange"] = main_res["exchange"]
     if one_gpu is not None:
         b = brief(main_res, one_gpu)
-        out["same_workload_1gpu"], out["speedup_vs_1gpu"] = b["same_workload_1gpu"], b["speedup_vs_1gpu"]
+        out["same_workload_1gpu"], out["speedup_vs_1gpu"] = b["same_workload_1gpu"], b.get("speedup_vs_1gpu")
     if extras:
         out["extra_workloads"] = [brief(ex, ex1) for ex, ex1 in extras]
     if world == 1 and not a.no_cpu_baseline:

@@ -22,10 +22,12 @@ constexpr int RADIX_REPLICAS = 8;  // histogram replicas, one per XCD
 constexpr int RADIX_TILE = 4096;           // pairs per workgroup of a radix pass
 constexpr long long RADIX_SHORT_N = 1ll << 22;  // at most this many pairs: the 1024-thread configuration
 
-constexpr long long RADIX_MAX_N = (1ll << 30) - 1;  // counts share a word with two flag bits
+constexpr long long RADIX_MAX_N = (1ll << 31) - 1;  // prefixes share a word with one flag bit; tile ranges are int32
 
-// look-back state word: [31] inclusive prefix available, [30] workgroup aggregate available, [29:0] value
-constexpr uint32_t LB_PRE = 0x80000000u, LB_AGG = 0x40000000u, LB_VAL = 0x3FFFFFFFu;
+// look-back state word: 0 = nothing yet; bit 31 set = inclusive prefix in [30:0]; otherwise the workgroup's aggregate + 1
+// (an aggregate is at most one tile, 4096, so "+ 1" can never reach bit 31).  31 value bits: up to 2^31 - 1 pairs --
+// one MI355X holds the 1.2e9 pairs of the 40 M-Gaussian 4K frame (configs[4]) in ~25 GB of its 288 GB.
+constexpr uint32_t LB_PRE = 0x80000000u, LB_VAL = 0x7FFFFFFFu;
 constexpr int LB_WINDOW = 4;  // independent state loads in flight per thread (look-back is short in practice)
 // 64-bit variant for the offsets scan (values up to 2^32)
 constexpr unsigned long long LB64_PRE = 2ull << 62, LB64_AGG = 1ull << 62, LB64_VAL = (1ull << 62) - 1ull;
@@ -217,7 +219,7 @@ __device__ __forceinline__ void onesweep_scatter(OnesweepSmem<ITEMS, THREADS> &s
             tot += cnt[w];
         }
         uint32_t *row = state + (size_t)bid * RADIX_DIGITS;
-        if (live) st_agent(&row[d], tot | (bid == 0 ? LB_PRE : LB_AGG));
+        if (live) st_agent(&row[d], bid == 0 ? (tot | LB_PRE) : (tot + 1u));
         uint32_t all;
         uint32_t run = block_exclusive_scan_n<WAVES>(tot, sm.scan_tmp, &all);  // local start of digit d
         uint32_t gh = 0;  // pass histogram = sum of the per-XCD replicas
@@ -237,12 +239,12 @@ __device__ __forceinline__ void onesweep_scatter(OnesweepSmem<ITEMS, THREADS> &s
                 for (int k = 0; k < LB_WINDOW; k++) {
                     if (!done) {
                         uint32_t x = v[k];
-                        while ((x & (LB_PRE | LB_AGG)) == 0u) {
+                        while (x == 0u) {
                             __builtin_amdgcn_s_sleep(1);
                             x = ld_agent(&state[(size_t)(j - k) * RADIX_DIGITS + d]);
                         }
-                        excl += x & LB_VAL;
                         done = (x & LB_PRE) != 0u;
+                        excl += done ? (x & LB_VAL) : (x - 1u);
                     }
                 }
                 j -= LB_WINDOW;

@@ -324,16 +324,23 @@ def _batched_exchange_final(m2_views, rgb_views, co_views, radii_views, depths_v
         per_cam = [sum(sizes[i][me][k] for i in range(W)) for k in cams]
         perm = inv_perm = None
         if sum(1 for n in per_cam if n) > 1:
+            # segments (source i, camera k) arrive source-major; list them camera-major.  The row permutation is
+            # expanded ON THE DEVICE from the W * nb segment descriptors (a few hundred bytes of host data)
             off, o = {}, 0
             for i in range(W):
                 for k in cams:
                     off[(i, k)] = o
                     o += sizes[i][me][k]
-            order = torch.cat([torch.arange(off[(i, k)], off[(i, k)] + sizes[i][me][k], dtype=torch.int32)
-                               for k in cams for i in range(W)])
-            inv = torch.empty_like(order)
-            inv[order.long()] = torch.arange(order.numel(), dtype=torch.int32)
-            perm, inv_perm = order.to(dev), inv.to(dev)
+            segs = [(off[(i, k)], sizes[i][me][k]) for k in cams for i in range(W) if sizes[i][me][k] > 0]
+            total = sum(n for _, n in segs)
+            lens = torch.tensor([n for _, n in segs], dtype=torch.int64)
+            dst0 = torch.cumsum(lens, 0) - lens
+            shift = (torch.tensor([b for b, _ in segs], dtype=torch.int64) - dst0).to(dev)
+            order = (torch.repeat_interleave(shift, lens.to(dev), output_size=total)
+                     + torch.arange(total, dtype=torch.int64, device=dev))
+            inv = torch.empty(total, dtype=torch.int32, device=dev)
+            inv[order] = torch.arange(total, dtype=torch.int32, device=dev)
+            perm, inv_perm = order.to(torch.int32), inv
         meta = (k0, nb, P, width, height, seg_off, send_splits, recv_splits, perm, inv_perm, group, chunkcnt, B, bands,
                 cur if overlap else None, holder)
         views = [m2_views[k] for k in cams] + [rgb_views[k] for k in cams] + [co_views[k] for k in cams]
