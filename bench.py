@@ -51,7 +51,6 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
-SIMDS, CLOCK_HZ, VALU_CYCLES = 1024, 2.4e9, 2  # 256 CUs x 4 SIMD-32; a wave64 VALU instruction issues in 2 cycles
 
 WORKLOADS = {
     # name: (gaussians_total, width, height, bsz or None = world, description)
@@ -421,12 +420,13 @@ def main():
         pk = (pmc or {}).get("kernels", {}).get(dom, {})
         valu = None
         if pk.get("SQ_INSTS_VALU"):
-            # issue-slot view: wave64 VALU instructions x 2 cycles over (1024 SIMDs x kernel duration x 2.4 GHz)
-            valu = {"insts_per_launch": pk["SQ_INSTS_VALU"], "active_cycles_per_launch": pk.get("SQ_ACTIVE_INST_VALU"),
+            # measured issue-pipe view: SQ_ACTIVE_INST_VALU (quad-cycles, summed over the SIMDs) against the SIMD cycles
+            # of the launch (SQ_BUSY_CYCLES is summed over the 32 shader engines): the fraction of time the VALU pipes
+            # were busy; a wave64 VALU instruction occupies its SIMD ~4.1-4.2 cycles on this chip (same counters)
+            valu = {"insts_per_launch": pk["SQ_INSTS_VALU"], "active_quad_cycles_per_launch": pk.get("SQ_ACTIVE_INST_VALU"),
                     "busy_cycles_per_launch": pk.get("SQ_BUSY_CYCLES"), "profiled_avg_ms": pk.get("avg_ms"),
-                    "frac": round(pk["SQ_INSTS_VALU"] * VALU_CYCLES / (SIMDS * CLOCK_HZ * pk["avg_ms"] * 1e-3), 4)
-                    if pk.get("avg_ms") else None,
-                    "peak": "1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md)"}
+                    "frac": pk.get("valu_busy_frac"), "cycles_per_inst": pk.get("cycles_per_valu_inst"),
+                    "derivation": "frac = 4 * SQ_ACTIVE_INST_VALU / (SQ_BUSY_CYCLES / 32 * 1024 SIMDs)"}
         roofline = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4) if ach else None,
                     "traffic": pk.get("hbm_bytes_per_launch"),

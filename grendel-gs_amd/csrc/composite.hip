@@ -224,17 +224,24 @@ composite_forward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
 // (px, py relative to the tile origin: integers 0..15) by the binomial expansion.  So the per-tile reduction IS a
 // dense contraction over the 64 pixels of a quadrant:  [entries x pixels] . [pixels x 9].  It runs on the MATRIX
 // pipe (v_mfma_f32_16x16x4_f32: exact fp32, an fmaf chain) instead of as a cross-lane VALU reduction:
-//   phase A (lane = pixel): walk the entries back to front, recompute alpha, carry T and rho = R.g (R = colour behind
-//       the entry: one scalar recurrence instead of three), and store (w, q) of the entry into a wave-private LDS
-//       matrix [slot][pixel] -- ~28 VALU instructions per (wave, entry) instead of ~80 with the butterfly reduction
-//       this replaces (measured: the kernel is VALU-issue bound, SQ_ACTIVE_INST_VALU ~ 0.9 of the SIMD cycles);
-//   phase B (every 16 entries): 16 K-steps of 4 pixels; lane (k = lane >> 4, i = lane & 15) reads (w, q) of slot i,
-//       pixel 4 t + k (the A operands; conflict-free with the row stride of 66) and issues two MFMAs against
-//       per-lane constant B operands (the position polynomials / the pixel gradients g); the 16 x 9 results are
-//       added (ds_add_f32) into the workgroup's per-chunk table, where the four quadrant waves of the tile combine;
-//   flush (once per 64-entry chunk): moments -> gradients, 9 adjacent lanes add one (tile, entry) pair's nine values
-//       into that Gaussian's 36-byte row of the [P,9] record (means2D 0:2, rgb 2:5, conic_opacity 5:9).
-// The matrix pipe runs beside the VALU (different waves of the SIMD overlap); its work is 32 MFMAs per 16 entries.
+//   phase A (lane = pixel): walk the entries back to front, two per iteration; recompute alpha, carry T and
+//       rho = R.g (R = colour behind the entry: ONE scalar recurrence instead of three), and store (q, w) of the entry
+//       into a wave-private LDS matrix [slot][pixel] -- ~28 VALU instructions per (wave, entry) where the transposed
+//       butterfly reduction this replaces needed ~80 (SQ_INSTS_VALU 277 M -> 160 M per launch on the bench view);
+//   phase B (every 8 entries): 16 K-steps of 4 pixels.  Lane (k = lane >> 4, i = lane & 15) reads component i >> 3 of
+//       slot i & 7, pixel 4 t + k -- the A operand: rows 0-7 are the q-rows of the eight slots, rows 8-15 their w-rows;
+//       conflict-free with the row stride of 66 -- and issues ONE v_mfma_f32_16x16x4_f32 against a per-lane constant
+//       B operand (columns 0-5 the position polynomials, 6-8 the pixel's dL/dcolour).  Rows 0-7 x columns 0-5 of the
+//       result are the q moments, rows 8-15 x columns 6-8 the colour gradients; they are STORED into the wave's own
+//       per-chunk table (an entry is in exactly one batch of a wave; LDS float atomics measured ~50 cycles each);
+//   flush (once per 64-entry chunk, after a workgroup barrier): the four quadrant waves' tables are added, moments ->
+//       gradients, and 9 adjacent lanes add one (tile, entry) pair's nine values into that Gaussian's 36-byte row
+//       of the [P,9] record (means2D 0:2, rgb 2:5, conic_opacity 5:9); positions / conics / ids come from the slab
+//       of the wave that walks the longest list (no global loads in the flush).
+// The list entries of a chunk are prefetched one chunk ahead (their indices two).  The matrix pipe runs beside the
+// VALU (16 MFMAs per 8 entries = 64 matrix-pipe cycles per entry, ~19 % busy); 4 workgroups per CU (38 KB of LDS,
+// <= 128 VGPRs).  Measured (profiles/r02_*): 0.496 -> 0.384 ms per launch at 1 M Gaussians / 1080p, VALU busy 0.61,
+// LDS 0.32, half of each wave's life still waits on LDS / barriers -- the kernel is latency-bound now, not VALU-bound.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int MB = 8;      // entries per MFMA batch: rows 0-7 of the 16 x 16 result are their q-rows, rows 8-15 their w-rows

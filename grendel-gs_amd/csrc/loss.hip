@@ -42,14 +42,21 @@ __device__ __forceinline__ float block_sum(float v, float *smem) {
 }
 
 // Both kernels are separable 11-tap convolutions out of LDS with REGISTER sliding windows: a thread produces
-// 4 adjacent outputs from 14 loaded values (horizontal: 4 columns of a row, vertical: 4 rows of a column), i.e.
-// 3.5 LDS reads per output and map instead of 11 -- the passes are LDS-bandwidth-bound, not FMA-bound.
+// 4 adjacent outputs from 14 loaded values (horizontal: 4 columns of a row, vertical: VO rows of a column), i.e.
+// 3.5 LDS reads per output and map instead of 11.  The forward is VALU-bound (measured: SQ_ACTIVE_INST_VALU 0.86 of
+// the SIMD cycles, 30 M instructions per 1080p launch), so its five maps are carried as PACKED pairs -- (x, y) and
+// (x^2, y^2) in v_pk_mul_f32 / v_pk_fma_f32, the products formed once per loaded element instead of once per tap:
+// 3 instructions per tap and output instead of 7.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 __global__ void __launch_bounds__(LT)
 l1_ssim_forward_kernel(int rows, int W, const float *__restrict__ image, long long img_cstride,
                        const uint8_t *__restrict__ gt, float *__restrict__ partials, float *__restrict__ M1,
                        float *__restrict__ M2, float *__restrict__ M3) {
-    __shared__ float sX[HH][HW + 1], sY[HH][HW + 1];
-    __shared__ float hor[5][HH][HSTR];
+    __shared__ v2f sXY[HH][HW + 1];     // (x, y): rendered band / ground truth
+    __shared__ v2f hAB[HH][HSTR];       // horizontal pass of (x, y)
+    __shared__ v2f hCD[HH][HSTR];       // ... of (x^2, y^2)
+    __shared__ float hE[HH][HSTR];      // ... of x y
     __shared__ float red[LT / 64];
     const int c = blockIdx.z, ox = blockIdx.x * TW, oy = blockIdx.y * TH;
     const int tid = threadIdx.x;
@@ -58,53 +65,67 @@ l1_ssim_forward_kernel(int rows, int W, const float *__restrict__ image, long lo
     for (int idx = tid; idx < HH * HW; idx += LT) {
         const int ly = idx / HW, lx = idx % HW;
         const int gy = oy + ly - 5, gx = ox + lx - 5;
-        float x = 0.f, y = 0.f;
+        v2f v = {0.f, 0.f};
         if (gy >= 0 && gy < rows && gx >= 0 && gx < W) {
-            x = img_c[(size_t)gy * W + gx];
-            y = (float)gt_c[(size_t)gy * W + gx] * (1.0f / 255.0f);
+            v.x = img_c[(size_t)gy * W + gx];
+            v.y = (float)gt_c[(size_t)gy * W + gx] * (1.0f / 255.0f);
         }
-        sX[ly][lx] = x;
-        sY[ly][lx] = y;
+        sXY[ly][lx] = v;
     }
     __syncthreads();
     for (int task = tid; task < HH * (TW / 4); task += LT) {
         const int r = task / (TW / 4), cx0 = (task % (TW / 4)) * 4;
-        float xv[14], yv[14];
+        v2f xy[14], sq[14];
+        float pr[14];
 #pragma unroll
         for (int i = 0; i < 14; i++) {
-            xv[i] = sX[r][cx0 + i];
-            yv[i] = sY[r][cx0 + i];
+            xy[i] = sXY[r][cx0 + i];
+            sq[i] = xy[i] * xy[i];
+            pr[i] = xy[i].x * xy[i].y;
         }
 #pragma unroll
         for (int o = 0; o < 4; o++) {
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+            v2f a = {0.f, 0.f}, b = {0.f, 0.f};
+            float e = 0.f;
 #pragma unroll
             for (int k = 0; k < 11; k++) {
-                const float w = WIN[k], x = xv[o + k], y = yv[o + k];
-                a0 += w * x;
-                a1 += w * y;
-                a2 += w * x * x;
-                a3 += w * y * y;
-                a4 += w * x * y;
+                const float w = WIN[k];
+                a += xy[o + k] * w;
+                b += sq[o + k] * w;
+                e += pr[o + k] * w;
             }
-            hor[0][r][cx0 + o] = a0; hor[1][r][cx0 + o] = a1; hor[2][r][cx0 + o] = a2;
-            hor[3][r][cx0 + o] = a3; hor[4][r][cx0 + o] = a4;
+            hAB[r][cx0 + o] = a;
+            hCD[r][cx0 + o] = b;
+            hE[r][cx0 + o] = e;
         }
     }
     __syncthreads();
     const int tx = tid % TW, ty0 = (tid / TW) * VO;
-    float acc[5][VO];
+    v2f vab[VO], vcd[VO];
+    float ve[VO];
+    {
+        v2f p[10 + VO], q[10 + VO];
+        float t[10 + VO];
 #pragma unroll
-    for (int m = 0; m < 5; m++) {
-        float v[10 + VO];
-#pragma unroll
-        for (int i = 0; i < 10 + VO; i++) v[i] = hor[m][ty0 + i][tx];
+        for (int i = 0; i < 10 + VO; i++) {
+            p[i] = hAB[ty0 + i][tx];
+            q[i] = hCD[ty0 + i][tx];
+            t[i] = hE[ty0 + i][tx];
+        }
 #pragma unroll
         for (int o = 0; o < VO; o++) {
-            float a = 0.f;
+            v2f a = {0.f, 0.f}, b = {0.f, 0.f};
+            float e = 0.f;
 #pragma unroll
-            for (int k = 0; k < 11; k++) a += WIN[k] * v[o + k];
-            acc[m][o] = a;
+            for (int k = 0; k < 11; k++) {
+                const float w = WIN[k];
+                a += p[o + k] * w;
+                b += q[o + k] * w;
+                e += t[o + k] * w;
+            }
+            vab[o] = a;
+            vcd[o] = b;
+            ve[o] = e;
         }
     }
     const int gx = ox + tx;
@@ -113,20 +134,22 @@ l1_ssim_forward_kernel(int rows, int W, const float *__restrict__ image, long lo
     for (int o = 0; o < VO; o++) {
         const int ty = ty0 + o, gy = oy + ty;
         if (gy < rows && gx < W) {
-            const float mu1 = acc[0][o], mu2 = acc[1][o], e11 = acc[2][o], e22 = acc[3][o], e12 = acc[4][o];
-            const float x = sX[ty + 5][tx + 5], y = sY[ty + 5][tx + 5];
+            const float mu1 = vab[o].x, mu2 = vab[o].y, e11 = vcd[o].x, e22 = vcd[o].y, e12 = ve[o];
+            const v2f cxy = sXY[ty + 5][tx + 5];
+            const float x = cxy.x, y = cxy.y;
             const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
             const float s1 = e11 - mu1_sq, s2 = e22 - mu2_sq, s12 = e12 - mu12;
             const float A = 2.f * mu12 + SSIM_C1, B = 2.f * s12 + SSIM_C2;
             const float Cd = mu1_sq + mu2_sq + SSIM_C1, Dd = s1 + s2 + SSIM_C2;
-            const float inv = 1.0f / (Cd * Dd);
+            const float inv_d = __builtin_amdgcn_rcpf(Dd);   // v_rcp_f32 (1 ulp) instead of two IEEE divisions per
+            const float inv = __builtin_amdgcn_rcpf(Cd) * inv_d;  // output: ~20 VALU instructions each; Cd, Dd >= C1, C2 > 0
             const float ssim = A * B * inv;
             ssim_sum += ssim;
             l1 += fabsf(x - y);
             if (M1) {
                 const size_t off = ((size_t)c * rows + gy) * W + gx;
                 M1[off] = 2.f * mu2 * (B - A) * inv - ssim * 2.f * mu1 * (Dd - Cd) * inv;
-                M2[off] = -ssim / Dd;
+                M2[off] = -ssim * inv_d;
                 M3[off] = 2.f * A * inv;
             }
         }

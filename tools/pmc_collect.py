@@ -34,7 +34,7 @@ GROUPS = [  # (group, substrings of the kernel symbol, substring that marks ONE 
                  "emit_pairs_kernel", "tile_ranges"], "touch_count_kernel"),
     ("l1_ssim_forward", ["l1_ssim_forward_kernel", "l1_ssim_finalize_kernel"], "l1_ssim_forward_kernel"),
     ("l1_ssim_backward", ["l1_ssim_backward_kernel"], "l1_ssim_backward_kernel"),
-    ("adam", ["adam_kernel"], None),
+    ("adam", ["adam_kernel", "adam_multi_kernel"], None),
 ]
 MiB256 = 256 * 1024 * 1024
 
