@@ -204,6 +204,66 @@ def _resolve_deferred_timings(st):
             st[key] = float(ev[0].elapsed_time(ev[1]))
 
 
+# How the load balancer gets its timings at W > 1 (bsz < W, large images: the heuristics are live):
+#   "exact"     : the reference's semantics (workload_division.py:953-966) -- this step's render / loss times, which costs
+#                 a wait for this step's backward plus a device all-gather + read-back: the host cannot run ahead;
+#   "pipelined" : the PREVIOUS step's times (their HIP events completed long ago: resolving them waits for nothing),
+#                 all-gathered over a host-side (gloo) group -- no device synchronisation at all, the cut points lag one
+#                 step behind (SURVEY.md 7 lists this as the documented alternative).
+_BALANCE = {"mode": "pipelined", "group": None}
+
+
+def set_balance_timing(mode):
+    assert mode in ("exact", "pipelined")
+    _BALANCE["mode"] = mode
+
+
+def _host_group():
+    """a gloo group over the same ranks: the timing all-gather is a host-only operation"""
+    import torch.distributed as dist
+
+    if _BALANCE["group"] is None:
+        _BALANCE["group"] = dist.new_group(backend="gloo")  # collective: every rank makes its first call here
+    return _BALANCE["group"]
+
+
+def _gather_times_on_host(mine):
+    import torch.distributed as dist
+
+    g = _host_group()
+    out = [None] * g.size()
+    dist.all_gather_object(out, [float(x) for x in mine], group=g)
+    return out
+
+
+def _update_heuristics(batched_cameras, strategy_history, batched_strategies, times, frozen):
+    args = utils.get_args()
+    strategy_history.store_stats(batched_cameras, times, batched_strategies)
+    if frozen:
+        return
+    for k, (camera, strategy) in enumerate(zip(batched_cameras, batched_strategies)):
+        new = torch.zeros((utils.TILE_Y,), dtype=torch.float32)
+        for j, g in enumerate(strategy.gpu_ids):
+            l, r = strategy.division_pos[j], strategy.division_pos[j + 1]
+            new[l:r] = times[g][k] / (r - l)
+        if args.heuristic_decay == 0:
+            strategy_history.accum_heuristic[camera.uid] = new
+        else:
+            old = strategy_history.accum_heuristic[camera.uid].to("cpu")
+            strategy_history.accum_heuristic[camera.uid] = old * args.heuristic_decay + new * (1 - args.heuristic_decay)
+
+
+def _my_times(batched_strategies, batched_statistic_collector):
+    mine = []
+    for k, strategy in enumerate(batched_strategies):
+        if utils.GLOBAL_RANK not in strategy.gpu_ids:
+            mine.append(-1.0)
+            continue
+        st = batched_statistic_collector[k]
+        mine.append(float(st["forward_render_time"] + st["backward_render_time"] + st["forward_loss_time"] * 2))
+    return mine
+
+
 def finish_strategy_final(batched_cameras, strategy_history, batched_strategies, batched_statistic_collector):
     """all-gather each rank's measured (fwd render + bwd render + 2 x fwd loss) ms per camera and turn
     it into the next per-row cost estimate (same skip rules as workload_division.py:968-978)"""
@@ -222,31 +282,24 @@ def finish_strategy_final(batched_cameras, strategy_history, batched_strategies,
                 st.pop(evkey, None)
         return
 
-    mine = []
+    if W > 1 and _BALANCE["mode"] == "pipelined":
+        prev = getattr(strategy_history, "_gsr_pending", None)
+        strategy_history._gsr_pending = (batched_cameras, batched_strategies, batched_statistic_collector, frozen)
+        if prev is None:
+            return  # first step: nothing measured yet
+        p_cams, p_strategies, p_stats, p_frozen = prev
+        for st in p_stats:
+            _resolve_deferred_timings(st)  # events of the previous step: complete, no wait
+        times = _gather_times_on_host(_my_times(p_strategies, p_stats))
+        _update_heuristics(p_cams, strategy_history, p_strategies, times, p_frozen)
+        return
+
     if W > 1:
         for st in batched_statistic_collector:
             _resolve_deferred_timings(st)
-    for k, strategy in enumerate(batched_strategies):
-        if utils.GLOBAL_RANK not in strategy.gpu_ids:
-            mine.append(-1.0)
-            continue
-        st = batched_statistic_collector[k]
-        mine.append(float(st["forward_render_time"] + st["backward_render_time"] + st["forward_loss_time"] * 2))
+    mine = _my_times(batched_strategies, batched_statistic_collector)
     if W == 1:
         times = [list(mine)]  # nothing to gather: no device round trip (the reference's helper syncs the device here)
     else:
         times = utils.our_allgather_among_cpu_processes_float_list(mine, utils.DEFAULT_GROUP)
-    strategy_history.store_stats(batched_cameras, times, batched_strategies)
-    if frozen:
-        return
-
-    for k, (camera, strategy) in enumerate(zip(batched_cameras, batched_strategies)):
-        new = torch.zeros((utils.TILE_Y,), dtype=torch.float32)
-        for j, g in enumerate(strategy.gpu_ids):
-            l, r = strategy.division_pos[j], strategy.division_pos[j + 1]
-            new[l:r] = times[g][k] / (r - l)
-        if args.heuristic_decay == 0:
-            strategy_history.accum_heuristic[camera.uid] = new
-        else:
-            old = strategy_history.accum_heuristic[camera.uid].to("cpu")
-            strategy_history.accum_heuristic[camera.uid] = old * args.heuristic_decay + new * (1 - args.heuristic_decay)
+    _update_heuristics(batched_cameras, strategy_history, batched_strategies, times, frozen)

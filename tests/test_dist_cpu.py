@@ -51,8 +51,9 @@ def _worker(rank, world, port, bsz, q):
         dgr._C.get_local2j_ids_bool = staticmethod(k2)
         from gaussian_renderer import all_to_all_communication_final, get_cuda_args_final
         from gaussian_renderer.workload_division import (DivisionStrategyHistoryFinal, finish_strategy_final,
-                                                         start_strategy_final)
+                                                         set_balance_timing, start_strategy_final)
 
+        set_balance_timing("exact")  # the history is inspected after ONE step below
         cams = S.orbit_cameras(max(bsz, 2), W, H)[:bsz]
         hist = DivisionStrategyHistoryFinal(S.SyntheticDataset(cams), world, rank)
         if bsz < world:  # skew the cost so that the cut is not in the middle
@@ -308,6 +309,64 @@ def test_redistribute_gaussians_single_packed_all_to_all(world):
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=redistribution_worker, args=(r, world, port, False, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in results:
+        assert msg == "ok", f"rank {rank}:\n{msg}"
+
+
+def _balance_worker(rank, world, port, q):
+    try:
+        for p in (os.path.join(ROOT, "grendel-gs_amd"), ROOT):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                          MASTER_PORT=str(port))
+        torch.set_num_threads(1)
+        import synthetic_scene as S
+        import utils.general_utils as utils
+        from gaussian_renderer.workload_division import (DivisionStrategyHistoryFinal, finish_strategy_final,
+                                                         set_balance_timing, start_strategy_final)
+
+        utils.init_distributed(backend="gloo")
+        W, H = 1920, 1088  # 68 tile rows; bsz 1 < world and a large image: the heuristics are live
+        utils.set_img_size(H, W)
+        utils.set_args(utils.default_args(bsz=1, save_strategy_history=True))
+        set_balance_timing("pipelined")
+        cams = S.orbit_cameras(2, W, H)[:1]
+        hist = DivisionStrategyHistoryFinal(S.SyntheticDataset(cams), world, rank)
+        cuts = []
+        for it in range(3):
+            utils.set_cur_iter(1 + it)
+            strategies, tasks = start_strategy_final(cams, hist)
+            cuts.append(list(strategies[0].division_pos))
+            # rank 0 is three times slower per row than the others
+            stats = [{"forward_render_time": 3.0 if rank == 0 else 1.0, "backward_render_time": 0.0, "forward_loss_time": 0.0}]
+            finish_strategy_final(cams, hist, strategies, stats)
+            assert len(hist.history) == it, "the timings of step t are consumed at step t + 1"
+        assert cuts[0] == cuts[1], "step 1 is still cut with the initial heuristics (one-step lag)"
+        assert cuts[2][1] < cuts[1][1], "then the slow rank 0 gets a smaller band"
+        every = [None] * world
+        dist.all_gather_object(every, cuts)
+        assert all(c == every[0] for c in every), "every rank computes the same cut points"
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        q.put((rank, traceback.format_exc()))
+
+
+def test_pipelined_load_balancer_lags_one_step_and_needs_no_device_sync():
+    """a14 in "pipelined" mode: the previous step's timings, gathered over a host-side gloo group, move the cut points
+    one step later; identical on every rank"""
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_balance_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=300) for _ in procs]

@@ -63,8 +63,9 @@ def _worker(rank, world, port, bsz, q):
         from gaussian_renderer import distributed_preprocess3dgs_and_all2all_final, render_final
         from gaussian_renderer.loss_distribution import batched_loss_computation, load_camera_from_cpu_to_all_gpu
         from gaussian_renderer.workload_division import (DivisionStrategyHistoryFinal, finish_strategy_final,
-                                                         start_strategy_final)
+                                                         set_balance_timing, start_strategy_final)
 
+        set_balance_timing("exact")  # the history is inspected after ONE step below
         torch.cuda.set_device(0)
         dev = torch.device("cuda", 0)
         utils.init_distributed(backend="gloo")
