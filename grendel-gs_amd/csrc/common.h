@@ -21,6 +21,19 @@
 
 static inline int gsr_div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// Workgroup b is dispatched to XCD b % 8 (each XCD has its own 4 MiB L2).  Neighbouring tiles share most of their
+// inputs (the Gaussians of a tile list, the halo of a loss tile), so hand every XCD a CONTIGUOUS span of tile ids
+// instead of every 8th tile: the re-reads of one span then hit one L2.  Bijective for any tile count
+// (cdna_hip_programming.md section 5).
+__device__ __forceinline__ int gsr_xcd_span_of_block(int b, int nwg) {
+#ifdef GSR_NO_XCD_MAP
+    return b;
+#else
+    const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+#endif
+}
+
 // tile rect [min,max) of (pixel centre, radius): C truncation, clamped to the grid
 // (restates SURVEY.md A.2 step 7; identical in preprocess, K2 and K3 so that the three agree).
 __device__ __forceinline__ void gsr_get_rect(float px, float py, int radius, int gx, int gy, int &minx, int &miny,

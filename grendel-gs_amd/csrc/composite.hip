@@ -24,18 +24,6 @@ constexpr float LOG2E = 1.4426950408889634f;
 constexpr float ALPHA_MIN = 1.0f / 255.0f;
 constexpr float T_STOP = 0.0001f;
 
-// Workgroup b is dispatched to XCD b % 8 (each XCD has its own 4 MiB L2).  Neighbouring tiles share most
-// of their Gaussians, so hand every XCD a CONTIGUOUS span of tile ids instead of every 8th tile: the
-// gathers of one span then hit one L2.  Bijective for any tile count (cdna_hip_programming.md §5).
-__device__ __forceinline__ int xcd_tile_of_block(int b, int nwg) {
-#ifdef GSR_NO_XCD_MAP
-    return b;
-#else
-    const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-#endif
-}
-
 #ifdef GSR_STATS
 __device__ unsigned long long g_stats[8];
 #define GSR_STAT(i, v) do { const unsigned long long sv__ = (unsigned long long)(v); if (lane == 0) atomicAdd(&g_stats[i], sv__); } while (0)
@@ -115,7 +103,7 @@ composite_forward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
                          const float4 *__restrict__ conic_opacity, const float *__restrict__ rgb,
                          const uint8_t *__restrict__ compute_locally, const float *__restrict__ bg,
                          float *__restrict__ out_color, float *__restrict__ final_T, int32_t *__restrict__ n_contrib) {
-    const int tile = xcd_tile_of_block(blockIdx.x, gridDim.x);
+    const int tile = gsr_xcd_span_of_block(blockIdx.x, gridDim.x);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tx = tile % gx, ty = tile / gx;
     const int qx0 = tx * GSR_BLOCK_X + (wave & 1) * 8, qy0 = ty * GSR_BLOCK_Y + (wave >> 1) * 8;
@@ -276,7 +264,7 @@ composite_backward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
                           const uint8_t *__restrict__ compute_locally, const float *__restrict__ bg,
                           const float *__restrict__ final_T, const int32_t *__restrict__ n_contrib,
                           const float *__restrict__ dL_dpixels, float *__restrict__ dL_record) {
-    const int tile = xcd_tile_of_block(blockIdx.x, gridDim.x);
+    const int tile = gsr_xcd_span_of_block(blockIdx.x, gridDim.x);
     if (!compute_locally[tile]) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tx = tile % gx, ty = tile / gx;

@@ -78,17 +78,24 @@ __global__ void __launch_bounds__(256) adam_multi_kernel(AdamBatch a, float grad
     for (int r = 0; r < 4; r++) {
         const long long i4 = base + ((long long)r * 256 + threadIdx.x) * 4;
         if (i4 + 3 < n) {
-            float4 p = *reinterpret_cast<float4 *>(param + i4);
-            float4 g = *reinterpret_cast<const float4 *>(grad + i4);
-            float4 m = *reinterpret_cast<float4 *>(em + i4);
-            float4 v = *reinterpret_cast<float4 *>(ev + i4);
+            // streaming hints: the gradient and both moments are touched exactly once per step and nothing reads them
+            // before the next step (measured: 0.303 -> 0.252 ms for the 59 M elements of a 1 M-Gaussian model,
+            // 5.5 -> 6.6 TB/s); the parameters stay cacheable -- 236 MB of them fit the 256 MB memory-side cache and
+            // the next iteration's K1 reads them from there (0.075 -> 0.056 ms; streaming them too was slower)
+            typedef float vf4 __attribute__((ext_vector_type(4)));
+            vf4 pn = *reinterpret_cast<vf4 *>(param + i4);
+            vf4 gn = __builtin_nontemporal_load(reinterpret_cast<const vf4 *>(grad + i4));
+            vf4 mn = __builtin_nontemporal_load(reinterpret_cast<vf4 *>(em + i4));
+            vf4 vn = __builtin_nontemporal_load(reinterpret_cast<vf4 *>(ev + i4));
+            float4 p = make_float4(pn.x, pn.y, pn.z, pn.w), g = make_float4(gn.x, gn.y, gn.z, gn.w);
+            float4 m = make_float4(mn.x, mn.y, mn.z, mn.w), v = make_float4(vn.x, vn.y, vn.z, vn.w);
             adam1<float>(p.x, g.x * grad_scale, m.x, v.x, lr_c, b1, b2, omb1, omb2, inv_sqrt_bc2, eps);
             adam1<float>(p.y, g.y * grad_scale, m.y, v.y, lr_c, b1, b2, omb1, omb2, inv_sqrt_bc2, eps);
             adam1<float>(p.z, g.z * grad_scale, m.z, v.z, lr_c, b1, b2, omb1, omb2, inv_sqrt_bc2, eps);
             adam1<float>(p.w, g.w * grad_scale, m.w, v.w, lr_c, b1, b2, omb1, omb2, inv_sqrt_bc2, eps);
             *reinterpret_cast<float4 *>(param + i4) = p;
-            *reinterpret_cast<float4 *>(em + i4) = m;
-            *reinterpret_cast<float4 *>(ev + i4) = v;
+            __builtin_nontemporal_store(vf4{m.x, m.y, m.z, m.w}, reinterpret_cast<vf4 *>(em + i4));
+            __builtin_nontemporal_store(vf4{v.x, v.y, v.z, v.w}, reinterpret_cast<vf4 *>(ev + i4));
         } else {
             for (long long i = i4; i < n && i < i4 + 4; i++) {
                 float p = param[i], m = em[i], v = ev[i];
