@@ -5,7 +5,7 @@ O=$R/gpurun_out/${1:-big}
 mkdir -p $O
 cd $R
 for w in c2 c4; do
-  timeout 600 python bench.py --workload $w --steps 5 --warmup 2 --repeats 1 --render-steps 3 --no-cpu-baseline > $O/bench_$w.json 2> $O/bench_$w.err
+  timeout 600 python bench.py --workload $w --steps 16 --warmup 8 --repeats 1 --render-steps 8 --no-cpu-baseline > $O/bench_$w.json 2> $O/bench_$w.err
   echo "$w exit $?"; tail -c 300 $O/bench_$w.err
   python - <<PY
 import json
