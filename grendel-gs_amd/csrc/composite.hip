@@ -96,6 +96,40 @@ __device__ __forceinline__ Entry load_entry(bool have, uint32_t id, const float2
     return e;
 }
 
+
+// ---- packed pairs.  A wave instruction on this chip retires in four cycles whether it is v_fma_f32 or v_pk_fma_f32,
+// so the arithmetic that is independent between two list entries (offsets, the exponent's quadratic form, the colour
+// terms) is done for TWO entries per instruction.  For that the RELEVANT entries of a chunk are compacted (in walk
+// order) into pair records in the wave's LDS slab, the two entries' values of each field next to each other, so
+// that one broadcast read returns register PAIRS: rec = {xa xb ya yb | a2a a2b b2a b2b | c2a c2b oa ob | ra rb ga gb |
+// ba bb - -}.  Slots behind the last entry are zeroed (K8) or never evaluated (K10).
+typedef float v2f __attribute__((ext_vector_type(2)));
+constexpr int PREC = 20;  // floats per pair record (80 bytes: 16-byte aligned reads)
+struct PairRec {
+    v2f x, y, a2, b2, c2, o, r, g, b;
+};
+__device__ __forceinline__ void pair_store(float *__restrict__ slab, int pos, const Entry &e, float r, float g, float b) {
+    float *rec = slab + (pos >> 1) * PREC + (pos & 1);
+    rec[0] = e.x;  rec[2] = e.y;  rec[4] = e.a2;  rec[6] = e.b2;  rec[8] = e.c2;
+    rec[10] = e.o; rec[12] = r;   rec[14] = g;    rec[16] = b;
+}
+__device__ __forceinline__ PairRec pair_load(const float *__restrict__ slab, int pair) {  // wave-uniform address
+    const float4 *q = reinterpret_cast<const float4 *>(slab + pair * PREC);
+    const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+    const float2 q4 = *reinterpret_cast<const float2 *>(q + 4);
+    PairRec p;
+    p.x = v2f{q0.x, q0.y};  p.y = v2f{q0.z, q0.w};  p.a2 = v2f{q1.x, q1.y};  p.b2 = v2f{q1.z, q1.w};
+    p.c2 = v2f{q2.x, q2.y}; p.o = v2f{q2.z, q2.w};  p.r = v2f{q3.x, q3.y};   p.g = v2f{q3.z, q3.w};
+    p.b = v2f{q4.x, q4.y};
+    return p;
+}
+// exponents of both entries of a pair at this lane's pixel: a2 dx^2 + b2 dx dy + c2 dy^2 + log2 o  (7 packed instructions)
+__device__ __forceinline__ v2f pair_exponent(const PairRec &p, float pxf, float pyf) {
+    const v2f dx = p.x - pxf, dy = p.y - pyf;
+    return __builtin_elementwise_fma(__builtin_elementwise_fma(p.a2, dx, p.b2 * dy), dx,
+                                     __builtin_elementwise_fma(p.c2 * dy, dy, p.o));
+}
+
 // ------------------------------------------------------------------------------------------- K8
 __global__ void __launch_bounds__(256)
 composite_forward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
@@ -129,7 +163,9 @@ composite_forward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
     int last = 0;
     bool done = !inside;
-    __shared__ float4 slab[4][64][3];
+    __shared__ __attribute__((aligned(16))) float slab[4][32 * PREC];
+    v2f A0 = {0.f, 0.f}, A1 = {0.f, 0.f}, A2 = {0.f, 0.f};  // colour sums of the even / odd pair slots (added at the end)
+    float *wslab = slab[wave];
 
     for (int c = 0; c < n; c += 64) {
         if (__all(done)) break;
@@ -145,52 +181,68 @@ composite_forward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
         unsigned long long m = __ballot(e.relevant);
         GSR_STAT(0, __popcll(__ballot(have)));
         GSR_STAT(1, __popcll(m));
-        // Stage the chunk in this wave's private LDS slab (lane k writes entry k) and broadcast-read it back:
-        // an LDS read with a wave-uniform address returns the entry to all 64 lanes WITHOUT spending VALU
-        // issue slots (9 v_readlane per entry before), and the VALU is what bounds this kernel.  No barrier:
-        // the slab is private to the wave and LDS operations of one wave execute in order.
-        slab[wave][lane][0] = make_float4(e.x, e.y, e.a2, e.b2);
-        slab[wave][lane][1] = make_float4(e.c2, e.o, r, g);
-        slab[wave][lane][2] = make_float4(b, 0.f, 0.f, 0.f);
-        // Entries are taken UF at a time: their alphas are independent (ILP across the LDS and v_exp latency),
-        // only the short T / colour chain is sequential, and the wave tests "everybody done?" once per group.
-        constexpr int UF = 4;
-        while (m) {
-            int kk[UF];
-            float al[UF], cr[UF], cg[UF], cb[UF];
-            bool ok[UF];
+        // Stage the chunk's relevant entries, compacted in list order, as pair records in this wave's private LDS slab
+        // and broadcast-read them back: an LDS read with a wave-uniform address returns the values to all 64 lanes
+        // WITHOUT spending VALU issue slots, and the VALU is what bounds this kernel.  No barrier: the slab is private to
+        // the wave and LDS operations of one wave execute in order.
+        const int nrel = __popcll(m);
+        if (e.relevant) pair_store(wslab, __popcll(m & ((1ull << lane) - 1ull)), e, r, g, b);
+        {   // the walk below takes four slots at a time: zero the <= 3 slots behind the last entry (a stale colour times
+            // a zero weight would still be a NaN if the stale bits are one)
+            const int pad = (-nrel) & 3, slot = nrel + lane / 9;
+            if (lane < 9 * pad) wslab[(slot >> 1) * PREC + 2 * (lane % 9) + (slot & 1)] = 0.f;
+        }
+        // Entries are taken four (two pairs) at a time: their alphas are independent (ILP across the LDS and v_exp
+        // latency), only the short T chain is sequential, and the wave tests "everybody done?" once per group.
+        for (int p0 = 0; p0 < nrel; p0 += 4) {  // wave-uniform
+            float al[4];
+            bool ok[4];
+            int kk[4];
+            v2f cr[2], cg[2], cb[2];
 #pragma unroll
-            for (int u = 0; u < UF; u++) {
-                const bool live = m != 0;  // wave-uniform
-                const int k = live ? __builtin_ctzll(m) : 0;
-                m &= m - 1;  // 0 & ~0 stays 0
-                kk[u] = k;
-                const float4 q0 = slab[wave][k][0], q1 = slab[wave][k][1];
-                cb[u] = slab[wave][k][2].x;
-                cr[u] = q1.z;
-                cg[u] = q1.w;
-                const float dx = q0.x - pxf, dy = q0.y - pyf;
-                const float pe = entry_exponent(q0, q1, dx, dy);
-                al[u] = fminf(0.99f, entry_alpha_raw(q1, pe));
-                ok[u] = live && entry_power_ok(q1, pe) && al[u] >= ALPHA_MIN;
+            for (int h = 0; h < 2; h++) {
+                const PairRec pr = pair_load(wslab, (p0 >> 1) + h);
+                const v2f pe = pair_exponent(pr, pxf, pyf);
+                cr[h] = pr.r;
+                cg[h] = pr.g;
+                cb[h] = pr.b;
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const bool live = m != 0;  // wave-uniform: entry p0 + 2 h + u exists
+                    kk[2 * h + u] = live ? __builtin_ctzll(m) : 0;
+                    m &= m - 1;  // 0 & ~0 stays 0
+                    const float pe1 = u ? pe.y : pe.x, lo = u ? pr.o.y : pr.o.x;
+                    al[2 * h + u] = fminf(0.99f, __builtin_amdgcn_exp2f(pe1));
+                    ok[2 * h + u] = live && pe1 <= lo && al[2 * h + u] >= ALPHA_MIN;  // power <= 0  <=>  exponent <= log2 o
+                }
             }
+            float wv[4];
 #pragma unroll
-            for (int u = 0; u < UF; u++) {
+            for (int u = 0; u < 4; u++) {
                 const bool take = !done && ok[u];
-                const float test_T = T * (1.0f - al[u]);
-                const bool stop = take && test_T < T_STOP;
+                const float w0 = al[u] * T;
+                const float test_T = T - w0;  // T (1 - alpha) >= 0: compared as an integer so that `!stop` below is the
+                // complement of ONE compare (a float `<` and its negation are two instructions: NaN semantics)
+                const bool stop = take && __float_as_int(test_T) < __float_as_int(T_STOP);
                 done = done || stop;
                 const bool blend = take && !stop;
-                const float w = blend ? al[u] * T : 0.f;
-                C0 += cr[u] * w;
-                C1 += cg[u] * w;
-                C2 += cb[u] * w;
+                wv[u] = blend ? w0 : 0.f;
                 T = blend ? test_T : T;
                 last = blend ? c + kk[u] + 1 : last;
+            }
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const v2f w2 = {wv[2 * h], wv[2 * h + 1]};
+                A0 = __builtin_elementwise_fma(cr[h], w2, A0);
+                A1 = __builtin_elementwise_fma(cg[h], w2, A1);
+                A2 = __builtin_elementwise_fma(cb[h], w2, A2);
             }
             if (__all(done)) break;
         }
     }
+    C0 = A0.x + A0.y;
+    C1 = A1.x + A1.y;
+    C2 = A2.x + A2.y;
     if (inside) {
         out_color[pid] = C0 + T * bg[0];
         out_color[HW + pid] = C1 + T * bg[1];
@@ -289,7 +341,8 @@ composite_backward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
 
     __shared__ float2 smat[4][MB * MSTR];   // [wave][slot * MSTR + pixel] = (q, w)
     __shared__ float sacc[4][64 * 9];       // [wave][entry * 9 + moment]: plain stores (LDS float atomics cost ~50 cycles)
-    __shared__ float4 slab[4][64][3];       // [wave][entry] = (x, y, a2, b2 | c2, log2 o, r, g | b, id, o, -)
+    __shared__ __attribute__((aligned(16))) float slab[4][32 * PREC];  // [wave]: pair records of the relevant entries
+    __shared__ float4 fslab[64][2];         // [entry of the chunk] = (x, y, a2, b2 | c2, id, o, -): what the flush needs
     __shared__ int s_wmax[4];
     int wmax = last;
 #pragma unroll
@@ -325,7 +378,7 @@ composite_backward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
     // A operand of K-step t: component (i >> 3) of element [slot i & 7][pixel 4 t + kq]
     const float *arow = reinterpret_cast<const float *>(&smat[wave][(j & 7) * MSTR + kq]) + (j >> 3);
     const bool my_cols = kq < 2 ? j < 6 : (j >= 6 && j < 9);  // the columns that mean something in this lane's rows
-    const float4 *wslab = &slab[wave][0][0];
+    float *wslab = slab[wave];
 
     float T = T_final;
     float rho = 0.f;  // (colour accumulated BEHIND the current position) . g
@@ -357,10 +410,15 @@ composite_backward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
             GSR_STAT(0, __popcll(__ballot(have)));
             GSR_STAT(1, __popcll(m));
             GSR_STAT(6, 1);
-            // wave-private LDS slab + broadcast reads (see K8): entry k is read back by all lanes with a uniform address
-            slab[wave][lane][0] = make_float4(e.x, e.y, e.a2, e.b2);
-            slab[wave][lane][1] = make_float4(e.c2, e.o, raw.r, raw.g);
-            slab[wave][lane][2] = make_float4(raw.b, __uint_as_float(id_cur), raw.co.w, 0.f);
+            // wave-private LDS slab + broadcast reads (see K8): the relevant entries, compacted in WALK order (back to
+            // front: rank = relevant lanes above), as pair records -- slot 0 of a pair is walked first
+            if (e.relevant) pair_store(wslab, __popcll((m >> lane) >> 1), e, raw.r, raw.g, raw.b);
+            // the flush below reads positions / conics / ids by chunk index from the wave that walks the longest list
+            // (it holds every entry of every chunk)
+            if (wave == wbest) {
+                fslab[lane][0] = make_float4(e.x, e.y, e.a2, e.b2);
+                fslab[lane][1] = make_float4(e.c2, __uint_as_float(id_cur), raw.co.w, 0.f);
+            }
             // chunk index of the entry in each slot: 8 bytes in a scalar register pair (wave-uniform, SALU only)
             unsigned long long sk = 0ull;
             // phase B: [rows x pixels] . [pixels x columns] on the matrix pipe.  Result element r of a lane: row
@@ -389,22 +447,19 @@ composite_backward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
             int s = 0;  // filled slots of the current batch (wave-uniform)
             // Entries are taken two at a time: their LDS reads and alphas are independent (one wait for both), only
             // the short T / rho chain is sequential.  MB is even, so a pair never straddles a batch.
-            while (m) {
+            for (int pi = 0; m; pi++) {
                 const int ka = 63 - __builtin_clzll(m);  // back to front
                 m &= ~(1ull << ka);
                 const bool two = m != 0ull;              // wave-uniform
                 const int kb = two ? 63 - __builtin_clzll(m) : ka;
                 m &= ~(1ull << kb);
-                const float4 *ea = wslab + 3 * ka, *eb = wslab + 3 * kb;  // wave-uniform addresses: LDS broadcasts
-                const float4 a0 = ea[0], a1 = ea[1], b0 = eb[0], b1 = eb[1];
-                const float acb = ea[2].x, bcb = eb[2].x;
-                const float adx = a0.x - pxf, ady = a0.y - pyf, bdx = b0.x - pxf, bdy = b0.y - pyf;
-                const float ape = entry_exponent(a0, a1, adx, ady), bpe = entry_exponent(b0, b1, bdx, bdy);
-                const float aar = entry_alpha_raw(a1, ape), bar = entry_alpha_raw(b1, bpe);   // o * exp(power), unclamped
+                const PairRec pr = pair_load(wslab, pi);  // wave-uniform address: LDS broadcasts
+                const v2f pe = pair_exponent(pr, pxf, pyf);
+                const float aar = __builtin_amdgcn_exp2f(pe.x), bar = __builtin_amdgcn_exp2f(pe.y);  // o exp(power), unclamped
                 const float aal = fminf(0.99f, aar), bal = fminf(0.99f, bar);
-                const bool atake = (c + ka + 1 <= last) && entry_power_ok(a1, ape) && aal >= ALPHA_MIN;
-                const bool btake = two && (c + kb + 1 <= last) && entry_power_ok(b1, bpe) && bal >= ALPHA_MIN;
-                const float acg = fmaf(acb, g2, fmaf(a1.w, g1, a1.z * g0)), bcg = fmaf(bcb, g2, fmaf(b1.w, g1, b1.z * g0));
+                const bool atake = (c + ka + 1 <= last) && pe.x <= pr.o.x && aal >= ALPHA_MIN;  // power <= 0 <=> exponent <= log2 o
+                const bool btake = two && (c + kb + 1 <= last) && pe.y <= pr.o.y && bal >= ALPHA_MIN;
+                const v2f cg = __builtin_elementwise_fma(pr.b, v2f{g2, g2}, __builtin_elementwise_fma(pr.g, v2f{g1, g1}, pr.r * g0));
                 GSR_STAT(2, two ? 2 : 1);
                 GSR_STAT(3, (__builtin_amdgcn_ballot_w64(atake) != 0ull) + (__builtin_amdgcn_ballot_w64(btake) != 0ull));
                 GSR_STAT(4, __popcll(__builtin_amdgcn_ballot_w64(atake)) + __popcll(__builtin_amdgcn_ballot_w64(btake)));
@@ -413,26 +468,28 @@ composite_backward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
                 // two VALU instructions per entry.  A lane that does not take an entry runs the same arithmetic with
                 // alpha = 0: T / (1 - 0) and rho + 0 * (...) leave its state untouched and it stores (0, 0) (the
                 // factors are SELECTED, never multiplied by an inf / NaN).
+                const v2f qa = {atake ? aar : 0.f, atake ? aal : 0.f};   // (o G, alpha) of the first entry, or (0, 0)
+                const v2f qb = {btake ? bar : 0.f, btake ? bal : 0.f};
+                const v2f inv = {__builtin_amdgcn_rcpf(1.f - qa.y), __builtin_amdgcn_rcpf(1.f - qb.y)};  // 1 ulp, inside the 1e-4 budget
+                const v2f tbi = inv * tb;
                 {
-                    const float ae = atake ? aal : 0.f, are = atake ? aar : 0.f;
-                    const float inv_1ma = __builtin_amdgcn_rcpf(1.f - ae);  // 1 ulp, inside the 1e-4 budget
-                    const float Tn = T * inv_1ma;                           // transmittance in front of the entry
-                    const float dot = acg - rho;                            // (c - R) . g
-                    const float da = fmaf(dot, Tn, -(tb * inv_1ma));        // dL/dalpha
-                    smat[wave][s * MSTR + lane] = make_float2(are * da, ae * Tn);   // (q = o G dL/dalpha, w)
-                    rho = fmaf(ae, dot, rho);
+                    const float Tn = T * inv.x;                     // transmittance in front of the entry
+                    const float dot = cg.x - rho;                   // (c - R) . g
+                    const float da = fmaf(dot, Tn, -tbi.x);         // dL/dalpha
+                    const v2f qw = qa * v2f{da, Tn};                // (q = o G dL/dalpha, w = alpha T)
+                    smat[wave][s * MSTR + lane] = make_float2(qw.x, qw.y);
+                    rho = fmaf(qa.y, dot, rho);
                     T = Tn;
                 }
                 sk |= (unsigned long long)ka << (8 * s);
                 s++;
                 if (two) {
-                    const float ae = btake ? bal : 0.f, are = btake ? bar : 0.f;
-                    const float inv_1ma = __builtin_amdgcn_rcpf(1.f - ae);
-                    const float Tn = T * inv_1ma;
-                    const float dot = bcg - rho;
-                    const float da = fmaf(dot, Tn, -(tb * inv_1ma));
-                    smat[wave][s * MSTR + lane] = make_float2(are * da, ae * Tn);
-                    rho = fmaf(ae, dot, rho);
+                    const float Tn = T * inv.y;
+                    const float dot = cg.y - rho;
+                    const float da = fmaf(dot, Tn, -tbi.y);
+                    const v2f qw = qb * v2f{da, Tn};
+                    smat[wave][s * MSTR + lane] = make_float2(qw.x, qw.y);
+                    rho = fmaf(qb.y, dot, rho);
                     T = Tn;
                     sk |= (unsigned long long)kb << (8 * s);
                     s++;
@@ -460,7 +517,7 @@ composite_backward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
             if (idx < 576 && c + e < bmax) {
                 const int b9 = 9 * e;
                 auto S = [&](int v) { return (sacc[0][b9 + v] + sacc[1][b9 + v]) + (sacc[2][b9 + v] + sacc[3][b9 + v]); };
-                const float4 *se = &slab[wbest][e][0];
+                const float4 *se = &fslab[e][0];
                 float val;
                 if (col >= 2 && col < 5) {
                     val = S(6 + (col - 2));
@@ -476,10 +533,10 @@ composite_backward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
                     else if (col == 5) val = -0.5f * (fmaf(fmaf(ex, A0, -2.f * Ax), ex, S(3)));
                     else if (col == 6) val = -(fmaf(ex, My, -ey * Ax) + S(4));   // ex ey M0 - ex Ay - ey Ax + Axy
                     else if (col == 7) val = -0.5f * (fmaf(fmaf(ey, A0, -2.f * Ay), ey, S(5)));
-                    else val = A0 == 0.f ? 0.f : A0 / se[2].z;
+                    else val = A0 == 0.f ? 0.f : A0 / se[1].z;
                 }
 #ifndef GSR_ABL_NOATOMIC
-                if (val != 0.f) atomicAdd(dL_record + 9 * (size_t)__float_as_uint(se[2].y) + col, val);
+                if (val != 0.f) atomicAdd(dL_record + 9 * (size_t)__float_as_uint(se[1].y) + col, val);
 #else
                 asm volatile("" ::"v"(val));
 #endif
