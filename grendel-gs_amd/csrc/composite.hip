@@ -342,7 +342,8 @@ composite_backward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
     __shared__ float2 smat[4][MB * MSTR];   // [wave][slot * MSTR + pixel] = (q, w)
     __shared__ float sacc[4][64 * 9];       // [wave][entry * 9 + moment]: plain stores (LDS float atomics cost ~50 cycles)
     __shared__ __attribute__((aligned(16))) float slab[4][32 * PREC];  // [wave]: pair records of the relevant entries
-    __shared__ float4 fslab[64][2];         // [entry of the chunk] = (x, y, a2, b2 | c2, id, o, -): what the flush needs
+    __shared__ float fslab[64 * 7];         // [entry of the chunk][x, y, a2, b2, c2, id, o]: what the flush needs
+    __shared__ float sout[64 * 10];         // [entry][9 gradient values, id]: mapped by ONE wave, added by all (see the flush)
     __shared__ int s_wmax[4];
     int wmax = last;
 #pragma unroll
@@ -416,8 +417,10 @@ composite_backward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
             // the flush below reads positions / conics / ids by chunk index from the wave that walks the longest list
             // (it holds every entry of every chunk)
             if (wave == wbest) {
-                fslab[lane][0] = make_float4(e.x, e.y, e.a2, e.b2);
-                fslab[lane][1] = make_float4(e.c2, __uint_as_float(id_cur), raw.co.w, 0.f);
+                float *fe = &fslab[7 * lane];
+                fe[0] = e.x;  fe[1] = e.y;  fe[2] = e.a2;  fe[3] = e.b2;  fe[4] = e.c2;
+                fe[5] = __uint_as_float(id_cur);
+                fe[6] = raw.co.w;
             }
             // chunk index of the entry in each slot: 8 bytes in a scalar register pair (wave-uniform, SALU only)
             unsigned long long sk = 0ull;
@@ -502,49 +505,61 @@ composite_backward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
             if (s > 0) contract_batch(s);
         }
         __syncthreads();
-        // flush, (entry, value)-major: 576 (entry, column) outputs per chunk over 256 threads; 9 ADJACENT lanes add the 9
-        // values of one (tile, entry) pair into that Gaussian's 36-byte gradient record, so a wave instruction touches
-        // ~8 records instead of 64 scattered words.  Everything the maps need is in the slab of the longest-walking wave
-        // (no global loads here).  The four quadrant waves' raw pixel moments (about the TILE origin) add up; then
+        // Flush.  The four quadrant waves' raw pixel moments (about the TILE origin) add up; then
         //   M0 = sum q, Mx = sum q dx = ex M0 - Ax, Mxx = sum q dx^2 = ex^2 M0 - 2 ex Ax + Axx, ... (ex = x_e - tile x0)
         //   dL/dmean = -(A Mx + B My, B Mx + C My) * (W/2, H/2);  dL/d(A,B,C) = -(Mxx / 2, Mxy, Myy / 2);
         //   dL/dopacity = sum G dL/dalpha = M0 / o  (q carries the factor o);  dL/drgb = sum w g.
-        const float tx0 = (float)(tx * GSR_BLOCK_X), ty0 = (float)(ty * GSR_BLOCK_Y);
+        // Step 1, ONE wave (they take turns), lane = entry: add the four tables (rows are 9 words apart: conflict-free)
+        // and map the moments to the nine gradient values -- straight-line code, each sum formed once.  (With one lane
+        // per (entry, value) every lane re-added up to 16 table words and the nine value formulas ran as divergent
+        // branches in all four waves: 0.045 ms of the 0.38 ms kernel.)  Everything the maps need is in the slab of the
+        // longest-walking wave: no global loads.
+        // Step 2, all waves, lane = (entry, value): 9 ADJACENT lanes add the nine values of one (tile, entry) pair into
+        // that Gaussian's 36-byte gradient record, so a wave instruction touches ~8 records instead of 64 scattered words.
+        if (wave == ((c >> 6) & 3)) {
+            const float tx0 = (float)(tx * GSR_BLOCK_X), ty0 = (float)(ty * GSR_BLOCK_Y);
+            const int e9 = 9 * lane;
+            float Sv[9];
+#pragma unroll
+            for (int v = 0; v < 9; v++) Sv[v] = (sacc[0][e9 + v] + sacc[1][e9 + v]) + (sacc[2][e9 + v] + sacc[3][e9 + v]);
+            const float *fe = &fslab[7 * lane];
+            const float ex = fe[0] - tx0, ey = fe[1] - ty0;
+            // conic back from the log2-scaled copy: A = a2 / (-log2(e) / 2), B = b2 / (-log2 e), C likewise
+            const float cA = fe[2] * (-2.0f / LOG2E), cB = fe[3] * (-1.0f / LOG2E), cC = fe[4] * (-2.0f / LOG2E);
+            const float A0 = Sv[0], Ax = Sv[1], Ay = Sv[2];
+            const float Mx = fmaf(ex, A0, -Ax), My = fmaf(ey, A0, -Ay);
+            float o[9];
+            o[0] = -(cA * Mx + cB * My) * ddelx_dx;
+            o[1] = -(cB * Mx + cC * My) * ddely_dy;
+            o[2] = Sv[6];
+            o[3] = Sv[7];
+            o[4] = Sv[8];
+            o[5] = -0.5f * (fmaf(fmaf(ex, A0, -2.f * Ax), ex, Sv[3]));
+            o[6] = -(fmaf(ex, My, -ey * Ax) + Sv[4]);   // ex ey M0 - ex Ay - ey Ax + Axy
+            o[7] = -0.5f * (fmaf(fmaf(ey, A0, -2.f * Ay), ey, Sv[5]));
+            o[8] = A0 == 0.f ? 0.f : A0 / fe[6];
+            const bool live = c + lane < bmax;
+            float *so = &sout[10 * lane];
+#pragma unroll
+            for (int v = 0; v < 9; v++) so[v] = live ? o[v] : 0.f;
+            so[9] = fe[5];
+        }
+        __syncthreads();
 #pragma unroll
         for (int r = 0; r < 3; r++) {
             const int idx = threadIdx.x + 256 * r;
             const int e = idx / 9, col = idx - 9 * e;
-            if (idx < 576 && c + e < bmax) {
-                const int b9 = 9 * e;
-                auto S = [&](int v) { return (sacc[0][b9 + v] + sacc[1][b9 + v]) + (sacc[2][b9 + v] + sacc[3][b9 + v]); };
-                const float4 *se = &fslab[e][0];
-                float val;
-                if (col >= 2 && col < 5) {
-                    val = S(6 + (col - 2));
-                } else {
-                    const float A0 = S(0), Ax = S(1), Ay = S(2);
-                    const float4 e0 = se[0];
-                    const float ex = e0.x - tx0, ey = e0.y - ty0;
-                    // conic back from the log2-scaled copy: A = a2 / (-log2(e) / 2), B = b2 / (-log2 e), C likewise
-                    const float cA = e0.z * (-2.0f / LOG2E), cB = e0.w * (-1.0f / LOG2E), cC = se[1].x * (-2.0f / LOG2E);
-                    const float Mx = fmaf(ex, A0, -Ax), My = fmaf(ey, A0, -Ay);
-                    if (col == 0) val = -(cA * Mx + cB * My) * ddelx_dx;
-                    else if (col == 1) val = -(cB * Mx + cC * My) * ddely_dy;
-                    else if (col == 5) val = -0.5f * (fmaf(fmaf(ex, A0, -2.f * Ax), ex, S(3)));
-                    else if (col == 6) val = -(fmaf(ex, My, -ey * Ax) + S(4));   // ex ey M0 - ex Ay - ey Ax + Axy
-                    else if (col == 7) val = -0.5f * (fmaf(fmaf(ey, A0, -2.f * Ay), ey, S(5)));
-                    else val = A0 == 0.f ? 0.f : A0 / se[1].z;
-                }
+            if (idx < 576) {
+                const float val = sout[10 * e + col];
 #ifndef GSR_ABL_NOATOMIC
-                if (val != 0.f) atomicAdd(dL_record + 9 * (size_t)__float_as_uint(se[1].y) + col, val);
+                if (val != 0.f) atomicAdd(dL_record + 9 * (size_t)__float_as_uint(sout[10 * e + 9]) + col, val);
 #else
                 asm volatile("" ::"v"(val));
 #endif
             }
         }
-        __syncthreads();
-        // every wave clears ITS OWN table behind the reads above (LDS operations of one wave execute in order, so the
-        // next chunk's stores of this wave follow the clears)
+        // every wave clears ITS OWN table (the mapping wave read it before the barrier above; LDS operations of one wave
+        // execute in order, so the next chunk's stores of this wave follow the clears)
 #pragma unroll
         for (int i = 0; i < 9; i++) acc_tab[64 * i + lane] = 0.f;
         raw = raw_nxt;

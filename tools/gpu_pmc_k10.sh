@@ -11,7 +11,7 @@ export TMPDIR=/tmp
 cd /tmp
 i=0
 for set in "SQ_INST_LEVEL_LDS SQ_INSTS_LDS SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM SQ_LEVEL_WAVES SQ_LDS_CMD_FIFO_FULL SQ_LDS_DATA_FIFO_FULL SQ_IFETCH_LEVEL" \
-           "SQ_INSTS_LDS_ATOMIC SQ_INSTS_LDS_LOAD SQ_INSTS_LDS_STORE SQ_VALU_MFMA_COEXEC_CYCLES SQ_IFETCH SQ_INSTS_BRANCH SQ_BUSY_CYCLES SQ_WAVE_CYCLES" \
+           "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_LDS_STORE SQ_VALU_MFMA_COEXEC_CYCLES SQ_INST_CYCLES_VMEM SQ_INSTS_BRANCH SQ_BUSY_CYCLES SQ_WAVE_CYCLES" \
            "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_CYCLES"; do
   i=$((i+1))
   rm -rf $O/set$i
