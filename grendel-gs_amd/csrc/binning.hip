@@ -301,13 +301,19 @@ __global__ void __launch_bounds__(THREADS)
 emit_scatter_kernel(int P, long long D, int xbits, const uint2 *__restrict__ rects,
                     const uint32_t *__restrict__ sorted_ids, const uint32_t *__restrict__ offsets,
                     const uint32_t *__restrict__ ghist, uint32_t *__restrict__ state, uint32_t *__restrict__ ticket,
-                    uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out) {
+                    uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, bool bounded) {
     constexpr int WAVES = THREADS / 64;
     __shared__ OnesweepSmem<ITEMS, THREADS> sm;
+    if (bounded) {  // the grid covers a capacity D; the true pair count is offsets[P] (K4's total)
+        const long long d = offsets[P];
+        if (d > D) return;
+        D = d;
+    }
     __shared__ uint32_t s_off[WAVES][65];
     __shared__ uint32_t s_g[WAVES][64];
     __shared__ uint2 s_rect[WAVES][64];
     const uint32_t bid = onesweep_begin(sm, ticket);
+    if ((long long)bid * (ITEMS * THREADS) >= D) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long wbase = (long long)bid * (ITEMS * THREADS) + (long long)wave * (ITEMS * 64);
     uint32_t key[ITEMS], val[ITEMS];
@@ -376,7 +382,13 @@ emit_scatter_kernel(int P, long long D, int xbits, const uint2 *__restrict__ rec
 // locally keep the empty range
 __global__ void __launch_bounds__(GSR_ONE_DIM_BLOCK)
 tile_ranges_yx_kernel(long long D, int gx, int xbits, const uint32_t *__restrict__ keys,
-                      const uint8_t *__restrict__ mask, int2 *__restrict__ ranges) {
+                      const uint8_t *__restrict__ mask, int2 *__restrict__ ranges,
+                      const uint32_t *__restrict__ D_dev) {
+    if (D_dev) {
+        const long long d = *D_dev;
+        if (d > D) return;
+        D = d;
+    }
     const long long j = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (j >= D) return;
     uint32_t k[6];  // k[0] = predecessor, k[1..4] = own, k[5] = successor
@@ -457,26 +469,37 @@ PrepLayout prep_layout(int P, int W, int H) {
     L.total = o;
     return L;
 }
-// Two pinned, device-mapped words per device: K4's last workgroup stores the pair count and then the call's
-// sequence tag; the host POLLS the tag (a few microseconds after the store lands) instead of paying a stream
-// synchronise (interrupt + wake-up, ~30-40 us measured) -- everything the host launches after this point is on
+// Pinned, device-mapped result slots (64 per device, two words each): K4's last workgroup stores the pair count and
+// then the call's sequence tag; the host POLLS the tag (a few microseconds after the store lands) instead of paying a
+// stream synchronise (interrupt + wake-up, ~30-40 us measured) -- everything the host launches after this point is on
 // the critical path of the iteration.  If the tag does not show up within ~2 ms the host falls back to
-// hipStreamSynchronize (which also surfaces a faulted kernel).  The mutex is held from the launch to the read,
-// so concurrent callers on one device take turns.
-std::mutex g_total_mutex;
+// hipStreamSynchronize (which also surfaces a faulted kernel).  A call's ticket is its sequence number; slot =
+// ticket % 64, so up to 64 counts can be outstanding per device (gsr_bin_prepare_async / gsr_bin_count_wait).
+constexpr int TOTAL_SLOTS = 64;
+std::mutex g_total_mutex;  // slot table set-up and ticket numbering only
 uint32_t *g_total_word[64] = {};
 uint32_t g_total_seq = 0;
-int total_word(uint32_t **host) {
+int total_slot(uint32_t **host, uint32_t *seq_out) {
     int dev = 0;
     GSR_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) return GSR_EINVAL;
+    std::lock_guard<std::mutex> guard(g_total_mutex);
     if (!g_total_word[dev]) {
         void *p = nullptr;
-        GSR_HIP(hipHostMalloc(&p, 256, hipHostMallocDefault));
+        GSR_HIP(hipHostMalloc(&p, sizeof(uint32_t) * 2 * TOTAL_SLOTS, hipHostMallocDefault));
         g_total_word[dev] = reinterpret_cast<uint32_t *>(p);
-        g_total_word[dev][0] = g_total_word[dev][1] = 0;
+        memset(p, 0, sizeof(uint32_t) * 2 * TOTAL_SLOTS);
     }
-    *host = g_total_word[dev];
+    const uint32_t seq = ++g_total_seq ? g_total_seq : ++g_total_seq;  // never 0
+    *seq_out = seq;
+    *host = g_total_word[dev] + 2 * (seq % TOTAL_SLOTS);
+    return 0;
+}
+int slot_of_ticket(uint32_t seq, uint32_t **host) {
+    int dev = 0;
+    GSR_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !g_total_word[dev] || seq == 0) return GSR_EINVAL;
+    *host = g_total_word[dev] + 2 * (seq % TOTAL_SLOTS);
     return 0;
 }
 int wait_total(hipStream_t stream, uint32_t *host_total, uint32_t seq, uint32_t *total) {
@@ -521,12 +544,12 @@ extern "C" size_t gsr_bin_prepare_bytes(int P, int width, int height) {
     return prep_layout(P, width, height).total;
 }
 
-extern "C" int gsr_bin_prepare(int P, int width, int height, const float *means2D, const float *depths,
-                               const int32_t *radii, const float *conic_opacity, const uint8_t *compute_locally,
-                               void *prep, size_t prep_bytes, int64_t *num_rendered_host, gsr_stream_t stream_) {
+extern "C" int gsr_bin_prepare_async(int P, int width, int height, const float *means2D, const float *depths,
+                                     const int32_t *radii, const float *conic_opacity, const uint8_t *compute_locally,
+                                     void *prep, size_t prep_bytes, uint32_t *ticket, gsr_stream_t stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-    if (P < 0 || width <= 0 || height <= 0 || !num_rendered_host) return GSR_EINVAL;
-    *num_rendered_host = 0;
+    if (P < 0 || width <= 0 || height <= 0 || !ticket) return GSR_EINVAL;
+    *ticket = 0;  // 0: nothing was launched, the count is 0
     if (P == 0) return 0;
     if (!means2D || !depths || !radii || !conic_opacity || !compute_locally || !prep) return GSR_EINVAL;
     if (P > RADIX_MAX_N) return GSR_EINVAL;
@@ -562,20 +585,42 @@ extern "C" int gsr_bin_prepare(int P, int width, int height, const float *means2
         sorted_ids = vA;
     }
     const int nbs = gsr_div_up(P, SCAN_TILE);
-    std::lock_guard<std::mutex> guard(g_total_mutex);
     uint32_t *host_total = nullptr;
-    rc = total_word(&host_total);
+    uint32_t seq = 0;
+    rc = total_slot(&host_total, &seq);
     if (rc) return rc;
-    const uint32_t seq = ++g_total_seq ? g_total_seq : ++g_total_seq;  // never 0
     hipLaunchKernelGGL(scan_gather_lookback_kernel, dim3(nbs), dim3(SCAN_THREADS), 0, stream, tt, sorted_ids, offsets,
                        (long long)P, reinterpret_cast<unsigned long long *>(ctrl + L.C.scan_state),
                        reinterpret_cast<uint32_t *>(ctrl + L.C.tickets), nbs, host_total, seq);
     GSR_LAUNCH_CHECK();
+    *ticket = seq;
+    return 0;
+}
+
+extern "C" int gsr_bin_count_wait(uint32_t ticket, int64_t *num_rendered_host, gsr_stream_t stream_) {
+    if (!num_rendered_host) return GSR_EINVAL;
+    *num_rendered_host = 0;
+    if (ticket == 0) return 0;
+    uint32_t *host_total = nullptr;
+    int rc = slot_of_ticket(ticket, &host_total);
+    if (rc) return rc;
     uint32_t total = 0;
-    rc = wait_total(stream, host_total, seq, &total);
+    rc = wait_total(reinterpret_cast<hipStream_t>(stream_), host_total, ticket, &total);
     if (rc) return rc;
     *num_rendered_host = (int64_t)total;
     return 0;
+}
+
+extern "C" int gsr_bin_prepare(int P, int width, int height, const float *means2D, const float *depths,
+                               const int32_t *radii, const float *conic_opacity, const uint8_t *compute_locally,
+                               void *prep, size_t prep_bytes, int64_t *num_rendered_host, gsr_stream_t stream_) {
+    if (!num_rendered_host) return GSR_EINVAL;
+    *num_rendered_host = 0;
+    uint32_t ticket = 0;
+    const int rc = gsr_bin_prepare_async(P, width, height, means2D, depths, radii, conic_opacity, compute_locally, prep,
+                                         prep_bytes, &ticket, stream_);
+    if (rc) return rc;
+    return gsr_bin_count_wait(ticket, num_rendered_host, stream_);
 }
 
 namespace {
@@ -607,10 +652,11 @@ extern "C" size_t gsr_bin_sort_bytes(int P, int64_t num_rendered, int width, int
     return sort_layout(num_rendered, passes < 2 ? 2 : passes).total;  // the (row, column) path always runs 2 passes
 }
 
-extern "C" int gsr_bin_sort(int P, int width, int height, const uint8_t *compute_locally, const void *prep,
-                            int64_t D, void *scratch, size_t scratch_bytes, uint32_t *point_list, int32_t *ranges,
-                            gsr_stream_t stream_) {
-    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+namespace {
+// `bounded`: D is a CAPACITY; the kernels read the pair count from the prep workspace (K4's total) and do nothing past it
+int bin_sort_impl(int P, int width, int height, const uint8_t *compute_locally, const void *prep, int64_t D,
+                  void *scratch, size_t scratch_bytes, uint32_t *point_list, int32_t *ranges, hipStream_t stream,
+                  bool bounded) {
     if (P < 0 || width <= 0 || height <= 0 || D < 0 || !ranges) return GSR_EINVAL;
     const int gx = (width + GSR_BLOCK_X - 1) / GSR_BLOCK_X, gy = (height + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y;
     GSR_HIP(hipMemsetAsync(ranges, 0, sizeof(int32_t) * 2 * (size_t)gx * gy, stream));
@@ -631,21 +677,23 @@ extern "C" int gsr_bin_sort(int P, int width, int height, const uint8_t *compute
     char *ctrl = sbase + S.ctrl;
 
     GSR_HIP(hipMemsetAsync(ctrl, 0, S.C.total, stream));
+    if (bounded && !yx_path(gx, gy)) return GSR_EINVAL;
     if (yx_path(gx, gy)) {
         const int xbits = bits_for(gx), ybits = bits_for(gy);
         const uint32_t *thist = reinterpret_cast<const uint32_t *>(pbase + L.thist);
         const int nb = (int)radix_blocks(D);
+        const uint32_t *D_dev = bounded ? offsets + P : nullptr;
         uint32_t *tickets = reinterpret_cast<uint32_t *>(ctrl + S.C.tickets);
         uint32_t *state = reinterpret_cast<uint32_t *>(ctrl + S.C.radix_state);
         // pass 0 (column digit) fused with the emission: pairs land in (kB, vB); pass 1 (row digit) -> (kA, point_list)
         hipLaunchKernelGGL((emit_scatter_kernel<RADIX_TILE / 512, 512>), dim3(nb), dim3(512), 0, stream, P, (long long)D,
-                           xbits, rects, sorted_ids, offsets, thist, state, tickets + 1, kB, vB);
+                           xbits, rects, sorted_ids, offsets, thist, state, tickets + 1, kB, vB, bounded);
         hipLaunchKernelGGL((radix_onesweep_kernel<RADIX_TILE / 512, 512>), dim3(nb), dim3(512), 0, stream, kB, vB, kA,
                            point_list, (long long)D, xbits, ybits, thist + RADIX_DIGITS,
-                           state + (size_t)nb * RADIX_DIGITS, tickets + 2);
+                           state + (size_t)nb * RADIX_DIGITS, tickets + 2, D_dev);
         hipLaunchKernelGGL(tile_ranges_yx_kernel, dim3(gsr_div_up(gsr_div_up(D, 4), GSR_ONE_DIM_BLOCK)),
                            dim3(GSR_ONE_DIM_BLOCK), 0, stream, (long long)D, gx, xbits, kA, compute_locally,
-                           reinterpret_cast<int2 *>(ranges));
+                           reinterpret_cast<int2 *>(ranges), D_dev);
         GSR_LAUNCH_CHECK();
         return 0;
     }
@@ -662,4 +710,32 @@ extern "C" int gsr_bin_sort(int P, int width, int height, const uint8_t *compute
                        reinterpret_cast<int2 *>(ranges));
     GSR_LAUNCH_CHECK();
     return 0;
+}
+}  // namespace
+
+extern "C" int gsr_bin_sort(int P, int width, int height, const uint8_t *compute_locally, const void *prep,
+                            int64_t D, void *scratch, size_t scratch_bytes, uint32_t *point_list, int32_t *ranges,
+                            gsr_stream_t stream_) {
+    return bin_sort_impl(P, width, height, compute_locally, prep, D, scratch, scratch_bytes, point_list, ranges,
+                         reinterpret_cast<hipStream_t>(stream_), false);
+}
+
+extern "C" int gsr_bin_sort_bounded(int P, int width, int height, const uint8_t *compute_locally, const void *prep,
+                                    int64_t capacity, void *scratch, size_t scratch_bytes, uint32_t *point_list,
+                                    int32_t *ranges, gsr_stream_t stream_) {
+    if (capacity <= 0) return GSR_EINVAL;
+    return bin_sort_impl(P, width, height, compute_locally, prep, capacity, scratch, scratch_bytes, point_list, ranges,
+                         reinterpret_cast<hipStream_t>(stream_), true);
+}
+
+extern "C" int64_t gsr_bin_sort_capacity(int P, size_t scratch_bytes, int width, int height) {
+    if (width <= 0 || height <= 0) return 0;
+    const int gx = (width + GSR_BLOCK_X - 1) / GSR_BLOCK_X, gy = (height + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y;
+    if (!yx_path(gx, gy)) return 0;  // bounded launches exist for the (row, column) path only
+    int64_t lo = 0, hi = RADIX_MAX_N;  // largest D with gsr_bin_sort_bytes(P, D, ...) <= scratch_bytes
+    while (lo < hi) {
+        const int64_t mid = lo + (hi - lo + 1) / 2;
+        if (gsr_bin_sort_bytes(P, mid, width, height) <= scratch_bytes) lo = mid; else hi = mid - 1;
+    }
+    return lo;
 }

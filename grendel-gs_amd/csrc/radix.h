@@ -300,9 +300,15 @@ __global__ void __launch_bounds__(THREADS)
 radix_onesweep_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
                       uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, long long n, int shift,
                       int nbits, const uint32_t *__restrict__ ghist, uint32_t *__restrict__ state,
-                      uint32_t *__restrict__ ticket) {
+                      uint32_t *__restrict__ ticket, const uint32_t *__restrict__ n_dev = nullptr) {
     __shared__ OnesweepSmem<ITEMS, THREADS> sm;
+    if (n_dev) {  // bounded launch: the grid covers a capacity `n`, the true count is on the device
+        const long long d = *n_dev;
+        if (d > n) return;  // does not fit: the caller re-runs with the exact count
+        n = d;
+    }
     const uint32_t bid = onesweep_begin(sm, ticket);
+    if ((long long)bid * (ITEMS * THREADS) >= n) return;  // tiles past the end (bounded launches only)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // wave w owns the contiguous sub-chunk [base + w*ITEMS*64, +ITEMS*64), walked in ITEMS rounds of 64
     const long long wbase = (long long)bid * (ITEMS * THREADS) + (long long)wave * (ITEMS * 64);

@@ -118,7 +118,9 @@ def _ptr(t):
 
 
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # the raw handle of the current stream of the current device (torch.cuda.current_stream() builds a Stream object
+    # through three Python layers: ~10 us per call, and every C-ABI call needs one)
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
 def _f32c(t, name):
@@ -430,6 +432,7 @@ def _bucket(nbytes):
 
 
 _SORT_SCRATCH = {}  # (device index, stream) -> grow-only uint8 buffer
+_MAX_PAIRS = {}     # (device index, stream) -> largest pair count sorted there
 
 
 def _sort_scratch(nbytes, dev):
@@ -450,11 +453,23 @@ def _sort_scratch(nbytes, dev):
 def release_workspaces():
     """drop the cached sort scratch (e.g. before switching to a much smaller scene)"""
     _SORT_SCRATCH.clear()
+    _MAX_PAIRS.clear()
+
+
+_SPECULATIVE_SORT = [True]
+
+
+def set_speculative_sort(on):
+    """True (default): launch the tile sort for the scratch's capacity before the pair count has reached the host
+    (gsr_bin_sort_bounded); False: the reference's order -- read num_rendered, size the buffers, sort."""
+    _SPECULATIVE_SORT[0] = bool(on)
 
 
 def bin_gaussians(means2D, depths, radii, conic_opacity, compute_locally, width, height):
-    """K3-K7: returns (point_list uint32-as-int32 [D], ranges int32 [tiles,2], D).  One host sync
-    (the pair count sizes the sort buffers), like the reference's own num_rendered read-back.
+    """K3-K7: returns (point_list uint32-as-int32 [D], ranges int32 [tiles,2], D).  One host read-back (the pair count
+    D, like the reference's own num_rendered) -- but the GPU does not wait for it: once a view of this size has been
+    sorted, the next sort is launched for the CAPACITY of the scratch kept from then, the kernels take D from device
+    memory, and the host reads D while they run (it only re-sorts if D outgrew the capacity).
     Per tile the list is the reference's (depth, then index) order restricted to the Gaussians that
     can reach alpha >= 1/255 somewhere in the tile's neighbourhood (see include/gsraster.h)."""
     P = means2D.shape[0]
@@ -463,16 +478,34 @@ def bin_gaussians(means2D, depths, radii, conic_opacity, compute_locally, width,
     ranges = torch.empty((gx * gy, 2), dtype=torch.int32, device=dev)
     prep_bytes = lib.gsr_bin_prepare_bytes(P, width, height)
     prep = torch.empty((max(prep_bytes, 4),), dtype=torch.uint8, device=dev)
+    stream = _stream()
+    ticket = ctypes.c_uint32(0)
+    check(lib.gsr_bin_prepare_async(P, width, height, _ptr(means2D), _ptr(depths), _ptr(radii), _ptr(conic_opacity),
+                                    _ptr(compute_locally), _ptr(prep), prep_bytes, ctypes.byref(ticket), stream),
+          "gsr_bin_prepare_async")
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), int(stream.value or 0))
+    cap, point_list = 0, None
+    kept = _SORT_SCRATCH.get(key)
+    if _SPECULATIVE_SORT[0] and kept is not None and ticket.value != 0:
+        # pairs the kept scratch can sort, but no more than the largest count seen here plus some slack (point_list
+        # is allocated at the capacity)
+        cap = min(int(lib.gsr_bin_sort_capacity(P, kept.numel(), width, height)), _bucket(4 * _MAX_PAIRS.get(key, 0)) // 4)
+        if cap > 0:
+            point_list = torch.empty((cap,), dtype=torch.int32, device=dev)
+            check(lib.gsr_bin_sort_bounded(P, width, height, _ptr(compute_locally), _ptr(prep), cap, _ptr(kept),
+                                           kept.numel(), _ptr(point_list), _ptr(ranges), stream), "gsr_bin_sort_bounded")
     D = ctypes.c_int64(0)
-    check(lib.gsr_bin_prepare(P, width, height, _ptr(means2D), _ptr(depths), _ptr(radii), _ptr(conic_opacity),
-                              _ptr(compute_locally), _ptr(prep), prep_bytes, ctypes.byref(D), _stream()),
-          "gsr_bin_prepare")
+    check(lib.gsr_bin_count_wait(ticket, ctypes.byref(D), stream), "gsr_bin_count_wait")
     D = int(D.value)
+    if D > _MAX_PAIRS.get(key, 0):
+        _MAX_PAIRS[key] = D
+    if cap > 0 and D <= cap:
+        return point_list[:max(D, 1)], ranges, D
     sort_bytes = lib.gsr_bin_sort_bytes(P, D, width, height)
     scratch = _sort_scratch(max(sort_bytes, 4), dev)
     point_list = torch.empty((_bucket(max(D, 1) * 4) // 4,), dtype=torch.int32, device=dev)[:max(D, 1)]
     check(lib.gsr_bin_sort(P, width, height, _ptr(compute_locally), _ptr(prep), D, _ptr(scratch), sort_bytes,
-                           _ptr(point_list), _ptr(ranges), _stream()), "gsr_bin_sort")
+                           _ptr(point_list), _ptr(ranges), stream), "gsr_bin_sort")
     return point_list, ranges, D
 
 

@@ -31,6 +31,12 @@ SIGNATURES = {
     "gsr_bin_sort_bytes": (c_size_t, [c_int, c_int64, c_int, c_int]),
     "gsr_bin_sort": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_size_t, c_void_p,
                              c_void_p, c_void_p]),
+    "gsr_bin_prepare_async": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_size_t, ctypes.POINTER(ctypes.c_uint32), c_void_p]),
+    "gsr_bin_count_wait": (c_int, [ctypes.c_uint32, ctypes.POINTER(c_int64), c_void_p]),
+    "gsr_bin_sort_capacity": (c_int64, [c_int, c_size_t, c_int, c_int]),
+    "gsr_bin_sort_bounded": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_size_t, c_void_p,
+                                     c_void_p, c_void_p]),
     "gsr_render_forward": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gsr_l1_ssim_num_partials": (c_int, [c_int, c_int, c_int]),
@@ -70,7 +76,7 @@ SIGNATURES = {
     "gsr_render_backward": (c_int, [c_int, c_int, c_int] + [c_void_p] * 12),
 }
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 def _load():

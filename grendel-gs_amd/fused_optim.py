@@ -10,7 +10,7 @@ import ctypes
 
 import torch
 
-from diff_gaussian_rasterization import _lib, kernel_timer
+from diff_gaussian_rasterization import _lib, _stream, kernel_timer
 
 
 class FusedAdam(torch.optim.Optimizer):
@@ -25,11 +25,13 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        batch = []
+        batch, steps = [], []
         for group in self.param_groups:
             b1, b2 = group["betas"]
+            lr, eps = group["lr"], group["eps"]
             for p in group["params"]:
-                if p.grad is None:
+                g = p.grad
+                if g is None:
                     continue
                 if not p.is_cuda:
                     raise RuntimeError("FusedAdam: parameters must live on the gfx950 device (no CPU fallback)")
@@ -38,25 +40,28 @@ class FusedAdam(torch.optim.Optimizer):
                     st["step"] = torch.tensor(0.0)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["step"] += 1
-                g = p.grad
-                if not (p.is_contiguous() and g.is_contiguous() and p.dtype == torch.float32 and
-                        g.dtype == torch.float32):
+                if not (p.dtype == torch.float32 and g.dtype == torch.float32 and p.is_contiguous() and
+                        g.is_contiguous()):
                     raise RuntimeError("FusedAdam: dense fp32 parameters and gradients expected")
-                batch.append((p, g, st, float(group["lr"]), float(b1), float(b2), float(group["eps"])))
+                steps.append(st["step"])
+                batch.append((p, g, st, lr, b1, b2, eps))
+        if steps:
+            torch._foreach_add_(steps, 1)  # host tensors, as in the stock optimizer's state
         for i in range(0, len(batch), 16):
             part = batch[i:i + 16]
             K = len(part)
             VP, D, I64 = ctypes.c_void_p * K, ctypes.c_double * K, ctypes.c_int64 * K
             dev = part[0][0].device
-            if any(b[0].device != dev for b in part):
-                raise RuntimeError("FusedAdam: all parameters of one step must live on one device")
-            with torch.cuda.device(dev), kernel_timer.range("adam", numel=sum(b[0].numel() for b in part)):
+            numels = [b[0].numel() for b in part]
+            for b in part:
+                if b[0].device != dev:
+                    raise RuntimeError("FusedAdam: all parameters of one step must live on one device")
+            with torch.cuda.device(dev), kernel_timer.range("adam", numel=sum(numels)):
                 _lib.check(_lib.lib.gsr_adam_step_multi(
-                    K, I64(*[b[0].numel() for b in part]), VP(*[b[0].data_ptr() for b in part]),
+                    K, I64(*numels), VP(*[b[0].data_ptr() for b in part]),
                     VP(*[b[1].data_ptr() for b in part]), VP(*[b[2]["exp_avg"].data_ptr() for b in part]),
                     VP(*[b[2]["exp_avg_sq"].data_ptr() for b in part]), D(*[b[3] for b in part]),
                     D(*[b[4] for b in part]), D(*[b[5] for b in part]), D(*[b[6] for b in part]),
                     I64(*[int(b[2]["step"].item()) for b in part]), float(grad_scale),
-                    ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "gsr_adam_step_multi")
+                    _stream()), "gsr_adam_step_multi")
         return loss

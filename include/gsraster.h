@@ -110,6 +110,27 @@ size_t gsr_bin_sort_bytes(int P, int64_t num_rendered, int width, int height);
 int gsr_bin_sort(int P, int width, int height, const uint8_t *compute_locally, const void *prep,
                  int64_t num_rendered, void *scratch, size_t scratch_bytes, uint32_t *point_list, int32_t *ranges,
                  gsr_stream_t stream);
+/* The same two steps WITHOUT the idle GPU between them.  The reference's rasterizer (and gsr_bin_prepare above) reads
+ * num_rendered back to size its sort buffers, and the GPU has nothing to do until the host has seen the count and
+ * launched the sort (~25-35 us per view).  Callers that keep a grow-only scratch can instead
+ *   gsr_bin_prepare_async  : launch K3-K4; `*ticket` identifies the count (0 = P was 0, the count is 0);
+ *   gsr_bin_sort_bounded   : launch the sort for up to `capacity` pairs -- the kernels read the pair count D from the
+ *                            prep workspace ON THE DEVICE and do nothing past it; if D > capacity they write nothing
+ *                            useful, and the caller, who learns D from gsr_bin_count_wait, must run gsr_bin_sort with
+ *                            buffers of the right size.  point_list must hold `capacity` words.  Only frames of
+ *                            <= 256 x 256 tiles (GSR_EINVAL otherwise: use gsr_bin_sort);
+ *   gsr_bin_count_wait     : the pair count of `ticket` (polls a pinned word; up to 64 counts may be outstanding per
+ *                            device);
+ *   gsr_bin_sort_capacity  : the largest num_rendered whose gsr_bin_sort_bytes fits `scratch_bytes` (0 when bounded
+ *                            launches do not apply to this frame size). */
+int gsr_bin_prepare_async(int P, int width, int height, const float *means2D, const float *depths, const int32_t *radii,
+                          const float *conic_opacity, const uint8_t *compute_locally, void *prep, size_t prep_bytes,
+                          uint32_t *ticket, gsr_stream_t stream);
+int gsr_bin_count_wait(uint32_t ticket, int64_t *num_rendered_host, gsr_stream_t stream);
+int64_t gsr_bin_sort_capacity(int P, size_t scratch_bytes, int width, int height);
+int gsr_bin_sort_bounded(int P, int width, int height, const uint8_t *compute_locally, const void *prep,
+                         int64_t capacity, void *scratch, size_t scratch_bytes, uint32_t *point_list, int32_t *ranges,
+                         gsr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K8  composite forward -- the rest of render_gaussians (gaussian_renderer/__init__.py:1271-1282).

@@ -111,6 +111,49 @@ def test_binning_is_ordered_subsequence_of_reference_lists(device, N, W, H, sc, 
     print(f"pairs kept {kept_total}, dropped {dropped_total} of {pl_ref.numel()}")
 
 
+def test_speculative_sort_equals_the_sized_sort(device):
+    """gsr_bin_sort_bounded (sort launched for the scratch's capacity, pair count read on the device) gives bit-identical
+    lists and ranges to gsr_bin_sort with the count read back first -- when the count fits the capacity, when it is far
+    below it, and (through the fall-back) when it outgrows it; also with an empty view"""
+    import diff_gaussian_rasterization as dgr
+    from oracle import cref as C
+
+    W, H = 333, 211
+    cam = S.orbit_cameras(4, W, H)[1]
+
+    def inputs(N, sc, seed):
+        g = S.make_gaussians(N, W, H, seed=seed, scale_coef=sc)
+        m2, rgb, co, radii, depths, _, _ = C.preprocess_forward(*[g[k] for k in KEYS], **cam_kwargs(cam))
+        mask = _full_mask(cam)
+        mask[2, :] = False
+        return [t.to(device) for t in (m2, depths, radii, co, mask.view(-1).to(torch.uint8))]
+
+    small, large, larger = inputs(3000, 0.02, 5), inputs(9000, 0.03, 6), inputs(9000, 0.06, 7)
+    empty = [t.clone() for t in small]
+    empty[2].zero_()  # no Gaussian is visible: D = 0
+    ref = {}
+    dgr.release_workspaces()
+    dgr.set_speculative_sort(False)
+    try:
+        for name, x in (("small", small), ("large", large), ("larger", larger), ("empty", empty)):
+            pl, rg, D = dgr.bin_gaussians(*x, W, H)
+            ref[name] = (pl.clone(), rg.clone(), D)
+        assert ref["small"][2] < ref["large"][2] < ref["larger"][2] and ref["empty"][2] == 0
+        dgr.release_workspaces()
+        dgr.set_speculative_sort(True)
+        # first call sizes the scratch (no capacity yet); then: fits / far below / outgrows (falls back, grows) / empty / fits
+        for name in ("large", "large", "small", "larger", "empty", "large", "larger"):
+            x = {"small": small, "large": large, "larger": larger, "empty": empty}[name]
+            pl, rg, D = dgr.bin_gaussians(*x, W, H)
+            assert D == ref[name][2], name
+            assert torch.equal(rg, ref[name][1]), name
+            if D:
+                assert pl.numel() == D and torch.equal(pl, ref[name][0]), name
+    finally:
+        dgr.set_speculative_sort(True)
+        dgr.release_workspaces()
+
+
 @pytest.mark.parametrize("N,W,H,sc,seed,ci", SCENES)
 @pytest.mark.parametrize("bgv,sh_degree", [(0.0, 3), (0.7, 3), (0.0, 0), (0.7, 1), (0.0, 2)])
 def test_full_chain_matches_c_oracle(device, N, W, H, sc, seed, ci, bgv, sh_degree):
