@@ -297,7 +297,7 @@ emit_pairs_kernel(int P, long long D, int gx, int tiles, const uint2 *__restrict
 // at a time) and runs the pass-0 scatter on them directly.  All tiles of the rect are emitted, computed locally
 // or not: K7 leaves the ranges of tiles that are not computed locally empty, and K8 / K10 never look at them.
 template <int ITEMS, int THREADS>
-__global__ void __launch_bounds__(THREADS)
+__global__ void __launch_bounds__(THREADS, 8)  // <= 64 VGPRs: four 8-wave workgroups per CU
 emit_scatter_kernel(int P, long long D, int xbits, const uint2 *__restrict__ rects,
                     const uint32_t *__restrict__ sorted_ids, const uint32_t *__restrict__ offsets,
                     const uint32_t *__restrict__ ghist, uint32_t *__restrict__ state, uint32_t *__restrict__ ticket,
@@ -309,9 +309,12 @@ emit_scatter_kernel(int P, long long D, int xbits, const uint2 *__restrict__ rec
         if (d > D) return;
         D = d;
     }
-    __shared__ uint32_t s_off[WAVES][65];
-    __shared__ uint32_t s_g[WAVES][64];
-    __shared__ uint2 s_rect[WAVES][64];
+    // the decode's per-wave windows live in the pass's staging area (it is only written behind the workgroup barriers
+    // of onesweep_scatter, when every wave has finished decoding): no LDS of their own, four workgroups per CU
+    static_assert(260 * WAVES <= ITEMS * THREADS, "windows fit the key staging area");
+    uint32_t *const s_off = sm.skey + 260 * (threadIdx.x >> 6);    // [65]
+    uint32_t *const s_g = s_off + 66;                              // [64]
+    uint2 *const s_rect = reinterpret_cast<uint2 *>(s_off + 130);  // [64], 8-byte aligned
     const uint32_t bid = onesweep_begin(sm, ticket);
     if ((long long)bid * (ITEMS * THREADS) >= D) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -349,10 +352,10 @@ emit_scatter_kernel(int P, long long D, int xbits, const uint2 *__restrict__ rec
                     const uint32_t end = offsets[min(j + 1, P)];
                     const uint32_t g = (j < P && end > off) ? sorted_ids[j] : 0u;
                     __builtin_amdgcn_wave_barrier();
-                    s_off[wave][lane] = off;
-                    if (lane == 63) s_off[wave][64] = end;
-                    s_g[wave][lane] = g;
-                    s_rect[wave][lane] = (j < P && end > off) ? rects[g] : make_uint2(0u, 0u);
+                    s_off[lane] = off;
+                    if (lane == 63) s_off[64] = end;
+                    s_g[lane] = g;
+                    s_rect[lane] = (j < P && end > off) ? rects[g] : make_uint2(0u, 0u);
                     __builtin_amdgcn_wave_barrier();
                     wend = __builtin_amdgcn_readlane(end, 63);
                     have_window = true;
@@ -362,14 +365,14 @@ emit_scatter_kernel(int P, long long D, int xbits, const uint2 *__restrict__ rec
 #pragma unroll
                     for (int it = 0; it < 6; it++) {
                         const int mid = (a + bnd + 1) >> 1;
-                        if (s_off[wave][mid] <= s) a = mid; else bnd = mid - 1;
+                        if (s_off[mid] <= s) a = mid; else bnd = mid - 1;
                     }
-                    const uint2 rc = s_rect[wave][a];
-                    const uint32_t t = s - s_off[wave][a];
+                    const uint2 rc = s_rect[a];
+                    const uint32_t t = s - s_off[a];
                     const uint32_t minx = rc.x & 0xFFFFu, w = (rc.x >> 16) - minx, miny = rc.y & 0xFFFFu;
                     const uint32_t q = t / w;
                     key[r] = ((miny + q) << xbits) | (minx + (t - q * w));
-                    val[r] = s_g[wave][a];
+                    val[r] = s_g[a];
                     pending = false;
                 }
             }

@@ -171,7 +171,10 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_n(uint32_t v, uint32_t 
 // LDS of one radix pass workgroup
 template <int ITEMS, int THREADS>
 struct OnesweepSmem {
-    uint32_t wtab[THREADS / 64][RADIX_DIGITS];
+    // per-wave digit counts, then per-wave cursors: 16-bit (a wave owns <= 512 pairs, a cursor is < 4096), so that the
+    // workgroup's LDS stays under 40 KB and FOUR workgroups fit a CU (the passes are latency chains: throughput is
+    // the number of workgroups in flight).  The histogram adds go through the 32-bit view (two digits per word).
+    uint16_t wtab[THREADS / 64][RADIX_DIGITS];
     uint32_t gbase[RADIX_DIGITS];  // global start of the digit's run minus its local start
     uint32_t skey[ITEMS * THREADS], sval[ITEMS * THREADS];
     uint32_t scan_tmp[THREADS / 64];
@@ -206,7 +209,10 @@ __device__ __forceinline__ void onesweep_scatter(OnesweepSmem<ITEMS, THREADS> &s
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
         const long long j = wbase + r * 64 + lane;
-        if (j < n) atomicAdd(&sm.wtab[wave][(key[r] >> shift) & mask], 1u);
+        if (j < n) {
+            const uint32_t dg = (key[r] >> shift) & mask;
+            atomicAdd(reinterpret_cast<uint32_t *>(sm.wtab[wave]) + (dg >> 1), 1u << (16 * (dg & 1u)));  // no carry: <= 512
+        }
     }
     __syncthreads();
     {  // thread d: digit d
@@ -255,7 +261,7 @@ __device__ __forceinline__ void onesweep_scatter(OnesweepSmem<ITEMS, THREADS> &s
             sm.gbase[d] = dstart + excl - run;
 #pragma unroll
             for (int w = 0; w < WAVES; w++) {
-                sm.wtab[w][d] = run;
+                sm.wtab[w][d] = (uint16_t)run;
                 run += cnt[w];
             }
         }
@@ -269,11 +275,11 @@ __device__ __forceinline__ void onesweep_scatter(OnesweepSmem<ITEMS, THREADS> &s
         const uint32_t d = (key[r] >> shift) & mask;
         const unsigned long long m = match_digit(d, valid, nbits);
         const uint32_t rank = __popcll(m & lt);
-        volatile uint32_t *cursor = sm.wtab[wave];
+        volatile uint16_t *cursor = sm.wtab[wave];
         uint32_t pos = 0;
         if (valid) pos = cursor[d] + rank;
         __builtin_amdgcn_wave_barrier();
-        if (valid && rank == 0) cursor[d] = pos + (uint32_t)__popcll(m);  // group leader advances the cursor
+        if (valid && rank == 0) cursor[d] = (uint16_t)(pos + (uint32_t)__popcll(m));  // group leader advances the cursor
         __builtin_amdgcn_wave_barrier();
         if (valid) {
             sm.skey[pos] = key[r];
@@ -296,7 +302,7 @@ __device__ __forceinline__ void onesweep_scatter(OnesweepSmem<ITEMS, THREADS> &s
 }
 
 template <int ITEMS, int THREADS>
-__global__ void __launch_bounds__(THREADS)
+__global__ void __launch_bounds__(THREADS, THREADS >= 1024 ? 4 : 8)  // 8-wave workgroups: <= 64 VGPRs, four per CU
 radix_onesweep_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
                       uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, long long n, int shift,
                       int nbits, const uint32_t *__restrict__ ghist, uint32_t *__restrict__ state,
