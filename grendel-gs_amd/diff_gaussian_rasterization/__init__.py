@@ -16,6 +16,7 @@ PyTorch is used for device memory, streams and autograd plumbing only; every ker
 the HIP library and the module refuses to work without it (no CPU / eager fallback).
 """
 import ctypes
+import os
 from typing import NamedTuple
 
 import torch
@@ -456,7 +457,7 @@ def release_workspaces():
     _MAX_PAIRS.clear()
 
 
-_SPECULATIVE_SORT = [True]
+_SPECULATIVE_SORT = [os.environ.get("GSR_SPECULATIVE_SORT", "1") != "0"]  # env: A/B measurements only
 
 
 def set_speculative_sort(on):
