@@ -219,18 +219,30 @@ def set_balance_timing(mode):
 
 
 def _host_group():
-    """a gloo group over the same ranks: the timing all-gather is a host-only operation"""
+    """a gloo group over the same ranks: the timing all-gather is a host-only operation.  Returns None when gloo
+    cannot be brought up (the caller then gathers through the device group, as the reference does)"""
+    import os
+
     import torch.distributed as dist
 
     if _BALANCE["group"] is None:
-        _BALANCE["group"] = dist.new_group(backend="gloo")  # collective: every rank makes its first call here
-    return _BALANCE["group"]
+        if os.environ.get("LOCAL_WORLD_SIZE") == os.environ.get("WORLD_SIZE"):
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # one node: the container hostname may not resolve
+        try:
+            _BALANCE["group"] = dist.new_group(backend="gloo")  # collective: every rank makes its first call here
+        except Exception as e:  # noqa: BLE001
+            print(f"[workload_division] no host-side gloo group ({type(e).__name__}: {e}); timing gather stays on the "
+                  f"device group", flush=True)
+            _BALANCE["group"] = False
+    return _BALANCE["group"] or None
 
 
 def _gather_times_on_host(mine):
     import torch.distributed as dist
 
     g = _host_group()
+    if g is None:
+        return utils.our_allgather_among_cpu_processes_float_list(mine, utils.DEFAULT_GROUP)
     out = [None] * g.size()
     dist.all_gather_object(out, [float(x) for x in mine], group=g)
     return out
