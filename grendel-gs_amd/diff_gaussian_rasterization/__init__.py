@@ -15,6 +15,7 @@ C-ABI of include/gsraster.h (libgsraster.so, hand-written HIP for gfx950):
 PyTorch is used for device memory, streams and autograd plumbing only; every kernel on the path is in
 the HIP library and the module refuses to work without it (no CPU / eager fallback).
 """
+import contextlib
 import ctypes
 import os
 from typing import NamedTuple
@@ -100,6 +101,73 @@ class _KernelTimer:
 
 
 kernel_timer = _KernelTimer()
+
+
+
+# ------------------------------------------------------------------ native GPU-timer logs (--zhx_time)
+# The reference's rasterizer writes per-stage GPU times of the logged iterations to
+# <log_folder>/gpu_time_ws=<W>_rk=<r>.log when cuda_args["zhx_time"] is "True" (gaussian_renderer/__init__.py:524-538);
+# analyze_statistic.py:747-805 parses "it=<n>, ..." headers followed by "<stage name>: <ms> ms" lines and :1972-1991
+# lists the stage names.  The same file is written here from HIP events around the C-ABI calls.  Stages this build has
+# fused report 0: "24 ...updateTileTouched" = K3 + depth sort + offsets scan (the reference's 24 + 30), "50 SortPairs"
+# = emission + tile sort + ranges (its 40 + 50 + 60).
+_ZHX_STAGES = ["10 preprocess time", "24 updateDistributedStatLocally.updateTileTouched time", "30 InclusiveSum time",
+               "40 duplicateWithKeys time", "50 SortPairs time", "60 identifyTileRanges time", "70 render time",
+               "81 sum_n_render time", "82 sum_n_consider time", "83 sum_n_contrib time", "b10 render time",
+               "b20 preprocess time"]
+_NULL_RANGE = contextlib.nullcontext()
+
+
+def _zhx_on(ca):
+    if not isinstance(ca, dict) or str(ca.get("zhx_time")) != "True" or ca.get("mode") != "train":
+        return False
+    try:
+        it, every = int(ca.get("iteration", -1)), max(int(ca.get("log_interval", 1)), 1)
+    except (TypeError, ValueError):
+        return False
+    return bool(ca.get("log_folder")) and it >= 0 and (every == 1 or it % every == 1)
+
+
+class _ZhxRange:
+    def __init__(self, targets, label):
+        self.targets, self.label = targets, label
+
+    def __enter__(self):
+        self.e0 = torch.cuda.Event(enable_timing=True)
+        self.e1 = torch.cuda.Event(enable_timing=True)
+        self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        self.e1.record()
+        for ca in self.targets:
+            ca.setdefault("_zhx_events", []).append((self.label, self.e0, self.e1, 1.0 / len(self.targets)))
+            if self.label == "b20 preprocess time":
+                _zhx_flush(ca)
+
+
+def zhx_range(cuda_args, label):
+    """HIP-event bracket of one stage for every cuda_args dict (one, or a list for a camera batch) that asks for the
+    native timer log on this iteration; a no-op context otherwise"""
+    cas = cuda_args if isinstance(cuda_args, (list, tuple)) else (cuda_args,)
+    targets = [ca for ca in cas if _zhx_on(ca)]
+    return _ZhxRange(targets, label) if targets else _NULL_RANGE
+
+
+def _zhx_flush(ca):
+    events = ca.pop("_zhx_events", [])
+    if not events:
+        return
+    events[-1][2].synchronize()
+    ms = dict.fromkeys(_ZHX_STAGES, 0.0)
+    for label, e0, e1, share in events:
+        ms[label] = ms.get(label, 0.0) + e0.elapsed_time(e1) * share
+    os.makedirs(ca["log_folder"], exist_ok=True)
+    path = os.path.join(ca["log_folder"], f"gpu_time_ws={ca.get('world_size', '1')}_rk={ca.get('global_rank', '0')}.log")
+    with open(path, "a") as f:
+        f.write(f"it={ca.get('iteration')}, mode={ca.get('mode')}, mp_rank={ca.get('mp_rank', '0')}\n")
+        for label in _ZHX_STAGES:
+            f.write(f"{label}: {ms[label]:.6f} ms\n")
 
 
 def local_pixels(mask, W, H):
@@ -188,7 +256,9 @@ class _PreprocessGaussians(torch.autograd.Function):
         conic_opacity = torch.empty((P, 4), dtype=torch.float32, device=dev)
         rgb = torch.empty((P, 3), dtype=torch.float32, device=dev)
         clamped = torch.empty((P, 3), dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev), kernel_timer.range("preprocess_forward", N=P, B=1, M=M):
+        ctx.cuda_args = cuda_args
+        with torch.cuda.device(dev), kernel_timer.range("preprocess_forward", N=P, B=1, M=M), \
+                zhx_range(cuda_args, "10 preprocess time"):
             check(lib.gsr_preprocess_forward(
                 P, int(rs.sh_degree), M, _ptr(means3D), _ptr(scales), float(rs.scale_modifier), _ptr(rotations),
                 _ptr(shs), _ptr(opacities), _ptr(view), _ptr(proj), _ptr(campos), int(rs.image_width),
@@ -213,7 +283,8 @@ class _PreprocessGaussians(torch.autograd.Function):
         d_rot = torch.empty((P, 4), dtype=torch.float32, device=dev)
         d_shs = torch.empty((P, M, 3), dtype=torch.float32, device=dev)
         d_opac = torch.empty((P, 1), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev), kernel_timer.range("preprocess_backward", N=P, B=1, M=M):
+        with torch.cuda.device(dev), kernel_timer.range("preprocess_backward", N=P, B=1, M=M), \
+                zhx_range(ctx.cuda_args, "b20 preprocess time"):
             check(lib.gsr_preprocess_backward(
                 P, int(rs.sh_degree), M, _ptr(means3D), _ptr(scales), float(rs.scale_modifier), _ptr(rotations),
                 _ptr(shs), _ptr(view), _ptr(proj), _ptr(campos), int(rs.image_width), int(rs.image_height),
@@ -248,7 +319,9 @@ class _PreprocessGaussiansRaw(torch.autograd.Function):
         conic_opacity = torch.empty((P, 4), dtype=torch.float32, device=dev)
         rgb = torch.empty((P, 3), dtype=torch.float32, device=dev)
         clamped = torch.empty((P, 3), dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev), kernel_timer.range("preprocess_forward", N=P, B=1, M=M):
+        ctx.cuda_args = cuda_args
+        with torch.cuda.device(dev), kernel_timer.range("preprocess_forward", N=P, B=1, M=M), \
+                zhx_range(cuda_args, "10 preprocess time"):
             check(lib.gsr_preprocess_forward_raw(
                 P, int(rs.sh_degree), M, _ptr(xyz), _ptr(scaling), float(rs.scale_modifier), _ptr(rotation),
                 _ptr(features_dc), _ptr(features_rest), _ptr(opacity), _ptr(view), _ptr(proj), _ptr(campos),
@@ -275,7 +348,8 @@ class _PreprocessGaussiansRaw(torch.autograd.Function):
         d_dc = torch.empty((P, 1, 3), dtype=torch.float32, device=dev)
         d_rest = torch.empty((P, M - 1, 3), dtype=torch.float32, device=dev)
         d_opac = torch.empty((P, 1), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev), kernel_timer.range("preprocess_backward", N=P, B=1, M=M):
+        with torch.cuda.device(dev), kernel_timer.range("preprocess_backward", N=P, B=1, M=M), \
+                zhx_range(ctx.cuda_args, "b20 preprocess time"):
             check(lib.gsr_preprocess_backward_raw(
                 P, int(rs.sh_degree), M, _ptr(xyz), _ptr(scaling), float(rs.scale_modifier), _ptr(rotation),
                 _ptr(f_dc), _ptr(f_rest), _ptr(opacity), _ptr(view), _ptr(proj), _ptr(campos), int(rs.image_width),
@@ -318,11 +392,12 @@ class _PreprocessGaussiansRawBatched(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xyz, scaling, rotation, features_dc, features_rest, opacity, cams, sh_degree, scale_modifier,
-                width, height, tanfov0):
+                width, height, tanfov0, cuda_args_list=None):
         xyz, scaling, rotation = _f32c(xyz, "xyz"), _f32c(scaling, "scaling"), _f32c(rotation, "rotation")
         features_dc, features_rest = _f32c(features_dc, "features_dc"), _f32c(features_rest, "features_rest")
         opacity, cams = _f32c(opacity, "opacity"), _f32c(cams, "cams")
         ctx.tanfov0 = tanfov0
+        ctx.cuda_args_list = cuda_args_list
         ctx.set_materialize_grads(False)  # unused outputs arrive as None, not as zero-filled tensors
         P, B = xyz.shape[0], cams.shape[0]
         if cams.dim() != 2 or cams.shape[1] != 40:
@@ -336,7 +411,8 @@ class _PreprocessGaussiansRawBatched(torch.autograd.Function):
         conic_opacity = torch.empty((B, P, 4), dtype=torch.float32, device=dev)
         rgb = torch.empty((B, P, 3), dtype=torch.float32, device=dev)
         clamped = torch.empty((B, P, 3), dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev), kernel_timer.range("preprocess_forward", N=P, B=B, M=M):
+        with torch.cuda.device(dev), kernel_timer.range("preprocess_forward", N=P, B=B, M=M), \
+                zhx_range(cuda_args_list, "10 preprocess time"):
             check(lib.gsr_preprocess_forward_raw_batched(
                 P, B, int(sh_degree), M, _ptr(xyz), _ptr(scaling), float(scale_modifier), _ptr(rotation),
                 _ptr(features_dc), _ptr(features_rest), _ptr(opacity), _ptr(cams), int(width), int(height),
@@ -391,7 +467,8 @@ class _PreprocessGaussiansRawBatched(torch.autograd.Function):
         d_dc = torch.empty((P, 1, 3), dtype=torch.float32, device=dev)
         d_rest = torch.empty((P, M - 1, 3), dtype=torch.float32, device=dev)
         d_opac = torch.empty((P, 1), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev), kernel_timer.range("preprocess_backward", N=P, B=B, M=M):
+        with torch.cuda.device(dev), kernel_timer.range("preprocess_backward", N=P, B=B, M=M), \
+                zhx_range(ctx.cuda_args_list, "b20 preprocess time"):
             if B == 1 and ctx.tanfov0 is not None:
                 # single camera: the leaner one-camera kernel (no accumulators); camera fields are slices of `cams`
                 base = cams.data_ptr()
@@ -407,16 +484,16 @@ class _PreprocessGaussiansRawBatched(torch.autograd.Function):
                     _ptr(opacity), _ptr(cams), W, H, _ptr(radii), _ptr(cov3D), _ptr(clamped), _ptr(g_means2D),
                     _ptr(g_conic_opacity), _ptr(g_rgb), gstride, _ptr(d_xyz), _ptr(d_scaling), _ptr(d_rot),
                     _ptr(d_dc), _ptr(d_rest), _ptr(d_opac), _stream()), "gsr_preprocess_backward_raw_batched")
-        return d_xyz, d_scaling, d_rot, d_dc, d_rest, d_opac, None, None, None, None, None, None
+        return d_xyz, d_scaling, d_rot, d_dc, d_rest, d_opac, None, None, None, None, None, None, None
 
 
 def preprocess_gaussians_raw_batched(xyz, scaling, rotation, features_dc, features_rest, opacity, cams, sh_degree,
-                                     scale_modifier, width, height, tanfov0=None):
+                                     scale_modifier, width, height, tanfov0=None, cuda_args_list=None):
     """-> per-camera lists (means2D [P,2], rgb [P,3], conic_opacity [P,4], radii int32 [P], depths [P]) x B for the B
     cameras packed in `cams` [B,40] (pack_camera); entry k of each list is a dense view of a camera-major [B,P,.]
     buffer.  Extension of this build used by the gaussian_renderer mirror."""
     flat = _PreprocessGaussiansRawBatched.apply(xyz, scaling, rotation, features_dc, features_rest, opacity, cams,
-                                                sh_degree, scale_modifier, width, height, tanfov0)
+                                                sh_degree, scale_modifier, width, height, tanfov0, cuda_args_list)
     return tuple([flat[5 * k + c] for k in range(cams.shape[0])] for c in range(5))
 
 
@@ -466,7 +543,7 @@ def set_speculative_sort(on):
     _SPECULATIVE_SORT[0] = bool(on)
 
 
-def bin_gaussians(means2D, depths, radii, conic_opacity, compute_locally, width, height):
+def bin_gaussians(means2D, depths, radii, conic_opacity, compute_locally, width, height, cuda_args=None):
     """K3-K7: returns (point_list uint32-as-int32 [D], ranges int32 [tiles,2], D).  One host read-back (the pair count
     D, like the reference's own num_rendered) -- but the GPU does not wait for it: once a view of this size has been
     sorted, the next sort is launched for the CAPACITY of the scratch kept from then, the kernels take D from device
@@ -481,9 +558,10 @@ def bin_gaussians(means2D, depths, radii, conic_opacity, compute_locally, width,
     prep = torch.empty((max(prep_bytes, 4),), dtype=torch.uint8, device=dev)
     stream = _stream()
     ticket = ctypes.c_uint32(0)
-    check(lib.gsr_bin_prepare_async(P, width, height, _ptr(means2D), _ptr(depths), _ptr(radii), _ptr(conic_opacity),
-                                    _ptr(compute_locally), _ptr(prep), prep_bytes, ctypes.byref(ticket), stream),
-          "gsr_bin_prepare_async")
+    with zhx_range(cuda_args, "24 updateDistributedStatLocally.updateTileTouched time"):
+        check(lib.gsr_bin_prepare_async(P, width, height, _ptr(means2D), _ptr(depths), _ptr(radii), _ptr(conic_opacity),
+                                        _ptr(compute_locally), _ptr(prep), prep_bytes, ctypes.byref(ticket), stream),
+              "gsr_bin_prepare_async")
     key = (dev.index if dev.index is not None else torch.cuda.current_device(), int(stream.value or 0))
     cap, point_list = 0, None
     kept = _SORT_SCRATCH.get(key)
@@ -493,8 +571,10 @@ def bin_gaussians(means2D, depths, radii, conic_opacity, compute_locally, width,
         cap = min(int(lib.gsr_bin_sort_capacity(P, kept.numel(), width, height)), _bucket(4 * _MAX_PAIRS.get(key, 0)) // 4)
         if cap > 0:
             point_list = torch.empty((cap,), dtype=torch.int32, device=dev)
-            check(lib.gsr_bin_sort_bounded(P, width, height, _ptr(compute_locally), _ptr(prep), cap, _ptr(kept),
-                                           kept.numel(), _ptr(point_list), _ptr(ranges), stream), "gsr_bin_sort_bounded")
+            with zhx_range(cuda_args, "50 SortPairs time"):
+                check(lib.gsr_bin_sort_bounded(P, width, height, _ptr(compute_locally), _ptr(prep), cap, _ptr(kept),
+                                               kept.numel(), _ptr(point_list), _ptr(ranges), stream),
+                      "gsr_bin_sort_bounded")
     D = ctypes.c_int64(0)
     check(lib.gsr_bin_count_wait(ticket, ctypes.byref(D), stream), "gsr_bin_count_wait")
     D = int(D.value)
@@ -505,8 +585,9 @@ def bin_gaussians(means2D, depths, radii, conic_opacity, compute_locally, width,
     sort_bytes = lib.gsr_bin_sort_bytes(P, D, width, height)
     scratch = _sort_scratch(max(sort_bytes, 4), dev)
     point_list = torch.empty((_bucket(max(D, 1) * 4) // 4,), dtype=torch.int32, device=dev)[:max(D, 1)]
-    check(lib.gsr_bin_sort(P, width, height, _ptr(compute_locally), _ptr(prep), D, _ptr(scratch), sort_bytes,
-                           _ptr(point_list), _ptr(ranges), stream), "gsr_bin_sort")
+    with zhx_range(cuda_args, "50 SortPairs time"):
+        check(lib.gsr_bin_sort(P, width, height, _ptr(compute_locally), _ptr(prep), D, _ptr(scratch), sort_bytes,
+                               _ptr(point_list), _ptr(ranges), stream), "gsr_bin_sort")
     return point_list, ranges, D
 
 
@@ -543,14 +624,15 @@ class _RenderGaussians(torch.autograd.Function):
                 ev1 = torch.cuda.Event(enable_timing=True)
                 ev0.record()
             with kernel_timer.range("binning", P=P, tiles=gx * gy) as kt:
-                point_list, ranges, D = bin_gaussians(means2D, depths, radii, conic_opacity, mask, W, H)
+                point_list, ranges, D = bin_gaussians(means2D, depths, radii, conic_opacity, mask, W, H, cuda_args)
                 kt.meta["D"] = D
             out = torch.empty((3, H, W), dtype=torch.float32, device=dev)
             final_T = torch.empty((H, W), dtype=torch.float32, device=dev)
             n_contrib = torch.empty((H, W), dtype=torch.int32, device=dev)
             # bench bookkeeping: the launch's local pixel count is derived from the mask AFTER the run (no sync here)
             ctx.px_meta = dict(mask=mask, W=W, H=H) if kernel_timer.enabled else {}
-            with kernel_timer.range("composite_forward", P=P, D=D, **ctx.px_meta):
+            ctx.cuda_args = cuda_args
+            with kernel_timer.range("composite_forward", P=P, D=D, **ctx.px_meta), zhx_range(cuda_args, "70 render time"):
                 check(lib.gsr_render_forward(P, W, H, _ptr(ranges), _ptr(point_list), _ptr(means2D),
                                              _ptr(conic_opacity), _ptr(rgb), _ptr(mask), _ptr(bg), _ptr(out),
                                              _ptr(final_T), _ptr(n_contrib), _stream()), "gsr_render_forward")
@@ -592,7 +674,8 @@ class _RenderGaussians(torch.autograd.Function):
                 ev0 = torch.cuda.Event(enable_timing=True)
                 ev1 = torch.cuda.Event(enable_timing=True)
                 ev0.record()
-            with kernel_timer.range("composite_backward", P=P, D=ctx.num_rendered, **ctx.px_meta):
+            with kernel_timer.range("composite_backward", P=P, D=ctx.num_rendered, **ctx.px_meta), \
+                    zhx_range(ctx.cuda_args, "b10 render time"):
                 check(lib.gsr_render_backward(P, W, H, _ptr(ranges), _ptr(point_list), _ptr(means2D),
                                               _ptr(conic_opacity), _ptr(rgb), _ptr(mask), _ptr(bg), _ptr(final_T),
                                               _ptr(n_contrib), _ptr(g_out), _ptr(record), _stream()),

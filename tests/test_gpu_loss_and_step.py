@@ -50,6 +50,69 @@ def test_fused_loss_fwd_bwd_matches_torch_restatement(device, H, W, y0, y1):
     assert xi.grad[:, outside.to(device)].abs().sum().item() == 0.0
 
 
+def test_native_gpu_timer_log(device, tmp_path):
+    """--zhx_time: the per-stage GPU times of a logged iteration land in <log_folder>/gpu_time_ws=1_rk=0.log in the format
+    the reference's analyze_statistic.py:747-805 parses ("it=<n>, ..." header, then "<stage>: <ms> ms" lines with the stage
+    names of :1972-1991) -- for the camera-batched mirror path and for the reference-shaped operator calls"""
+    import diff_gaussian_rasterization as dgr
+    import utils.general_utils as utils
+    from gaussian_renderer import distributed_preprocess3dgs_and_all2all_final, render_final
+    from gaussian_renderer.loss_distribution import batched_loss_computation, load_camera_from_cpu_to_all_gpu
+    from gaussian_renderer.workload_division import DivisionStrategyHistoryFinal, start_strategy_final
+
+    def parse(path):  # the reference's parser, restated
+        its = []
+        for line in open(path):
+            if line.startswith("it="):
+                its.append({"iteration": int(line[3:line.find(",")])})
+                continue
+            parts = line.split(":")
+            if len(parts) == 2:
+                its[-1][parts[0]] = float(parts[1].strip().split("ms")[0].strip())
+        return its
+
+    N, W, H = 4000, 208, 144
+    utils.GLOBAL_RANK, utils.WORLD_SIZE = 0, 1
+    utils.DEFAULT_GROUP = utils.IN_NODE_GROUP = utils.SingleGPUGroup()
+    log_folder = str(tmp_path / "logs")
+    utils.set_args(utils.default_args(bsz=2, zhx_time=True, log_interval=1, log_folder=log_folder))
+    utils.set_img_size(H, W)
+    utils.set_cur_iter(7)
+    model = S.SyntheticGaussianModel(N, W, H, seed=4, device=device, scale_coef=0.012)
+    cams = S.orbit_cameras(2, W, H, device=device)
+    for k, c in enumerate(cams):
+        c.original_image_backup = S.make_gt_image(W, H, seed=10 + k)
+    hist = DivisionStrategyHistoryFinal(S.SyntheticDataset(cams), 1, 0)
+    bg = torch.tensor([0.1, 0.2, 0.3], device=device)
+    pipe = type("P", (), {"debug": False})()
+    try:
+        strategies, tasks = start_strategy_final(cams, hist)
+        load_camera_from_cpu_to_all_gpu(cams, strategies, tasks)
+        pkg = distributed_preprocess3dgs_and_all2all_final(cams, model, pipe, bg, batched_strategies=strategies)
+        images, masks = render_final(pkg, strategies)
+        stats = [ca["stats_collector"] for ca in pkg["batched_cuda_args"]]
+        loss, _ = batched_loss_computation(images, cams, masks, strategies, stats)
+        loss.backward()
+        path = os.path.join(log_folder, "gpu_time_ws=1_rk=0.log")
+        its = parse(path)
+        assert len(its) == 2  # one record per camera of the batch
+        for rec in its:
+            assert set(dgr._ZHX_STAGES) <= set(rec)
+            for stage in ("10 preprocess time", "24 updateDistributedStatLocally.updateTileTouched time",
+                          "50 SortPairs time", "70 render time", "b10 render time", "b20 preprocess time"):
+                assert 0.0 < rec[stage] < 100.0, (stage, rec[stage])
+        # nothing is written when the flag is off
+        utils.set_args(utils.default_args(bsz=2, zhx_time=False, log_interval=1, log_folder=log_folder))
+        size = os.path.getsize(path)
+        strategies, tasks = start_strategy_final(cams, hist)
+        pkg = distributed_preprocess3dgs_and_all2all_final(cams, model, pipe, bg, batched_strategies=strategies)
+        images, masks = render_final(pkg, strategies)
+        sum(im.sum() for im in images).backward()
+        assert os.path.getsize(path) == size
+    finally:
+        utils.set_args(utils.default_args(bsz=1))
+
+
 def test_training_iteration_through_mirror_matches_oracle(device):
     """start_strategy_final -> GT staging -> preprocess(+exchange) -> render_final -> batched loss ->
     backward, world size 1, against the C restatement + torch loss restatement"""
