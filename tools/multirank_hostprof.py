@@ -39,7 +39,7 @@ def worker(rank, world, port, profile, gaussians, size):
     utils.init_distributed = lambda *a, **k: orig(backend="gloo")
     sys.argv = ["bench.py", "--gpus", str(world), "--steps", "100", "--warmup", "10", "--no-cpu-baseline",
                 "--gaussians", str(gaussians), "--width", str(size), "--height", str(size), "--render-steps", "1",
-                "--repeats", "1", "--no-extra"] + (["--workload", os.environ["GSR_WORKLOAD"]] if "GSR_WORKLOAD" in os.environ else []) + os.environ.get("GSR_BENCH_EXTRA", "").split()
+                "--repeats", "1"] + ([] if os.environ.get("GSR_WITH_EXTRA") else ["--no-extra"]) + (["--workload", os.environ["GSR_WORKLOAD"]] if "GSR_WORKLOAD" in os.environ else []) + os.environ.get("GSR_BENCH_EXTRA", "").split()
     import bench
 
     if profile and rank == 0:
