@@ -131,13 +131,17 @@ __device__ __forceinline__ void multihist_flush(uint32_t (*mh)[RADIX_DIGITS], co
 
 // lanes holding the same digit (restricted to `valid` lanes)
 __device__ __forceinline__ unsigned long long match_digit(uint32_t d, bool valid, int nbits) {
-    unsigned long long m = __ballot(valid);
+    const unsigned long long v = __ballot(valid);
+    uint32_t mlo = (uint32_t)v, mhi = (uint32_t)(v >> 32);
     for (int b = 0; b < nbits; b++) {
-        const bool bit = (d >> b) & 1;
-        const unsigned long long bm = __ballot(bit);
-        m &= bit ? bm : ~bm;
+        // s = all ones where this lane's bit b is set; a peer keeps its place in the mask when its bit equals ours:
+        // m &= ~(ballot ^ s)  -- bfe, compare, and per half one xnor + one and
+        const int s = ((int)(d << (31 - b))) >> 31;
+        const unsigned long long bm = __ballot(s != 0);
+        mlo &= ~((uint32_t)bm ^ (uint32_t)s);
+        mhi &= ~((uint32_t)(bm >> 32) ^ (uint32_t)s);
     }
-    return m;
+    return ((unsigned long long)mhi << 32) | mlo;
 }
 
 // ------------------------------------------------------------------------- one radix pass, one kernel
@@ -275,11 +279,15 @@ __device__ __forceinline__ void onesweep_scatter(OnesweepSmem<ITEMS, THREADS> &s
         const uint32_t d = (key[r] >> shift) & mask;
         const unsigned long long m = match_digit(d, valid, nbits);
         const uint32_t rank = __popcll(m & lt);
-        volatile uint16_t *cursor = sm.wtab[wave];
+        // (plain LDS accesses fenced for the compiler: a `volatile` pointer here turned them into FLAT loads / stores with
+        // system-scope bits and a vmcnt(0) wait each -- ~1 us per round; LDS operations of one wave execute in order)
+        uint16_t *cursor = sm.wtab[wave];
         uint32_t pos = 0;
         if (valid) pos = cursor[d] + rank;
+        asm volatile("" ::: "memory");
         __builtin_amdgcn_wave_barrier();
         if (valid && rank == 0) cursor[d] = (uint16_t)(pos + (uint32_t)__popcll(m));  // group leader advances the cursor
+        asm volatile("" ::: "memory");
         __builtin_amdgcn_wave_barrier();
         if (valid) {
             sm.skey[pos] = key[r];
