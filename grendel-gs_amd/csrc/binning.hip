@@ -370,7 +370,10 @@ emit_scatter_kernel(int P, long long D, int xbits, const uint2 *__restrict__ rec
                     const uint2 rc = s_rect[a];
                     const uint32_t t = s - s_off[a];
                     const uint32_t minx = rc.x & 0xFFFFu, w = (rc.x >> 16) - minx, miny = rc.y & 0xFFFFu;
-                    const uint32_t q = t / w;
+                    // t / w without the integer-division sequence (~15 VALU): the frame has <= 256 x 256 tiles on this
+                    // path, so the quotient is < 256 and (t + 0.5) / w stays >= 0.5 / 256 away from every integer --
+                    // orders of magnitude more than the error of rcp (1 ulp) and the product: the truncation is exact
+                    const uint32_t q = (uint32_t)(((float)t + 0.5f) * __builtin_amdgcn_rcpf((float)w));
                     key[r] = ((miny + q) << xbits) | (minx + (t - q * w));
                     val[r] = s_g[a];
                     pending = false;
