@@ -301,9 +301,13 @@ __global__ void __launch_bounds__(THREADS, 8)  // <= 64 VGPRs: four 8-wave workg
 emit_scatter_kernel(int P, long long D, int xbits, const uint2 *__restrict__ rects,
                     const uint32_t *__restrict__ sorted_ids, const uint32_t *__restrict__ offsets,
                     const uint32_t *__restrict__ ghist, uint32_t *__restrict__ state, uint32_t *__restrict__ ticket,
-                    uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, bool bounded) {
+                    uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, bool bounded,
+                    int32_t *__restrict__ ranges_flat, int ranges_words) {
     constexpr int WAVES = THREADS / 64;
     __shared__ OnesweepSmem<ITEMS, THREADS> sm;
+    // K7 only writes the tiles that own pairs: clear the range table here (it runs two kernels later on this stream)
+    // instead of in a memset launch of its own.  Every workgroup takes part, before any of the early exits below.
+    for (int t = blockIdx.x * THREADS + threadIdx.x; t < ranges_words; t += gridDim.x * THREADS) ranges_flat[t] = 0;
     if (bounded) {  // the grid covers a capacity D; the true pair count is offsets[P] (K4's total)
         const long long d = offsets[P];
         if (d > D) return;
@@ -665,7 +669,8 @@ int bin_sort_impl(int P, int width, int height, const uint8_t *compute_locally, 
                   bool bounded) {
     if (P < 0 || width <= 0 || height <= 0 || D < 0 || !ranges) return GSR_EINVAL;
     const int gx = (width + GSR_BLOCK_X - 1) / GSR_BLOCK_X, gy = (height + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y;
-    GSR_HIP(hipMemsetAsync(ranges, 0, sizeof(int32_t) * 2 * (size_t)gx * gy, stream));
+    if (D == 0 || P == 0 || !yx_path(gx, gy))  // (the (row, column) path clears the table inside its first kernel)
+        GSR_HIP(hipMemsetAsync(ranges, 0, sizeof(int32_t) * 2 * (size_t)gx * gy, stream));
     if (D == 0 || P == 0) return 0;
     if (!compute_locally || !prep || !scratch || !point_list) return GSR_EINVAL;
     if (D > RADIX_MAX_N) return GSR_EINVAL;
@@ -693,7 +698,8 @@ int bin_sort_impl(int P, int width, int height, const uint8_t *compute_locally, 
         uint32_t *state = reinterpret_cast<uint32_t *>(ctrl + S.C.radix_state);
         // pass 0 (column digit) fused with the emission: pairs land in (kB, vB); pass 1 (row digit) -> (kA, point_list)
         hipLaunchKernelGGL((emit_scatter_kernel<RADIX_TILE / 512, 512>), dim3(nb), dim3(512), 0, stream, P, (long long)D,
-                           xbits, rects, sorted_ids, offsets, thist, state, tickets + 1, kB, vB, bounded);
+                           xbits, rects, sorted_ids, offsets, thist, state, tickets + 1, kB, vB, bounded, ranges,
+                           2 * gx * gy);
         hipLaunchKernelGGL((radix_onesweep_kernel<RADIX_TILE / 512, 512>), dim3(nb), dim3(512), 0, stream, kB, vB, kA,
                            point_list, (long long)D, xbits, ybits, thist + RADIX_DIGITS,
                            state + (size_t)nb * RADIX_DIGITS, tickets + 2, D_dev);

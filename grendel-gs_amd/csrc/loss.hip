@@ -206,8 +206,8 @@ __global__ void __launch_bounds__(LT)
 l1_ssim_backward_kernel(int rows, int W, int gxT, int gyT, const float *__restrict__ image, long long img_cstride,
                         const uint8_t *__restrict__ gt, const float *__restrict__ M1, const float *__restrict__ M2,
                         const float *__restrict__ M3, const float *__restrict__ grad_l1_sum,
-                        const float *__restrict__ grad_ssim_sum, float *__restrict__ grad_image,
-                        long long grad_cstride) {
+                        const float *__restrict__ grad_ssim_sum, float scale_l1, float scale_ssim,
+                        float *__restrict__ grad_image, long long grad_cstride) {
     __shared__ float sM[3][HH][HW + 1];
     __shared__ float hor[3][HH][HSTR];
     int c, ox, oy;
@@ -287,7 +287,7 @@ l1_ssim_backward_kernel(int rows, int W, int gxT, int gyT, const float *__restri
     }
     const int gx = ox + tx;
     if (gx >= W) return;
-    const float gl1 = grad_l1_sum[0], gss = grad_ssim_sum[0];
+    const float gl1 = grad_l1_sum[0] * scale_l1, gss = grad_ssim_sum[0] * scale_ssim;
 #pragma unroll
     for (int o = 0; o < VO; o++) {
         const int gy = oy + ty0 + o;
@@ -365,8 +365,8 @@ extern "C" int gsr_l1_ssim_forward(int channels, int rows, int width, const floa
 extern "C" int gsr_l1_ssim_backward(int channels, int rows, int width, const float *image,
                                     int64_t image_channel_stride, const uint8_t *gt, const float *dm_dmu1,
                                     const float *dm_dE11, const float *dm_dE12, const float *grad_l1_sum,
-                                    const float *grad_ssim_sum, float *grad_image, int64_t grad_channel_stride,
-                                    gsr_stream_t stream) {
+                                    const float *grad_ssim_sum, float scale_l1, float scale_ssim, float *grad_image,
+                                    int64_t grad_channel_stride, gsr_stream_t stream) {
     if (channels <= 0 || rows < 0 || width <= 0) return GSR_EINVAL;
     if (rows == 0) return 0;
     if (!image || !gt || !dm_dmu1 || !dm_dE11 || !dm_dE12 || !grad_l1_sum || !grad_ssim_sum || !grad_image)
@@ -377,11 +377,11 @@ extern "C" int gsr_l1_ssim_backward(int channels, int rows, int width, const flo
     if (vec)
         hipLaunchKernelGGL(l1_ssim_backward_kernel<true>, grid, dim3(LT), 0, reinterpret_cast<hipStream_t>(stream), rows,
                            width, gxT, gyT, image, (long long)image_channel_stride, gt, dm_dmu1, dm_dE11, dm_dE12,
-                           grad_l1_sum, grad_ssim_sum, grad_image, (long long)grad_channel_stride);
+                           grad_l1_sum, grad_ssim_sum, scale_l1, scale_ssim, grad_image, (long long)grad_channel_stride);
     else
         hipLaunchKernelGGL(l1_ssim_backward_kernel<false>, grid, dim3(LT), 0, reinterpret_cast<hipStream_t>(stream), rows,
                            width, gxT, gyT, image, (long long)image_channel_stride, gt, dm_dmu1, dm_dE11, dm_dE12,
-                           grad_l1_sum, grad_ssim_sum, grad_image, (long long)grad_channel_stride);
+                           grad_l1_sum, grad_ssim_sum, scale_l1, scale_ssim, grad_image, (long long)grad_channel_stride);
     GSR_LAUNCH_CHECK();
     return 0;
 }

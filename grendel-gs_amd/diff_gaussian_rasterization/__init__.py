@@ -786,7 +786,8 @@ class _FusedL1SSIMBand(torch.autograd.Function):
         gband_ptr = ctypes.c_void_p(grad.data_ptr() + 4 * y0 * W)
         with torch.cuda.device(dev), kernel_timer.range("l1_ssim_backward", Px=rows * W):
             check(lib.gsr_l1_ssim_backward(C, rows, W, band_ptr, H * W, _ptr(gt_u8), _ptr(maps[0]), _ptr(maps[1]),
-                                           _ptr(maps[2]), _ptr(g_l1), _ptr(g_ssim), gband_ptr, H * W, _stream()),
+                                           _ptr(maps[2]), _ptr(g_l1), _ptr(g_ssim), 1.0, 1.0, gband_ptr, H * W,
+                                           _stream()),
                   "gsr_l1_ssim_backward")
         return grad, None, None, None
 
@@ -848,18 +849,15 @@ class _FusedBandLoss(torch.autograd.Function):
         y0, y1 = ctx.y0, ctx.y1
         rows = y1 - y0
         dev = image.device
-        key = (dev, ctx.coef)
-        coef = _FusedBandLoss._coef_cache.get(key)
-        if coef is None:
-            coef = _FusedBandLoss._coef_cache[key] = torch.tensor(ctx.coef, dtype=torch.float32, device=dev)
-        gvec = (coef * g_loss.float()).contiguous()  # (dL/dS_l1, dL/dS_ssim): one launch, read on the device
+        g_loss = g_loss if (g_loss.dtype == torch.float32 and g_loss.is_contiguous()) else g_loss.float().contiguous()
+        # (dL/dS_l1, dL/dS_ssim) = dL/dloss * (c_l1, c_ssim): the product is formed inside the kernel
         grad = torch.empty_like(image) if rows == H else torch.zeros_like(image)
         band_ptr = ctypes.c_void_p(image.data_ptr() + 4 * y0 * W)
         gband_ptr = ctypes.c_void_p(grad.data_ptr() + 4 * y0 * W)
         with torch.cuda.device(dev), kernel_timer.range("l1_ssim_backward", Px=rows * W):
             check(lib.gsr_l1_ssim_backward(C, rows, W, band_ptr, H * W, _ptr(gt_u8), _ptr(maps[0]), _ptr(maps[1]),
-                                           _ptr(maps[2]), ctypes.c_void_p(gvec.data_ptr()),
-                                           ctypes.c_void_p(gvec.data_ptr() + 4), gband_ptr, H * W, _stream()),
+                                           _ptr(maps[2]), _ptr(g_loss), _ptr(g_loss), float(ctx.coef[0]),
+                                           float(ctx.coef[1]), gband_ptr, H * W, _stream()),
                   "gsr_l1_ssim_backward")
         return grad, None, None, None, None, None
 

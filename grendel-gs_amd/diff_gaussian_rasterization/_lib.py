@@ -43,7 +43,7 @@ SIGNATURES = {
     "gsr_l1_ssim_forward": (c_int, [c_int, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p]),
     "gsr_l1_ssim_backward": (c_int, [c_int, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
-                                     c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+                                     c_void_p, c_void_p, c_float, c_float, c_void_p, c_int64, c_void_p]),
     "gsr_l1_ssim_finalize": (c_int, [c_int, c_void_p, c_float, c_float, c_float, c_float, c_void_p, c_void_p]),
     "gsr_exchange_need": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p]),

@@ -423,7 +423,7 @@ def distributed_preprocess3dgs_and_all2all_final(batched_viewpoint_cameras, pc, 
             packed.append(cached[1])
         rs0 = rasterizers[0].raster_settings
         m2_all, rgb_all, co_all, radii_all, depths_all = _dgr.preprocess_gaussians_raw_batched(
-            *raw, torch.stack(packed), pc.active_sh_degree, scaling_modifier, rs0.image_width, rs0.image_height,
+            *raw, packed[0].view(1, -1) if len(packed) == 1 else torch.stack(packed), pc.active_sh_degree, scaling_modifier, rs0.image_width, rs0.image_height,
             tanfov0=(rs0.tanfovx, rs0.tanfovy), cuda_args_list=cuda_args_list)
         for k in range(len(rasterizers)):
             means2D = m2_all[k]

@@ -165,16 +165,17 @@ int gsr_render_backward(int P, int width, int height, const int32_t *ranges, con
  *           caller adds them up.  dm_* [C, rows, width] receive the derivative maps the backward
  *           needs (all three NULL for a forward-only evaluation).
  * backward: grad_image (same addressing as `image`, channel stride grad_channel_stride) =
- *           *grad_l1_sum * sign(x - y) + *grad_ssim_sum * d(sum ssim)/dx ; both scalars are read on
- *           the device (no host sync). */
+ *           scale_l1 * *grad_l1_sum * sign(x - y) + scale_ssim * *grad_ssim_sum * d(sum ssim)/dx ; the two device
+ *           scalars are read on the device (no host sync) -- a caller whose loss is c_l1 * S_l1 + c_ssim * S_ssim passes
+ *           the incoming dL/dloss for both pointers and (c_l1, c_ssim) as the scales: no glue kernel. */
 int gsr_l1_ssim_num_partials(int channels, int rows, int width);
 int gsr_l1_ssim_forward(int channels, int rows, int width, const float *image, int64_t image_channel_stride,
                         const uint8_t *gt, float *partials, float *dm_dmu1, float *dm_dE11, float *dm_dE12,
                         gsr_stream_t stream);
 int gsr_l1_ssim_backward(int channels, int rows, int width, const float *image, int64_t image_channel_stride,
                          const uint8_t *gt, const float *dm_dmu1, const float *dm_dE11, const float *dm_dE12,
-                         const float *grad_l1_sum, const float *grad_ssim_sum, float *grad_image,
-                         int64_t grad_channel_stride, gsr_stream_t stream);
+                         const float *grad_l1_sum, const float *grad_ssim_sum, float scale_l1, float scale_ssim,
+                         float *grad_image, int64_t grad_channel_stride, gsr_stream_t stream);
 /* finalize: adds the partials up (fixed order, fp64 accumulation) and forms the band's loss terms in one
  * launch: out3[0] = c_l1 * S_l1 + c_ssim * S_ssim + bias  (batched_loss_computation's
  * (1 - lambda) * Ll1 + lambda * (1 - ssim) with c_l1 = (1-lambda)/n, c_ssim = -lambda/n, bias = lambda;

@@ -7,13 +7,17 @@ import sys
 from collections import OrderedDict
 
 
+WIDE = "--wide" in sys.argv
+
+
 def short(n):
-    return n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:44]
+    n = n.replace("(anonymous namespace)::", "").replace("void ", "")
+    return n[:200] if WIDE else n.split("(")[0][:44]
 
 
 def main():
     db = sys.argv[1]
-    skip = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    skip = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 8
     c = sqlite3.connect(db)
     cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
     s_col = "start" if "start" in cols else "start_timestamp"
@@ -47,7 +51,7 @@ def main():
             gap = sum(max(0, it[i][1] - max(x[2] for x in it[:i])) for it in its) / n / 1e3
         tot_k += dur
         tot_g += gap
-        print(f"{i:3d} {its[0][i][0]:44s} {dur:8.2f} {gap:13.2f}")
+        print(f"{i:3d} {its[0][i][0]:44s} {dur:8.2f} {gap:13.2f}" if not WIDE else f"{i:3d} {dur:8.2f} {gap:8.2f}  {its[0][i][0]}")
     span = sum(it[-1][2] - it[0][1] for it in its) / n / 1e3
     print(f"sum of kernel durations {tot_k:.1f} us, sum of idle gaps {tot_g:.1f} us, first-start to last-end {span:.1f} us")
 
