@@ -6,10 +6,11 @@
 //     (coalesced index read + one 36-byte gather per lane);
 //   * each lane tests ITS entry against the wave's quadrant (exact: minimum of the conic's quadratic form over
 //     the box vs the alpha >= 1/255 level) and a 64-bit ballot gives the entries that can touch the quadrant;
-//   * the chunk is staged in a wave-private LDS slab (lane k stores entry k) and the wave iterates over the set
-//     bits only, reading entry k back with a wave-uniform address: an LDS broadcast costs no VALU issue slot
-//     (9 v_readlane per entry did), and VALU issue is what bounds both kernels (profiles/r02_pmc.txt:
-//     SQ_ACTIVE_INST_VALU covers 0.9-1.07 of the SIMD cycles);
+//   * the relevant entries of the chunk are compacted (in list order) into PAIR RECORDS in a wave-private LDS slab and
+//     read back with wave-uniform addresses: an LDS broadcast costs no VALU issue slot (9 v_readlane per entry did),
+//     one read returns the values of two entries in adjacent registers, and what is independent between entries
+//     (offsets, the exponent's quadratic form, colour accumulation) runs as packed fp32 for two entries per instruction;
+//     VALU issue is what bounds the forward (profiles/r02_pmc.txt: SQ_ACTIVE_INST_VALU covers 0.85 of the SIMD cycles);
 //   * early termination is per wave: __all(done) leaves the loop.
 // Entries skipped by the quadrant test would have been rejected per pixel by the alpha < 1/255 rule,
 // so the image and n_contrib are those of the plain algorithm.
@@ -264,24 +265,26 @@ composite_forward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
 // (px, py relative to the tile origin: integers 0..15) by the binomial expansion.  So the per-tile reduction IS a
 // dense contraction over the 64 pixels of a quadrant:  [entries x pixels] . [pixels x 9].  It runs on the MATRIX
 // pipe (v_mfma_f32_16x16x4_f32: exact fp32, an fmaf chain) instead of as a cross-lane VALU reduction:
-//   phase A (lane = pixel): walk the entries back to front, two per iteration; recompute alpha, carry T and
-//       rho = R.g (R = colour behind the entry: ONE scalar recurrence instead of three), and store (q, w) of the entry
-//       into a wave-private LDS matrix [slot][pixel] -- ~28 VALU instructions per (wave, entry) where the transposed
-//       butterfly reduction this replaces needed ~80 (SQ_INSTS_VALU 277 M -> 160 M per launch on the bench view);
+//   phase A (lane = pixel): walk the pair records back to front; recompute alpha, carry T and rho = R.g (R = colour
+//       behind the entry: ONE scalar recurrence instead of three), and store (q, w) of the entry into a wave-private
+//       LDS matrix [slot][pixel] -- ~20 VALU instructions per (wave, entry) where the transposed butterfly reduction
+//       this replaces needed ~80 (SQ_INSTS_VALU 277 M -> 98 M per launch on the bench views);
 //   phase B (every 8 entries): 16 K-steps of 4 pixels.  Lane (k = lane >> 4, i = lane & 15) reads component i >> 3 of
 //       slot i & 7, pixel 4 t + k -- the A operand: rows 0-7 are the q-rows of the eight slots, rows 8-15 their w-rows;
 //       conflict-free with the row stride of 66 -- and issues ONE v_mfma_f32_16x16x4_f32 against a per-lane constant
 //       B operand (columns 0-5 the position polynomials, 6-8 the pixel's dL/dcolour).  Rows 0-7 x columns 0-5 of the
 //       result are the q moments, rows 8-15 x columns 6-8 the colour gradients; they are STORED into the wave's own
 //       per-chunk table (an entry is in exactly one batch of a wave; LDS float atomics measured ~50 cycles each);
-//   flush (once per 64-entry chunk, after a workgroup barrier): the four quadrant waves' tables are added, moments ->
-//       gradients, and 9 adjacent lanes add one (tile, entry) pair's nine values into that Gaussian's 36-byte row
-//       of the [P,9] record (means2D 0:2, rgb 2:5, conic_opacity 5:9); positions / conics / ids come from the slab
-//       of the wave that walks the longest list (no global loads in the flush).
-// The list entries of a chunk are prefetched one chunk ahead (their indices two).  The matrix pipe runs beside the
-// VALU (16 MFMAs per 8 entries = 64 matrix-pipe cycles per entry, ~19 % busy); 4 workgroups per CU (38 KB of LDS,
-// <= 128 VGPRs).  Measured (profiles/r02_*): 0.496 -> 0.384 ms per launch at 1 M Gaussians / 1080p, VALU busy 0.61,
-// LDS 0.32, half of each wave's life still waits on LDS / barriers -- the kernel is latency-bound now, not VALU-bound.
+//   flush (once per 64-entry chunk, between two workgroup barriers): ONE wave (they take turns), lane = entry, adds the
+//       four quadrant waves' tables and maps moments -> gradients; then all waves, 9 adjacent lanes per (tile, entry)
+//       pair, add the nine values into that Gaussian's 36-byte row of the [P,9] record (means2D 0:2, rgb 2:5,
+//       conic_opacity 5:9); positions / conics / ids come from the LDS copy kept by the wave that walks the longest
+//       list (no global loads in the flush).
+// The list entries of a chunk are prefetched one chunk ahead (their indices two).  4 workgroups per CU (40.7 KB of LDS,
+// 128 VGPRs).  Measured (profiles/r02_*): 0.496 -> 0.335 ms per launch at 1 M Gaussians / 1080p; by
+// ablation the MFMA phase is 0.087 ms of it -- the fp32 MFMA runs at the VALU's own rate and does NOT overlap it
+// (SQ_VALU_MFMA_COEXEC_CYCLES = 0): what it buys is the cross-lane reduction, 16 VALU-equivalents per entry against ~52 --
+// the record atomics 0.018 ms, the barriers 0.016 ms, the rest is the walk.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int MB = 8;      // entries per MFMA batch: rows 0-7 of the 16 x 16 result are their q-rows, rows 8-15 their w-rows
