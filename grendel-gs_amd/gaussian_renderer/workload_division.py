@@ -243,9 +243,11 @@ def _gather_times_on_host(mine):
     g = _host_group()
     if g is None:
         return utils.our_allgather_among_cpu_processes_float_list(mine, utils.DEFAULT_GROUP)
-    out = [None] * g.size()
-    dist.all_gather_object(out, [float(x) for x in mine], group=g)
-    return out
+    # (a tensor all-gather: all_gather_object pickles and runs two collectives, several times the cost for W short lists)
+    t = torch.tensor([float(x) for x in mine], dtype=torch.float64)
+    outs = [torch.empty_like(t) for _ in range(g.size())]
+    dist.all_gather(outs, t, group=g)
+    return [o.tolist() for o in outs]
 
 
 def _update_heuristics(batched_cameras, strategy_history, batched_strategies, times, frozen):
