@@ -372,6 +372,15 @@ def distributed_preprocess3dgs_and_all2all_final(batched_viewpoint_cameras, pc, 
     assert utils.DEFAULT_GROUP.size() == 1 or (args.gaussians_distribution and args.image_distribution), \
         "Ensure distributed training given multiple GPU. "
 
+    if hasattr(_dgr, "set_timing_mode"):
+        # the operator records its render timings (HIP events, resolved by finish_strategy_final) only when the load
+        # balancer or a saved strategy history will read them
+        try:
+            from gaussian_renderer.workload_division import timings_have_consumer
+            wanted = mode != "train" or timings_have_consumer()
+        except ImportError:  # grafted over the reference's workload_division
+            wanted = True
+        _dgr.set_timing_mode("deferred" if wanted else "off")
     if timers is not None:
         timers.start("forward_prepare_gaussians")
     raw = [getattr(pc, n, None) for n in ("_xyz", "_scaling", "_rotation", "_features_dc", "_features_rest", "_opacity")]

@@ -152,6 +152,15 @@ def pixelwise_ssim_with_mask(img1, img2, pixel_mask=None):
     return m if pixel_mask is None else m * pixel_mask.unsqueeze(0)
 
 
+def _timings_wanted():
+    """HIP events around the loss only when somebody reads the timing (workload_division.timings_have_consumer)"""
+    try:
+        from gaussian_renderer.workload_division import timings_have_consumer
+    except ImportError:  # grafted over the reference's workload_division: keep the reference's behaviour (always timed)
+        return True
+    return timings_have_consumer()
+
+
 def final_system_loss_computation(image, viewpoint_cam, compute_locally, strategy, statistic_collector):
     """-> (Ll1, ssim) partial sums of this rank's row band, each / (H * W * 3); fills
     statistic_collector["forward_loss_time"] (ms) for the load balancer."""
@@ -162,8 +171,10 @@ def final_system_loss_computation(image, viewpoint_cam, compute_locally, strateg
     if not image.is_cuda:
         raise RuntimeError("final_system_loss_computation: the rendered band must live on the gfx950 device "
                            "(there is no CPU path)")
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ev0.record()
+    timed = _timings_wanted()
+    if timed:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     if _FUSED is not None:
         # one HIP kernel each way (include/gsraster.h: gsr_l1_ssim_forward / _backward)
         l1_sum, ssim_sum = _FUSED(image, viewpoint_cam.original_image, y0, y1)
@@ -173,10 +184,11 @@ def final_system_loss_computation(image, viewpoint_cam, compute_locally, strateg
         gt = torch.clamp(viewpoint_cam.original_image / 255.0, 0.0, 1.0)
         Ll1 = pixelwise_l1_with_mask(band, gt).sum() / n
         ssim = pixelwise_ssim_with_mask(band, gt).sum() / n
-    ev1.record()
     # no device sync here (the reference synchronises twice per camera, loss_distribution.py:2566,2578):
     # finish_strategy_final resolves the event pair when -- and only when -- the balancer needs it
-    statistic_collector["_loss_events"] = (ev0, ev1)
+    if timed:
+        ev1.record()
+        statistic_collector["_loss_events"] = (ev0, ev1)
     statistic_collector.setdefault("forward_loss_time", 0.0)
     return Ll1, ssim
 
@@ -206,12 +218,15 @@ def batched_loss_computation(batched_image, batched_cameras, batched_compute_loc
             # reference's two device syncs per camera (loss_distribution.py:2566,2578)
             j = strategy.gpu_ids.index(utils.GLOBAL_RANK)
             y0, y1 = get_coverage_y_min_max(strategy.division_pos[j], strategy.division_pos[j + 1])
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            ev0.record()
+            timed = _timings_wanted()
+            if timed:
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
             loss, Ll1, ssim = _FUSED_LOSS(image, camera.original_image, y0, y1, args.lambda_dssim,
                                           utils.get_num_pixels() * 3)
-            ev1.record()
-            stats["_loss_events"] = (ev0, ev1)
+            if timed:
+                ev1.record()
+                stats["_loss_events"] = (ev0, ev1)
             stats.setdefault("forward_loss_time", 0.0)
             parts.append([Ll1, ssim])
         else:

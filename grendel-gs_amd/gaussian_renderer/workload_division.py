@@ -278,6 +278,20 @@ def _my_times(batched_strategies, batched_statistic_collector):
     return mine
 
 
+def timings_have_consumer():
+    """Does anybody read this iteration's render / loss timings?  The load balancer does when its heuristics are live
+    (the skip rules of workload_division.py:968-978), the strategy history does when it is saved
+    (train_internal.py:274-284).  Otherwise -- always at world size 1 -- the ops record no HIP events at all (six event
+    packets per camera are ~2 % of a 1.3 ms iteration) and the statistics keep their 0.0 placeholders."""
+    args = utils.get_args()
+    W = utils.DEFAULT_GROUP.size()
+    small = utils.get_img_height() <= 600 or utils.get_img_width() <= 1000
+    whole_images = args.bsz >= W and (utils.get_img_height() <= 1080 or utils.get_img_width() <= 1920)
+    frozen = (utils.get_cur_iter() <= args.adjust_strategy_warmp_iterations or W == 1 or args.no_heuristics_update
+              or whole_images or small)
+    return (not frozen) or bool(getattr(args, "save_strategy_history", False))
+
+
 def finish_strategy_final(batched_cameras, strategy_history, batched_strategies, batched_statistic_collector):
     """all-gather each rank's measured (fwd render + bwd render + 2 x fwd loss) ms per camera and turn
     it into the next per-row cost estimate (same skip rules as workload_division.py:968-978)"""
