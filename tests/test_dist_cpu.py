@@ -201,6 +201,45 @@ def test_partitioned_exchange_render_matches_single_rank(world, bsz):
         assert msg == "ok", f"rank {rank}:\n{msg}"
 
 
+def test_timing_events_only_when_somebody_reads_them():
+    """workload_division.timings_have_consumer: the skip rules of the reference's finish_strategy_final
+    (workload_division.py:968-978) decide whether the ops record render / loss timing events at all"""
+    sys.path.insert(0, os.path.join(ROOT, "grendel-gs_amd"))
+    import utils.general_utils as utils
+    from gaussian_renderer.workload_division import timings_have_consumer
+
+    class Group:
+        def __init__(self, n):
+            self.n = n
+
+        def size(self):
+            return self.n
+
+    saved = (utils.DEFAULT_GROUP,)
+    try:
+        utils.set_cur_iter(100)
+        utils.set_img_size(1080, 1920)
+        utils.set_args(utils.default_args(bsz=1))
+        utils.DEFAULT_GROUP = Group(1)
+        assert not timings_have_consumer()                     # one rank: nothing to balance
+        utils.DEFAULT_GROUP = Group(4)
+        assert timings_have_consumer()                         # one 1080p image over four ranks: heuristics live
+        utils.set_args(utils.default_args(bsz=4))
+        assert not timings_have_consumer()                     # whole images per rank at <= 1080p: frozen
+        utils.set_args(utils.default_args(bsz=4, save_strategy_history=True))
+        assert timings_have_consumer()                         # ... unless the history is saved
+        utils.set_args(utils.default_args(bsz=1))
+        utils.set_img_size(500, 800)
+        assert not timings_have_consumer()                     # small images: frozen
+        utils.set_img_size(2160, 3840)
+        utils.set_args(utils.default_args(bsz=1, no_heuristics_update=True))
+        assert not timings_have_consumer()
+    finally:
+        utils.DEFAULT_GROUP = saved[0]
+        utils.set_args(utils.default_args(bsz=1))
+        utils.set_img_size(1080, 1920)
+
+
 def test_start_strategy_cut_points():
     """cut-point arithmetic of start_strategy_final against hand-computed cases (workload_division.py:852-941)"""
     sys.path.insert(0, os.path.join(ROOT, "grendel-gs_amd"))
