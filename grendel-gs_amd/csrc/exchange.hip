@@ -102,9 +102,15 @@ exchange_count_kernel(int P, int B, int W, int k0, int gx, int gy, int nchunk, c
 }
 
 struct SegOffsets {
-    int32_t off[512];  // first message row of segment (destination g, camera kk) = off[g * B + kk]
+    int32_t off[513];  // first message row of segment (destination g, camera kk) = off[g * B + kk]; SLAB: off[s + 1] is
+                       // also the END of segment s (its capacity is off[s + 1] - off[s])
 };
 
+// SLAB = false: the segments are exactly as long as the counts say (the caller has read them back).
+// SLAB = true : the segments are capacity slabs chosen BEFORE the counts were known (no read-back): a record whose
+//               position falls past its segment's end is not written (overflow -- the caller learns it from the counts
+//               later and repeats the exchange with the sized layout).
+template <bool SLAB>
 __global__ void __launch_bounds__(256)
 exchange_pack_kernel(int P, int B, int W, int k0, int cntB, int cnt0, int gx, int gy, int nchunk,
                      const float2 *__restrict__ means2D,
@@ -150,8 +156,8 @@ exchange_pack_kernel(int P, int B, int W, int k0, int cntB, int cnt0, int gx, in
             const unsigned long long m = __ballot(hit);
             if (m == 0ull) continue;
             const int32_t base = s_base[wave][g];
-            if (hit) {
-                const size_t pos = (size_t)base + __popcll(m & lt);
+            const size_t pos = (size_t)base + __popcll(m & lt);
+            if (hit && (!SLAB || (int64_t)pos < (int64_t)seg.off[g * B + kk + 1])) {
                 float *dst = msg + pos * 11;
 #pragma unroll
                 for (int c = 0; c < 11; c++) dst[c] = rec[c];
@@ -164,7 +170,23 @@ exchange_pack_kernel(int P, int B, int W, int k0, int cntB, int cnt0, int gx, in
     }
 }
 
-// dst[idx[r]][0:9] += src[r][0:9]; 9 adjacent lanes per row
+// SLAB: the unused tail of every segment -- rows [min(count, capacity), capacity) -- becomes an all-zero record
+// (radius 0 = "culled": the receiver's K3 drops it) with send_idx -1 (the backward's scatter-add skips it).
+// grid (segments, TAIL_SPLIT)
+constexpr int TAIL_SPLIT = 8;
+__global__ void __launch_bounds__(256)
+exchange_slab_tail_kernel(int B, int cntB, int cnt0, const int32_t *__restrict__ counts, SegOffsets seg,
+                          float *__restrict__ msg, int32_t *__restrict__ send_idx) {
+    const int s = blockIdx.x, g = s / B, kk = s - g * B;
+    const int32_t lo = seg.off[s], hi = seg.off[s + 1];
+    const int32_t n = min(counts[(size_t)g * cntB + cnt0 + kk], hi - lo);
+    const long long first = (long long)(lo + n) * 11, last = (long long)hi * 11;
+    for (long long e = first + (long long)blockIdx.y * 256 + threadIdx.x; e < last; e += 256LL * TAIL_SPLIT) msg[e] = 0.f;
+    for (int32_t r = lo + n + (int32_t)blockIdx.y * 256 + (int32_t)threadIdx.x; r < hi; r += 256 * TAIL_SPLIT)
+        send_idx[r] = -1;
+}
+
+// dst[idx[r]][0:9] += src[r][0:9]; 9 adjacent lanes per row; rows with idx < 0 (slab padding) are skipped
 __global__ void __launch_bounds__(256)
 scatter_add_rows_kernel(long long n, const int32_t *__restrict__ idx, const float *__restrict__ src,
                         float *__restrict__ dst) {
@@ -173,7 +195,8 @@ scatter_add_rows_kernel(long long n, const int32_t *__restrict__ idx, const floa
         const long long r = e / 9;
         const int c = (int)(e - r * 9);
         const float v = src[e];
-        if (v != 0.f) atomicAdd(dst + (size_t)idx[r] * 9 + c, v);
+        const int32_t row = idx[r];
+        if (v != 0.f && row >= 0) atomicAdd(dst + (size_t)row * 9 + c, v);
     }
 }
 }  // namespace
@@ -198,29 +221,82 @@ extern "C" int gsr_exchange_count(int P, int B_total, int k0, int B, int W, int 
     return 0;
 }
 
+static int exchange_pack_impl(bool slab, int P, int B_total, int k0, int B, int W, int width, int height,
+                              int count_cameras, int count_first, const float *means2D, const float *rgb,
+                              const float *conic_opacity, const int32_t *radii, const float *depths,
+                              const int32_t *bands, const int32_t *chunkcnt, const int32_t *counts,
+                              const int32_t *layout, int64_t n_send, float *msg, int32_t *send_idx,
+                              hipStream_t stream) {
+    if (P < 0 || B < 1 || B > 65535 || k0 < 0 || k0 + B > B_total || W < 1 || W > 256 || W * B > 512 ||
+        width <= 0 || height <= 0 || n_send < 0 || !layout || count_cameras < B || count_first < 0 ||
+        k0 < count_first || k0 - count_first + B > count_cameras)
+        return GSR_EINVAL;
+    SegOffsets seg;
+    if (slab) {  // layout = capacities: prefix sums give the segment starts, the total must be the buffer's row count
+        int64_t o = 0;
+        for (int i = 0; i < W * B; i++) {
+            if (layout[i] < 0) return GSR_EINVAL;
+            seg.off[i] = (int32_t)o;
+            o += layout[i];
+        }
+        if (o != n_send || o > 0x7fffffffLL) return GSR_EINVAL;
+        seg.off[W * B] = (int32_t)o;
+    } else {
+        for (int i = 0; i < W * B; i++) seg.off[i] = layout[i];
+        seg.off[W * B] = (int32_t)(n_send > 0x7fffffffLL ? 0x7fffffff : n_send);
+    }
+    if (n_send == 0) return 0;
+    if (!msg || !send_idx) return GSR_EINVAL;
+    const int gx = (width + GSR_BLOCK_X - 1) / GSR_BLOCK_X, gy = (height + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y;
+    const int nchunk = gsr_div_up(P, XCHUNK);
+    if (P > 0) {
+        if (!means2D || !rgb || !conic_opacity || !radii || !depths || !bands || !chunkcnt) return GSR_EINVAL;
+        if (slab)
+            hipLaunchKernelGGL(exchange_pack_kernel<true>, dim3(gsr_div_up(nchunk, 4), B), dim3(256), 0, stream, P, B, W,
+                               k0, count_cameras, k0 - count_first, gx, gy, nchunk,
+                               reinterpret_cast<const float2 *>(means2D), rgb,
+                               reinterpret_cast<const float4 *>(conic_opacity), radii, depths, bands, chunkcnt, seg, msg,
+                               send_idx);
+        else
+            hipLaunchKernelGGL(exchange_pack_kernel<false>, dim3(gsr_div_up(nchunk, 4), B), dim3(256), 0, stream, P, B, W,
+                               k0, count_cameras, k0 - count_first, gx, gy, nchunk,
+                               reinterpret_cast<const float2 *>(means2D), rgb,
+                               reinterpret_cast<const float4 *>(conic_opacity), radii, depths, bands, chunkcnt, seg, msg,
+                               send_idx);
+        GSR_LAUNCH_CHECK();
+    }
+    if (slab) {
+        if (!counts) return GSR_EINVAL;
+        hipLaunchKernelGGL(exchange_slab_tail_kernel, dim3(W * B, TAIL_SPLIT), dim3(256), 0, stream, B, count_cameras,
+                           k0 - count_first, counts, seg, msg, send_idx);
+        GSR_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
 extern "C" int gsr_exchange_pack(int P, int B_total, int k0, int B, int W, int width, int height, int count_cameras,
                                  int count_first, const float *means2D, const float *rgb, const float *conic_opacity,
                                  const int32_t *radii, const float *depths, const int32_t *bands,
                                  const int32_t *chunkcnt, const int32_t *segment_offsets, int64_t n_send, float *msg,
                                  int32_t *send_idx, gsr_stream_t stream_) {
-    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-    if (P < 0 || B < 1 || B > 65535 || k0 < 0 || k0 + B > B_total || W < 1 || W > 256 || W * B > 512 ||
-        width <= 0 || height <= 0 || n_send < 0 || !segment_offsets || count_cameras < B || count_first < 0 ||
-        k0 < count_first || k0 - count_first + B > count_cameras)
-        return GSR_EINVAL;
-    if (P == 0 || n_send == 0) return 0;
-    if (!means2D || !rgb || !conic_opacity || !radii || !depths || !bands || !chunkcnt || !msg || !send_idx)
-        return GSR_EINVAL;
-    SegOffsets seg;
-    for (int i = 0; i < W * B; i++) seg.off[i] = segment_offsets[i];
-    const int gx = (width + GSR_BLOCK_X - 1) / GSR_BLOCK_X, gy = (height + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y;
-    const int nchunk = gsr_div_up(P, XCHUNK);
-    hipLaunchKernelGGL(exchange_pack_kernel, dim3(gsr_div_up(nchunk, 4), B), dim3(256), 0, stream, P, B, W, k0,
-                       count_cameras, k0 - count_first, gx, gy, nchunk, reinterpret_cast<const float2 *>(means2D), rgb,
-                       reinterpret_cast<const float4 *>(conic_opacity), radii, depths, bands, chunkcnt, seg, msg,
-                       send_idx);
-    GSR_LAUNCH_CHECK();
-    return 0;
+    if (P == 0 || n_send == 0) {
+        if (P < 0 || n_send < 0 || !segment_offsets) return GSR_EINVAL;
+        return 0;
+    }
+    return exchange_pack_impl(false, P, B_total, k0, B, W, width, height, count_cameras, count_first, means2D, rgb,
+                              conic_opacity, radii, depths, bands, chunkcnt, nullptr, segment_offsets, n_send, msg,
+                              send_idx, reinterpret_cast<hipStream_t>(stream_));
+}
+
+extern "C" int gsr_exchange_pack_slab(int P, int B_total, int k0, int B, int W, int width, int height,
+                                      int count_cameras, int count_first, const float *means2D, const float *rgb,
+                                      const float *conic_opacity, const int32_t *radii, const float *depths,
+                                      const int32_t *bands, const int32_t *chunkcnt, const int32_t *counts,
+                                      const int32_t *capacities, int64_t n_rows, float *msg, int32_t *send_idx,
+                                      gsr_stream_t stream_) {
+    return exchange_pack_impl(true, P, B_total, k0, B, W, width, height, count_cameras, count_first, means2D, rgb,
+                              conic_opacity, radii, depths, bands, chunkcnt, counts, capacities, n_rows, msg, send_idx,
+                              reinterpret_cast<hipStream_t>(stream_));
 }
 
 extern "C" int gsr_scatter_add_rows(int64_t n, const int32_t *idx, const float *src, float *dst,

@@ -29,7 +29,7 @@ from ._lib import check, lib
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "_C", "load_image_tiles_by_pos",
            "merge_image_tiles_by_pos", "set_timing_mode", "fused_l1_ssim_band", "fused_band_loss", "fused_activations", "pack_camera",
            "preprocess_gaussians_raw_batched", "knn_mean_dist2", "group_rows", "gather_rows", "exchange_need",
-           "exchange_count", "exchange_pack", "scatter_add_rows", "scatter_rows", "local_pixels"]
+           "exchange_count", "exchange_pack", "exchange_pack_slab", "scatter_add_rows", "scatter_rows", "local_pixels"]
 
 BLOCK_X, BLOCK_Y, ONE_DIM_BLOCK_SIZE = 16, 16, 256
 
@@ -976,9 +976,34 @@ def exchange_pack(means2D_all, rgb_all, co_all, radii_all, depths_all, bands, ch
     return msg, send_idx
 
 
+def exchange_pack_slab(means2D_all, rgb_all, co_all, radii_all, depths_all, bands, chunkcnt, counts, capacities, k0, nb,
+                       width, height, count_cameras=None, count_first=None):
+    """the exchange's pack WITHOUT this step's counts on the host (include/gsraster.h: gsr_exchange_pack_slab):
+    capacities = python ints [W * nb], rows reserved per (destination, camera of [k0, k0 + nb)); `counts` = the DEVICE
+    tensor exchange_count returned with `chunkcnt`.  -> (msg fp32 [sum(capacities), 11], send_idx int32
+    [sum(capacities)]): every slab holds its records at the front (reference order), then all-zero padding rows
+    (radius 0) whose send_idx is -1; records that do not fit are dropped (the caller detects that from the counts)."""
+    B, P = radii_all.shape
+    W = bands.shape[1]
+    dev = radii_all.device
+    if len(capacities) != W * nb:
+        raise ValueError("capacities must have W * nb entries")
+    n_rows = int(sum(capacities))
+    msg = torch.empty((n_rows, 11), dtype=torch.float32, device=dev)
+    send_idx = torch.empty((n_rows,), dtype=torch.int32, device=dev)
+    caps = (ctypes.c_int32 * (W * nb))(*[int(c) for c in capacities])
+    with torch.cuda.device(dev):
+        check(lib.gsr_exchange_pack_slab(P, B, k0, nb, W, width, height, nb if count_cameras is None else count_cameras,
+                                         k0 if count_first is None else count_first, _ptr(means2D_all), _ptr(rgb_all),
+                                         _ptr(co_all), _ptr(radii_all), _ptr(depths_all), _ptr(bands), _ptr(chunkcnt),
+                                         _ptr(counts), caps, n_rows, _ptr(msg), _ptr(send_idx), _stream()),
+              "gsr_exchange_pack_slab")
+    return msg, send_idx
+
+
 def scatter_add_rows(idx, src, n_rows, dst=None):
-    """-> dst fp32 [n_rows, 9] with dst[idx[r]] += src[r] (rows of 9 floats; duplicates in idx accumulate); `dst`:
-    an existing contiguous [n_rows, 9] view to add into (default: a fresh zero tensor)"""
+    """-> dst fp32 [n_rows, 9] with dst[idx[r]] += src[r] (rows of 9 floats; duplicates in idx accumulate; rows with
+    idx[r] < 0 are skipped); `dst`: an existing contiguous [n_rows, 9] view to add into (default: a fresh zero tensor)"""
     src = _f32c(src, "src")
     if src.dim() != 2 or src.shape[1] != 9 or idx.dtype != torch.int32 or not idx.is_contiguous():
         raise ValueError("src must be [n, 9] fp32 and idx contiguous int32")

@@ -227,7 +227,8 @@ int gsr_exchange_need(int P, int B, int W, int width, int height, const float *m
  *       [count_first, count_first + count_cameras) (which must contain [k0, k0 + B): one count launch for the batch,
  *       one pack launch per camera when the exchanges are pipelined);
  *   gsr_scatter_add_rows : dst[idx[r]][0:9] += src[r][0:9] -- the backward's mirror step on the gradient rows the
- *       peers send back (dst fp32 [rows][9], zeroed by the caller; a Gaussian needed by two bands is added twice). */
+ *       peers send back (dst fp32 [rows][9], zeroed by the caller; a Gaussian needed by two bands is added twice);
+ *       rows with idx[r] < 0 are skipped. */
 size_t gsr_exchange_chunks(int P);
 int gsr_exchange_count(int P, int B_total, int k0, int B, int W, int width, int height, const float *means2D,
                        const int32_t *radii, const int32_t *bands, int32_t *chunkcnt, int32_t *counts,
@@ -238,6 +239,24 @@ int gsr_exchange_pack(int P, int B_total, int k0, int B, int W, int width, int h
                       const int32_t *bands, const int32_t *chunkcnt, const int32_t *segment_offsets, int64_t n_send,
                       float *msg, int32_t *send_idx, gsr_stream_t stream);
 int gsr_scatter_add_rows(int64_t n, const int32_t *idx, const float *src, float *dst, gsr_stream_t stream);
+/* The exchange WITHOUT the host read-back (round 3).  gsr_exchange_pack needs the segment layout, i.e. the counts of
+ * this very step on the host: the reference's `.cpu()` of gaussian_renderer/__init__.py:572-585, one device round trip
+ * per iteration in the middle of the forward.  gsr_exchange_pack_slab instead packs into CAPACITY slabs the caller
+ * chose beforehand (from earlier iterations): capacities[g * B + kk] (HOST, W * B <= 512 entries, sum == n_rows) rows
+ * are reserved for (destination g, camera k0 + kk), back to back; the records go to the front of their slab in the
+ * same (local index) order, records past the capacity are dropped, and the unused tail of every slab is written as
+ * all-zero records (radius 0: the receiving rank's binning culls them) with send_idx -1 (gsr_scatter_add_rows skips
+ * negative rows).  `counts` is the DEVICE array gsr_exchange_count wrote (same launch as chunkcnt).  The caller sends
+ * whole slabs (all-to-all-v with the capacities as split sizes), learns the true counts later (an asynchronous copy
+ * that has long completed when it polls the pair count of the first render) and repeats the exchange with
+ * gsr_exchange_pack when any count exceeded its capacity -- the same speculate / verify scheme as
+ * gsr_bin_sort_bounded.  Received rows keep the reference's order (source rank, then the source's index); padding
+ * rows sit between the sources' blocks. */
+int gsr_exchange_pack_slab(int P, int B_total, int k0, int B, int W, int width, int height, int count_cameras,
+                           int count_first, const float *means2D, const float *rgb, const float *conic_opacity,
+                           const int32_t *radii, const float *depths, const int32_t *bands, const int32_t *chunkcnt,
+                           const int32_t *counts, const int32_t *capacities, int64_t n_rows, float *msg,
+                           int32_t *send_idx, gsr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * N4  `simple_knn._C.distCUDA2(points)` (scene/gaussian_model.py:20,163-166; submodule

@@ -67,8 +67,37 @@ def exchange_pack(means2D_all, rgb_all, co_all, radii_all, depths_all, bands, ch
     return msg, send_idx
 
 
+def exchange_pack_slab(means2D_all, rgb_all, co_all, radii_all, depths_all, bands, chunkcnt, counts, capacities, k0, nb,
+                       width, height, count_cameras=None, count_first=None):
+    """gsr_exchange_pack_slab: capacity slabs per (destination, camera); records at the front in the reference order,
+    overflowing records dropped, all-zero padding (radius 0) with send_idx -1 behind them"""
+    B, P = radii_all.shape
+    W = bands.shape[1]
+    dt = means2D_all.dtype
+    n_rows = int(sum(capacities))
+    msg = torch.zeros((n_rows, 11), dtype=dt)
+    send_idx = torch.full((n_rows,), -1, dtype=torch.int32)
+    o = 0
+    for g in range(W):
+        for kk in range(nb):
+            k = k0 + kk
+            cap = int(capacities[g * nb + kk])
+            ids = _hits(means2D_all, radii_all, bands.cpu(), k, width, height)[g].nonzero().squeeze(1)[:cap]
+            rows = slice(o, o + ids.numel())
+            msg[rows, 0:2] = means2D_all[k].detach()[ids]
+            msg[rows, 2:5] = rgb_all[k].detach()[ids]
+            msg[rows, 5:9] = co_all[k].detach()[ids]
+            msg[rows, 9] = radii_all[k][ids].to(torch.int32).view(torch.float32) if dt == torch.float32 \
+                else radii_all[k][ids].to(dt)
+            msg[rows, 10] = depths_all[k].detach()[ids]
+            send_idx[rows] = (kk * P + ids).to(torch.int32)
+            o += cap
+    return msg, send_idx
+
+
 def scatter_add_rows(idx, src, n_rows, dst=None):
     if dst is None:
         dst = torch.zeros((n_rows, 9), dtype=src.dtype)
-    dst.index_add_(0, idx.long(), src)
+    keep = idx >= 0  # slab padding rows carry -1
+    dst.index_add_(0, idx[keep].long(), src[keep])
     return dst
