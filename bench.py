@@ -58,6 +58,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/
 WORKLOADS = {
     # name: (gaussians_total, width, height, bsz or None = world, description)
     "c1": (1_000_000, 1920, 1080, 1, "BASELINE configs[1]: Mip360-bicycle-sized scene on one GPU"),
+    "c1_4k": (1_000_000, 3840, 2160, 1, "the configs[1] scene at 3840x2160 (north_star: 1080p and 4K)"),
     "c2": (6_000_000, 1920, 1080, 1, "BASELINE configs[2] shape: one 1080p image split into row bands over the ranks"),
     "c4": (40_000_000, 3840, 2160, 1, "BASELINE configs[4] shape: one 4K image split into row bands over the ranks"),
     "weak": (1_000_000, 1920, 1080, None, "bsz = N whole images per step on the configs[1] scene sharded N ways"),
@@ -75,6 +76,8 @@ def algorithmic_bytes(kernel, m):
     if kernel == "binning":  # the reference's algorithm: 64-bit (tile | depth) keys, LSD passes of 8 bits
         key_bits = 32 + max(1, math.ceil(math.log2(max(m["tiles"], 2))))
         return m["P"] * 16 + m["D"] * 12 + m["D"] * 24 * math.ceil(key_bits / 8) + m["D"] * 8
+    if kernel == "binning_own":  # what THIS build's binning moves by construction: 64 B / Gaussian
+        return 64 * m["P"] + 40 * m["D"]  # (K3 + four depth passes + scan) and 40 B / pair (emission, tile sort, ranges)
     if kernel == "composite_forward":
         return 40 * m["D"] + 20 * m["Px"]
     if kernel == "composite_backward":
@@ -89,7 +92,7 @@ def algorithmic_bytes(kernel, m):
 
 
 def source_hash():
-    """sha256 over the kernel sources: profiles/r02_pmc.json is only quoted for the build it was measured on"""
+    """sha256 over the kernel sources: a profiles/rNN_pmc.json is only quoted for the build it was measured on"""
     h = hashlib.sha256()
     d = os.path.join(PKG, "csrc")
     for f in sorted(os.listdir(d)):
@@ -131,7 +134,28 @@ def cpu_baseline(W, H, n_total, seconds=12.0):
     dt = (time.time() - t0) / it
     return {"value": 1.0 / dt, "unit": "images/s", "cores": C.num_threads(), "kind": "port",
             "sample": f"{n} Gaussians, {w}x{h} (1/16 of the Gaussians on a 1/16-area image), rasterizer "
-                      f"fwd+bwd only (no loss/optimizer), {it} iterations, oracle/gsraster_ref.c with OpenMP"}
+                      f"fwd+bwd only (no loss/optimizer), {it} iterations, oracle/gsraster_ref.c with OpenMP",
+            "full_size_equiv": round(1.0 / (16.0 * dt), 4),
+            "full_size_equiv_note": "images/s the same port would reach on the FULL workload if its cost scaled with "
+                                    "Gaussians and pairs (x16): the figure to hold against `value`, not the sample's"}
+
+
+def load_pmc(src):
+    """-> (blob | None, note): the newest profiles/r*_pmc.json (tools/pmc_collect.py) measured on THIS kernel source"""
+    import glob
+
+    note = "no profiles/r*_pmc.json"
+    for pp in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):
+        try:
+            blob = json.load(open(pp))
+        except Exception as e:  # noqa: BLE001
+            note = f"{os.path.basename(pp)} unreadable: {e}"
+            continue
+        if blob.get("source_hash") == src:
+            return blob, f"{os.path.basename(pp)}: {blob.get('command', '')}"
+        note = (f"{os.path.basename(pp)} was measured on source hash {blob.get('source_hash')}, this build is {src}: "
+                f"not quoted")
+    return None, note
 
 
 class _SingleRankView:
@@ -182,7 +206,7 @@ def run_workload(a, name, world, rank, dev, steps, warmup, repeats, render_steps
     utils.set_img_size(H, W)
     utils.set_cur_iter(1)
 
-    if name == "c1" and not a.device_scene:  # the headline scene: SURVEY.md 8(d) generator on the host, seed 0
+    if name.startswith("c1") and not a.device_scene:  # the headline scene: SURVEY.md 8(d) generator on the host, seed 0
         model = S.SyntheticGaussianModel(n_total, W, H, seed=0, rank=rank, world_size=world, device=dev,
                                          opacity_logit_mean=a.opacity_logit_mean, opacity_logit_std=a.opacity_logit_std)
         scene = "host generator, seed 0"
@@ -258,7 +282,7 @@ def run_workload(a, name, world, rank, dev, steps, warmup, repeats, render_steps
     # the caching allocator a hipMalloc (multi-GB at the 40 M / 4K shape) and the speculative tile sort a fall-back --
     # first-epoch effects that would dominate the few steps those legs run.  Not used for the headline workload c1
     # (measured there: no effect).  Reported as `setup.priming_steps`.
-    priming = -(-n_views // bsz) if (name != "c1" and not a.no_priming) else 0
+    priming = -(-n_views // bsz) if (name != "c1" and not a.no_priming) else 0  # (c1_4k etc.: primed)
     for _ in range(priming):
         train_step()
     state["it"] = 0
@@ -320,6 +344,12 @@ def run_workload(a, name, world, rank, dev, steps, warmup, repeats, render_steps
             kern[kname]["frac_hbm_peak"] = round(kern[kname]["GBps"] / HBM_PEAK_GBS, 4)
         if D_sum:
             kern[kname]["mean_pairs_D"] = D_sum // n
+        if kname == "binning" and tot_ms > 0:
+            own = sum(algorithmic_bytes("binning_own", dict(meta)) for _, meta in recs)
+            kern[kname].update({"algo_MB_note": "the REFERENCE's algorithm (64-bit keys, 6 LSD passes over 12-byte pairs)",
+                                "own_MB": round(own / n / 1e6, 3), "own_GBps": round(own / (tot_ms * 1e-3) / 1e9, 1),
+                                "own_frac_hbm_peak": round(own / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                "own_note": "64 B x P + 40 B x D: what this build's split-key binning moves"})
     out["kernels"] = kern
     if world > 1 and state["sizes"] is not None:
         sizes = state["sizes"]  # sizes[i][j][k]: rows rank i sends to rank j for camera k (last step)
@@ -353,7 +383,11 @@ def main():
     ap.add_argument("--device-scene", action="store_true", help="draw the c1 scene on the device as well")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-priming", action="store_true", help="skip the untimed set-up pass over the distinct cameras")
-    ap.add_argument("--no-extra", action="store_true", help="N > 1: skip the second workload (c4)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra workloads (N = 1: 4K, low opacity, 6 M "
+                                                                "Gaussians; N > 1: c4)")
+    ap.add_argument("--balance-timing", default="pipelined", choices=["exact", "pipelined"],
+                    help="N > 1 with live heuristics: how finish_strategy_final gets its timings (the library default "
+                         "is the reference's `exact`, which waits for the iteration's own events every step)")
     ap.add_argument("--no-1gpu-leg", action="store_true", help="N > 1: skip the same-workload single-GPU leg")
     ap.add_argument("--render-steps", type=int, default=20, help="forward-only views/sec leg (untimed by driver)")
     ap.add_argument("--pmc-calib", action="store_true", help="also run a 256 MiB streaming multiply (PMC calibration)")
@@ -372,6 +406,10 @@ def main():
     utils.init_distributed(backend="nccl" if world > 1 else None)
     rank = utils.GLOBAL_RANK
 
+    if world > 1:
+        from gaussian_renderer.workload_division import set_balance_timing
+
+        set_balance_timing(a.balance_timing)
     name = a.workload if a.workload != "auto" else ("c1" if world == 1 else "c2")
     main_res = run_workload(a, name, world, rank, dev, a.steps, a.warmup, a.repeats, a.render_steps)
 
@@ -391,6 +429,23 @@ def main():
 
     extras = []
     one_gpu = None
+    extras_1gpu = []
+    if world == 1 and a.workload == "auto" and not a.no_extra and not (a.gaussians or a.width or a.height or a.bsz):
+        import copy
+
+        # the same JSON line tells the rest of the story: north_star's 4K, the hard (low-opacity:
+        # tile lists walked ~3x deeper) variant of the headline scene, and configs[2]'s 6 M Gaussians on one GPU
+        for wname, over in (("c1_4k", {}), ("c1", {"opacity_logit_mean": -2.0, "opacity_logit_std": 1.0}), ("c2", {})):
+            b = copy.copy(a)
+            for k_, v_ in over.items():
+                setattr(b, k_, v_)
+            try:
+                r = run_workload(b, wname, 1, 0, dev, 10, 3, 1, 5)
+                r["variant"] = "low opacity: logit ~ N(-2, 1)" if over else None
+            except Exception as e:  # noqa: BLE001
+                r = {"name": wname, "error": f"{type(e).__name__}: {e}"}
+                torch.cuda.empty_cache()
+            extras_1gpu.append(r)
     if world > 1:
         if not a.no_1gpu_leg:
             one_gpu = same_workload_1gpu(name)
@@ -428,20 +483,16 @@ def main():
     kern = main_res["kernels"]
     dom = max(kern, key=lambda k: kern[k]["avg_ms"] * kern[k]["launches"]) if kern else None
     roofline = None
+    src = source_hash()
+    pmc, pmc_note = load_pmc(src)
+    for kname, kv in kern.items():  # measured HBM bytes (PMC, separate rocprofv3 passes of this command) per kernel
+        pk_ = (pmc or {}).get("kernels", {}).get(kname, {})
+        if pk_.get("hbm_bytes_per_launch") and pk_.get("avg_ms"):
+            kv["measured_MB"] = round(pk_["hbm_bytes_per_launch"] / 1e6, 3)
+            kv["frac_measured"] = round(pk_["hbm_bytes_per_launch"] / (pk_["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        if pk_.get("valu_busy_frac") is not None:
+            kv["valu_busy"] = pk_.get("valu_busy_frac")
     if dom:
-        src = source_hash()
-        pmc, pmc_note = None, "profiles/r02_pmc.json absent"
-        pp = os.path.join(ROOT, "profiles", "r02_pmc.json")
-        if os.path.exists(pp):
-            try:
-                blob = json.load(open(pp))
-                if blob.get("source_hash") == src:
-                    pmc, pmc_note = blob, blob.get("command", "")
-                else:
-                    pmc_note = (f"profiles/r02_pmc.json was measured on source hash {blob.get('source_hash')}, this "
-                                f"build is {src}: not quoted")
-            except Exception as e:  # noqa: BLE001
-                pmc_note = f"unreadable: {e}"
         ach = kern[dom]["GBps"]
         pk = (pmc or {}).get("kernels", {}).get(dom, {})
         valu = None
@@ -505,6 +556,27 @@ def main():
         out["same_workload_1gpu"], out["speedup_vs_1gpu"] = b["same_workload_1gpu"], b.get("speedup_vs_1gpu")
     if extras:
         out["extra_workloads"] = [brief(ex, ex1) for ex, ex1 in extras]
+    if extras_1gpu:
+        ews = []
+        for r in extras_1gpu:
+            if "error" in r:
+                ews.append({"workload": r["name"], "error": r["error"]})
+                continue
+            top = sorted(r["kernels"].items(), key=lambda kv: -kv[1]["avg_ms"] * kv[1]["launches"])[:3]
+            ews.append({"workload": f"{r['name']}: {r['desc']}" + (f" [{r['variant']}]" if r.get("variant") else ""),
+                        "gaussians_total": r["gaussians_total"], "image": r["image"], "bsz": r["bsz"],
+                        "value": round(r["images_per_s"], 3), "unit": "images/s",
+                        "ms_per_step": round(r["ms_per_step"], 4), "steps": r["steps"],
+                        "rendered_views_per_sec": round(r.get("rendered_views_per_sec", 0.0), 3),
+                        "dominant_kernels": {k_: {"avg_ms": v_["avg_ms"], "frac_hbm_peak": v_.get("frac_hbm_peak"),
+                                                  **({"own_frac_hbm_peak": v_["own_frac_hbm_peak"]}
+                                                     if "own_frac_hbm_peak" in v_ else {})} for k_, v_ in top}})
+        out["extra_workloads"] = ews
+    if world > 1:
+        out["config"]["balance_timing"] = a.balance_timing
+        import gaussian_renderer as gr
+
+        out["exchange_layouts"] = dict(gr.exchange_stats)
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(W, H, n_total)
     print(json.dumps(out), flush=True)

@@ -450,6 +450,39 @@ tile_ranges_kernel(long long D, uint32_t tiles, const uint32_t *__restrict__ til
     }
 }
 
+// Optional (gsr_set_depth_tie_order(1)): order Gaussians of EXACTLY equal depth by their screen position instead of by
+// their arrival index.  The reference breaks depth ties by the index in the array the op is given -- at world size
+// > 1 that is (source rank, index on the source), gaussian_renderer/__init__.py:624-640 -- so two runs that shard or
+// order the same Gaussians differently composite tied pairs in different orders (measured on the bench scene, whose
+// generator produces ~N^2 / 3.6e7 exact ties: 1e-4 .. 1e-3 relative on the gradients).  (x, y) of means2D does not depend
+// on who computed it.  After the stable depth sort tied Gaussians are adjacent: the first thread of a run (runs are a
+// handful of elements; culled Gaussians, key 0xFFFFFFFF, are not a run) insertion-sorts its ids in place.
+__global__ void __launch_bounds__(GSR_ONE_DIM_BLOCK)
+depth_tie_fixup_kernel(long long n, const uint32_t *__restrict__ keys, uint32_t *__restrict__ ids,
+                       const float2 *__restrict__ means2D) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t k = keys[i];
+    if (k == 0xFFFFFFFFu || (i > 0 && keys[i - 1] == k) || i + 1 >= n || keys[i + 1] != k) return;
+    long long e = i + 2;
+    while (e < n && keys[e] == k) e++;
+    auto before = [&](uint32_t a, uint32_t b) {
+        const float2 pa = means2D[a], pb = means2D[b];
+        if (pa.x != pb.x) return pa.x < pb.x;
+        if (pa.y != pb.y) return pa.y < pb.y;
+        return a < b;
+    };
+    for (long long a = i + 1; a < e; a++) {
+        const uint32_t v = ids[a];
+        long long b = a - 1;
+        while (b >= i && before(v, ids[b])) {
+            ids[b + 1] = ids[b];
+            b--;
+        }
+        ids[b + 1] = v;
+    }
+}
+
 __global__ void __launch_bounds__(GSR_ONE_DIM_BLOCK)
 copy_u32_kernel(long long n, const uint32_t *__restrict__ src, uint32_t *__restrict__ dst) {
     const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -536,6 +569,7 @@ bool yx_path(int gx, int gy) {
     if (e && strcmp(e, "generic") == 0) return false;
     return gx <= RADIX_DIGITS && gy <= RADIX_DIGITS;
 }
+std::atomic<int> g_tie_order{0};  // 0: arrival index (the reference), 1: screen position
 int bits_for(int n) {  // bits needed for the values 0 .. n-1 (at least 1)
     int b = 1;
     while ((1 << b) < n) b++;
@@ -594,6 +628,9 @@ extern "C" int gsr_bin_prepare_async(int P, int width, int height, const float *
                            (long long)P, vB, vA);
         sorted_ids = vA;
     }
+    if (g_tie_order.load(std::memory_order_relaxed) == 1)
+        hipLaunchKernelGGL(depth_tie_fixup_kernel, dim3(gsr_div_up(P, GSR_ONE_DIM_BLOCK)), dim3(GSR_ONE_DIM_BLOCK), 0,
+                           stream, (long long)P, in_first ? kA : kB, sorted_ids, reinterpret_cast<const float2 *>(means2D));
     const int nbs = gsr_div_up(P, SCAN_TILE);
     uint32_t *host_total = nullptr;
     uint32_t seq = 0;
@@ -604,6 +641,12 @@ extern "C" int gsr_bin_prepare_async(int P, int width, int height, const float *
                        reinterpret_cast<uint32_t *>(ctrl + L.C.tickets), nbs, host_total, seq);
     GSR_LAUNCH_CHECK();
     *ticket = seq;
+    return 0;
+}
+
+extern "C" int gsr_set_depth_tie_order(int mode) {
+    if (mode != 0 && mode != 1) return GSR_EINVAL;
+    g_tie_order.store(mode, std::memory_order_relaxed);
     return 0;
 }
 

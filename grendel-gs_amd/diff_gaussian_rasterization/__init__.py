@@ -29,7 +29,7 @@ from ._lib import check, lib
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "_C", "load_image_tiles_by_pos",
            "merge_image_tiles_by_pos", "set_timing_mode", "fused_l1_ssim_band", "fused_band_loss", "fused_activations", "pack_camera",
            "preprocess_gaussians_raw_batched", "knn_mean_dist2", "group_rows", "gather_rows", "exchange_need",
-           "exchange_count", "exchange_pack", "exchange_pack_slab", "scatter_add_rows", "scatter_rows", "local_pixels"]
+           "exchange_count", "exchange_pack", "exchange_pack_slab", "scatter_add_rows", "set_tie_order", "scatter_rows", "local_pixels"]
 
 BLOCK_X, BLOCK_Y, ONE_DIM_BLOCK_SIZE = 16, 16, 256
 
@@ -543,6 +543,16 @@ def set_speculative_sort(on):
     _SPECULATIVE_SORT[0] = bool(on)
 
 
+def set_tie_order(order):
+    """order of Gaussians with EXACTLY equal depth inside a tile list: "arrival" (default; the reference: index in the
+    arrays the op is given, i.e. (source rank, index on the source) at world size > 1) or "position" (means2D.x, .y,
+    then index): the image and the gradients then do not depend on the number of ranks or on the order of the
+    Gaussians (include/gsraster.h: gsr_set_depth_tie_order)."""
+    if order not in ("arrival", "position"):
+        raise ValueError('tie order must be "arrival" or "position"')
+    check(lib.gsr_set_depth_tie_order(1 if order == "position" else 0), "gsr_set_depth_tie_order")
+
+
 def bin_gaussians(means2D, depths, radii, conic_opacity, compute_locally, width, height, cuda_args=None):
     """K3-K7: returns (point_list uint32-as-int32 [D], ranges int32 [tiles,2], D).  One host read-back (the pair count
     D, like the reference's own num_rendered) -- but the GPU does not wait for it: once a view of this size has been
@@ -616,7 +626,9 @@ class _RenderGaussians(torch.autograd.Function):
             mask = compute_locally.to(device=dev).contiguous().view(-1)
             mask = mask.view(torch.uint8) if mask.dtype == torch.bool else mask.to(torch.uint8)
         bg = _f32c(rs.bg, "bg")
-        timing = _timing_mode()
+        # per call (the mirror asks through cuda_args, so a module-wide mode a user chose is never overridden), else
+        # the module-wide mode
+        timing = (cuda_args.get("_gsr_timing") if isinstance(cuda_args, dict) else None) or _timing_mode()
         stats = cuda_args.get("stats_collector") if isinstance(cuda_args, dict) else None
         with torch.cuda.device(dev):
             if timing != "off":

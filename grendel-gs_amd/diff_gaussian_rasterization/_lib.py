@@ -33,6 +33,7 @@ SIGNATURES = {
                              c_void_p, c_void_p]),
     "gsr_bin_prepare_async": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_size_t, ctypes.POINTER(ctypes.c_uint32), c_void_p]),
+    "gsr_set_depth_tie_order": (c_int, [c_int]),
     "gsr_bin_count_wait": (c_int, [ctypes.c_uint32, ctypes.POINTER(c_int64), c_void_p]),
     "gsr_bin_sort_capacity": (c_int64, [c_int, c_size_t, c_int, c_int]),
     "gsr_bin_sort_bounded": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_size_t, c_void_p,

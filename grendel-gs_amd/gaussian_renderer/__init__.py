@@ -31,9 +31,6 @@ from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianR
 
 import diff_gaussian_rasterization as _dgr
 
-if hasattr(_dgr, "set_timing_mode"):
-    _dgr.set_timing_mode("deferred")  # finish_strategy_final resolves the ops' HIP events
-
 N_DIFF = 9  # means2D (2) + rgb (3) + conic_opacity (4): columns that carry gradients
 N_AUX = 2   # radius (as float) + depth: no gradient
 
@@ -151,10 +148,15 @@ def all_to_all_communication_final(batched_rasterizers, batched_screenspace_para
 
 
 # ---- the fused exchange of the camera-batched state -------------------------------------------------------------
-# switches (parity tests flip them): pipeline the per-camera exchanges on a side HIP stream; use the fused kernels
-_EXCHANGE_OPTIONS = {"overlap": True}
+# switches (parity tests flip them):
+#   overlap   : pipeline the per-camera exchanges on a side HIP stream
+#   speculate : pack into capacity slabs chosen from earlier iterations, so that this iteration's counts never have to
+#               reach the host before the all-to-all is launched (no `.cpu()` between K1 and the render)
+_EXCHANGE_OPTIONS = {"overlap": True, "speculate": True, "forced": False}
 _SIDE_STREAMS = {}
 _BANDS_CACHE = {}
+_PLANNERS = {}
+exchange_stats = {"speculative": 0, "sized": 0, "redone": 0}  # how the exchanges of this process were laid out
 
 
 def set_exchange_overlap(enabled):
@@ -162,6 +164,22 @@ def set_exchange_overlap(enabled):
     runs beside camera k-1's K3-K8 in the forward and beside camera k+1's K10 in the backward (north_star); off: one
     exchange for the whole batch on the current stream"""
     _EXCHANGE_OPTIONS["overlap"] = bool(enabled)
+
+
+def set_exchange_speculation(enabled):
+    """True (default): capacity slabs, no host read-back of this iteration's counts before the all-to-all (they are
+    verified after the first render has polled its pair count, and the exchange is repeated with exact sizes if a slab
+    overflowed).  False: the reference's order -- all-gather the counts, read them back, size everything exactly
+    (gaussian_renderer/__init__.py:572-585)."""
+    _EXCHANGE_OPTIONS["speculate"] = bool(enabled)
+
+
+def set_exchange_forced(enabled):
+    """run the exchange in a ONE-rank group too (every visible row is "sent" to the rank itself through the real
+    collectives): the single-GPU tests and tools/overlap_trace.py exercise pack / RCCL / unpack / verification / the
+    mirror backward this way.  Off (default): world size 1 hands K1's outputs straight to the renderer, as the
+    reference does (gaussian_renderer/__init__.py:969-1000)."""
+    _EXCHANGE_OPTIONS["forced"] = bool(enabled)
 
 
 def _side_stream(dev):
@@ -200,24 +218,90 @@ def _camera_major_base(per_camera):
     return torch.stack([t.detach() for t in per_camera]).contiguous()
 
 
+class _SlabPlanner:
+    """Capacities of the read-back-free exchange: caps[i][j][k] rows are reserved for what rank i sends rank j of the
+    batch's k-th camera.  A pure function of the all-gathered count matrices of EARLIER iterations -- every rank holds
+    the same matrices, so every rank derives the same capacities and takes the same overflow decision without any
+    extra collective.  capacity = 1.25 x (largest count of the last 64 iterations) + 256, rounded up to 256 rows: the
+    exchange is latency-bound (~12 us per peer at link rate), padding rows cost 44 B each."""
+
+    WINDOW = 64
+
+    def __init__(self, W, B):
+        self.W, self.B = W, B
+        self.hist = []
+        self.caps = None        # int64 [W, W, B] (host)
+        self.caps_list = None   # the same as nested python lists
+        self.pending = None     # (event | None, host matrix, caps it was packed with) of an unverified iteration
+        self._ring, self._slot = [], 0
+
+    def observe(self, m):
+        self.hist.append(m.to(torch.int64).clone())
+        if len(self.hist) > self.WINDOW:
+            self.hist.pop(0)
+        peak = torch.stack(self.hist).amax(0)
+        want = (peak * 5 // 4 + 256 + 255) // 256 * 256
+        if self.caps is None or bool((want > self.caps).any()) or bool((want * 2 < self.caps).any()):
+            self.caps = want
+            self.caps_list = want.tolist()
+
+    def stage(self, all_counts):
+        """asynchronous copy of this iteration's all-gathered counts to the host; nothing waits for it here"""
+        if all_counts.is_cuda:
+            if len(self._ring) < 4:
+                self._ring.append(torch.empty(all_counts.shape, dtype=all_counts.dtype).pin_memory())
+            host = self._ring[self._slot % len(self._ring)] if len(self._ring) == 4 else self._ring[-1]
+            self._slot += 1
+            host.copy_(all_counts, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        else:
+            host, ev = all_counts.clone(), None
+        self.pending = (ev, host, self.caps.clone())
+
+    def resolve(self):
+        """-> (count matrix int64 [W, W, B] of the pending iteration, True when every count fitted its slab)"""
+        ev, host, caps = self.pending
+        self.pending = None
+        if ev is not None:
+            ev.synchronize()  # the copy was queued before the all-to-all: long complete when a render has polled D
+        m = host.view(self.W, self.W, self.B).to(torch.int64).clone()
+        self.observe(m)
+        return m, bool((m <= caps).all())
+
+
+def _planner(group, W, B):
+    key = (id(group), W, B)
+    p = _PLANNERS.get(key)
+    if p is None:
+        p = _PLANNERS[key] = _SlabPlanner(W, B)
+    return p
+
+
 class _ExchangeGroup(torch.autograd.Function):
-    """the exchange of the cameras [k0, k0 + nb) of a batch: pack (gsr_exchange_pack: 11-float records in
-    (destination, camera, local index) order, straight into the send buffer), ONE all-to-all-v, unpack.  Runs on the
-    stream that is current when it is called -- autograd runs the backward (gradient rows back through the mirror
+    """the exchange of the cameras [k0, k0 + nb) of a batch: pack (gsr_exchange_pack / gsr_exchange_pack_slab: 11-float
+    records in (destination, camera, local index) order, straight into the send buffer), ONE all-to-all-v, unpack.  Runs
+    on the stream that is current when it is called -- autograd runs the backward (gradient rows back through the mirror
     all-to-all-v, gsr_scatter_add_rows into the owners' rows) on the same stream.  Differentiable inputs: the per-camera
     means2D / rgb / conic_opacity views (their gradients come back as column views of one [nb*P, 9] record that the
     batched K11 reads through its row stride)."""
 
     @staticmethod
     def forward(ctx, meta, bases, token, *views):
-        (k0, nb, P, width, height, seg_off, send_splits, recv_splits, perm, inv_perm, group, chunkcnt, cnt_B, bands,
-         consumer_stream, holder) = meta
+        (k0, nb, P, width, height, layout, send_splits, recv_splits, perm, inv_perm, group, chunkcnt, counts, cnt_B,
+         bands, consumer_stream, holder) = meta
         m2_all, rgb_all, co_all, radii_all, depths_all = bases
         dev = radii_all.device
         n_send, n_recv = sum(send_splits), sum(recv_splits)
         cur = torch.cuda.current_stream() if dev.type == "cuda" else None
-        msg, send_idx = _dgr.exchange_pack(m2_all, rgb_all, co_all, radii_all, depths_all, bands, chunkcnt, seg_off,
-                                           n_send, k0, nb, width, height, count_cameras=cnt_B, count_first=0)
+        if layout[0] == "slab":  # capacities per (destination, camera); this iteration's counts stay on the device
+            msg, send_idx = _dgr.exchange_pack_slab(m2_all, rgb_all, co_all, radii_all, depths_all, bands, chunkcnt,
+                                                    counts, layout[1], k0, nb, width, height, count_cameras=cnt_B,
+                                                    count_first=0)
+        else:                    # exact segment offsets from counts the host has read
+            msg, send_idx = _dgr.exchange_pack(m2_all, rgb_all, co_all, radii_all, depths_all, bands, chunkcnt,
+                                               layout[1], n_send, k0, nb, width, height, count_cameras=cnt_B,
+                                               count_first=0)
         recv = torch.empty((n_recv, N_DIFF + N_AUX), dtype=msg.dtype, device=dev)
         dist.all_to_all_single(recv, msg, output_split_sizes=recv_splits, input_split_sizes=send_splits, group=group)
         outs = [torch.empty((n_recv, w), dtype=msg.dtype, device=dev) for w in (2, 3, 4, 1, 1)]
@@ -235,8 +319,13 @@ class _ExchangeGroup(torch.autograd.Function):
         ctx.mark_non_differentiable(r_radii, r_depths)
         # the token chains the per-camera exchanges of a batch: camera k's node consumes camera k-1's token, the last
         # one is handed to a render op, so every rank's backward runs the mirror collectives of ALL cameras (also of
-        # those it renders no part of) and in the same order, camera B-1 first
-        token_out = torch.empty((1,), dtype=outs[0].dtype, device=dev) if token is not None else None
+        # those it renders no part of) and in the same order, camera B-1 first.  Its VALUE is read by the < 10-Gaussian
+        # stand-in of render_final (0 * token): it must be a defined zero, not an uninitialised word
+        token_out = None
+        if token is not None:
+            token_out = torch.zeros((1,), dtype=outs[0].dtype, device=dev)
+            if consumer_stream is not None and consumer_stream != cur:
+                token_out.record_stream(consumer_stream)
         return outs[0], outs[1], outs[2], r_radii, r_depths, token_out
 
     @staticmethod
@@ -273,19 +362,52 @@ class _ExchangeGroup(torch.autograd.Function):
             if consumer_stream is not None and consumer_stream != cur:
                 holder["rec"].record_stream(consumer_stream)
         rec = holder["rec"][k0 * P:(k0 + nb) * P]
-        _dgr.scatter_add_rows(send_idx, back, nb * P, dst=rec)
+        _dgr.scatter_add_rows(send_idx, back, nb * P, dst=rec)  # slab padding rows carry index -1: skipped
         grads = []
         for a, b in ((0, 2), (2, 5), (5, 9)):
             grads += [rec[k * P:(k + 1) * P, a:b] for k in range(nb)]
         return (None, None, None) + tuple(grads)
 
 
+class _LazySizes:
+    """gpui_to_gpuj_imgk_size of a speculative exchange: the [W][W][B] python ints exist once the asynchronous copy of
+    the counts has been looked at (render_final does); list-like for the code that reads them afterwards"""
+
+    def __init__(self):
+        self._v = None
+        self._resolver = None
+
+    def _get(self):
+        if self._v is None:
+            self._resolver()
+        return self._v
+
+    def __getitem__(self, i):
+        return self._get()[i]
+
+    def __len__(self):
+        return len(self._get())
+
+    def __iter__(self):
+        return iter(self._get())
+
+    def __eq__(self, other):
+        return self._get() == (other._get() if isinstance(other, _LazySizes) else other)
+
+    def __repr__(self):
+        return repr(self._get())
+
+
 def _batched_exchange_final(m2_views, rgb_views, co_views, radii_views, depths_views, rasterizers,
-                            batched_strategies):
+                            batched_strategies, speculate=None, pipeline=None, _known=None):
     """all_to_all_communication_final for the camera-batched state: same return structure (+ the per-camera events a
-    consumer on another stream must wait for, None without overlap).  Host cost per batch: one count launch, one size
-    all-gather + the one read-back, then per exchange one pack launch, one all-to-all-v and one unpack launch."""
+    consumer on another stream must wait for, None without overlap; + the pending verification of a speculative
+    layout, None for an exact one).  Host cost per batch: one count launch, one size all-gather, then per exchange one
+    pack launch, one all-to-all-v and one unpack launch -- and, only when the layout is not speculative, the one
+    read-back of the counts the reference has too (gaussian_renderer/__init__.py:572-585)."""
     group = utils.DEFAULT_GROUP
+    if not isinstance(group, dist.ProcessGroup):  # set_exchange_forced in a process whose DEFAULT_GROUP is the stand-in
+        group = dist.group.WORLD
     W, me = group.size(), group.rank()
     B = len(radii_views)
     bases = [_camera_major_base(v) for v in (m2_views, rgb_views, co_views, radii_views, depths_views)]
@@ -295,13 +417,35 @@ def _batched_exchange_final(m2_views, rgb_views, co_views, radii_views, depths_v
     rs = rasterizers[0].raster_settings
     width, height = int(rs.image_width), int(rs.image_height)
     bands = _bands_tensor(batched_strategies, W, dev)
-    chunkcnt, counts = _dgr.exchange_count(bases[0], radii_all, bands, 0, B, width, height)
-    all_counts = torch.empty((W * W, B), dtype=torch.int32, device=dev)
-    dist.all_gather_into_tensor(all_counts, counts, group=group)
-    sizes = all_counts.view(W, W, B).cpu().tolist()  # the one host read-back of the exchange; sizes[i][j][k]
+    planner = _planner(group, W, B)
+    if planner.pending is not None:
+        # a speculative exchange whose consumer never went through render_final: look at its counts now
+        _, fitted = planner.resolve()
+        if not fitted:
+            raise RuntimeError("the previous iteration's speculative exchange overflowed a slab and was consumed "
+                               "without render_final()'s verification; call gaussian_renderer.render_final or "
+                               "set_exchange_speculation(False)")
+    speculate = _EXCHANGE_OPTIONS["speculate"] if speculate is None else speculate
+    if _known is not None:   # the repeat of an overflowed speculative exchange: counts already on the host
+        chunkcnt, counts, sizes = _known
+        speculate = False
+    else:
+        chunkcnt, counts = _dgr.exchange_count(bases[0], radii_all, bands, 0, B, width, height)
+        all_counts = torch.empty((W * W, B), dtype=torch.int32, device=dev)
+        dist.all_gather_into_tensor(all_counts, counts, group=group)
+        speculate = speculate and planner.caps is not None
+        if speculate:
+            planner.stage(all_counts)
+            sizes = _LazySizes()
+        else:
+            sizes = all_counts.view(W, W, B).cpu().tolist()  # the one host read-back of an exact exchange; sizes[i][j][k]
+            planner.observe(torch.tensor(sizes, dtype=torch.int64))
+    exchange_stats["speculative" if speculate else "sized"] += 1
+    layout_sizes = planner.caps_list if speculate else sizes  # rows per (source, destination, camera) of the buffers
 
-    pipelined = _EXCHANGE_OPTIONS["overlap"] and B > 1   # one exchange per camera ...
-    overlap = pipelined and dev.type == "cuda"            # ... on the side stream
+    pipeline = _EXCHANGE_OPTIONS["overlap"] if pipeline is None else pipeline
+    pipelined = (pipeline or speculate) and B > 1         # one exchange per camera ...
+    overlap = pipelined and pipeline and dev.type == "cuda"  # ... on the side stream
     groups = [(k, 1) for k in range(B)] if pipelined else [(0, B)]
     cur = torch.cuda.current_stream() if dev.type == "cuda" else None
     side = _side_stream(dev) if overlap else None
@@ -313,36 +457,40 @@ def _batched_exchange_final(m2_views, rgb_views, co_views, radii_views, depths_v
     token = torch.zeros((1,), dtype=bases[0].dtype, device=dev, requires_grad=True) if pipelined else None
     for (k0, nb) in groups:
         cams = range(k0, k0 + nb)
-        send_splits = [sum(sizes[me][j][k] for k in cams) for j in range(W)]
-        recv_splits = [sum(sizes[i][me][k] for k in cams) for i in range(W)]
-        seg_off, o = [0] * (W * nb), 0
-        for g in range(W):
-            for kk, k in enumerate(cams):
-                seg_off[g * nb + kk] = o
-                o += sizes[me][g][k]
-        # received rows are (source, camera)-major; the renderer wants camera-major with the source order kept
-        per_cam = [sum(sizes[i][me][k] for i in range(W)) for k in cams]
+        send_splits = [sum(layout_sizes[me][j][k] for k in cams) for j in range(W)]
+        recv_splits = [sum(layout_sizes[i][me][k] for k in cams) for i in range(W)]
+        per_cam = [sum(layout_sizes[i][me][k] for i in range(W)) for k in cams]
         perm = inv_perm = None
-        if sum(1 for n in per_cam if n) > 1:
-            # segments (source i, camera k) arrive source-major; list them camera-major.  The row permutation is
-            # expanded ON THE DEVICE from the W * nb segment descriptors (a few hundred bytes of host data)
-            off, o = {}, 0
-            for i in range(W):
-                for k in cams:
-                    off[(i, k)] = o
-                    o += sizes[i][me][k]
-            segs = [(off[(i, k)], sizes[i][me][k]) for k in cams for i in range(W) if sizes[i][me][k] > 0]
-            total = sum(n for _, n in segs)
-            lens = torch.tensor([n for _, n in segs], dtype=torch.int64)
-            dst0 = torch.cumsum(lens, 0) - lens
-            shift = (torch.tensor([b for b, _ in segs], dtype=torch.int64) - dst0).to(dev)
-            order = (torch.repeat_interleave(shift, lens.to(dev), output_size=total)
-                     + torch.arange(total, dtype=torch.int64, device=dev))
-            inv = torch.empty(total, dtype=torch.int32, device=dev)
-            inv[order] = torch.arange(total, dtype=torch.int32, device=dev)
-            perm, inv_perm = order.to(torch.int32), inv
-        meta = (k0, nb, P, width, height, seg_off, send_splits, recv_splits, perm, inv_perm, group, chunkcnt, B, bands,
-                cur if overlap else None, holder)
+        if speculate:
+            layout = ("slab", [layout_sizes[me][g][k] for g in range(W) for k in cams])
+        else:
+            seg_off, o = [0] * (W * nb), 0
+            for g in range(W):
+                for kk, k in enumerate(cams):
+                    seg_off[g * nb + kk] = o
+                    o += sizes[me][g][k]
+            layout = ("sized", seg_off)
+            # received rows are (source, camera)-major; the renderer wants camera-major with the source order kept
+            if sum(1 for n in per_cam if n) > 1:
+                # segments (source i, camera k) arrive source-major; list them camera-major.  The row permutation is
+                # expanded ON THE DEVICE from the W * nb segment descriptors (a few hundred bytes of host data)
+                off, o = {}, 0
+                for i in range(W):
+                    for k in cams:
+                        off[(i, k)] = o
+                        o += sizes[i][me][k]
+                segs = [(off[(i, k)], sizes[i][me][k]) for k in cams for i in range(W) if sizes[i][me][k] > 0]
+                total = sum(n for _, n in segs)
+                lens = torch.tensor([n for _, n in segs], dtype=torch.int64)
+                dst0 = torch.cumsum(lens, 0) - lens
+                shift = (torch.tensor([b for b, _ in segs], dtype=torch.int64) - dst0).to(dev)
+                order = (torch.repeat_interleave(shift, lens.to(dev), output_size=total)
+                         + torch.arange(total, dtype=torch.int64, device=dev))
+                inv = torch.empty(total, dtype=torch.int32, device=dev)
+                inv[order] = torch.arange(total, dtype=torch.int32, device=dev)
+                perm, inv_perm = order.to(torch.int32), inv
+        meta = (k0, nb, P, width, height, layout, send_splits, recv_splits, perm, inv_perm, group, chunkcnt, counts, B,
+                bands, cur if overlap else None, holder)
         views = [m2_views[k] for k in cams] + [rgb_views[k] for k in cams] + [co_views[k] for k in cams]
         if overlap:
             with torch.cuda.stream(side):
@@ -360,43 +508,45 @@ def _batched_exchange_final(m2_views, rgb_views, co_views, radii_views, depths_v
                 out[c][k] = r[c] if whole else r[c][start:start + n]
             events[k] = ev
             start += n
-    return out[0], out[1], out[2], out[3], out[4], sizes, (events, token)
+    pending = (planner, chunkcnt, counts, sizes) if speculate else None
+    return out[0], out[1], out[2], out[3], out[4], sizes, (events, token), pending
 
 
 def distributed_preprocess3dgs_and_all2all_final(batched_viewpoint_cameras, pc, pipe, bg_color, scaling_modifier=1.0,
-                                                 batched_strategies=None, mode="train"):
+                                                 batched_strategies=None, mode="train", _legacy=False):
     """every rank projects ITS shard of Gaussians for EVERY camera of the batch (K1), then the sparse
-    exchange hands each rank the Gaussians touching the bands it renders."""
+    exchange hands each rank the Gaussians touching the bands it renders.  (`_legacy`: set by the legacy single-camera
+    wrapper below, whose render() has no verification / stream hand-over: exact sizes, one exchange, current stream.)"""
     timers = utils.get_timers()
     args = utils.get_args()
     assert utils.DEFAULT_GROUP.size() == 1 or (args.gaussians_distribution and args.image_distribution), \
         "Ensure distributed training given multiple GPU. "
 
-    if hasattr(_dgr, "set_timing_mode"):
-        # the operator records its render timings (HIP events, resolved by finish_strategy_final) only when the load
-        # balancer or a saved strategy history will read them
-        try:
-            from gaussian_renderer.workload_division import timings_have_consumer
-            wanted = mode != "train" or timings_have_consumer()
-        except ImportError:  # grafted over the reference's workload_division
-            wanted = True
-        _dgr.set_timing_mode("deferred" if wanted else "off")
+    # the operator records its render timings (HIP events, resolved by finish_strategy_final) only when the load
+    # balancer or a saved strategy history will read them; asked for per call (cuda_args), not through the module-wide
+    # timing mode a user may have set
+    from gaussian_renderer.workload_division import timings_have_consumer
+    timing = "deferred" if (mode != "train" or timings_have_consumer()) else "off"
     if timers is not None:
         timers.start("forward_prepare_gaussians")
     raw = [getattr(pc, n, None) for n in ("_xyz", "_scaling", "_rotation", "_features_dc", "_features_rest", "_opacity")]
-    fused = hasattr(GaussianRasterizer, "preprocess_gaussians_raw") and all(torch.is_tensor(t) and t.is_cuda for t in raw)
-    if not fused:  # the reference's way: four stock-torch activation kernels, then the op on activated tensors
-        means3D, opacity, scales = pc.get_xyz, pc.get_opacity, pc.get_scaling
-        rotations, shs = pc.get_rotation, pc.get_features
-    # fused: exp / normalize / sigmoid / cat of the getters (scene/gaussian_model.py:109-129) happen inside K1 / K11
+    if not all(torch.is_tensor(t) for t in raw):
+        raise TypeError("distributed_preprocess3dgs_and_all2all_final: `pc` must expose GaussianModel's raw parameters "
+                        "(_xyz, _scaling, _rotation, _features_dc, _features_rest, _opacity; "
+                        "scene/gaussian_model.py:219-242): the getters' activations run inside K1 / K11")
+    if not all(t.is_cuda for t in raw):
+        raise RuntimeError("distributed_preprocess3dgs_and_all2all_final: the model must live on the gfx950 device "
+                           "(there is no CPU path)")
+    # exp / normalize / sigmoid / cat of the getters (scene/gaussian_model.py:109-129) happen inside K1 / K11
     if timers is not None:
         timers.stop("forward_prepare_gaussians")
         timers.start("forward_preprocess_gaussians")
 
     rasterizers, cuda_args_list, params = [], [], []
-    batched_state = None
     for camera, strategy in zip(batched_viewpoint_cameras, batched_strategies):
-        cuda_args_list.append(get_cuda_args_final(strategy, mode))
+        ca = get_cuda_args_final(strategy, mode)
+        ca["_gsr_timing"] = timing
+        cuda_args_list.append(ca)
         settings = GaussianRasterizationSettings(
             image_height=int(camera.image_height),
             image_width=int(camera.image_width),
@@ -412,46 +562,35 @@ def distributed_preprocess3dgs_and_all2all_final(batched_viewpoint_cameras, pc, 
             debug=pipe.debug,
         )
         rasterizers.append(GaussianRasterizer(raster_settings=settings))
-    same_size = len({(r.raster_settings.image_height, r.raster_settings.image_width) for r in rasterizers}) == 1
-    if fused and same_size and hasattr(_dgr, "preprocess_gaussians_raw_batched"):
-        # ONE launch for the whole batch: parameters read once, per-camera outputs camera-major
-        packed = []
-        for camera, rast in zip(batched_viewpoint_cameras, rasterizers):
-            # the packed record is valid as long as the camera's tensors are the same objects with the same contents:
-            # data_ptr + in-place version counter of each matrix (pose refinement / test-time edits repack)
-            rs_k = rast.raster_settings
-            key = (float(rs_k.tanfovx), float(rs_k.tanfovy)) + tuple(
-                (t.data_ptr(), t._version) for t in (rs_k.viewmatrix, rs_k.projmatrix, rs_k.campos))
-            cached = getattr(camera, "_gsr_packed", None)
-            if cached is None or cached[0] != key or cached[1].device != raw[0].device:
-                cached = (key, _dgr.pack_camera(rast.raster_settings))
-                try:
-                    camera._gsr_packed = cached  # cameras are static: packed once
-                except AttributeError:
-                    pass
-            packed.append(cached[1])
-        rs0 = rasterizers[0].raster_settings
-        m2_all, rgb_all, co_all, radii_all, depths_all = _dgr.preprocess_gaussians_raw_batched(
-            *raw, packed[0].view(1, -1) if len(packed) == 1 else torch.stack(packed), pc.active_sh_degree, scaling_modifier, rs0.image_width, rs0.image_height,
-            tanfov0=(rs0.tanfovx, rs0.tanfovy), cuda_args_list=cuda_args_list)
-        for k in range(len(rasterizers)):
-            means2D = m2_all[k]
-            if mode == "train":
-                means2D.retain_grad()  # densification reads means2D.grad (scene/gaussian_model.py:1046-1052)
-            params.append([means2D, rgb_all[k], co_all[k], radii_all[k], depths_all[k]])
-        batched_state = (rgb_all, co_all, radii_all, depths_all)
-    else:
-        for rasterizer, cuda_args in zip(rasterizers, cuda_args_list):
-            if fused:
-                means2D, rgb, conic_opacity, radii, depths = rasterizer.preprocess_gaussians_raw(
-                    *raw, cuda_args=cuda_args)
-            else:
-                means2D, rgb, conic_opacity, radii, depths = rasterizer.preprocess_gaussians(
-                    means3D=means3D, scales=scales, rotations=rotations, shs=shs, opacities=opacity,
-                    cuda_args=cuda_args)
-            if mode == "train":
-                means2D.retain_grad()  # densification reads means2D.grad (scene/gaussian_model.py:1046-1052)
-            params.append([means2D, rgb, conic_opacity, radii, depths])
+    if len({(r.raster_settings.image_height, r.raster_settings.image_width) for r in rasterizers}) != 1:
+        raise ValueError("all cameras of a batch must have one image size (the reference keeps ONE global image size, "
+                         "utils/general_utils.py:89-93, set from the first training camera, scene/__init__.py:93-97)")
+    # ONE launch for the whole batch: parameters read once, per-camera outputs camera-major
+    packed = []
+    for camera, rast in zip(batched_viewpoint_cameras, rasterizers):
+        # the packed record is valid as long as the camera's tensors are the same objects with the same contents:
+        # data_ptr + in-place version counter of each matrix (pose refinement / test-time edits repack)
+        rs_k = rast.raster_settings
+        key = (float(rs_k.tanfovx), float(rs_k.tanfovy)) + tuple(
+            (t.data_ptr(), t._version) for t in (rs_k.viewmatrix, rs_k.projmatrix, rs_k.campos))
+        cached = getattr(camera, "_gsr_packed", None)
+        if cached is None or cached[0] != key or cached[1].device != raw[0].device:
+            cached = (key, _dgr.pack_camera(rast.raster_settings))
+            try:
+                camera._gsr_packed = cached  # cameras are static: packed once
+            except AttributeError:
+                pass
+        packed.append(cached[1])
+    rs0 = rasterizers[0].raster_settings
+    m2_all, rgb_all, co_all, radii_all, depths_all = _dgr.preprocess_gaussians_raw_batched(
+        *raw, packed[0].view(1, -1) if len(packed) == 1 else torch.stack(packed), pc.active_sh_degree,
+        scaling_modifier, rs0.image_width, rs0.image_height, tanfov0=(rs0.tanfovx, rs0.tanfovy),
+        cuda_args_list=cuda_args_list)
+    for k in range(len(rasterizers)):
+        means2D = m2_all[k]
+        if mode == "train":
+            means2D.retain_grad()  # densification reads means2D.grad (scene/gaussian_model.py:1046-1052)
+        params.append([means2D, rgb_all[k], co_all[k], radii_all[k], depths_all[k]])
     if timers is not None:
         timers.stop("forward_preprocess_gaussians")
 
@@ -462,38 +601,68 @@ def distributed_preprocess3dgs_and_all2all_final(batched_viewpoint_cameras, pc, 
         "batched_rasterizers": rasterizers,
         "batched_cuda_args": cuda_args_list,
     }
-    if utils.DEFAULT_GROUP.size() == 1:
+    W = utils.DEFAULT_GROUP.size()
+    if W == 1 and not (_EXCHANGE_OPTIONS["forced"] and dist.is_initialized()):
         redistributed = tuple([p[c] for p in params] for c in range(5))
         sizes = [[[p[0].shape[0] for p in params]]]
-    else:
-        if timers is not None:
-            timers.start("forward_all_to_all_communication")
-        if batched_state is not None and hasattr(_dgr, "exchange_pack") and utils.DEFAULT_GROUP.size() * len(params) <= 512:
-            *redistributed, sizes, (events, token) = _batched_exchange_final(
-                [p[0] for p in params], *batched_state, rasterizers, batched_strategies)
-            pkg["_exchange_events"] = events
-            if token is not None:  # anchor of the exchange chain: the render op of the LAST camera this rank renders
-                mine = [k for k, st in enumerate(batched_strategies) if utils.GLOBAL_RANK in st.gpu_ids]
-                if mine:
-                    cuda_args_list[mine[-1]]["_exchange_token"] = token
-        else:
-            *redistributed, sizes = all_to_all_communication_final(rasterizers, params, cuda_args_list,
-                                                                   batched_strategies)
-        if timers is not None:
-            timers.stop("forward_all_to_all_communication")
-    for name, value in zip(("means2D", "rgb", "conic_opacity", "radii", "depths"), redistributed):
-        pkg[f"batched_{name}_redistributed"] = value
-    pkg["gpui_to_gpuj_imgk_size"] = sizes
+        _fill(pkg, redistributed, sizes)
+        return pkg
+    if W * len(params) > 512:
+        raise ValueError(f"world size x batch size = {W * len(params)} exceeds the 512 (destination, camera) segments "
+                         "one exchange launch carries (include/gsraster.h: gsr_exchange_count)")
+    if timers is not None:
+        timers.start("forward_all_to_all_communication")
+    mine = [k for k, st in enumerate(batched_strategies) if utils.GLOBAL_RANK in st.gpu_ids]
+
+    def exchange(known=None):
+        *redistributed, sizes, (events, token), pending = _batched_exchange_final(
+            [p[0] for p in params], rgb_all, co_all, radii_all, depths_all, rasterizers, batched_strategies,
+            speculate=False if _legacy else None, pipeline=False if _legacy else None, _known=known)
+        _fill(pkg, redistributed, sizes)
+        pkg["_exchange_events"] = events
+        for ca in cuda_args_list:
+            ca.pop("_exchange_token", None)
+        if token is not None and mine:  # anchor of the exchange chain: the render op of the LAST camera this rank renders
+            cuda_args_list[mine[-1]]["_exchange_token"] = token
+        pkg["_exchange_token"] = token
+        pkg.pop("_exchange_pending", None)
+        if pending is not None:
+            planner, chunkcnt, counts, lazy = pending
+            rendered = [(g, k) for k, st in enumerate(batched_strategies) for g in st.gpu_ids]
+
+            def verify():
+                """-> True when the speculative layout held (every count fitted its slab and no rendered band falls
+                under the reference's < 10-Gaussian rule, which needs the true row count); otherwise the exchange has
+                been repeated with exact sizes and the caller must render again.  The same decision on every rank:
+                it is a function of the all-gathered matrix."""
+                if pkg.get("_exchange_pending") is None:
+                    return True
+                pkg.pop("_exchange_pending")
+                m, fitted = planner.resolve()
+                lazy._v = m.tolist()
+                if fitted and all(int(m[:, g, k].sum()) >= 10 for (g, k) in rendered):
+                    return True
+                exchange_stats["redone"] += 1
+                exchange(known=(chunkcnt, counts, lazy._v))
+                return False
+
+            lazy._resolver = verify
+            pkg["_exchange_pending"] = verify
+
+    exchange()
+    if timers is not None:
+        timers.stop("forward_all_to_all_communication")
     return pkg
 
 
-def render_final(batched_screenspace_pkg, batched_strategies, tile_size=16):
-    """-> (images, masks) per camera: a [3,H,W] image (zero outside this rank's row band), a scalar
-    stand-in when fewer than 10 Gaussians arrived (keeps the autograd graph and the exchange's
-    backward alive, gaussian_renderer/__init__.py:1260-1269), or None when this rank renders no part
-    of the camera."""
+def _fill(pkg, redistributed, sizes):
+    for name, value in zip(("means2D", "rgb", "conic_opacity", "radii", "depths"), redistributed):
+        pkg[f"batched_{name}_redistributed"] = value
+    pkg["gpui_to_gpuj_imgk_size"] = sizes
+
+
+def _render_cameras(pkg, batched_strategies):
     timers = utils.get_timers()
-    pkg = batched_screenspace_pkg
     images, masks = [], []
     for k, strategy in enumerate(batched_strategies):
         if utils.GLOBAL_RANK not in strategy.gpu_ids:
@@ -529,6 +698,21 @@ def render_final(batched_screenspace_pkg, batched_strategies, tile_size=16):
     return images, masks
 
 
+def render_final(batched_screenspace_pkg, batched_strategies, tile_size=16):
+    """-> (images, masks) per camera: a [3,H,W] image (zero outside this rank's row band), a scalar
+    stand-in when fewer than 10 Gaussians arrived (keeps the autograd graph and the exchange's
+    backward alive, gaussian_renderer/__init__.py:1260-1269), or None when this rank renders no part
+    of the camera.  A speculative exchange (capacity slabs) is verified HERE, after the renders have polled their pair
+    counts -- the asynchronous copy of the exchange's counts is then long complete, so the check waits for nothing --
+    and, had a slab overflowed, exchange and render are repeated with exact sizes."""
+    pkg = batched_screenspace_pkg
+    images, masks = _render_cameras(pkg, batched_strategies)
+    verify = pkg.get("_exchange_pending")
+    if verify is not None and not verify():
+        images, masks = _render_cameras(pkg, batched_strategies)
+    return images, masks
+
+
 def _no_gsplat(*a, **k):
     raise NotImplementedError(
         "the gsplat backend is a third-party alternative whose source is not part of the reference tree "
@@ -556,8 +740,11 @@ def _local_camera_index(batched_strategies):
 def preprocess3dgs_and_all2all(batched_cameras, gaussians, pipe_args, background, batched_strategies, mode):
     """legacy entry point (gaussian_renderer/__init__.py:410-455): the package `render()` below consumes -- one
     local camera, keys `rasterizer`, `cuda_args`, `*_for_render` -- built from the live `final` path."""
+    # one exchange for the whole batch on the current stream with exact sizes: render() below has neither the stream
+    # hand-over nor the verification of the pipelined / speculative layouts, and without per-camera nodes there is no
+    # token chain to anchor
     pkg = distributed_preprocess3dgs_and_all2all_final(batched_cameras, gaussians, pipe_args, background,
-                                                       batched_strategies=batched_strategies, mode=mode)
+                                                       batched_strategies=batched_strategies, mode=mode, _legacy=True)
     k = _local_camera_index(batched_strategies)
     out = {
         "batched_locally_preprocessed_mean2D": pkg["batched_locally_preprocessed_mean2D"],

@@ -12,23 +12,16 @@ Each rank evaluates L1 and SSIM on ITS row band only, zero-padded at the band ed
 normalised by the FULL image's pixel count, so that the per-rank partial losses of a camera add up to
 the full-image loss up to the band-border SSIM term.
 """
-import math
-
 import torch
 import torch.distributed as dist
-import torch.nn.functional as F
 
 import utils.general_utils as utils
 
 # The fused HIP loss lives in this package's operator module.  A missing / unbuilt libgsraster.so makes this import
-# raise (no silent fallback); only an operator module WITHOUT the fused entry points (the reference's own CUDA
-# extension, when these files are dropped into the reference tree) selects the reference's torch arithmetic below.
-import diff_gaussian_rasterization as _dgr_loss
-
-_FUSED = getattr(_dgr_loss, "fused_l1_ssim_band", None)
-_FUSED_LOSS = getattr(_dgr_loss, "fused_band_loss", None)
-
-_WINDOW_CACHE = {}
+# raise; there is no torch / conv2d restatement of the loss in the product (oracle/loss_oracle.py holds one for the
+# tests, pinned on the reference's own pixelwise_l1_with_mask / pixelwise_ssim_with_mask).
+from diff_gaussian_rasterization import fused_band_loss as _FUSED_LOSS
+from diff_gaussian_rasterization import fused_l1_ssim_band as _FUSED
 
 
 def _device():
@@ -121,43 +114,10 @@ def load_camera_from_cpu_to_all_gpu_for_eval(batched_cameras, batched_strategies
 
 
 # ------------------------------------------------------------------------------------- loss
-def _window(channels, dtype, device):
-    key = (channels, dtype, str(device))
-    if key not in _WINDOW_CACHE:
-        g = torch.tensor([math.exp(-((x - 5) ** 2) / (2 * 1.5 ** 2)) for x in range(11)], dtype=torch.float32)
-        g = g / g.sum()
-        w2 = (g[:, None] @ g[None, :]).to(dtype)
-        _WINDOW_CACHE[key] = w2.expand(channels, 1, 11, 11).contiguous().to(device)
-    return _WINDOW_CACHE[key]
-
-
-def pixelwise_l1_with_mask(img1, img2, pixel_mask=None):
-    d = (img1 - img2).abs()
-    return d if pixel_mask is None else d * pixel_mask.unsqueeze(0)
-
-
-def pixelwise_ssim_with_mask(img1, img2, pixel_mask=None):
-    """SSIM map, 11x11 Gaussian window sigma 1.5, zero padding, C1 = 0.01^2, C2 = 0.03^2
-    (utils/loss_utils.py:98-132)"""
-    ch = img1.shape[-3]
-    w = _window(ch, img1.dtype, img1.device)
-    x, y = img1.unsqueeze(0), img2.unsqueeze(0)
-    stack = torch.cat([x, y, x * x, y * y, x * y], dim=1)  # one depthwise conv over 5 x ch planes
-    f = F.conv2d(stack, w.repeat(5, 1, 1, 1), padding=5, groups=5 * ch).squeeze(0)
-    mu1, mu2, e11, e22, e12 = f[0:ch], f[ch:2 * ch], f[2 * ch:3 * ch], f[3 * ch:4 * ch], f[4 * ch:5 * ch]
-    mu1_sq, mu2_sq, mu12 = mu1 * mu1, mu2 * mu2, mu1 * mu2
-    s11, s22, s12 = e11 - mu1_sq, e22 - mu2_sq, e12 - mu12
-    C1, C2 = 0.01 ** 2, 0.03 ** 2
-    m = ((2 * mu12 + C1) * (2 * s12 + C2)) / ((mu1_sq + mu2_sq + C1) * (s11 + s22 + C2))
-    return m if pixel_mask is None else m * pixel_mask.unsqueeze(0)
-
-
 def _timings_wanted():
     """HIP events around the loss only when somebody reads the timing (workload_division.timings_have_consumer)"""
-    try:
-        from gaussian_renderer.workload_division import timings_have_consumer
-    except ImportError:  # grafted over the reference's workload_division: keep the reference's behaviour (always timed)
-        return True
+    from gaussian_renderer.workload_division import timings_have_consumer
+
     return timings_have_consumer()
 
 
@@ -175,15 +135,9 @@ def final_system_loss_computation(image, viewpoint_cam, compute_locally, strateg
     if timed:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    if _FUSED is not None:
-        # one HIP kernel each way (include/gsraster.h: gsr_l1_ssim_forward / _backward)
-        l1_sum, ssim_sum = _FUSED(image, viewpoint_cam.original_image, y0, y1)
-        Ll1, ssim = l1_sum / n, ssim_sum / n
-    else:  # on the reference's own CUDA operator (no fused entry points): the reference's arithmetic, on the device
-        band = image[:, y0:y1, :].contiguous()
-        gt = torch.clamp(viewpoint_cam.original_image / 255.0, 0.0, 1.0)
-        Ll1 = pixelwise_l1_with_mask(band, gt).sum() / n
-        ssim = pixelwise_ssim_with_mask(band, gt).sum() / n
+    # one HIP kernel each way (include/gsraster.h: gsr_l1_ssim_forward / _backward)
+    l1_sum, ssim_sum = _FUSED(image, viewpoint_cam.original_image, y0, y1)
+    Ll1, ssim = l1_sum / n, ssim_sum / n
     # no device sync here (the reference synchronises twice per camera, loss_distribution.py:2566,2578):
     # finish_strategy_final resolves the event pair when -- and only when -- the balancer needs it
     if timed:
@@ -211,7 +165,7 @@ def batched_loss_computation(batched_image, batched_cameras, batched_compute_loc
         if image.dim() == 0:  # scalar stand-in (< 10 Gaussians): keeps the graph, contributes nothing
             loss = image * 0
             parts.append([loss, 0.0])
-        elif _FUSED_LOSS is not None:
+        else:
             if not image.is_cuda:
                 raise RuntimeError("batched_loss_computation: images must live on the gfx950 device (no CPU path)")
             # the whole band loss in one autograd node (map kernel + finalize); HIP events instead of the
@@ -228,10 +182,6 @@ def batched_loss_computation(batched_image, batched_cameras, batched_compute_loc
                 ev1.record()
                 stats["_loss_events"] = (ev0, ev1)
             stats.setdefault("forward_loss_time", 0.0)
-            parts.append([Ll1, ssim])
-        else:
-            Ll1, ssim = final_system_loss_computation(image, camera, mask, strategy, stats)
-            loss = (1.0 - args.lambda_dssim) * Ll1 + args.lambda_dssim * (1.0 - ssim)
             parts.append([Ll1, ssim])
         total = loss if total is None else total + loss
     assert torch.is_tensor(total) and total.dim() == 0, "The loss_sum must be a scalar tensor."

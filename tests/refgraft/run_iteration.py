@@ -322,7 +322,7 @@ def main():
         out[tag + "cuts"] = np.array([x for s in strategies for x in ([-1] + list(s.gpu_ids) + [-2] + list(s.division_pos))],
                                      np.int64)
         out[tag + "tasks"] = np.array([x for g in tasks for t in g for x in t] or [0], np.int64)
-        out[tag + "sizes"] = np.array(pkg["gpui_to_gpuj_imgk_size"], np.int64)
+        out[tag + "sizes"] = np.array([[list(b) for b in a_] for a_ in pkg["gpui_to_gpuj_imgk_size"]], np.int64)
         out[tag + "loss"] = np.float64(loss.item())
         out[tag + "parts"] = np.array([[float(p[0]), float(p[1])] for p in parts], np.float64)
         last = it == iters - 1
@@ -341,9 +341,11 @@ def main():
                 m2 = pkg["batched_locally_preprocessed_mean2D"][k]
                 out[f"means2D_grad_{k}"] = (torch.zeros_like(m2) if m2.grad is None else m2.grad).detach().cpu().numpy()
                 out[f"radii_{k}"] = pkg["batched_locally_preprocessed_radii"][k].detach().cpu().numpy()
-                if images[k] is not None:  # the rows this rank rendered camera k from, in arrival order (row a6)
-                    out[f"recv_means2D_{k}"] = pkg["batched_means2D_redistributed"][k].detach().cpu().numpy()
-                    out[f"recv_depths_{k}"] = pkg["batched_depths_redistributed"][k].detach().cpu().numpy()
+                if images[k] is not None:  # the rows this rank rendered camera k from, in arrival order (row a6);
+                    # the mirror's capacity slabs carry padding rows (radius 0) between the sources' blocks
+                    keep = pkg["batched_radii_redistributed"][k] > 0
+                    out[f"recv_means2D_{k}"] = pkg["batched_means2D_redistributed"][k].detach()[keep].cpu().numpy()
+                    out[f"recv_depths_{k}"] = pkg["batched_depths_redistributed"][k].detach()[keep].cpu().numpy()
             for attr in ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity"):
                 g = getattr(pc, attr).grad
                 out["grad" + attr] = (torch.zeros_like(getattr(pc, attr)) if g is None else g).detach().cpu().numpy()

@@ -40,7 +40,8 @@ def _worker(rank, world, port, bsz, q):
 
         utils.init_distributed(backend="gloo")
         utils.set_args(utils.default_args(bsz=bsz, save_strategy_history=(world == 2)))
-        N, W, H = 1200, 160, 112
+        # 7 tile rows; 17 for the 4-rank, 33 for the 8-rank partitions (every band needs >= 2 rows)
+        N, W, H = 1200, (160 if world < 8 else 96), {2: 112, 3: 112, 4: 272}.get(world, 528)
         utils.set_img_size(H, W)
         utils.set_cur_iter(1)
 
@@ -88,11 +89,15 @@ def _worker(rank, world, port, bsz, q):
         from oracle import exchange_oracle as XO
 
         dgr.exchange_count, dgr.exchange_pack, dgr.scatter_add_rows = XO.exchange_count, XO.exchange_pack, XO.scatter_add_rows
+        dgr.exchange_pack_slab = XO.exchange_pack_slab
         dgr.gather_rows = DO.gather_rows
 
         def one_pass(mode):
             """mode: 'reference' = all_to_all_communication_final (the reference-shaped per-camera path),
-            'batched' = _batched_exchange_final as ONE exchange, 'pipelined' = one exchange per camera"""
+            'batched' = _batched_exchange_final as ONE exchange with exact sizes, 'pipelined' = one exchange per camera,
+            'speculative' = capacity slabs (no read-back of this iteration's counts before the all-to-all; the
+            capacities come from the earlier passes), 'overflow' = the same with capacities that are too small: the
+            verification must notice and repeat the exchange with exact sizes"""
             mine = {k: v[sl].double().clone().requires_grad_(True) for k, v in full.items()}
             params, cargs = [], []
             for cam, st in zip(cams, strategies):
@@ -105,10 +110,39 @@ def _worker(rank, world, port, bsz, q):
                                                                                         strategies)
             else:
                 gr.set_exchange_overlap(mode == "pipelined")
-                m2s, rgbs, cos, radiis, depthss, sizes, (events, token) = gr._batched_exchange_final(
-                    *[[p[c] for p in params] for c in range(5)], [R() for _ in cams], strategies)
+                spec = mode in ("speculative", "overflow")
+                planner = gr._planner(utils.DEFAULT_GROUP, world, bsz)
+                if mode == "overflow":  # every slab one row short of what is needed (where anything is sent)
+                    true_sizes = torch.tensor(sizes_ref, dtype=torch.int64)
+                    planner.caps = torch.clamp(true_sizes - 1, min=0)
+                    planner.caps_list = planner.caps.tolist()
+                redone0 = gr.exchange_stats["redone"]
+
+                def run(known=None):
+                    return gr._batched_exchange_final(*[[p[c] for p in params] for c in range(5)], [R() for _ in cams],
+                                                      strategies, speculate=spec, _known=known)
+
+                m2s, rgbs, cos, radiis, depthss, sizes, (events, token), pending = run()
+                assert (pending is not None) == spec
+                if spec:  # what render_final does after the renders: look at the counts, repeat if a slab overflowed
+                    pl, chunkcnt, counts, lazy = pending
+                    m, fitted = pl.resolve()
+                    assert m.tolist() == sizes_ref
+                    assert fitted == (mode == "speculative")
+                    if not fitted:
+                        m2s, rgbs, cos, radiis, depthss, sizes, (events, token), pending = run(
+                            known=(chunkcnt, counts, m.tolist()))
+                        assert pending is None
+                    else:
+                        sizes = m.tolist()
+                        # padding rows: radius 0, behind every source's block; the valid rows are the exact layout's
+                        for k in range(bsz):
+                            keep = radiis[k] > 0
+                            assert int(keep.sum()) == sum(sizes_ref[i][rank][k] for i in range(world))
+                            assert radiis[k].shape[0] == sum(pl.caps_list[i][rank][k] for i in range(world)) or \
+                                rank not in strategies[k].gpu_ids
                 assert all(e is None for e in events)  # no side stream on the CPU
-                assert (token is not None) == (mode == "pipelined" and bsz > 1)
+                assert (token is not None) == ((mode == "pipelined" or (spec and pending is not None)) and bsz > 1)
             assert len(sizes) == world and len(sizes[0]) == world and len(sizes[0][0]) == bsz
             loss = torch.zeros((), dtype=torch.float64)
             images = []
@@ -116,12 +150,12 @@ def _worker(rank, world, port, bsz, q):
                 img = torch.zeros(3, H, W, dtype=torch.float64)
                 if rank in st.gpu_ids:
                     mask = st.get_compute_locally()
-                    assert m2s[k].shape[0] == sum(sizes[i][rank][k] for i in range(world))
+                    assert int((radiis[k] > 0).sum()) == sum(sizes[i][rank][k] for i in range(world))
                     if m2s[k].shape[0] > 0:
                         img, _, _ = O.render(m2s[k], cos[k], rgbs[k], depthss[k], radiis[k], mask, bg=bg, W=W, H=H)
                     loss = loss + (img * wgts[k]).sum()
                 else:
-                    assert m2s[k].shape[0] == 0
+                    assert int((radiis[k] > 0).sum()) == 0
                 images.append(img.detach())
             loss = loss + 0.0 * sum(p[0].sum() for p in params)  # keep the graph alive on idle ranks
             if mode != "reference" and token is not None:
@@ -129,11 +163,12 @@ def _worker(rank, world, port, bsz, q):
             loss.backward()
             grads = [mine[k].grad if mine[k].grad is not None else torch.zeros_like(mine[k]) for k in keys]
             m2_grads = [p[0].grad for p in params]  # densification's input survives the exchange
-            received = [(m2s[k].detach(), radiis[k].clone(), depthss[k].detach()) for k in range(bsz)]
+            received = [(m2s[k].detach()[radiis[k] > 0], radiis[k][radiis[k] > 0], depthss[k].detach()[radiis[k] > 0])
+                        for k in range(bsz)]
             return images, grads, cargs, m2_grads, received, sizes
 
         images, grads, cargs, m2g_ref, recv_ref, sizes_ref = one_pass("reference")
-        for mode in ("batched", "pipelined"):
+        for mode in ("batched", "pipelined", "speculative", "overflow"):
             im2, gr2, _, m2g, recv2, sizes2 = one_pass(mode)
             assert sizes2 == sizes_ref, mode
             for k in range(bsz):
@@ -186,7 +221,7 @@ def _worker(rank, world, port, bsz, q):
         q.put((rank, traceback.format_exc()))
 
 
-@pytest.mark.parametrize("world,bsz", [(2, 1), (2, 2), (3, 2)])
+@pytest.mark.parametrize("world,bsz", [(2, 1), (2, 2), (3, 2), (4, 1), (8, 1), (8, 4), (8, 8)])
 def test_partitioned_exchange_render_matches_single_rank(world, bsz):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

@@ -123,6 +123,25 @@ def test_fullsize_band_union_and_permutation(device, N, W, H):
     print(f"[permutation {N} {W}x{H}] {ties} exact depth ties; image rel {e_img:.1e}, d_means3D rel {e_g:.1e}")
     assert e_img < 1e-3
     assert e_g < 1e-2
+    # with depth ties broken by screen position (set_tie_order("position"): not by the index in the input arrays) the
+    # render does not depend on the order of the Gaussians at all: the image bitwise, the gradients up to the order of
+    # K10's float atomics
+    import diff_gaussian_rasterization as dgr
+
+    dgr.set_tie_order("position")
+    try:
+        img1t, gr1t = run([(0, gy)])
+        imgpt, grpt = run([(0, gy)], perm)
+    finally:
+        dgr.set_tie_order("arrival")
+    e_img = rel_err(imgpt, img1t)
+    errs = {k: rel_err(grpt[k][inv.to(device)], gr1t[k]) for k in KEYS}
+    print(f"[permutation {N} {W}x{H}, ties by position] image rel {e_img:.1e}, gradients "
+          + ", ".join(f"{k} {v:.1e}" for k, v in errs.items()))
+    assert torch.equal(imgpt, img1t), "tie order by position: the image must not depend on the order of the Gaussians"
+    for k, v in errs.items():
+        assert v < 1e-4, f"{k}: {v}"
+    assert rel_err(img1t, img1) < 1e-3  # the two tie rules render (slightly) different scenes
 
 
 def test_backward_is_linear_in_incoming_gradient(device):

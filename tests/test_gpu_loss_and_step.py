@@ -287,8 +287,8 @@ def test_exchange_path_on_device_single_rank_rccl(device):
         pkg = gr.distributed_preprocess3dgs_and_all2all_final(cams, model, pipe, bg, batched_strategies=strategies)
         utils.DEFAULT_GROUP = dist.group.WORLD
         lists = [pkg[f"batched_{n}_redistributed"] for n in ("rgb", "conic_opacity", "radii", "depths")]
-        m2, rgb, co, radii, depths, sizes, (events, token) = gr._batched_exchange_final(
-            pkg["batched_locally_preprocessed_mean2D"], *lists, pkg["batched_rasterizers"], strategies)
+        m2, rgb, co, radii, depths, sizes, (events, token), _pending = gr._batched_exchange_final(
+            pkg["batched_locally_preprocessed_mean2D"], *lists, pkg["batched_rasterizers"], strategies, speculate=False)
         pkg["_exchange_events"] = events
         if token is not None:
             pkg["batched_cuda_args"][-1]["_exchange_token"] = token
@@ -484,3 +484,126 @@ def test_legacy_render_equals_render_final(device):
         grads.append(model._xyz.grad.clone())
     assert torch.equal(images[0], images[1])
     assert rel_err(grads[1], grads[0]) < 1e-6
+
+
+def test_speculative_exchange_reads_nothing_back(device):
+    """the read-back-free exchange (capacity slabs): in the steady state the whole iteration -- K1, count, size
+    all-gather, pack, all-to-all-v over RCCL, unpack, K3-K8, loss, K10, mirror all-to-all-v, K11 -- issues NO
+    .cpu() / .item() / .tolist() on a device tensor and no torch.cuda.synchronize(); the only host waits are the
+    pair-count poll of the render (inside the C-ABI) and the verification's look at an event that has completed.
+    Results equal the world-size-1 path (a one-rank RCCL group: every visible row is sent to the rank itself)."""
+    import torch.distributed as dist
+
+    import gaussian_renderer as gr
+    import utils.general_utils as utils
+    from gaussian_renderer.loss_distribution import batched_loss_computation, load_camera_from_cpu_to_all_gpu
+    from gaussian_renderer.workload_division import (DivisionStrategyHistoryFinal, finish_strategy_final,
+                                                     start_strategy_final)
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        created = True
+    counts = {"cpu": 0, "item": 0, "tolist": 0, "synchronize": 0, "event_sync": 0}
+    saved = (torch.Tensor.cpu, torch.Tensor.item, torch.Tensor.tolist, torch.cuda.synchronize,
+             torch.cuda.Event.synchronize)
+
+    def counting(name, fn):
+        def f(self, *a, **k):
+            if getattr(self, "is_cuda", False):
+                counts[name] += 1
+            return fn(self, *a, **k)
+        return f
+
+    try:
+        N, W, H, B = 6000, 240, 160, 2
+        utils.GLOBAL_RANK, utils.WORLD_SIZE = 0, 1
+        utils.DEFAULT_GROUP = utils.IN_NODE_GROUP = utils.SingleGPUGroup()
+        utils.set_args(utils.default_args(bsz=B))
+        utils.set_img_size(H, W)
+        utils.set_cur_iter(1)
+        cams = S.orbit_cameras(B, W, H, device=device)
+        for k, c in enumerate(cams):
+            c.original_image_backup = S.make_gt_image(W, H, seed=20 + k, device=device)
+        bg = torch.tensor([0.1, 0.2, 0.3], device=device)
+        pipe = type("P", (), {"debug": False})()
+
+        def iteration(model, hist):
+            strategies, tasks = start_strategy_final(cams, hist)
+            load_camera_from_cpu_to_all_gpu(cams, strategies, tasks)
+            pkg = gr.distributed_preprocess3dgs_and_all2all_final(cams, model, pipe, bg, batched_strategies=strategies)
+            images, masks = gr.render_final(pkg, strategies)
+            stats = [ca["stats_collector"] for ca in pkg["batched_cuda_args"]]
+            loss, _ = batched_loss_computation(images, cams, masks, strategies, stats)
+            loss.backward()
+            finish_strategy_final(cams, hist, strategies, stats)
+            return loss, images, pkg
+
+        def fresh():
+            m = S.SyntheticGaussianModel(N, W, H, seed=4, device=device, scale_coef=0.012)
+            return m, DivisionStrategyHistoryFinal(S.SyntheticDataset(cams), 1, 0)
+
+        model, hist = fresh()
+        loss_a, images_a, _ = iteration(model, hist)
+        ga = {n: getattr(model, n).grad.clone() for n in ("_xyz", "_features_rest", "_scaling", "_opacity")}
+
+        gr.set_exchange_forced(True)
+        gr._PLANNERS.clear()
+        before = dict(gr.exchange_stats)
+        for overlap in (True, False):
+            gr.set_exchange_overlap(overlap)
+            gr._PLANNERS.clear()  # no capacities yet: the first iteration below is sized exactly
+            model, hist = fresh()
+            iteration(model, hist)   # exact sizes (nothing known yet) -> the capacities of the next iterations
+            for n in ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity"):
+                getattr(model, n).grad = None
+            iteration(model, hist)   # speculative; allocator warm
+            for n in ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity"):
+                getattr(model, n).grad = None
+            torch.cuda.synchronize()
+            for k in counts:
+                counts[k] = 0
+            torch.Tensor.cpu, torch.Tensor.item = counting("cpu", saved[0]), counting("item", saved[1])
+            torch.Tensor.tolist = counting("tolist", saved[2])
+
+            def sync(*a, **k):
+                counts["synchronize"] += 1
+                return saved[3](*a, **k)
+
+            def ev_sync(self):
+                counts["event_sync"] += 1
+                return saved[4](self)
+
+            torch.cuda.synchronize, torch.cuda.Event.synchronize = sync, ev_sync
+            try:
+                loss_b, images_b, pkg = iteration(model, hist)
+            finally:
+                (torch.Tensor.cpu, torch.Tensor.item, torch.Tensor.tolist, torch.cuda.synchronize,
+                 torch.cuda.Event.synchronize) = saved
+            assert counts["cpu"] == counts["item"] == counts["tolist"] == counts["synchronize"] == 0, (overlap, counts)
+            assert counts["event_sync"] <= 1, counts  # the verification's look at the (completed) copy of the counts
+            torch.cuda.synchronize()
+            sizes = pkg["gpui_to_gpuj_imgk_size"]
+            assert [sizes[0][0][k] for k in range(B)] == [int((r > 0).sum()) for r in
+                                                          pkg["batched_locally_preprocessed_radii"]]
+            # padded rows: received tensors are capacity-sized, valid rows first
+            for k in range(B):
+                rad = pkg["batched_radii_redistributed"][k]
+                assert rad.shape[0] % 256 == 0 and int((rad > 0).sum()) == sizes[0][0][k]
+            assert abs(loss_b.item() - loss_a.item()) <= 1e-6 * abs(loss_a.item())
+            for a_, b_ in zip(images_a, images_b):
+                assert rel_err(b_, a_) < 1e-6
+            for n, g in ga.items():
+                assert rel_err(getattr(model, n).grad, g) < 1e-5, n
+        after = gr.exchange_stats
+        assert after["speculative"] - before["speculative"] == 4 and after["sized"] - before["sized"] == 2
+        assert after["redone"] == before["redone"]
+    finally:
+        gr.set_exchange_forced(False)
+        gr.set_exchange_overlap(True)
+        gr._PLANNERS.clear()
+        utils.DEFAULT_GROUP = utils.IN_NODE_GROUP = utils.SingleGPUGroup()
+        if created:
+            dist.destroy_process_group()

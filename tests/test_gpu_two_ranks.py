@@ -71,7 +71,7 @@ def _worker(rank, world, port, bsz, q):
         utils.init_distributed(backend="gloo")
         _stage_collectives_through_host()
         utils.set_args(utils.default_args(bsz=bsz, save_strategy_history=(world == 2)))
-        N, W, H = 6000, 208, 144
+        N, W, H = 6000, 208, (144 if world < 4 else 272)  # 9 tile rows (17 for the 4- and 8-rank partitions)
         utils.set_img_size(H, W)
         utils.set_cur_iter(1)
         model = S.SyntheticGaussianModel(N, W, H, seed=4, rank=rank, world_size=world, device=dev, scale_coef=0.012)
@@ -84,14 +84,25 @@ def _worker(rank, world, port, bsz, q):
         bg = torch.tensor([0.1, 0.2, 0.3], device=dev)
         pipe = type("P", (), {"debug": False})()
 
-        strategies, tasks = start_strategy_final(cams, hist)
-        load_camera_from_cpu_to_all_gpu(cams, strategies, tasks)
-        pkg = distributed_preprocess3dgs_and_all2all_final(cams, model, pipe, bg, batched_strategies=strategies)
-        images, masks = render_final(pkg, strategies)
-        stats = [ca["stats_collector"] for ca in pkg["batched_cuda_args"]]
-        loss, _ = batched_loss_computation(images, cams, masks, strategies, stats)
-        loss.backward()
-        finish_strategy_final(cams, hist, strategies, stats)
+        import gaussian_renderer as gr
+
+        # two passes over the same iteration: the first exchange is sized exactly (nothing known yet), the second one
+        # packs into the capacity slabs derived from the first -- no read-back of its counts before the all-to-all;
+        # the comparisons below are made on the SECOND pass
+        for step in range(2):
+            for nm in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"):
+                getattr(model, nm).grad = None
+            hist.history.clear()
+            strategies, tasks = start_strategy_final(cams, hist)
+            load_camera_from_cpu_to_all_gpu(cams, strategies, tasks)
+            pkg = distributed_preprocess3dgs_and_all2all_final(cams, model, pipe, bg, batched_strategies=strategies)
+            images, masks = render_final(pkg, strategies)
+            stats = [ca["stats_collector"] for ca in pkg["batched_cuda_args"]]
+            loss, _ = batched_loss_computation(images, cams, masks, strategies, stats)
+            loss.backward()
+            finish_strategy_final(cams, hist, strategies, stats)
+        assert gr.exchange_stats == {"speculative": 1, "sized": 1, "redone": 0}, gr.exchange_stats
+        assert pkg["gpui_to_gpuj_imgk_size"][rank][rank][0] >= 0  # the lazy [W][W][B] list resolves to python ints
         if world == 2:
             assert len(hist.history) == 1 and len(hist.history[0]["all_gpu_running_time"]) == world
         else:  # timings have no consumer (heuristics frozen, history not saved): no gather, nothing logged
@@ -170,7 +181,7 @@ def _worker(rank, world, port, bsz, q):
         q.put((rank, traceback.format_exc()))
 
 
-@pytest.mark.parametrize("world,bsz", [(2, 1), (2, 2), (3, 2)])
+@pytest.mark.parametrize("world,bsz", [(2, 1), (2, 2), (3, 2), (4, 1), (8, 4)])
 def test_partitioned_training_iteration_on_device(device, world, bsz):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

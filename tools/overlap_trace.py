@@ -70,8 +70,8 @@ def main():
         # force the exchange on the batched state (rank 0 "sends" every visible Gaussian to itself over RCCL)
         utils.DEFAULT_GROUP = dist.group.WORLD
         lists = [pkg[f"batched_{n}_redistributed"] for n in ("rgb", "conic_opacity", "radii", "depths")]
-        m2, rgb, co, radii, depths, sizes, (events, token) = gr._batched_exchange_final(
-            pkg["batched_locally_preprocessed_mean2D"], *lists, pkg["batched_rasterizers"], strategies)
+        m2, rgb, co, radii, depths, sizes, (events, token), _pending = gr._batched_exchange_final(
+            pkg["batched_locally_preprocessed_mean2D"], *lists, pkg["batched_rasterizers"], strategies, speculate=False)
         for name, val in zip(("means2D", "rgb", "conic_opacity", "radii", "depths"), (m2, rgb, co, radii, depths)):
             pkg[f"batched_{name}_redistributed"] = val
         pkg["_exchange_events"] = events
