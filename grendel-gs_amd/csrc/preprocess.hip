@@ -260,29 +260,35 @@ __device__ __forceinline__ float4 grad_ld4(const float *__restrict__ p, size_t i
 }
 
 constexpr int REST_W = 45;  // (16 - 1) * 3 floats of _features_rest per Gaussian
+// workgroup size of K11 (one lane per Gaussian): the LDS stage below costs 180 B per lane whatever the size, so the
+// resident waves per CU are the same; smaller workgroups interleave their load / compute / store phases more finely
+#ifndef GSR_K11_BLOCK
+#define GSR_K11_BLOCK 256
+#endif
+constexpr int K11_BLOCK = GSR_K11_BLOCK;
 // workgroup-cooperative, coalesced copy of the block's rows of a [P, 45] array into / out of LDS
 __device__ __forceinline__ void rest_stage_in(float *__restrict__ s_rest, const float *__restrict__ g, int P) {
-    const size_t row0 = (size_t)blockIdx.x * GSR_ONE_DIM_BLOCK;
-    const int nw = (int)min((size_t)GSR_ONE_DIM_BLOCK, (size_t)P - row0) * REST_W;
+    const size_t row0 = (size_t)blockIdx.x * K11_BLOCK;
+    const int nw = (int)min((size_t)K11_BLOCK, (size_t)P - row0) * REST_W;
     const float4 *src4 = reinterpret_cast<const float4 *>(g + row0 * REST_W);  // 46080-byte blocks: 16-byte aligned
     float4 *s4 = reinterpret_cast<float4 *>(s_rest);
-    for (int k = threadIdx.x; k < nw / 4; k += GSR_ONE_DIM_BLOCK) s4[k] = src4[k];
-    for (int k = (nw & ~3) + threadIdx.x; k < nw; k += GSR_ONE_DIM_BLOCK) s_rest[k] = g[row0 * REST_W + k];
+    for (int k = threadIdx.x; k < nw / 4; k += K11_BLOCK) s4[k] = src4[k];
+    for (int k = (nw & ~3) + threadIdx.x; k < nw; k += K11_BLOCK) s_rest[k] = g[row0 * REST_W + k];
 }
 __device__ __forceinline__ void rest_stage_out(const float *__restrict__ s_rest, float *__restrict__ g, int P) {
-    const size_t row0 = (size_t)blockIdx.x * GSR_ONE_DIM_BLOCK;
-    const int nw = (int)min((size_t)GSR_ONE_DIM_BLOCK, (size_t)P - row0) * REST_W;
+    const size_t row0 = (size_t)blockIdx.x * K11_BLOCK;
+    const int nw = (int)min((size_t)K11_BLOCK, (size_t)P - row0) * REST_W;
     float4 *dst4 = reinterpret_cast<float4 *>(g + row0 * REST_W);
     const float4 *s4 = reinterpret_cast<const float4 *>(s_rest);
     // streaming stores: this gradient (180 of the 236 gradient bytes per Gaussian) is read exactly once, by the
     // optimizer, and written with cacheable stores it evicts the PARAMETERS from the 256 MB memory-side cache -- which
     // the optimizer and the next iteration's K1 would otherwise hit (measured: Adam 0.253 -> 0.238 ms, K11 +0.004 ms)
     typedef float vf4 __attribute__((ext_vector_type(4)));
-    for (int k = threadIdx.x; k < nw / 4; k += GSR_ONE_DIM_BLOCK) {
+    for (int k = threadIdx.x; k < nw / 4; k += K11_BLOCK) {
         const float4 v = s4[k];
         __builtin_nontemporal_store(vf4{v.x, v.y, v.z, v.w}, reinterpret_cast<vf4 *>(dst4 + k));
     }
-    for (int k = (nw & ~3) + threadIdx.x; k < nw; k += GSR_ONE_DIM_BLOCK) g[row0 * REST_W + k] = s_rest[k];
+    for (int k = (nw & ~3) + threadIdx.x; k < nw; k += K11_BLOCK) g[row0 * REST_W + k] = s_rest[k];
 }
 
 template <int DEG, bool RAW>
@@ -561,7 +567,7 @@ preprocess_backward_body(const int i, const float *__restrict__ rest_in, float *
 // lane by lane touches a different cache line in every lane of every load.  They are staged through LDS with
 // coalesced 16-byte accesses instead (row stride 45 words: conflict-free), both ways.
 template <int DEG, bool RAW>
-__global__ void __launch_bounds__(GSR_ONE_DIM_BLOCK)
+__global__ void __launch_bounds__(K11_BLOCK)
 preprocess_backward_kernel(int P, int M, const float *__restrict__ means3D, const float *__restrict__ scales,
                            float scale_modifier, const float *__restrict__ rotations, const float *__restrict__ shs,
                            const float *__restrict__ shs_rest, const float *__restrict__ opacities_raw,
@@ -575,7 +581,7 @@ preprocess_backward_kernel(int P, int M, const float *__restrict__ means3D, cons
                            float *__restrict__ dL_dshs_rest, float *__restrict__ dL_dopacities) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if constexpr (RAW) {
-        __shared__ float s_rest[GSR_ONE_DIM_BLOCK * REST_W];
+        __shared__ float s_rest[K11_BLOCK * REST_W];
         if (M == 16) {  // block-uniform
             rest_stage_in(s_rest, shs_rest, P);
             __syncthreads();
@@ -743,7 +749,7 @@ preprocess_forward_batched_kernel(int P, int B, int M, const float *__restrict__
 }
 
 template <int DEG>
-__global__ void __launch_bounds__(GSR_ONE_DIM_BLOCK)
+__global__ void __launch_bounds__(K11_BLOCK)
 preprocess_backward_batched_kernel(int P, int B, int M, const float *__restrict__ xyz,
                                    const float *__restrict__ scaling, float scale_modifier,
                                    const float *__restrict__ rotation, const float *__restrict__ f_dc,
@@ -757,7 +763,7 @@ preprocess_backward_batched_kernel(int P, int B, int M, const float *__restrict_
                                    float4 *__restrict__ dL_drotation, float *__restrict__ dL_ddc,
                                    float *__restrict__ dL_drest, float *__restrict__ dL_dopacity) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    __shared__ float s_rest[GSR_ONE_DIM_BLOCK * REST_W];
+    __shared__ float s_rest[K11_BLOCK * REST_W];
     const bool staged = M == 16;  // _features_rest in, its gradient out: coalesced through LDS
     if (staged) {
         rest_stage_in(s_rest, f_rest, P);
@@ -1057,7 +1063,7 @@ int gsr_launch_preprocess_backward(int P, int D, int M, const float *means3D, co
                                    float *dL_dshs, float *dL_dshs_rest, float *dL_dopacities,
                                    hipStream_t stream) {
     if (P == 0) return 0;
-    const dim3 grid(gsr_div_up(P, GSR_ONE_DIM_BLOCK)), block(GSR_ONE_DIM_BLOCK);
+    const dim3 grid(gsr_div_up(P, K11_BLOCK)), block(K11_BLOCK);
 #define GSR_BWD(RAWF)                                                                                              \
     GSR_DISPATCH_DEG(D, hipLaunchKernelGGL((preprocess_backward_kernel<DEG, RAWF>), grid, block, 0, stream, P, M,  \
                                            means3D, scales, scale_modifier, rotations, shs, shs_rest,              \
@@ -1123,7 +1129,7 @@ extern "C" int gsr_preprocess_backward_raw_batched(int P, int B, int sh_degree, 
         !clamped || !dL_dmeans2D || !dL_dconic_opacity || !dL_drgb || !dL_dxyz || !dL_dscaling || !dL_drotation ||
         !dL_dfeatures_dc || !dL_dfeatures_rest || !dL_dopacity)
         return GSR_EINVAL;
-    const dim3 grid(gsr_div_up(P, GSR_ONE_DIM_BLOCK)), block(GSR_ONE_DIM_BLOCK);
+    const dim3 grid(gsr_div_up(P, K11_BLOCK)), block(K11_BLOCK);
     GSR_DISPATCH_DEG(sh_degree,
                      hipLaunchKernelGGL(preprocess_backward_batched_kernel<DEG>, grid, block, 0,
                                         reinterpret_cast<hipStream_t>(stream), P, B, sh_coeffs, xyz, scaling,

@@ -182,8 +182,8 @@ def set_exchange_forced(enabled):
     _EXCHANGE_OPTIONS["forced"] = bool(enabled)
 
 
-def _side_stream(dev):
-    key = (dev.type, dev.index)
+def _side_stream(dev, purpose="exchange"):
+    key = (dev.type, dev.index, purpose)
     if key not in _SIDE_STREAMS:
         _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
     return _SIDE_STREAMS[key]
@@ -432,12 +432,24 @@ def _batched_exchange_final(m2_views, rgb_views, co_views, radii_views, depths_v
     else:
         chunkcnt, counts = _dgr.exchange_count(bases[0], radii_all, bands, 0, B, width, height)
         all_counts = torch.empty((W * W, B), dtype=torch.int32, device=dev)
-        dist.all_gather_into_tensor(all_counts, counts, group=group)
         speculate = speculate and planner.caps is not None
-        if speculate:
+        if speculate and dev.type == "cuda":
+            # nothing on this stream needs the gathered matrix (the pack works from the LOCAL counts): the all-gather and
+            # the copy to the host run beside the pack, on the collective's own stream and a helper stream
+            work = dist.all_gather_into_tensor(all_counts, counts, group=group, async_op=True)
+            aux = _side_stream(dev, "counts")
+            with torch.cuda.stream(aux):
+                work.wait()  # the helper stream waits for the collective; the host and the current stream do not
+                planner.stage(all_counts)
+            counts.record_stream(aux)
+            all_counts.record_stream(aux)
+            sizes = _LazySizes()
+        elif speculate:
+            dist.all_gather_into_tensor(all_counts, counts, group=group)
             planner.stage(all_counts)
             sizes = _LazySizes()
         else:
+            dist.all_gather_into_tensor(all_counts, counts, group=group)
             sizes = all_counts.view(W, W, B).cpu().tolist()  # the one host read-back of an exact exchange; sizes[i][j][k]
             planner.observe(torch.tensor(sizes, dtype=torch.int64))
     exchange_stats["speculative" if speculate else "sized"] += 1

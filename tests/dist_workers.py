@@ -10,6 +10,16 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+class _DoneWork:
+    """what an already-completed collective returns for async_op=True"""
+
+    def wait(self, *a, **k):
+        return True
+
+    def is_completed(self):
+        return True
+
+
 def stage_collectives_through_host():
     """gloo's device support is not under test: device tensors take a round trip through the host"""
     a2a, agi = dist.all_to_all_single, dist.all_gather_into_tensor
@@ -27,6 +37,7 @@ def stage_collectives_through_host():
         o = torch.empty(output.shape, dtype=output.dtype)
         agi(o, input.detach().cpu().contiguous(), group=group)
         output.copy_(o)
+        return _DoneWork() if kw.get("async_op") else None
 
     dist.all_to_all_single = all_to_all_single
     dist.all_gather_into_tensor = all_gather_into_tensor

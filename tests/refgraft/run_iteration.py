@@ -21,6 +21,16 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 
 
+class _DoneWork:
+    """what an already-completed collective returns for async_op=True"""
+
+    def wait(self, *a, **k):
+        return True
+
+    def is_completed(self):
+        return True
+
+
 def stage_collectives_through_host(dist, torch):
     """device tensors take a round trip through the host inside every collective the path uses"""
     orig = {n: getattr(dist, n) for n in ("all_to_all_single", "all_gather_into_tensor", "all_to_all", "all_reduce",
@@ -42,6 +52,7 @@ def stage_collectives_through_host(dist, torch):
         o = torch.empty(output.numel(), dtype=output.dtype)  # gloo wants the flat [W * n] form
         orig["all_gather_into_tensor"](o, cpu(input).reshape(-1), group=group)
         output.copy_(o.view(output.shape))
+        return _DoneWork() if kw.get("async_op") else None
 
     def all_to_all(output_tensor_list, input_tensor_list, group=None, **kw):
         # gloo has no list all-to-all: one all_to_all_single over the flattened pieces (only element counts matter, as

@@ -62,6 +62,7 @@ CASES = {
     "w2": dict(n=3072, width=208, height=144, views=2, bsz=1, world=2, iters=2, skew=True),
     "w2b2": dict(n=4096, width=256, height=256, views=2, bsz=2, world=2, iters=1),
     "w4b2": dict(n=4096, width=256, height=256, views=2, bsz=2, world=4, iters=1, skew=True),
+    "w8b4": dict(n=8192, width=256, height=272, views=4, bsz=4, world=8, iters=2, skew=True),  # configs[3]'s shape
     "hd": dict(n=200_000, width=1920, height=1080, views=2, bsz=1, world=1, iters=1, scale_coef=0.004),
     "hdw2": dict(n=100_000, width=1920, height=1088, views=2, bsz=1, world=2, iters=4, fake_times=True,
                  scale_coef=0.004),

@@ -30,6 +30,16 @@ def _free_port():
     return p
 
 
+class _DoneWork:
+    """what an already-completed collective returns for async_op=True"""
+
+    def wait(self, *a, **k):
+        return True
+
+    def is_completed(self):
+        return True
+
+
 def _stage_collectives_through_host():
     a2a, agi = dist.all_to_all_single, dist.all_gather_into_tensor
 
@@ -46,6 +56,7 @@ def _stage_collectives_through_host():
         o = torch.empty(output.shape, dtype=output.dtype)
         agi(o, input.detach().cpu().contiguous(), group=group)
         output.copy_(o)
+        return _DoneWork() if kw.get("async_op") else None
 
     dist.all_to_all_single = all_to_all_single
     dist.all_gather_into_tensor = all_gather_into_tensor

@@ -9,7 +9,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 export TMPDIR=/tmp
-BENCH="python $R/bench.py --no-cpu-baseline --steps 16 --warmup 4 --repeats 1 --render-steps 8"
+BENCH="python $R/bench.py --no-cpu-baseline --no-extra --steps 16 --warmup 4 --repeats 1 --render-steps 8"
 has() { [[ " $STAGES " == *" $1 "* ]]; }
 cd $R
 if has test; then
@@ -43,7 +43,7 @@ if has trace || has sq || has fetch || has write; then
   find $O -name "*.db" -size +20M -delete
 fi
 if has lowop; then
-  timeout 600 python bench.py --no-cpu-baseline --opacity-logit-mean -2 --opacity-logit-std 1 > $O/bench_lowopacity.json 2> $O/bench_lowopacity.err
+  timeout 600 python bench.py --no-cpu-baseline --no-extra --opacity-logit-mean -2 --opacity-logit-std 1 > $O/bench_lowopacity.json 2> $O/bench_lowopacity.err
   echo "lowop exit $?"
 fi
 if has multirank; then

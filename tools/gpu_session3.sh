@@ -18,7 +18,7 @@ fi
 if has ab; then
   run() {  # name, env assignments...
     local name=$1; shift
-    env "$@" timeout 300 python bench.py --no-cpu-baseline --steps 30 --warmup 6 --repeats 3 --render-steps 10 > $O/ab_$name.json 2> $O/ab_$name.err
+    env "$@" timeout 300 python bench.py --no-cpu-baseline --no-extra --steps 30 --warmup 6 --repeats 3 --render-steps 10 > $O/ab_$name.json 2> $O/ab_$name.err
     python - <<PY
 import json
 try:
@@ -31,7 +31,6 @@ except Exception as e:
 PY
   }
   run production X=1 | tee -a $O/ab.txt
-  run norectsort GSR_RECT_SORTED=0 | tee -a $O/ab.txt
   for lib in $(ls variants/libgsraster_*.so 2>/dev/null); do
     [[ $lib == *stats* || $lib == *base* ]] && continue
     n=$(basename $lib .so); n=${n#libgsraster_}
