@@ -126,7 +126,7 @@ touch_count_kernel(int P, int gx, int gy, const float2 *__restrict__ means2D, co
                    const int32_t *__restrict__ radii, const float4 *__restrict__ conic_opacity,
                    const uint8_t *__restrict__ mask, RadixPlan plan, uint32_t *__restrict__ tt,
                    uint32_t *__restrict__ keys, uint32_t *__restrict__ vals, uint2 *__restrict__ rects,
-                   uint32_t *__restrict__ ghist, uint32_t *__restrict__ tile_hist) {
+                   uint32_t *__restrict__ ghist, uint32_t *__restrict__ tile_hist, int32_t *__restrict__ hull_out) {
     __shared__ int s_lo, s_hi;
     __shared__ uint32_t mh[RADIX_MAX_PASSES][RADIX_DIGITS];
     // digit histograms of the TILE sort (keys (y, x): pass 0 = column, pass 1 = row), known here without looking at
@@ -156,6 +156,10 @@ touch_count_kernel(int P, int gx, int gy, const float2 *__restrict__ means2D, co
     }
     __syncthreads();
     const int hull0 = s_lo, hull1 = s_hi;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {  // K8 / K10 spread THE BAND over the XCDs (gsr_xcd_span_of_block_band)
+        hull_out[0] = hull1 > hull0 ? hull0 : 0;
+        hull_out[1] = hull1 > hull0 ? hull1 : 0;
+    }
     for (long long base = (long long)blockIdx.x * TC_THREADS; base < P; base += (long long)gridDim.x * TC_THREADS) {
         const long long i = base + threadIdx.x;
         const bool valid = i < P;
@@ -302,12 +306,13 @@ emit_scatter_kernel(int P, long long D, int xbits, const uint2 *__restrict__ rec
                     const uint32_t *__restrict__ sorted_ids, const uint32_t *__restrict__ offsets,
                     const uint32_t *__restrict__ ghist, uint32_t *__restrict__ state, uint32_t *__restrict__ ticket,
                     uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, bool bounded,
-                    int32_t *__restrict__ ranges_flat, int ranges_words) {
+                    int32_t *__restrict__ ranges_flat, int ranges_words, const int32_t *__restrict__ hull) {
     constexpr int WAVES = THREADS / 64;
     __shared__ OnesweepSmem<ITEMS, THREADS> sm;
     // K7 only writes the tiles that own pairs: clear the range table here (it runs two kernels later on this stream)
     // instead of in a memset launch of its own.  Every workgroup takes part, before any of the early exits below.
     for (int t = blockIdx.x * THREADS + threadIdx.x; t < ranges_words; t += gridDim.x * THREADS) ranges_flat[t] = 0;
+    if (blockIdx.x == 0 && threadIdx.x < 2) ranges_flat[ranges_words + threadIdx.x] = hull[threadIdx.x];  // row `tiles`
     if (bounded) {  // the grid covers a capacity D; the true pair count is offsets[P] (K4's total)
         const long long d = offsets[P];
         if (d > D) return;
@@ -490,7 +495,7 @@ copy_u32_kernel(long long n, const uint32_t *__restrict__ src, uint32_t *__restr
 }
 
 struct PrepLayout {
-    size_t tt, kA, vA, kB, vB, offsets, rects, thist, ctrl, total;
+    size_t tt, kA, vA, kB, vB, offsets, rects, hull, thist, ctrl, total;
     CtrlLayout C;
 };
 PrepLayout prep_layout(int P, int W, int H) {
@@ -505,6 +510,7 @@ PrepLayout prep_layout(int P, int W, int H) {
     L.vB = o; o += np;
     L.offsets = o; o += np;
     L.rects = o; o += align_up((size_t)(P + 1) * 8);
+    L.hull = o; o += 256;  // int32 [2]: the row hull of the mask (written by K3, copied into the range table by the sort)
     L.thist = o; o += align_up(sizeof(uint32_t) * RADIX_REPLICAS * RADIX_MAX_PASSES * RADIX_DIGITS);  // zeroed with ctrl
     L.ctrl = o;
     L.C = ctrl_layout(P, 4, true);
@@ -617,7 +623,8 @@ extern "C" int gsr_bin_prepare_async(int P, int width, int height, const float *
     hipLaunchKernelGGL(touch_count_kernel, dim3(blocks), dim3(TC_THREADS), 0, stream, P, gx, gy,
                        reinterpret_cast<const float2 *>(means2D), depths, radii,
                        reinterpret_cast<const float4 *>(conic_opacity), compute_locally, plan, tt, kA, vA, rects,
-                       reinterpret_cast<uint32_t *>(ctrl + L.C.ghist), tile_hist);
+                       reinterpret_cast<uint32_t *>(ctrl + L.C.ghist), tile_hist,
+                       reinterpret_cast<int32_t *>(base + L.hull));
     int in_first = 1;
     int rc = radix_sort_pairs(kA, vA, kB, vB, P, plan, ctrl, L.C, &in_first, stream, nullptr);
     if (rc) return rc;
@@ -713,7 +720,7 @@ int bin_sort_impl(int P, int width, int height, const uint8_t *compute_locally, 
     if (P < 0 || width <= 0 || height <= 0 || D < 0 || !ranges) return GSR_EINVAL;
     const int gx = (width + GSR_BLOCK_X - 1) / GSR_BLOCK_X, gy = (height + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y;
     if (D == 0 || P == 0 || !yx_path(gx, gy))  // (the (row, column) path clears the table inside its first kernel)
-        GSR_HIP(hipMemsetAsync(ranges, 0, sizeof(int32_t) * 2 * (size_t)gx * gy, stream));
+        GSR_HIP(hipMemsetAsync(ranges, 0, sizeof(int32_t) * 2 * ((size_t)gx * gy + 1), stream));  // + the hull row: (0, 0)
     if (D == 0 || P == 0) return 0;
     if (!compute_locally || !prep || !scratch || !point_list) return GSR_EINVAL;
     if (D > RADIX_MAX_N) return GSR_EINVAL;
@@ -742,7 +749,7 @@ int bin_sort_impl(int P, int width, int height, const uint8_t *compute_locally, 
         // pass 0 (column digit) fused with the emission: pairs land in (kB, vB); pass 1 (row digit) -> (kA, point_list)
         hipLaunchKernelGGL((emit_scatter_kernel<RADIX_TILE / 512, 512>), dim3(nb), dim3(512), 0, stream, P, (long long)D,
                            xbits, rects, sorted_ids, offsets, thist, state, tickets + 1, kB, vB, bounded, ranges,
-                           2 * gx * gy);
+                           2 * gx * gy, reinterpret_cast<const int32_t *>(pbase + L.hull));
         hipLaunchKernelGGL((radix_onesweep_kernel<RADIX_TILE / 512, 512>), dim3(nb), dim3(512), 0, stream, kB, vB, kA,
                            point_list, (long long)D, xbits, ybits, thist + RADIX_DIGITS,
                            state + (size_t)nb * RADIX_DIGITS, tickets + 2, D_dev);
@@ -763,6 +770,8 @@ int bin_sort_impl(int P, int width, int height, const uint8_t *compute_locally, 
     hipLaunchKernelGGL(tile_ranges_kernel, dim3(gsr_div_up(gsr_div_up(D, 4), GSR_ONE_DIM_BLOCK)),
                        dim3(GSR_ONE_DIM_BLOCK), 0, stream, (long long)D, (uint32_t)(gx * gy), ks,
                        reinterpret_cast<int2 *>(ranges));
+    GSR_HIP(hipMemcpyAsync(ranges + 2 * (size_t)gx * gy, pbase + L.hull, 2 * sizeof(int32_t), hipMemcpyDeviceToDevice,
+                           stream));
     GSR_LAUNCH_CHECK();
     return 0;
 }

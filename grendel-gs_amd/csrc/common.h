@@ -34,6 +34,26 @@ __device__ __forceinline__ int gsr_xcd_span_of_block(int b, int nwg) {
 #endif
 }
 
+// The same for a launch in which only the tile rows [lo, hi) (a Grendel row band: the hull of the mask) carry work and
+// the other tiles exit at once: block -> tile such that EVERY XCD gets a contiguous 1/8 of the BAND (and a contiguous
+// 1/8 of the rest).  With the plain span map a band that is 1/8 of the image is exactly one XCD's span: 32 of the 256
+// CUs would composite the whole band (measured on one rank of an 8-rank partition: K8 / K10 as slow as for the whole
+// image).  hull = number of tiles in the band, first = first tile of the band, nwg = all tiles.  Bijective; equal
+// to gsr_xcd_span_of_block when the band is the whole grid.
+__device__ __forceinline__ int gsr_xcd_span_of_block_band(int b, int nwg, int first, int hull) {
+#ifdef GSR_NO_XCD_MAP
+    return b;
+#else
+    const int xcd = b & 7, j = b >> 3;
+    const int hl = (hull - xcd + 7) >> 3;                       // band tiles of this XCD ...
+    const int hs = xcd * (hull >> 3) + min(xcd, hull & 7);      // ... starting at this band-local index
+    if (j < hl) return first + hs + j;
+    const int ts = xcd * (nwg >> 3) + min(xcd, nwg & 7);        // blocks of the XCDs before this one
+    const int n = (ts - hs) + (j - hl);                         // index among the tiles outside the band
+    return n < first ? n : n + hull;
+#endif
+}
+
 // tile rect [min,max) of (pixel centre, radius): C truncation, clamped to the grid
 // (restates SURVEY.md A.2 step 7; identical in preprocess, K2 and K3 so that the three agree).
 __device__ __forceinline__ void gsr_get_rect(float px, float py, int radius, int gx, int gy, int &minx, int &miny,

@@ -131,6 +131,17 @@ __device__ __forceinline__ v2f pair_exponent(const PairRec &p, float pxf, float 
                                      __builtin_elementwise_fma(p.c2 * dy, dy, p.o));
 }
 
+// block -> tile: XCD-contiguous spans of the BAND this rank renders.  The binning leaves the band (the row hull of the
+// mask, [lo, hi) tile rows) in row `tiles` of the range table (include/gsraster.h: gsr_bin_sort); anything implausible
+// there falls back to spans of the whole grid.
+__device__ __forceinline__ int composite_tile_of_block(const int2 *__restrict__ ranges, int gx) {
+    const int tiles = (int)gridDim.x;
+    const int2 hull = ranges[tiles];
+    const int gy = tiles / gx;
+    if (hull.x < 0 || hull.y > gy || hull.x >= hull.y) return gsr_xcd_span_of_block(blockIdx.x, tiles);
+    return gsr_xcd_span_of_block_band(blockIdx.x, tiles, hull.x * gx, (hull.y - hull.x) * gx);
+}
+
 // ------------------------------------------------------------------------------------------- K8
 __global__ void __launch_bounds__(256)
 composite_forward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
@@ -138,7 +149,7 @@ composite_forward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
                          const float4 *__restrict__ conic_opacity, const float *__restrict__ rgb,
                          const uint8_t *__restrict__ compute_locally, const float *__restrict__ bg,
                          float *__restrict__ out_color, float *__restrict__ final_T, int32_t *__restrict__ n_contrib) {
-    const int tile = gsr_xcd_span_of_block(blockIdx.x, gridDim.x);
+    const int tile = composite_tile_of_block(ranges, gx);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tx = tile % gx, ty = tile / gx;
     const int qx0 = tx * GSR_BLOCK_X + (wave & 1) * 8, qy0 = ty * GSR_BLOCK_Y + (wave >> 1) * 8;
@@ -319,7 +330,7 @@ composite_backward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
                           const uint8_t *__restrict__ compute_locally, const float *__restrict__ bg,
                           const float *__restrict__ final_T, const int32_t *__restrict__ n_contrib,
                           const float *__restrict__ dL_dpixels, float *__restrict__ dL_record) {
-    const int tile = gsr_xcd_span_of_block(blockIdx.x, gridDim.x);
+    const int tile = composite_tile_of_block(ranges, gx);
     if (!compute_locally[tile]) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tx = tile % gx, ty = tile / gx;

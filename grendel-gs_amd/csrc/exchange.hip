@@ -57,7 +57,10 @@ exchange_need_kernel(int P, int B, int W, int gx, int gy, const float2 *__restri
     __syncthreads();
     if ((int)threadIdx.x < W && s_cnt[threadIdx.x]) atomicAdd(&counts[(size_t)threadIdx.x * B + k], s_cnt[threadIdx.x]);
 }
-constexpr int XCHUNK = 1024;  // Gaussians per wave-chunk: 16 rounds of 64 lanes
+#ifndef GSR_XCHUNK
+#define GSR_XCHUNK 1024
+#endif
+constexpr int XCHUNK = GSR_XCHUNK;  // Gaussians per wave-chunk: XCHUNK / 64 rounds of 64 lanes
 
 // rows [miny, maxy) of the 3-sigma tile rect of Gaussian r (the K2 rule); false when it touches nothing
 __device__ __forceinline__ bool rect_rows(const float2 *__restrict__ means2D, const int32_t *__restrict__ radii, size_t r,
@@ -173,7 +176,7 @@ exchange_pack_kernel(int P, int B, int W, int k0, int cntB, int cnt0, int gx, in
 // SLAB: the unused tail of every segment -- rows [min(count, capacity), capacity) -- becomes an all-zero record
 // (radius 0 = "culled": the receiver's K3 drops it) with send_idx -1 (the backward's scatter-add skips it).
 // grid (segments, TAIL_SPLIT)
-constexpr int TAIL_SPLIT = 8;
+constexpr int TAIL_SPLIT = 64;  // (8 workgroups per slab took 20 us for ~1 MB of padding: too few to fill the chip)
 __global__ void __launch_bounds__(256)
 exchange_slab_tail_kernel(int B, int cntB, int cnt0, const int32_t *__restrict__ counts, SegOffsets seg,
                           float *__restrict__ msg, int32_t *__restrict__ send_idx) {
@@ -184,6 +187,25 @@ exchange_slab_tail_kernel(int B, int cntB, int cnt0, const int32_t *__restrict__
     for (long long e = first + (long long)blockIdx.y * 256 + threadIdx.x; e < last; e += 256LL * TAIL_SPLIT) msg[e] = 0.f;
     for (int32_t r = lo + n + (int32_t)blockIdx.y * 256 + (int32_t)threadIdx.x; r < hi; r += 256 * TAIL_SPLIT)
         send_idx[r] = -1;
+}
+
+// The received slab [n][11] -> the five dense tensors the render op takes.  One lane per float of the slab: the reads
+// are one contiguous stream, the writes land in <= 5 short contiguous runs per wave.  (The generic row mover,
+// gsr_gather_rows, reads the width-1 columns with a 44-byte stride: 43 us for 0.65 M rows where this takes ~12.)
+__global__ void __launch_bounds__(256)
+exchange_unpack_kernel(long long n, const float *__restrict__ recv, float *__restrict__ means2D, float *__restrict__ rgb,
+                       float *__restrict__ conic_opacity, int32_t *__restrict__ radii, float *__restrict__ depths) {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n * 11;
+         e += (long long)gridDim.x * blockDim.x) {
+        const long long r = e / 11;
+        const int c = (int)(e - r * 11);
+        const float v = recv[e];
+        if (c < 2) means2D[2 * r + c] = v;
+        else if (c < 5) rgb[3 * r + (c - 2)] = v;
+        else if (c < 9) conic_opacity[4 * r + (c - 5)] = v;
+        else if (c == 9) radii[r] = __float_as_int(v);
+        else depths[r] = v;
+    }
 }
 
 // dst[idx[r]][0:9] += src[r][0:9]; 9 adjacent lanes per row; rows with idx < 0 (slab padding) are skipped
@@ -297,6 +319,27 @@ extern "C" int gsr_exchange_pack_slab(int P, int B_total, int k0, int B, int W, 
     return exchange_pack_impl(true, P, B_total, k0, B, W, width, height, count_cameras, count_first, means2D, rgb,
                               conic_opacity, radii, depths, bands, chunkcnt, counts, capacities, n_rows, msg, send_idx,
                               reinterpret_cast<hipStream_t>(stream_));
+}
+
+extern "C" int gsr_exchange_unpack(int64_t n, const float *recv, float *means2D, float *rgb, float *conic_opacity,
+                                   int32_t *radii, float *depths, gsr_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (n < 0) return GSR_EINVAL;
+    if (n == 0) return 0;
+    if (!recv || !means2D || !rgb || !conic_opacity || !radii || !depths) return GSR_EINVAL;
+    long long blocks = (n * 11 + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(exchange_unpack_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (long long)n, recv, means2D,
+                       rgb, conic_opacity, radii, depths);
+    GSR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gsr_zero_async(void *ptr, size_t bytes, gsr_stream_t stream_) {
+    if (bytes == 0) return 0;
+    if (!ptr) return GSR_EINVAL;
+    GSR_HIP(hipMemsetAsync(ptr, 0, bytes, reinterpret_cast<hipStream_t>(stream_)));
+    return 0;
 }
 
 extern "C" int gsr_scatter_add_rows(int64_t n, const int32_t *idx, const float *src, float *dst,

@@ -29,7 +29,8 @@ from ._lib import check, lib
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "_C", "load_image_tiles_by_pos",
            "merge_image_tiles_by_pos", "set_timing_mode", "fused_l1_ssim_band", "fused_band_loss", "fused_activations", "pack_camera",
            "preprocess_gaussians_raw_batched", "knn_mean_dist2", "group_rows", "gather_rows", "exchange_need",
-           "exchange_count", "exchange_pack", "exchange_pack_slab", "scatter_add_rows", "set_tie_order", "scatter_rows", "local_pixels"]
+           "exchange_count", "exchange_pack", "exchange_pack_slab", "exchange_unpack", "zeros_async", "scatter_add_rows",
+           "set_tie_order", "scatter_rows", "local_pixels"]
 
 BLOCK_X, BLOCK_Y, ONE_DIM_BLOCK_SIZE = 16, 16, 256
 
@@ -183,7 +184,9 @@ def local_pixels(mask, W, H):
 
 
 def _ptr(t):
-    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+    # a plain int: the prototypes declare c_void_p, ctypes converts (building a c_void_p object per argument was
+    # ~60 objects per iteration)
+    return t.data_ptr() if t is not None else None
 
 
 def _stream():
@@ -563,7 +566,9 @@ def bin_gaussians(means2D, depths, radii, conic_opacity, compute_locally, width,
     P = means2D.shape[0]
     dev = means2D.device
     gx, gy = (width + BLOCK_X - 1) // BLOCK_X, (height + BLOCK_Y - 1) // BLOCK_Y
-    ranges = torch.empty((gx * gy, 2), dtype=torch.int32, device=dev)
+    # tiles + 1 rows: the last one receives the row hull of the mask (the band), which K8 / K10 read through the same
+    # pointer; callers see the per-tile rows
+    ranges = torch.empty((gx * gy + 1, 2), dtype=torch.int32, device=dev)[:gx * gy]
     prep_bytes = lib.gsr_bin_prepare_bytes(P, width, height)
     prep = torch.empty((max(prep_bytes, 4),), dtype=torch.uint8, device=dev)
     stream = _stream()
@@ -1011,6 +1016,30 @@ def exchange_pack_slab(means2D_all, rgb_all, co_all, radii_all, depths_all, band
                                          _ptr(counts), caps, n_rows, _ptr(msg), _ptr(send_idx), _stream()),
               "gsr_exchange_pack_slab")
     return msg, send_idx
+
+
+def exchange_unpack(recv):
+    """received message fp32 [n, 11] -> (means2D [n,2], rgb [n,3], conic_opacity [n,4], radii int32 [n], depths [n]) in
+    one launch (include/gsraster.h: gsr_exchange_unpack)"""
+    if not recv.is_cuda or recv.dtype != torch.float32 or recv.dim() != 2 or recv.shape[1] != 11 or \
+            not recv.is_contiguous():
+        raise ValueError("recv must be a contiguous fp32 [n, 11] device tensor")
+    n, dev = recv.shape[0], recv.device
+    outs = [torch.empty((n, w), dtype=torch.float32, device=dev) for w in (2, 3, 4)]
+    radii = torch.empty((n,), dtype=torch.int32, device=dev)
+    depths = torch.empty((n,), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.gsr_exchange_unpack(n, _ptr(recv), _ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2]), _ptr(radii),
+                                      _ptr(depths), _stream()), "gsr_exchange_unpack")
+    return outs[0], outs[1], outs[2], radii, depths
+
+
+def zeros_async(shape, dtype, device):
+    """torch.zeros through hipMemsetAsync on the current stream (the fill kernel torch launches runs at ~1 TB/s)"""
+    t = torch.empty(shape, dtype=dtype, device=device)
+    with torch.cuda.device(device):
+        check(lib.gsr_zero_async(_ptr(t), t.numel() * t.element_size(), _stream()), "gsr_zero_async")
+    return t
 
 
 def scatter_add_rows(idx, src, n_rows, dst=None):

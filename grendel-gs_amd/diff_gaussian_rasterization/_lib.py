@@ -52,6 +52,8 @@ SIGNATURES = {
     "gsr_exchange_count": (c_int, [c_int] * 7 + [c_void_p] * 6),
     "gsr_exchange_pack": (c_int, [c_int] * 9 + [c_void_p] * 8 + [c_int64, c_void_p, c_void_p, c_void_p]),
     "gsr_exchange_pack_slab": (c_int, [c_int] * 9 + [c_void_p] * 9 + [c_int64, c_void_p, c_void_p, c_void_p]),
+    "gsr_exchange_unpack": (c_int, [c_int64] + [c_void_p] * 7),
+    "gsr_zero_async": (c_int, [c_void_p, c_size_t, c_void_p]),
     "gsr_scatter_add_rows": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gsr_knn_workspace_bytes": (c_size_t, [c_int]),
     "gsr_knn_mean_dist2": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -78,7 +80,7 @@ SIGNATURES = {
     "gsr_render_backward": (c_int, [c_int, c_int, c_int] + [c_void_p] * 12),
 }
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 def _load():

@@ -50,18 +50,28 @@ class FusedAdam(torch.optim.Optimizer):
         for i in range(0, len(batch), 16):
             part = batch[i:i + 16]
             K = len(part)
-            VP, D, I64 = ctypes.c_void_p * K, ctypes.c_double * K, ctypes.c_int64 * K
             dev = part[0][0].device
-            numels = [b[0].numel() for b in part]
-            for b in part:
-                if b[0].device != dev:
-                    raise RuntimeError("FusedAdam: all parameters of one step must live on one device")
-            with torch.cuda.device(dev), kernel_timer.range("adam", numel=sum(numels)):
+            # the pointer tables of parameters and moments only change when the model is rebuilt (densification,
+            # restore): cached per launch group, keyed by the parameters' addresses
+            key = tuple(b[0].data_ptr() for b in part) + tuple(b[2]["exp_avg"].data_ptr() for b in part)
+            plan = self._plans.get(i) if hasattr(self, "_plans") else None
+            if plan is None or plan[0] != key:
+                for b in part:
+                    if b[0].device != dev:
+                        raise RuntimeError("FusedAdam: all parameters of one step must live on one device")
+                VP, I64 = ctypes.c_void_p * K, ctypes.c_int64 * K
+                numels = [b[0].numel() for b in part]
+                plan = (key, I64(*numels), VP(*[b[0].data_ptr() for b in part]),
+                        VP(*[b[2]["exp_avg"].data_ptr() for b in part]),
+                        VP(*[b[2]["exp_avg_sq"].data_ptr() for b in part]), sum(numels))
+                if not hasattr(self, "_plans"):
+                    self._plans = {}
+                self._plans[i] = plan
+            VP, D, I64 = ctypes.c_void_p * K, ctypes.c_double * K, ctypes.c_int64 * K
+            with torch.cuda.device(dev), kernel_timer.range("adam", numel=plan[5]):
                 _lib.check(_lib.lib.gsr_adam_step_multi(
-                    K, I64(*numels), VP(*[b[0].data_ptr() for b in part]),
-                    VP(*[b[1].data_ptr() for b in part]), VP(*[b[2]["exp_avg"].data_ptr() for b in part]),
-                    VP(*[b[2]["exp_avg_sq"].data_ptr() for b in part]), D(*[b[3] for b in part]),
-                    D(*[b[4] for b in part]), D(*[b[5] for b in part]), D(*[b[6] for b in part]),
-                    I64(*[int(b[2]["step"].item()) for b in part]), float(grad_scale),
+                    K, plan[1], plan[2], VP(*[b[1].data_ptr() for b in part]), plan[3], plan[4],
+                    D(*[b[3] for b in part]), D(*[b[4] for b in part]), D(*[b[5] for b in part]),
+                    D(*[b[6] for b in part]), I64(*[int(b[2]["step"]) for b in part]), float(grad_scale),
                     _stream()), "gsr_adam_step_multi")
         return loss

@@ -23,6 +23,7 @@ mode there is no gradient all-reduce at all.
 """
 import math
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -229,19 +230,22 @@ class _SlabPlanner:
 
     def __init__(self, W, B):
         self.W, self.B = W, B
-        self.hist = []
-        self.caps = None        # int64 [W, W, B] (host)
+        self._hist, self._n = None, 0   # ring of the last WINDOW count matrices (numpy: these are W x W x B numbers)
+        self.caps = None        # int64 numpy [W, W, B]
         self.caps_list = None   # the same as nested python lists
         self.pending = None     # (event | None, host matrix, caps it was packed with) of an unverified iteration
         self._ring, self._slot = [], 0
 
     def observe(self, m):
-        self.hist.append(m.to(torch.int64).clone())
-        if len(self.hist) > self.WINDOW:
-            self.hist.pop(0)
-        peak = torch.stack(self.hist).amax(0)
+        """m: int64 numpy array [W, W, B]"""
+        if self._hist is None:
+            self._hist = np.zeros((self.WINDOW,) + m.shape, dtype=np.int64)
+            self._n = 0
+        self._hist[self._n % self.WINDOW] = m
+        self._n += 1
+        peak = self._hist[:min(self._n, self.WINDOW)].max(axis=0)
         want = (peak * 5 // 4 + 256 + 255) // 256 * 256
-        if self.caps is None or bool((want > self.caps).any()) or bool((want * 2 < self.caps).any()):
+        if self.caps is None or (want > self.caps).any() or (want * 2 < self.caps).any():
             self.caps = want
             self.caps_list = want.tolist()
 
@@ -257,15 +261,17 @@ class _SlabPlanner:
             ev.record()
         else:
             host, ev = all_counts.clone(), None
-        self.pending = (ev, host, self.caps.clone())
+        self.pending = (ev, host, self.caps)
 
     def resolve(self):
-        """-> (count matrix int64 [W, W, B] of the pending iteration, True when every count fitted its slab)"""
+        """-> (count matrix int64 numpy [W, W, B] of the pending iteration, True when every count fitted its slab)"""
         ev, host, caps = self.pending
         self.pending = None
         if ev is not None:
             ev.synchronize()  # the copy was queued before the all-to-all: long complete when a render has polled D
-        m = host.view(self.W, self.W, self.B).to(torch.int64).clone()
+        m = host.numpy().reshape(self.W, self.W, self.B).astype(np.int64)  # (a copy: the pinned buffer is reused)
+        if (m < 0).any():
+            raise RuntimeError("exchange: negative row counts read back (a missing stream dependency in the collective?)")
         self.observe(m)
         return m, bool((m <= caps).all())
 
@@ -304,8 +310,12 @@ class _ExchangeGroup(torch.autograd.Function):
                                                count_first=0)
         recv = torch.empty((n_recv, N_DIFF + N_AUX), dtype=msg.dtype, device=dev)
         dist.all_to_all_single(recv, msg, output_split_sizes=recv_splits, input_split_sizes=send_splits, group=group)
-        outs = [torch.empty((n_recv, w), dtype=msg.dtype, device=dev) for w in (2, 3, 4, 1, 1)]
-        _dgr.gather_rows(perm, n_recv, [recv[:, 0:2], recv[:, 2:5], recv[:, 5:9], recv[:, 9:10], recv[:, 10:11]], outs)
+        if perm is None:  # one exchange per camera (always, with capacity slabs): the message is camera-major already
+            outs = list(_dgr.exchange_unpack(recv))
+        else:             # several cameras in one exact exchange: (source, camera)-major -> camera-major
+            outs = [torch.empty((n_recv, w), dtype=msg.dtype, device=dev) for w in (2, 3, 4, 1, 1)]
+            _dgr.gather_rows(perm, n_recv, [recv[:, 0:2], recv[:, 2:5], recv[:, 5:9], recv[:, 9:10], recv[:, 10:11]],
+                             outs)
         if consumer_stream is not None and consumer_stream != cur:
             for t in outs:
                 t.record_stream(consumer_stream)  # allocated on the side stream, consumed by the renderer's stream
@@ -314,7 +324,9 @@ class _ExchangeGroup(torch.autograd.Function):
         ctx.meta = (k0, nb, P, cnt_B, send_splits, recv_splits, group, consumer_stream, holder)
         ctx.save_for_backward(send_idx, inv_perm if inv_perm is not None else send_idx[:0])
         ctx.has_perm = inv_perm is not None
-        r_radii = (outs[3].view(torch.int32) if outs[3].dtype == torch.float32 else outs[3].to(torch.int32)).reshape(n_recv)
+        r_radii = outs[3] if outs[3].dtype == torch.int32 else (
+            outs[3].view(torch.int32) if outs[3].dtype == torch.float32 else outs[3].to(torch.int32))
+        r_radii = r_radii.reshape(n_recv)
         r_depths = outs[4].reshape(n_recv)
         ctx.mark_non_differentiable(r_radii, r_depths)
         # the token chains the per-camera exchanges of a batch: camera k's node consumes camera k-1's token, the last
@@ -358,7 +370,7 @@ class _ExchangeGroup(torch.autograd.Function):
         # ONE [B*P, 9] record for the whole batch (the exchanges of its cameras add into their own row blocks); the
         # gradients that go back are its column views, which the batched K11 reads through the row stride
         if holder.get("rec") is None:
-            holder["rec"] = torch.zeros((B * P, N_DIFF), dtype=fdt, device=dev)
+            holder["rec"] = _dgr.zeros_async((B * P, N_DIFF), fdt, dev)
             if consumer_stream is not None and consumer_stream != cur:
                 holder["rec"].record_stream(consumer_stream)
         rec = holder["rec"][k0 * P:(k0 + nb) * P]
@@ -367,6 +379,27 @@ class _ExchangeGroup(torch.autograd.Function):
         for a, b in ((0, 2), (2, 5), (5, 9)):
             grads += [rec[k * P:(k + 1) * P, a:b] for k in range(nb)]
         return (None, None, None) + tuple(grads)
+
+
+class _LazyPerCamera:
+    """a list whose k-th entry is fn(source[k]), evaluated on first access (one kernel launch per camera and iteration
+    that only densification steps need)"""
+
+    def __init__(self, source, fn):
+        self._src, self._fn, self._v = source, fn, [None] * len(source)
+
+    def __len__(self):
+        return len(self._src)
+
+    def __getitem__(self, k):
+        if isinstance(k, slice):
+            return [self[i] for i in range(*k.indices(len(self._src)))]
+        if self._v[k] is None:
+            self._v[k] = self._fn(self._src[k])
+        return self._v[k]
+
+    def __iter__(self):
+        return (self[k] for k in range(len(self._src)))
 
 
 class _LazySizes:
@@ -406,8 +439,8 @@ def _batched_exchange_final(m2_views, rgb_views, co_views, radii_views, depths_v
     pack launch, one all-to-all-v and one unpack launch -- and, only when the layout is not speculative, the one
     read-back of the counts the reference has too (gaussian_renderer/__init__.py:572-585)."""
     group = utils.DEFAULT_GROUP
-    if not isinstance(group, dist.ProcessGroup):  # set_exchange_forced in a process whose DEFAULT_GROUP is the stand-in
-        group = dist.group.WORLD
+    if group.size() == 1 and not isinstance(group, dist.ProcessGroup):
+        group = dist.group.WORLD  # set_exchange_forced in a process whose DEFAULT_GROUP is the one-rank stand-in
     W, me = group.size(), group.rank()
     B = len(radii_views)
     bases = [_camera_major_base(v) for v in (m2_views, rgb_views, co_views, radii_views, depths_views)]
@@ -432,12 +465,14 @@ def _batched_exchange_final(m2_views, rgb_views, co_views, radii_views, depths_v
     else:
         chunkcnt, counts = _dgr.exchange_count(bases[0], radii_all, bands, 0, B, width, height)
         all_counts = torch.empty((W * W, B), dtype=torch.int32, device=dev)
+        cur_stream = torch.cuda.current_stream() if dev.type == "cuda" else None
         speculate = speculate and planner.caps is not None
         if speculate and dev.type == "cuda":
             # nothing on this stream needs the gathered matrix (the pack works from the LOCAL counts): the all-gather and
             # the copy to the host run beside the pack, on the collective's own stream and a helper stream
             work = dist.all_gather_into_tensor(all_counts, counts, group=group, async_op=True)
             aux = _side_stream(dev, "counts")
+            aux.wait_stream(cur_stream)  # (explicit: the counts exist; the collective's own wait below implies it)
             with torch.cuda.stream(aux):
                 work.wait()  # the helper stream waits for the collective; the host and the current stream do not
                 planner.stage(all_counts)
@@ -451,7 +486,7 @@ def _batched_exchange_final(m2_views, rgb_views, co_views, radii_views, depths_v
         else:
             dist.all_gather_into_tensor(all_counts, counts, group=group)
             sizes = all_counts.view(W, W, B).cpu().tolist()  # the one host read-back of an exact exchange; sizes[i][j][k]
-            planner.observe(torch.tensor(sizes, dtype=torch.int64))
+            planner.observe(np.asarray(sizes, dtype=np.int64).reshape(W, W, B))
     exchange_stats["speculative" if speculate else "sized"] += 1
     layout_sizes = planner.caps_list if speculate else sizes  # rows per (source, destination, camera) of the buffers
 
@@ -608,7 +643,8 @@ def distributed_preprocess3dgs_and_all2all_final(batched_viewpoint_cameras, pc, 
 
     pkg = {
         "batched_locally_preprocessed_mean2D": [p[0] for p in params],
-        "batched_locally_preprocessed_visibility_filter": [p[3] > 0 for p in params],
+        # radii > 0 per camera (densification reads it, densification.py:16-26): computed when somebody looks
+        "batched_locally_preprocessed_visibility_filter": _LazyPerCamera([p[3] for p in params], lambda r: r > 0),
         "batched_locally_preprocessed_radii": [p[3] for p in params],
         "batched_rasterizers": rasterizers,
         "batched_cuda_args": cuda_args_list,
@@ -652,7 +688,8 @@ def distributed_preprocess3dgs_and_all2all_final(batched_viewpoint_cameras, pc, 
                 pkg.pop("_exchange_pending")
                 m, fitted = planner.resolve()
                 lazy._v = m.tolist()
-                if fitted and all(int(m[:, g, k].sum()) >= 10 for (g, k) in rendered):
+                recv_rows = m.sum(axis=0).tolist()  # [destination][camera]: rows a band receives
+                if fitted and all(recv_rows[g][k] >= 10 for (g, k) in rendered):
                     return True
                 exchange_stats["redone"] += 1
                 exchange(known=(chunkcnt, counts, lazy._v))

@@ -44,8 +44,27 @@ def get_coverage_y_min_max(tile_row_l, tile_row_r):
 
 # ------------------------------------------------------------------------------- GT staging
 def _band_of(camera, l, r, device):
+    """uint8 rows [l * 16, min(r * 16, H)) of the camera's ground truth, dense, on `device`.  When the image already
+    lives on the device (preload_dataset_to_gpu, scene/cameras.py:66-69) the dense band is a strided-slice copy kernel
+    per iteration: the last few bands of a camera are kept (a converged partition asks for the same rows again)."""
     y0, y1 = get_coverage_y_min_max(l, r)
-    return camera.original_image_backup[:, y0:y1, :].to(device, non_blocking=True).contiguous()
+    src = camera.original_image_backup
+    if not src.is_cuda:
+        return src[:, y0:y1, :].to(device, non_blocking=True).contiguous()
+    cache = getattr(camera, "_gsr_bands", None)
+    key = (y0, y1, src.data_ptr(), src._version)
+    if cache is None or cache[0][2:] != key[2:]:
+        cache = []
+    for k_, band in cache:
+        if k_ == key:
+            return band
+    band = src[:, y0:y1, :].to(device, non_blocking=True).contiguous()
+    cache = [(key, band)] + cache[:3]
+    try:
+        camera._gsr_bands = cache
+    except AttributeError:
+        pass
+    return band
 
 
 def load_camera_from_cpu_to_all_gpu(batched_cameras, batched_strategies, gpuid2tasks):

@@ -16,6 +16,7 @@ into row bands.  Difference from the reference in HOW (not WHAT): the per-row co
 host (they are TILE_Y floats per camera), so choosing the cut points costs no device sync per iteration
 (the reference's cumsum/searchsorted run on the GPU and read back, workload_division.py:92).
 """
+import numpy as np
 import torch
 
 import diff_gaussian_rasterization
@@ -37,10 +38,14 @@ def division_pos_heuristic(heuristic, tile_num, world_size, right=False):
     """cut `tile_num` rows with per-row cost `heuristic` into `world_size` parts of equal cost:
     [0, searchsorted(cumsum(h), k * total / W, right) for k = 1..W-1, tile_num]"""
     assert heuristic.shape[0] == tile_num, "the length of heuristics should be the same as the number of tiles."
-    prefix = torch.cumsum(heuristic.detach().to("cpu", torch.float32), dim=0)
-    per_worker = prefix[-1] / world_size
-    thresholds = torch.arange(1, world_size, dtype=torch.float32) * per_worker
-    cuts = torch.searchsorted(prefix, thresholds, right=right)
+    # fp32 throughout, as the reference computes it (tests/test_gpu_reference_b1.py holds the cut points to the
+    # reference's device cumsum / searchsorted on 400 seeded cost vectors); numpy: these are TILE_Y * bsz numbers
+    h = heuristic.detach().to("cpu", torch.float32).numpy() if torch.is_tensor(heuristic) else \
+        np.asarray(heuristic, dtype=np.float32)
+    prefix = np.cumsum(h, dtype=np.float32)
+    per_worker = np.float32(prefix[-1] / np.float32(world_size))
+    thresholds = np.arange(1, world_size, dtype=np.float32) * per_worker
+    cuts = np.searchsorted(prefix, thresholds, side="right" if right else "left")
     return [0] + cuts.tolist() + [tile_num]
 
 

@@ -100,7 +100,10 @@ int gsr_get_local2j_ids_bool(int P, int width, int height, int world_size, const
  *   untouched until gsr_bin_sort returns.
  * gsr_bin_sort    : emit the D pairs in depth order and stable-sort them by tile id, giving
  *   point_list uint32 [D] (Gaussian index per pair, grouped by tile, front-to-back inside a
- *   tile, ties by Gaussian index) and ranges int32 [tiles,2] = [start,end) per tile.
+ *   tile, ties by Gaussian index) and ranges int32 [tiles + 1, 2]: rows 0 .. tiles-1 = [start,end) per tile, row `tiles`
+ *   = [lo, hi) the tile ROWS that contain locally computed tiles (the band this rank renders; (0,0) when there is
+ *   none) -- gsr_render_forward / _backward read it to spread the band, not the whole grid, over the eight XCDs.
+ *   The caller allocates tiles + 1 rows (ABI 7).
  *   `scratch` is a device workspace of gsr_bin_sort_bytes(P, D, width, height) bytes. */
 size_t gsr_bin_prepare_bytes(int P, int width, int height);
 int gsr_bin_prepare(int P, int width, int height, const float *means2D, const float *depths, const int32_t *radii,
@@ -258,6 +261,13 @@ int gsr_scatter_add_rows(int64_t n, const int32_t *idx, const float *src, float 
  * gsr_exchange_pack when any count exceeded its capacity -- the same speculate / verify scheme as
  * gsr_bin_sort_bounded.  Received rows keep the reference's order (source rank, then the source's index); padding
  * rows sit between the sources' blocks. */
+/* gsr_exchange_unpack: the received message recv fp32 [n][11] (any mix of records and padding rows) -> the five dense
+ * tensors of the render op: means2D [n,2], rgb [n,3], conic_opacity [n,4], radii int32 [n] (the record's radius BITS),
+ * depths [n].  gsr_zero_async: hipMemsetAsync(ptr, 0, bytes) on the caller's stream (the gradient record the mirror
+ * exchange's scatter-add accumulates into). */
+int gsr_exchange_unpack(int64_t n, const float *recv, float *means2D, float *rgb, float *conic_opacity, int32_t *radii,
+                        float *depths, gsr_stream_t stream);
+int gsr_zero_async(void *ptr, size_t bytes, gsr_stream_t stream);
 int gsr_exchange_pack_slab(int P, int B_total, int k0, int B, int W, int width, int height, int count_cameras,
                            int count_first, const float *means2D, const float *rgb, const float *conic_opacity,
                            const int32_t *radii, const float *depths, const int32_t *bands, const int32_t *chunkcnt,

@@ -95,6 +95,17 @@ def exchange_pack_slab(means2D_all, rgb_all, co_all, radii_all, depths_all, band
     return msg, send_idx
 
 
+def exchange_unpack(recv):
+    """gsr_exchange_unpack: the five tensors of the render op out of the [n, 11] message"""
+    radii = recv[:, 9].contiguous().view(torch.int32) if recv.dtype == torch.float32 else recv[:, 9].to(torch.int32)
+    return (recv[:, 0:2].contiguous(), recv[:, 2:5].contiguous(), recv[:, 5:9].contiguous(), radii,
+            recv[:, 10].contiguous())
+
+
+def zeros_async(shape, dtype, device):
+    return torch.zeros(shape, dtype=dtype, device=device)
+
+
 def scatter_add_rows(idx, src, n_rows, dst=None):
     if dst is None:
         dst = torch.zeros((n_rows, 9), dtype=src.dtype)

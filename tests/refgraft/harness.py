@@ -90,7 +90,11 @@ def compare(ref, mir, tol=1e-5, multi_step_tol=2e-3, report=None):
             if iters == 1:
                 assert np.array_equal(a[k], b[k]), f"rank {r}: {k} differ"
         for k in [k for k in a if k.startswith("recv_depths_")]:
-            assert k in b and a[k].shape == b[k].shape, f"rank {r}: {k}: received row counts differ"
+            assert k in b, k
+            if iters > 1:  # after Adam steps a Gaussian near a band border may change sides: counts agree to 0.1 %
+                assert abs(a[k].shape[0] - b[k].shape[0]) <= 1 + a[k].shape[0] // 1000, f"rank {r}: {k}"
+                continue
+            assert a[k].shape == b[k].shape, f"rank {r}: {k}: received row counts differ"
             if iters == 1:  # same rows in the same order (source-rank major, then the source's index): row a6
                 assert np.array_equal(a[k], b[k]), f"rank {r}: {k}: received rows arrive in a different order"
                 k2 = k.replace("depths", "means2D")
@@ -160,6 +164,7 @@ def summarize(outs, rows=2048, seed=5):
 def compare_summary(summ, mir, tol=1e-5):
     lines = []
     for r, (s, b) in enumerate(zip(summ, mir)):
+        iters = len([k for k in s if k.endswith("_cuts")])
         for k, v in s.items():
             if k == "images_pooled":
                 e = rel(pool16(b["images"]), v)
@@ -170,9 +175,14 @@ def compare_summary(summ, mir, tol=1e-5):
             elif k.endswith("__rows"):
                 base = k[:-6]
                 idx = s[base + "__idx"]
+                if base.startswith("recv_") and iters > 1:
+                    # after Adam steps a Gaussian near a band border may change sides: the count agrees to 0.1 %
+                    assert abs(b[base].shape[0] - int(s[base + "__len"])) <= 1 + int(s[base + "__len"]) // 1000, base
+                    continue
                 assert b[base].shape[0] == int(s[base + "__len"]), f"rank {r}: {base} length"
                 if base.startswith(("radii_", "recv_depths")):
-                    assert np.array_equal(b[base][idx], v), f"rank {r}: {base} sampled rows differ"
+                    if iters == 1:  # (later iterations have been through Adam: values drift, the COUNT must still agree)
+                        assert np.array_equal(b[base][idx], v), f"rank {r}: {base} sampled rows differ"
                 else:
                     n = float(s[base + "__norm"])
                     e = abs(np.linalg.norm(b[base].astype(np.float64)) - n) / max(n, 1e-30)

@@ -78,3 +78,22 @@ def build_case(name):
     s.update(bsz=np.int64(c["bsz"]), world=np.int64(c["world"]), iters=np.int64(c["iters"]),
              fake_times=np.int64(1 if c.get("fake_times") else 0))
     return s
+
+
+def fuzz_heuristics(seed, rows):
+    """seeded per-row cost vectors of the cut-point fuzz (tests/refgraft/cuts_fuzz.py, test_gpu_reference_b1.py)"""
+    rs = np.random.RandomState(seed)
+    kind = seed % 4
+    if kind == 0:    # measured-time-like: per band a constant time / rows
+        h = np.repeat(rs.rand(8) * 3 + 0.05, (rows + 7) // 8)[:rows]
+    elif kind == 1:  # smooth
+        h = 0.2 + rs.rand(rows)
+    elif kind == 2:  # spiky
+        h = 0.01 + rs.rand(rows) ** 6 * 10
+    else:            # the initial all-ones
+        h = np.ones(rows)
+    return h.astype(np.float32)
+
+
+def fuzz_case(seed):
+    return [68, 135, 68 * 4, 35 * 4][seed % 4], [2, 4, 8, 8][(seed // 4) % 4]

@@ -91,6 +91,7 @@ def _worker(rank, world, port, bsz, q):
         dgr.exchange_count, dgr.exchange_pack, dgr.scatter_add_rows = XO.exchange_count, XO.exchange_pack, XO.scatter_add_rows
         dgr.exchange_pack_slab = XO.exchange_pack_slab
         dgr.gather_rows = DO.gather_rows
+        dgr.exchange_unpack, dgr.zeros_async = XO.exchange_unpack, XO.zeros_async
 
         def one_pass(mode):
             """mode: 'reference' = all_to_all_communication_final (the reference-shaped per-camera path),
@@ -113,8 +114,10 @@ def _worker(rank, world, port, bsz, q):
                 spec = mode in ("speculative", "overflow")
                 planner = gr._planner(utils.DEFAULT_GROUP, world, bsz)
                 if mode == "overflow":  # every slab one row short of what is needed (where anything is sent)
-                    true_sizes = torch.tensor(sizes_ref, dtype=torch.int64)
-                    planner.caps = torch.clamp(true_sizes - 1, min=0)
+                    import numpy as np
+
+                    true_sizes = np.asarray(sizes_ref, dtype=np.int64)
+                    planner.caps = np.clip(true_sizes - 1, 0, None)
                     planner.caps_list = planner.caps.tolist()
                 redone0 = gr.exchange_stats["redone"]
 

@@ -425,3 +425,51 @@ def test_fused_exchange_kernels_match_restatement(device):
     pre = torch.ones(3000, 9, device=device)
     dgr.scatter_add_rows(idx.to(device), src.to(device), 3000, dst=pre)
     assert rel_err(pre - 1.0, ref) < 1e-5
+
+
+def test_slab_exchange_kernels_match_restatement(device):
+    """gsr_exchange_pack_slab (capacity slabs: records at the front in the reference order, overflowing records dropped,
+    zero padding with send index -1), gsr_exchange_unpack and the index -1 skip of gsr_scatter_add_rows against their
+    torch restatements -- with capacities above, equal to and BELOW the true counts"""
+    from oracle import exchange_oracle as XO
+
+    g = torch.Generator().manual_seed(11)
+    B, P, W, width, height = 2, 7000, 3, 640, 360
+    gy = (height + 15) // 16
+    m2 = (torch.rand(B, P, 2, generator=g) * torch.tensor([width * 1.2, height * 1.2]) - 20.0)
+    radii = torch.randint(0, 60, (B, P), generator=g, dtype=torch.int32)
+    rgb, co, depths = torch.rand(B, P, 3, generator=g), torch.rand(B, P, 4, generator=g), torch.rand(B, P, generator=g)
+    bands = torch.zeros(B, W, 2, dtype=torch.int32)
+    parts = [[0, 6, 14, gy], [0, 9, gy]]
+    for k in range(B):
+        for j in range(len(parts[k]) - 1):
+            bands[k, j, 0], bands[k, j, 1] = parts[k][j], parts[k][j + 1]
+    dm2, drad, drgb, dco, ddep, dbands = [t.to(device) for t in (m2, radii, rgb, co, depths, bands)]
+    cc, cnt = dgr.exchange_count(dm2, drad, dbands, 0, B, width, height)
+    true = cnt.cpu()
+    for cams, rule in (([0], "above"), ([1], "above"), ([0], "equal"), ([1], "below"), ([0, 1], "mixed")):
+        caps = []
+        for gdst in range(W):
+            for k in cams:
+                n = int(true[gdst, k])
+                caps.append({"above": (n * 5 // 4 + 256) // 256 * 256, "equal": n, "below": max(n - 37, 0),
+                             "mixed": [n + 100, max(n - 5, 0), n][(gdst + k) % 3]}[rule])
+        msg_ref, idx_ref = XO.exchange_pack_slab(m2, rgb, co, radii, depths, bands, None, None, caps, cams[0], len(cams),
+                                                 width, height)
+        msg, idx = dgr.exchange_pack_slab(dm2, drgb, dco, drad, ddep, dbands, cc, cnt, caps, cams[0], len(cams), width,
+                                          height, count_cameras=B, count_first=0)
+        assert torch.equal(idx.cpu(), idx_ref), (cams, rule)
+        assert torch.equal(msg.cpu().view(torch.int32), msg_ref.view(torch.int32)), (cams, rule)
+        outs = dgr.exchange_unpack(msg)
+        refs = XO.exchange_unpack(msg_ref)
+        for a, b in zip(outs, refs):
+            assert torch.equal(a.cpu().reshape(b.shape), b), (cams, rule)
+        assert int((outs[3] > 0).sum()) == sum(min(c, int(true[gdst, k])) for c, (gdst, k) in
+                                                zip(caps, [(gd, k) for gd in range(W) for k in cams]))
+    # padding rows (index -1) are skipped by the backward's scatter-add
+    idx = torch.randint(-1, 500, (6000,), generator=g, dtype=torch.int32)
+    src = torch.randn(6000, 9, generator=g)
+    out = dgr.scatter_add_rows(idx.to(device), src.to(device), 500)
+    assert rel_err(out, XO.scatter_add_rows(idx, src.double(), 500)) < 1e-6
+    z = dgr.zeros_async((1000, 9), torch.float32, device)
+    assert float(z.abs().sum()) == 0.0

@@ -122,23 +122,14 @@ def test_cut_points_equal_the_reference_function(device):
                        capture_output=True, text=True, timeout=600, cwd=harness.REF_ROOT)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     ref = json.loads(r.stdout.strip().splitlines()[-1])
-    sys.path.insert(0, os.path.join(ROOT, "tests", "refgraft"))
-    import importlib.util
-
     import torch
 
-    spec = importlib.util.spec_from_file_location("cuts_fuzz_local", os.path.join(ROOT, "tests", "refgraft", "cuts_fuzz.py"))
-    # only the seeded generator is needed from that file; the mirror's function comes from this repo's package
-    src = open(spec.origin).read().split("def main()")[0].replace("import gaussian_renderer.workload_division as wd", "")
-    ns = {}
-    exec(compile(src, spec.origin, "exec"), ns)
     from gaussian_renderer.workload_division import division_pos_heuristic
 
     bad = []
     for seed in range(n):
-        rows = [68, 135, 68 * 4, 35 * 4][seed % 4]
-        world = [2, 4, 8, 8][(seed // 4) % 4]
-        mine = division_pos_heuristic(torch.from_numpy(ns["heuristics"](seed, rows)), rows, world, right=True)
+        rows, world = scenes.fuzz_case(seed)
+        mine = division_pos_heuristic(torch.from_numpy(scenes.fuzz_heuristics(seed, rows)), rows, world, right=True)
         if mine != ref[seed]:
             bad.append((seed, rows, world, mine, ref[seed]))
     _report("cut points vs the reference's division_pos_heuristic", [f"{n} cases, {len(bad)} differ"] + [str(b) for b in bad[:5]])

@@ -53,7 +53,7 @@ def main():
     libs = [("production", _lib.LIB_PATH)] + [(os.path.basename(p), p) for p in a.lib]
     for name, path in libs:
         lib = load(path)
-        ranges = torch.empty((gx * gy, 2), dtype=torch.int32, device=dev)
+        ranges = torch.empty((gx * gy + 1, 2), dtype=torch.int32, device=dev)
         nb = lib.gsr_bin_prepare_bytes(P, W, H)
         prep = torch.empty(nb, dtype=torch.uint8, device=dev)
         D = ctypes.c_int64(0)

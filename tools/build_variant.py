@@ -29,7 +29,7 @@ def main():
     objs = []
     for u in B.UNITS:
         obj = os.path.join(B.HERE, u + ".o")
-        if u in srcs or (u in ("binning", "composite", "loss", "optim", "preprocess") and defs):
+        if u in srcs or (u in ("binning", "composite", "loss", "optim", "preprocess", "exchange") and defs):
             obj = os.path.join(out_dir, f"{u}_{name}.o")
             src = srcs.get(u, os.path.join(B.HERE, u + ".hip"))
             subprocess.run([B._hipcc()] + B.FLAGS + defs + ["-I", B.HERE, "-c", src, "-o", obj], check=True)
