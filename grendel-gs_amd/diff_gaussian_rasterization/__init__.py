@@ -183,6 +183,15 @@ def local_pixels(mask, W, H):
     return int((m * hh[:, None] * ww[None, :]).sum())
 
 
+def _on(dev):
+    """`with torch.cuda.device(dev)` only when `dev` is not already the current device (the guard costs ~10 us per use
+    -- hipGetDevice / hipSetDevice pairs -- and every C-ABI call sits in one; one process drives one GPU)"""
+    idx = dev.index
+    if idx is None or idx == torch._C._cuda_getDevice():
+        return _NULL_RANGE
+    return torch.cuda.device(dev)
+
+
 def _ptr(t):
     # a plain int: the prototypes declare c_void_p, ctypes converts (building a c_void_p object per argument was
     # ~60 objects per iteration)
@@ -260,7 +269,7 @@ class _PreprocessGaussians(torch.autograd.Function):
         rgb = torch.empty((P, 3), dtype=torch.float32, device=dev)
         clamped = torch.empty((P, 3), dtype=torch.uint8, device=dev)
         ctx.cuda_args = cuda_args
-        with torch.cuda.device(dev), kernel_timer.range("preprocess_forward", N=P, B=1, M=M), \
+        with _on(dev), kernel_timer.range("preprocess_forward", N=P, B=1, M=M), \
                 zhx_range(cuda_args, "10 preprocess time"):
             check(lib.gsr_preprocess_forward(
                 P, int(rs.sh_degree), M, _ptr(means3D), _ptr(scales), float(rs.scale_modifier), _ptr(rotations),
@@ -286,7 +295,7 @@ class _PreprocessGaussians(torch.autograd.Function):
         d_rot = torch.empty((P, 4), dtype=torch.float32, device=dev)
         d_shs = torch.empty((P, M, 3), dtype=torch.float32, device=dev)
         d_opac = torch.empty((P, 1), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev), kernel_timer.range("preprocess_backward", N=P, B=1, M=M), \
+        with _on(dev), kernel_timer.range("preprocess_backward", N=P, B=1, M=M), \
                 zhx_range(ctx.cuda_args, "b20 preprocess time"):
             check(lib.gsr_preprocess_backward(
                 P, int(rs.sh_degree), M, _ptr(means3D), _ptr(scales), float(rs.scale_modifier), _ptr(rotations),
@@ -323,7 +332,7 @@ class _PreprocessGaussiansRaw(torch.autograd.Function):
         rgb = torch.empty((P, 3), dtype=torch.float32, device=dev)
         clamped = torch.empty((P, 3), dtype=torch.uint8, device=dev)
         ctx.cuda_args = cuda_args
-        with torch.cuda.device(dev), kernel_timer.range("preprocess_forward", N=P, B=1, M=M), \
+        with _on(dev), kernel_timer.range("preprocess_forward", N=P, B=1, M=M), \
                 zhx_range(cuda_args, "10 preprocess time"):
             check(lib.gsr_preprocess_forward_raw(
                 P, int(rs.sh_degree), M, _ptr(xyz), _ptr(scaling), float(rs.scale_modifier), _ptr(rotation),
@@ -351,7 +360,7 @@ class _PreprocessGaussiansRaw(torch.autograd.Function):
         d_dc = torch.empty((P, 1, 3), dtype=torch.float32, device=dev)
         d_rest = torch.empty((P, M - 1, 3), dtype=torch.float32, device=dev)
         d_opac = torch.empty((P, 1), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev), kernel_timer.range("preprocess_backward", N=P, B=1, M=M), \
+        with _on(dev), kernel_timer.range("preprocess_backward", N=P, B=1, M=M), \
                 zhx_range(ctx.cuda_args, "b20 preprocess time"):
             check(lib.gsr_preprocess_backward_raw(
                 P, int(rs.sh_degree), M, _ptr(xyz), _ptr(scaling), float(rs.scale_modifier), _ptr(rotation),
@@ -414,7 +423,7 @@ class _PreprocessGaussiansRawBatched(torch.autograd.Function):
         conic_opacity = torch.empty((B, P, 4), dtype=torch.float32, device=dev)
         rgb = torch.empty((B, P, 3), dtype=torch.float32, device=dev)
         clamped = torch.empty((B, P, 3), dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev), kernel_timer.range("preprocess_forward", N=P, B=B, M=M), \
+        with _on(dev), kernel_timer.range("preprocess_forward", N=P, B=B, M=M), \
                 zhx_range(cuda_args_list, "10 preprocess time"):
             check(lib.gsr_preprocess_forward_raw_batched(
                 P, B, int(sh_degree), M, _ptr(xyz), _ptr(scaling), float(scale_modifier), _ptr(rotation),
@@ -470,7 +479,7 @@ class _PreprocessGaussiansRawBatched(torch.autograd.Function):
         d_dc = torch.empty((P, 1, 3), dtype=torch.float32, device=dev)
         d_rest = torch.empty((P, M - 1, 3), dtype=torch.float32, device=dev)
         d_opac = torch.empty((P, 1), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev), kernel_timer.range("preprocess_backward", N=P, B=B, M=M), \
+        with _on(dev), kernel_timer.range("preprocess_backward", N=P, B=B, M=M), \
                 zhx_range(ctx.cuda_args_list, "b20 preprocess time"):
             if B == 1 and ctx.tanfov0 is not None:
                 # single camera: the leaner one-camera kernel (no accumulators); camera fields are slices of `cams`
@@ -635,7 +644,7 @@ class _RenderGaussians(torch.autograd.Function):
         # the module-wide mode
         timing = (cuda_args.get("_gsr_timing") if isinstance(cuda_args, dict) else None) or _timing_mode()
         stats = cuda_args.get("stats_collector") if isinstance(cuda_args, dict) else None
-        with torch.cuda.device(dev):
+        with _on(dev):
             if timing != "off":
                 ev0 = torch.cuda.Event(enable_timing=True)
                 ev1 = torch.cuda.Event(enable_timing=True)
@@ -686,7 +695,7 @@ class _RenderGaussians(torch.autograd.Function):
         record = torch.empty((P, 9), dtype=torch.float32, device=dev)
         d_means2D, d_rgb, d_conic_opacity = record[:, 0:2], record[:, 2:5], record[:, 5:9]
         timing = ctx.timing
-        with torch.cuda.device(dev):
+        with _on(dev):
             if timing != "off":
                 ev0 = torch.cuda.Event(enable_timing=True)
                 ev1 = torch.cuda.Event(enable_timing=True)
@@ -779,7 +788,7 @@ class _FusedL1SSIMBand(torch.autograd.Function):
         partials = torch.empty((max(nb, 1), 2), dtype=torch.float32, device=dev)
         maps = torch.empty((3, C, rows, W), dtype=torch.float32, device=dev) if need_grad else None
         band_ptr = ctypes.c_void_p(image.data_ptr() + 4 * y0 * W)
-        with torch.cuda.device(dev), kernel_timer.range("l1_ssim_forward", Px=rows * W):
+        with _on(dev), kernel_timer.range("l1_ssim_forward", Px=rows * W):
             check(lib.gsr_l1_ssim_forward(C, rows, W, band_ptr, H * W, _ptr(gt_u8), _ptr(partials),
                                           _ptr(maps[0]) if need_grad else None, _ptr(maps[1]) if need_grad else None,
                                           _ptr(maps[2]) if need_grad else None, _stream()), "gsr_l1_ssim_forward")
@@ -801,7 +810,7 @@ class _FusedL1SSIMBand(torch.autograd.Function):
         grad = torch.empty_like(image) if rows == H else torch.zeros_like(image)
         band_ptr = ctypes.c_void_p(image.data_ptr() + 4 * y0 * W)
         gband_ptr = ctypes.c_void_p(grad.data_ptr() + 4 * y0 * W)
-        with torch.cuda.device(dev), kernel_timer.range("l1_ssim_backward", Px=rows * W):
+        with _on(dev), kernel_timer.range("l1_ssim_backward", Px=rows * W):
             check(lib.gsr_l1_ssim_backward(C, rows, W, band_ptr, H * W, _ptr(gt_u8), _ptr(maps[0]), _ptr(maps[1]),
                                            _ptr(maps[2]), _ptr(g_l1), _ptr(g_ssim), 1.0, 1.0, gband_ptr, H * W,
                                            _stream()),
@@ -842,7 +851,7 @@ class _FusedBandLoss(torch.autograd.Function):
         out3 = torch.empty((3,), dtype=torch.float32, device=dev)
         c_l1, c_ssim = (1.0 - lambda_dssim) / n, -lambda_dssim / n
         band_ptr = ctypes.c_void_p(image.data_ptr() + 4 * y0 * W)
-        with torch.cuda.device(dev):
+        with _on(dev):
             with kernel_timer.range("l1_ssim_forward", Px=rows * W):
                 check(lib.gsr_l1_ssim_forward(C, rows, W, band_ptr, H * W, _ptr(gt_u8), _ptr(partials),
                                               _ptr(maps[0]) if need_grad else None,
@@ -871,7 +880,7 @@ class _FusedBandLoss(torch.autograd.Function):
         grad = torch.empty_like(image) if rows == H else torch.zeros_like(image)
         band_ptr = ctypes.c_void_p(image.data_ptr() + 4 * y0 * W)
         gband_ptr = ctypes.c_void_p(grad.data_ptr() + 4 * y0 * W)
-        with torch.cuda.device(dev), kernel_timer.range("l1_ssim_backward", Px=rows * W):
+        with _on(dev), kernel_timer.range("l1_ssim_backward", Px=rows * W):
             check(lib.gsr_l1_ssim_backward(C, rows, W, band_ptr, H * W, _ptr(gt_u8), _ptr(maps[0]), _ptr(maps[1]),
                                            _ptr(maps[2]), _ptr(g_loss), _ptr(g_loss), float(ctx.coef[0]),
                                            float(ctx.coef[1]), gband_ptr, H * W, _stream()),
@@ -898,7 +907,7 @@ class _FusedActivations(torch.autograd.Function):
         rotations = torch.empty((N, 4), dtype=torch.float32, device=dev)
         opacities = torch.empty((N, 1), dtype=torch.float32, device=dev)
         shs = torch.empty((N, 1 + rest, 3), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev), kernel_timer.range("activate_forward"):
+        with _on(dev), kernel_timer.range("activate_forward"):
             check(lib.gsr_activate_forward(N, rest, _ptr(scaling), _ptr(rotation), _ptr(opacity), _ptr(features_dc),
                                            _ptr(features_rest), _ptr(scales), _ptr(rotations), _ptr(opacities),
                                            _ptr(shs), _stream()), "gsr_activate_forward")
@@ -922,7 +931,7 @@ class _FusedActivations(torch.autograd.Function):
         d_opacity = torch.empty((N, 1), dtype=torch.float32, device=dev)
         d_dc = torch.empty((N, 1, 3), dtype=torch.float32, device=dev)
         d_rest = torch.empty((N, rest, 3), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev), kernel_timer.range("activate_backward"):
+        with _on(dev), kernel_timer.range("activate_backward"):
             check(lib.gsr_activate_backward(N, rest, _ptr(rotation), _ptr(scales), _ptr(opacities), _ptr(g_scales),
                                             _ptr(g_rotations), _ptr(g_opacities), _ptr(g_shs), _ptr(d_scaling),
                                             _ptr(d_rotation), _ptr(d_opacity), _ptr(d_dc), _ptr(d_rest), _stream()),
@@ -965,7 +974,7 @@ def exchange_count(means2D_all, radii_all, bands, k0, nb, width, height):
     nchunk = lib.gsr_exchange_chunks(P)
     chunkcnt = torch.empty((W * nb, max(nchunk, 1)), dtype=torch.int32, device=m2.device)
     counts = torch.empty((W, nb), dtype=torch.int32, device=m2.device)
-    with torch.cuda.device(m2.device):
+    with _on(m2.device):
         check(lib.gsr_exchange_count(P, B, k0, nb, W, width, height, _ptr(m2), _ptr(radii_all), _ptr(bands),
                                      _ptr(chunkcnt), _ptr(counts), _stream()), "gsr_exchange_count")
     return chunkcnt, counts
@@ -985,7 +994,7 @@ def exchange_pack(means2D_all, rgb_all, co_all, radii_all, depths_all, bands, ch
     if len(segment_offsets) != W * nb:
         raise ValueError("segment_offsets must have W * nb entries")
     seg = (ctypes.c_int32 * (W * nb))(*segment_offsets)
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(lib.gsr_exchange_pack(P, B, k0, nb, W, width, height, nb if count_cameras is None else count_cameras,
                                     k0 if count_first is None else count_first, _ptr(means2D_all), _ptr(rgb_all), _ptr(co_all),
                                     _ptr(radii_all), _ptr(depths_all), _ptr(bands), _ptr(chunkcnt), seg, n_send,
@@ -1009,7 +1018,7 @@ def exchange_pack_slab(means2D_all, rgb_all, co_all, radii_all, depths_all, band
     msg = torch.empty((n_rows, 11), dtype=torch.float32, device=dev)
     send_idx = torch.empty((n_rows,), dtype=torch.int32, device=dev)
     caps = (ctypes.c_int32 * (W * nb))(*[int(c) for c in capacities])
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(lib.gsr_exchange_pack_slab(P, B, k0, nb, W, width, height, nb if count_cameras is None else count_cameras,
                                          k0 if count_first is None else count_first, _ptr(means2D_all), _ptr(rgb_all),
                                          _ptr(co_all), _ptr(radii_all), _ptr(depths_all), _ptr(bands), _ptr(chunkcnt),
@@ -1028,7 +1037,7 @@ def exchange_unpack(recv):
     outs = [torch.empty((n, w), dtype=torch.float32, device=dev) for w in (2, 3, 4)]
     radii = torch.empty((n,), dtype=torch.int32, device=dev)
     depths = torch.empty((n,), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(lib.gsr_exchange_unpack(n, _ptr(recv), _ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2]), _ptr(radii),
                                       _ptr(depths), _stream()), "gsr_exchange_unpack")
     return outs[0], outs[1], outs[2], radii, depths
@@ -1037,7 +1046,7 @@ def exchange_unpack(recv):
 def zeros_async(shape, dtype, device):
     """torch.zeros through hipMemsetAsync on the current stream (the fill kernel torch launches runs at ~1 TB/s)"""
     t = torch.empty(shape, dtype=dtype, device=device)
-    with torch.cuda.device(device):
+    with _on(device):
         check(lib.gsr_zero_async(_ptr(t), t.numel() * t.element_size(), _stream()), "gsr_zero_async")
     return t
 
@@ -1052,7 +1061,7 @@ def scatter_add_rows(idx, src, n_rows, dst=None):
         dst = torch.zeros((n_rows, 9), dtype=torch.float32, device=src.device)
     elif tuple(dst.shape) != (n_rows, 9) or dst.dtype != torch.float32 or not dst.is_contiguous():
         raise ValueError("dst must be a contiguous fp32 [n_rows, 9] tensor")
-    with torch.cuda.device(src.device):
+    with _on(src.device):
         check(lib.gsr_scatter_add_rows(src.shape[0], _ptr(idx), _ptr(src), _ptr(dst), _stream()), "gsr_scatter_add_rows")
     return dst
 
@@ -1164,7 +1173,7 @@ class _CNamespace:
             raise ValueError("dist_global_strategy must have world_size + 1 entries")
         P = means2D.shape[0]
         out = torch.empty((P, mp_world_size), dtype=torch.uint8, device=means2D.device)
-        with torch.cuda.device(means2D.device):
+        with _on(means2D.device):
             check(lib.gsr_get_local2j_ids_bool(P, int(image_width), int(image_height), int(mp_world_size),
                                                _ptr(means2D), _ptr(radii), _ptr(div), _ptr(out), _stream()),
                   "gsr_get_local2j_ids_bool")

@@ -10,7 +10,7 @@ import ctypes
 
 import torch
 
-from diff_gaussian_rasterization import _lib, _stream, kernel_timer
+from diff_gaussian_rasterization import _lib, _on, _stream, kernel_timer
 
 
 class FusedAdam(torch.optim.Optimizer):
@@ -68,7 +68,7 @@ class FusedAdam(torch.optim.Optimizer):
                     self._plans = {}
                 self._plans[i] = plan
             VP, D, I64 = ctypes.c_void_p * K, ctypes.c_double * K, ctypes.c_int64 * K
-            with torch.cuda.device(dev), kernel_timer.range("adam", numel=plan[5]):
+            with _on(dev), kernel_timer.range("adam", numel=plan[5]):
                 _lib.check(_lib.lib.gsr_adam_step_multi(
                     K, plan[1], plan[2], VP(*[b[1].data_ptr() for b in part]), plan[3], plan[4],
                     D(*[b[3] for b in part]), D(*[b[4] for b in part]), D(*[b[5] for b in part]),

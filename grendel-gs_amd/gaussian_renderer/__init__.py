@@ -459,25 +459,19 @@ def _batched_exchange_final(m2_views, rgb_views, co_views, radii_views, depths_v
                                "without render_final()'s verification; call gaussian_renderer.render_final or "
                                "set_exchange_speculation(False)")
     speculate = _EXCHANGE_OPTIONS["speculate"] if speculate is None else speculate
+    gather_work = None
     if _known is not None:   # the repeat of an overflowed speculative exchange: counts already on the host
         chunkcnt, counts, sizes = _known
         speculate = False
     else:
         chunkcnt, counts = _dgr.exchange_count(bases[0], radii_all, bands, 0, B, width, height)
         all_counts = torch.empty((W * W, B), dtype=torch.int32, device=dev)
-        cur_stream = torch.cuda.current_stream() if dev.type == "cuda" else None
         speculate = speculate and planner.caps is not None
         if speculate and dev.type == "cuda":
-            # nothing on this stream needs the gathered matrix (the pack works from the LOCAL counts): the all-gather and
-            # the copy to the host run beside the pack, on the collective's own stream and a helper stream
-            work = dist.all_gather_into_tensor(all_counts, counts, group=group, async_op=True)
-            aux = _side_stream(dev, "counts")
-            aux.wait_stream(cur_stream)  # (explicit: the counts exist; the collective's own wait below implies it)
-            with torch.cuda.stream(aux):
-                work.wait()  # the helper stream waits for the collective; the host and the current stream do not
-                planner.stage(all_counts)
-            counts.record_stream(aux)
-            all_counts.record_stream(aux)
+            # nothing the pack / all-to-all / unpack below need depends on the gathered matrix (the pack works from the
+            # LOCAL counts): the collective runs on its own stream beside them, and this stream only joins it -- and
+            # queues the copy to the host -- AFTER the unpack has been enqueued (see the end of this function)
+            gather_work = dist.all_gather_into_tensor(all_counts, counts, group=group, async_op=True)
             sizes = _LazySizes()
         elif speculate:
             dist.all_gather_into_tensor(all_counts, counts, group=group)
@@ -555,6 +549,9 @@ def _batched_exchange_final(m2_views, rgb_views, co_views, radii_views, depths_v
                 out[c][k] = r[c] if whole else r[c][start:start + n]
             events[k] = ev
             start += n
+    if gather_work is not None:
+        gather_work.wait()          # stream-level join with the (long finished) size all-gather; the host does not wait
+        planner.stage(all_counts)   # asynchronous copy to pinned memory + event, behind the unpack in stream order
     pending = (planner, chunkcnt, counts, sizes) if speculate else None
     return out[0], out[1], out[2], out[3], out[4], sizes, (events, token), pending
 

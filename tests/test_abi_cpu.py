@@ -81,3 +81,48 @@ def test_product_path_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 txt = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", txt, flags=re.M), f"{f} imports oracle/"
+
+
+def test_band_aware_xcd_map_is_a_balanced_bijection():
+    """Python restatement of gsr_xcd_span_of_block_band (grendel-gs_amd/csrc/common.h): K8 / K10 hand every XCD a
+    contiguous 1/8 of the BAND a rank renders.  Bijective over all tiles, every XCD gets |band| / 8 (+-1) band tiles as
+    one contiguous run, and it equals the plain span map when the band is the whole grid.  (The device function itself is
+    exercised by the GPU band-union test: the SUM of band renders is bitwise the full render.)"""
+    import random
+    import re
+
+    src = open(os.path.join(ROOT, "grendel-gs_amd", "csrc", "common.h")).read()
+    body = src[src.index("gsr_xcd_span_of_block_band"):]
+    for needle in ("(hull - xcd + 7) >> 3", "xcd * (hull >> 3) + min(xcd, hull & 7)", "xcd * (nwg >> 3) + min(xcd, nwg & 7)",
+                   "n < first ? n : n + hull"):
+        assert needle in body, f"common.h no longer matches the restatement below: {needle}"
+    assert re.search(r"if \(j < hl\) return first \+ hs \+ j;", body)
+
+    def band_map(b, nwg, first, hull):
+        xcd, j = b & 7, b >> 3
+        hl = (hull - xcd + 7) >> 3
+        hs = xcd * (hull >> 3) + min(xcd, hull & 7)
+        if j < hl:
+            return first + hs + j
+        ts = xcd * (nwg >> 3) + min(xcd, nwg & 7)
+        n = (ts - hs) + (j - hl)
+        return n if n < first else n + hull
+
+    def span(b, nwg):
+        xcd, q, r = b & 7, nwg >> 3, nwg & 7
+        return (xcd * (q + 1) if xcd < r else r * (q + 1) + (xcd - r) * q) + (b >> 3)
+
+    rnd = random.Random(0)
+    cases = [(120, 68, 0, 68), (120, 68, 34, 43), (240, 135, 17, 34), (13, 9, 8, 9)]
+    cases += [(gx, gy, lo, rnd.randint(lo + 1, gy)) for gx, gy, lo in
+              ((rnd.randint(1, 40), g, rnd.randint(0, g - 1)) for g in (rnd.randint(1, 40) for _ in range(300)))]
+    for gx, gy, lo, hi in cases:
+        T, first, hull = gx * gy, lo * gx, (hi - lo) * gx
+        m = [band_map(b, T, first, hull) for b in range(T)]
+        assert sorted(m) == list(range(T)), (gx, gy, lo, hi)
+        for x in range(8):
+            bt = [t for b, t in enumerate(m) if b % 8 == x and first <= t < first + hull]
+            assert not bt or bt == list(range(bt[0], bt[0] + len(bt)))
+            assert abs(len(bt) - hull / 8) < 1 + 1e-9
+        if hull == T:
+            assert m == [span(b, T) for b in range(T)]
