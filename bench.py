@@ -8,7 +8,8 @@ A STEP is one training iteration of the hot path on one batch of synthetic camer
 reference's own call sequence (train_internal.py:134-329): start_strategy_final -> GT staging ->
 distributed_preprocess3dgs_and_all2all_final (activations + K1 per camera + the sparse exchange)
 -> render_final (K3-K8) -> batched_loss_computation (band-local L1 + SSIM) -> backward (K10, mirror
-exchange, K11, activation backward) -> finish_strategy_final -> grad /= bsz -> Adam step -> zero_grad.
+exchange, K11, activation backward) -> finish_strategy_final -> grad /= bsz -> Adam step -> zero_grad
+(K11 and the Adam step are ONE kernel unless --no-fuse-backward: fused_optim.py).
 Nothing is skipped or cached inside the timed region.  Inputs (parameters, cameras, uint8 ground-truth
 images) are resident in HBM before the timed region.
 
@@ -73,6 +74,8 @@ def algorithmic_bytes(kernel, m):
         return m["N"] * (in_g + 44 * m.get("B", 1))
     if kernel == "preprocess_backward":
         return m["N"] * (in_g + (44 + 36) * m.get("B", 1) + in_g)
+    if kernel == "preprocess_backward_adam":  # K11's reads + the optimizer's moments read, parameters / moments written:
+        return m["N"] * (in_g + (44 + 36) * m.get("B", 1) + 5 * in_g)  # the 2 x 236 B gradient round trip is gone
     if kernel == "binning":  # the reference's algorithm: 64-bit (tile | depth) keys, LSD passes of 8 bits
         key_bits = 32 + max(1, math.ceil(math.log2(max(m["tiles"], 2))))
         return m["P"] * 16 + m["D"] * 12 + m["D"] * 24 * math.ceil(key_bits / 8) + m["D"] * 8
@@ -223,7 +226,11 @@ def run_workload(a, name, world, rank, dev, steps, warmup, repeats, render_steps
     history = DivisionStrategyHistoryFinal(S.SyntheticDataset(cameras), world, rank)
     bg = torch.zeros(3, dtype=torch.float32, device=dev)
     pipe = type("Pipe", (), {"debug": False})()
-    opt = FusedAdam(model.param_groups(), lr=0.0, eps=1e-15)  # scene/gaussian_model.py:292 settings
+    # scene/gaussian_model.py:292 settings; grad /= bsz (train_internal.py:319-324) folded into the update.  With
+    # fuse_backward the projection backward K11 runs inside the optimizer kernel (fused_optim.py): same arithmetic, the
+    # six parameter gradients never reach HBM; --no-fuse-backward measures the two-kernel form
+    opt = FusedAdam(model.param_groups(), lr=0.0, eps=1e-15, fuse_backward=not a.no_fuse_backward,
+                    grad_scale=1.0 / bsz)
     state = {"it": 0, "sizes": None}
 
     def batch():
@@ -243,7 +250,7 @@ def run_workload(a, name, world, rank, dev, steps, warmup, repeats, render_steps
         loss, _ = batched_loss_computation(images, cams, masks, strategies, stats)
         loss.backward()
         finish_strategy_final(cams, history, strategies, stats)
-        opt.step(grad_scale=1.0 / bsz)  # grad /= bsz (train_internal.py:319-324) folded into the update
+        opt.step()
         opt.zero_grad(set_to_none=True)
         for cam in cams:
             cam.original_image = None
@@ -307,11 +314,21 @@ def run_workload(a, name, world, rank, dev, steps, warmup, repeats, render_steps
         dgr.kernel_timer.reset()
     extra = [timed(train_step, steps) for _ in range(max(repeats - 1, 0))]
     per_step = [1e3 * x / steps for x in [dt] + extra]
+    fused_steps = opt.fused_steps
+    dt_unfused = None
+    if opt.fuse_backward and repeats > 1:  # the same steps with K11 and Adam as two kernels (gradients through HBM)
+        opt.set_fuse_backward(False)
+        timed(train_step, min(steps, 3))
+        dt_unfused = timed(train_step, steps)
+        opt.set_fuse_backward(True)
 
     out = {"name": name, "desc": desc, "gaussians_total": n_total, "gaussians_this_rank": int(model._xyz.shape[0]),
            "image": [W, H], "bsz": bsz, "world": world, "scene": scene, "dt": dt, "steps": steps,
            "ms_per_step": 1e3 * dt / steps, "images_per_s": bsz * steps / dt, "priming_steps": priming,
            "kernels_region_ms_per_step": (1e3 * dt_instr / steps) if dt_instr else None,
+           "optimizer": {"fuse_backward": bool(opt.fuse_backward), "fused_steps": fused_steps,
+                         "materialized_steps": opt.materialized_steps,
+                         "ms_per_step_two_kernels": round(1e3 * dt_unfused / steps, 4) if dt_unfused else None},
            "timing": {"repeats": len(per_step), "ms_per_step_median": round(percentile(per_step, 0.5), 4),
                       "ms_per_step_p10": round(percentile(per_step, 0.1), 4),
                       "ms_per_step_p90": round(percentile(per_step, 0.9), 4),
@@ -361,6 +378,7 @@ def run_workload(a, name, world, rank, dev, steps, warmup, repeats, render_steps
             "rows_kept_local_per_rank": [rows[i][i] for i in range(world)],
             "bands_last_step": [[list(g), list(d)] for g, d in state.get("bands", [])],
             "note": "last step; all-to-all-v over xGMI, rank i -> rank j peer copies; local rows do not leave the GPU"}
+    opt.set_fuse_backward(False)
     del model, opt, cameras, history
     torch.cuda.empty_cache()
     return out
@@ -388,6 +406,9 @@ def main():
     ap.add_argument("--balance-timing", default="pipelined", choices=["exact", "pipelined"],
                     help="N > 1 with live heuristics: how finish_strategy_final gets its timings (the library default "
                          "is the reference's `exact`, which waits for the iteration's own events every step)")
+    ap.add_argument("--no-fuse-backward", action="store_true",
+                    help="run K11 and Adam as two kernels (the parameter gradients go through HBM) instead of the fused "
+                         "K11 + Adam launch")
     ap.add_argument("--no-1gpu-leg", action="store_true", help="N > 1: skip the same-workload single-GPU leg")
     ap.add_argument("--render-steps", type=int, default=20, help="forward-only views/sec leg (untimed by driver)")
     ap.add_argument("--pmc-calib", action="store_true", help="also run a 256 MiB streaming multiply (PMC calibration)")
@@ -536,7 +557,11 @@ def main():
                    "gaussians_total": n_total, "gaussians_per_gpu": main_res["gaussians_this_rank"], "image": [W, H],
                    "bsz": main_res["bsz"],
                    "parallelism": f"pixel-partition x{world} (row bands), Gaussian-sharded x{world}",
-                   "scene": main_res["scene"], "opacity_logit": [a.opacity_logit_mean, a.opacity_logit_std], "seed": 0},
+                   "scene": main_res["scene"], "opacity_logit": [a.opacity_logit_mean, a.opacity_logit_std], "seed": 0,
+                   "optimizer": ("FusedAdam, K11 fused into the step (gsr_preprocess_backward_adam_raw_batched): same "
+                                 "arithmetic as K11 + Adam, parameter gradients never written to HBM"
+                                 if main_res["optimizer"]["fuse_backward"] else "FusedAdam after K11 (two kernels)")},
+        "optimizer": main_res["optimizer"],
         "timing": main_res["timing"],
         "setup": {"priming_steps": main_res["priming_steps"],
                   "note": "untimed pass over the distinct synthetic cameras before the W warmup steps (large / multi-rank "

@@ -114,6 +114,18 @@ __device__ __forceinline__ bool gsr_can_touch_box(const float2 xy, const float4 
     return !(q > lim);  // NaN -> keep
 }
 
+// One element of the dense Adam update (torch.optim.Adam as the reference configures it, scene/gaussian_model.py:292:
+// no weight decay, no amsgrad).  Spelled with explicit roundings so that optim.hip (contraction on) and the fused
+// K11 + Adam kernel of preprocess.hip (contraction off) produce the SAME bits: the fused step is tested for equality
+// with K11 followed by gsr_adam_step_multi.  omb = 1 - beta rounded from double, as the stock optimizer's scalars are.
+__device__ __forceinline__ void gsr_adam1(float &p, float g, float &m, float &v, float lr_c, float b1, float b2,
+                                          float omb1, float omb2, float inv_sqrt_bc2, float eps) {
+    m = __builtin_fmaf(b1, m, __fmul_rn(omb1, g));
+    v = __builtin_fmaf(b2, v, __fmul_rn(__fmul_rn(omb2, g), g));
+    const float denom = __builtin_fmaf(__fsqrt_rn(v), inv_sqrt_bc2, eps);
+    p = __builtin_fmaf(-lr_c, __fdiv_rn(m, denom), p);
+}
+
 // ---- internal launchers (defined in the .hip files, called from api.hip) --------------------
 int gsr_launch_preprocess_forward(int P, int D, int M, const float *means3D, const float *scales, float scale_modifier,
                                   const float *rotations, const float *shs, const float *shs_rest,

@@ -10,15 +10,6 @@
 
 namespace {
 
-template <typename V>
-__device__ __forceinline__ void adam1(float &p, float g, float &m, float &v, float lr_c, float b1, float b2,
-                                      float omb1, float omb2, float inv_sqrt_bc2, float eps) {
-    m = b1 * m + omb1 * g;  // omb = 1 - beta rounded from double, as the stock optimizer's scalars are
-    v = b2 * v + omb2 * g * g;
-    const float denom = sqrtf(v) * inv_sqrt_bc2 + eps;
-    p -= lr_c * (m / denom);
-}
-
 __global__ void __launch_bounds__(256)
 adam_kernel(long long n, float *__restrict__ param, const float *__restrict__ grad, float *__restrict__ exp_avg,
             float *__restrict__ exp_avg_sq, float lr_c, float b1, float b2, float omb1, float omb2,
@@ -29,17 +20,17 @@ adam_kernel(long long n, float *__restrict__ param, const float *__restrict__ gr
         float4 g = *reinterpret_cast<const float4 *>(grad + i4);
         float4 m = *reinterpret_cast<float4 *>(exp_avg + i4);
         float4 v = *reinterpret_cast<float4 *>(exp_avg_sq + i4);
-        adam1<float>(p.x, g.x * grad_scale, m.x, v.x, lr_c, b1, b2, omb1, omb2, inv_sqrt_bc2, eps);
-        adam1<float>(p.y, g.y * grad_scale, m.y, v.y, lr_c, b1, b2, omb1, omb2, inv_sqrt_bc2, eps);
-        adam1<float>(p.z, g.z * grad_scale, m.z, v.z, lr_c, b1, b2, omb1, omb2, inv_sqrt_bc2, eps);
-        adam1<float>(p.w, g.w * grad_scale, m.w, v.w, lr_c, b1, b2, omb1, omb2, inv_sqrt_bc2, eps);
+        gsr_adam1(p.x, g.x * grad_scale, m.x, v.x, lr_c, b1, b2, omb1, omb2, inv_sqrt_bc2, eps);
+        gsr_adam1(p.y, g.y * grad_scale, m.y, v.y, lr_c, b1, b2, omb1, omb2, inv_sqrt_bc2, eps);
+        gsr_adam1(p.z, g.z * grad_scale, m.z, v.z, lr_c, b1, b2, omb1, omb2, inv_sqrt_bc2, eps);
+        gsr_adam1(p.w, g.w * grad_scale, m.w, v.w, lr_c, b1, b2, omb1, omb2, inv_sqrt_bc2, eps);
         *reinterpret_cast<float4 *>(param + i4) = p;
         *reinterpret_cast<float4 *>(exp_avg + i4) = m;
         *reinterpret_cast<float4 *>(exp_avg_sq + i4) = v;
     } else {
         for (long long i = i4; i < n; i++) {
             float p = param[i], m = exp_avg[i], v = exp_avg_sq[i];
-            adam1<float>(p, grad[i] * grad_scale, m, v, lr_c, b1, b2, omb1, omb2, inv_sqrt_bc2, eps);
+            gsr_adam1(p, grad[i] * grad_scale, m, v, lr_c, b1, b2, omb1, omb2, inv_sqrt_bc2, eps);
             param[i] = p;
             exp_avg[i] = m;
             exp_avg_sq[i] = v;
@@ -89,17 +80,17 @@ __global__ void __launch_bounds__(256) adam_multi_kernel(AdamBatch a, float grad
             vf4 vn = __builtin_nontemporal_load(reinterpret_cast<vf4 *>(ev + i4));
             float4 p = make_float4(pn.x, pn.y, pn.z, pn.w), g = make_float4(gn.x, gn.y, gn.z, gn.w);
             float4 m = make_float4(mn.x, mn.y, mn.z, mn.w), v = make_float4(vn.x, vn.y, vn.z, vn.w);
-            adam1<float>(p.x, g.x * grad_scale, m.x, v.x, lr_c, b1, b2, omb1, omb2, inv_sqrt_bc2, eps);
-            adam1<float>(p.y, g.y * grad_scale, m.y, v.y, lr_c, b1, b2, omb1, omb2, inv_sqrt_bc2, eps);
-            adam1<float>(p.z, g.z * grad_scale, m.z, v.z, lr_c, b1, b2, omb1, omb2, inv_sqrt_bc2, eps);
-            adam1<float>(p.w, g.w * grad_scale, m.w, v.w, lr_c, b1, b2, omb1, omb2, inv_sqrt_bc2, eps);
+            gsr_adam1(p.x, g.x * grad_scale, m.x, v.x, lr_c, b1, b2, omb1, omb2, inv_sqrt_bc2, eps);
+            gsr_adam1(p.y, g.y * grad_scale, m.y, v.y, lr_c, b1, b2, omb1, omb2, inv_sqrt_bc2, eps);
+            gsr_adam1(p.z, g.z * grad_scale, m.z, v.z, lr_c, b1, b2, omb1, omb2, inv_sqrt_bc2, eps);
+            gsr_adam1(p.w, g.w * grad_scale, m.w, v.w, lr_c, b1, b2, omb1, omb2, inv_sqrt_bc2, eps);
             *reinterpret_cast<float4 *>(param + i4) = p;
             __builtin_nontemporal_store(vf4{m.x, m.y, m.z, m.w}, reinterpret_cast<vf4 *>(em + i4));
             __builtin_nontemporal_store(vf4{v.x, v.y, v.z, v.w}, reinterpret_cast<vf4 *>(ev + i4));
         } else {
             for (long long i = i4; i < n && i < i4 + 4; i++) {
                 float p = param[i], m = em[i], v = ev[i];
-                adam1<float>(p, grad[i] * grad_scale, m, v, lr_c, b1, b2, omb1, omb2, inv_sqrt_bc2, eps);
+                gsr_adam1(p, grad[i] * grad_scale, m, v, lr_c, b1, b2, omb1, omb2, inv_sqrt_bc2, eps);
                 param[i] = p;
                 em[i] = m;
                 ev[i] = v;

@@ -291,9 +291,75 @@ __device__ __forceinline__ void rest_stage_out(const float *__restrict__ s_rest,
     for (int k = (nw & ~3) + threadIdx.x; k < nw; k += K11_BLOCK) g[row0 * REST_W + k] = s_rest[k];
 }
 
-template <int DEG, bool RAW>
+// Fused K11 + Adam (ADAM = true): the six parameter gradients never reach HBM.  A Gaussian's gradient is complete
+// when its lane leaves the camera loop (every band's contribution arrived through the exchange before the launch), so
+// the dense Adam update of scene/gaussian_model.py:292's optimizer is applied right there: the 14 per-lane floats
+// (xyz, scaling, rotation, features_dc, opacity) by the lane that owns them, the workgroup's 256 x 45 floats of
+// _features_rest in the coalesced order of the LDS stage-out (the gradient is read from LDS instead of being
+// streamed to HBM and back).  Saves the 236 B gradient write of K11, the 236 B gradient read and (through L2) most of
+// the 236 B parameter read of the optimizer per Gaussian; the arithmetic is gsr_adam1's, bit for bit
+// (tests/test_gpu_loss_and_step.py::test_fused_backward_step_equals_k11_then_adam).
+// Tensor order: xyz, scaling, rotation, features_dc, features_rest, opacity.
+struct K11Adam {
+    float *m[6], *v[6];
+    float lr_c[6], b1[6], b2[6], omb1[6], omb2[6], inv_sqrt_bc2[6], eps[6];
+    float grad_scale;
+};
+
+template <int K>
+__device__ __forceinline__ void k11_adam_row(const K11Adam &ad, int t, float *__restrict__ param, size_t row,
+                                             const float (&pv)[K], const float (&g)[K]) {
+    float *mp = ad.m[t] + row * K, *vp = ad.v[t] + row * K, *pp = param + row * K;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        float p = pv[k], m = __builtin_nontemporal_load(mp + k), v = __builtin_nontemporal_load(vp + k);
+        gsr_adam1(p, __fmul_rn(g[k], ad.grad_scale), m, v, ad.lr_c[t], ad.b1[t], ad.b2[t], ad.omb1[t], ad.omb2[t],
+                  ad.inv_sqrt_bc2[t], ad.eps[t]);
+        pp[k] = p;
+        __builtin_nontemporal_store(m, mp + k);
+        __builtin_nontemporal_store(v, vp + k);
+    }
+}
+
+// the workgroup's rows of _features_rest: gradient from LDS, parameter (just staged in by this workgroup: L2) and
+// both moments from HBM, 16 bytes per lane and access
+__device__ __forceinline__ void rest_adam_out(const float *__restrict__ s_rest, float *__restrict__ param,
+                                              const K11Adam &ad, int P) {
+    constexpr int t = 4;
+    const size_t row0 = (size_t)blockIdx.x * K11_BLOCK;
+    const int nw = (int)min((size_t)K11_BLOCK, (size_t)P - row0) * REST_W;
+    typedef float vf4 __attribute__((ext_vector_type(4)));
+    vf4 *p4 = reinterpret_cast<vf4 *>(param + row0 * REST_W);
+    vf4 *m4 = reinterpret_cast<vf4 *>(ad.m[t] + row0 * REST_W);
+    vf4 *v4 = reinterpret_cast<vf4 *>(ad.v[t] + row0 * REST_W);
+    const float4 *s4 = reinterpret_cast<const float4 *>(s_rest);
+    const float gs = ad.grad_scale, lr_c = ad.lr_c[t], b1 = ad.b1[t], b2 = ad.b2[t], omb1 = ad.omb1[t],
+                omb2 = ad.omb2[t], isb = ad.inv_sqrt_bc2[t], eps = ad.eps[t];
+    for (int k = threadIdx.x; k < nw / 4; k += K11_BLOCK) {
+        const float4 g = s4[k];
+        const vf4 pn = p4[k], mn = __builtin_nontemporal_load(m4 + k), vn = __builtin_nontemporal_load(v4 + k);
+        float pa[4] = {pn.x, pn.y, pn.z, pn.w}, ma[4] = {mn.x, mn.y, mn.z, mn.w}, va[4] = {vn.x, vn.y, vn.z, vn.w};
+        const float ga[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+            gsr_adam1(pa[c], __fmul_rn(ga[c], gs), ma[c], va[c], lr_c, b1, b2, omb1, omb2, isb, eps);
+        p4[k] = vf4{pa[0], pa[1], pa[2], pa[3]};
+        __builtin_nontemporal_store(vf4{ma[0], ma[1], ma[2], ma[3]}, m4 + k);
+        __builtin_nontemporal_store(vf4{va[0], va[1], va[2], va[3]}, v4 + k);
+    }
+    for (int k = (nw & ~3) + threadIdx.x; k < nw; k += K11_BLOCK) {
+        const size_t o = row0 * REST_W + k;
+        float p = param[o], m = ad.m[t][o], v = ad.v[t][o];
+        gsr_adam1(p, __fmul_rn(s_rest[k], gs), m, v, lr_c, b1, b2, omb1, omb2, isb, eps);
+        param[o] = p;
+        ad.m[t][o] = m;
+        ad.v[t][o] = v;
+    }
+}
+
+template <int DEG, bool RAW, bool ADAM = false>
 __device__ __forceinline__ void
-preprocess_backward_body(const int i, const float *__restrict__ rest_in, float *__restrict__ rest_out, int P, int M, const float *__restrict__ means3D, const float *__restrict__ scales,
+preprocess_backward_body(const K11Adam &ad, const int i, const float *__restrict__ rest_in, float *__restrict__ rest_out, int P, int M, const float *__restrict__ means3D, const float *__restrict__ scales,
                            float scale_modifier, const float *__restrict__ rotations, const float *__restrict__ shs,
                            const float *__restrict__ shs_rest, const float *__restrict__ opacities_raw,
                            const float *__restrict__ view, const float *__restrict__ proj,
@@ -307,6 +373,24 @@ preprocess_backward_body(const int i, const float *__restrict__ rest_in, float *
     constexpr int NC = (DEG + 1) * (DEG + 1);
     float *dsh_out = dL_dshs + (size_t)i * M * 3;
 
+    if (ADAM && radii[i] <= 0) {  // invisible: zero gradient, the moments still decay and still move the parameter
+        const float z[4] = {0.f, 0.f, 0.f, 0.f};
+        const float z3[3] = {0.f, 0.f, 0.f}, z1[1] = {0.f};
+        const float px[3] = {means3D[3 * (size_t)i], means3D[3 * (size_t)i + 1], means3D[3 * (size_t)i + 2]};
+        const float ps[3] = {scales[3 * (size_t)i], scales[3 * (size_t)i + 1], scales[3 * (size_t)i + 2]};
+        const float4 q4 = *reinterpret_cast<const float4 *>(rotations + 4 * (size_t)i);
+        const float pq[4] = {q4.x, q4.y, q4.z, q4.w};
+        const float pd[3] = {shs[3 * (size_t)i], shs[3 * (size_t)i + 1], shs[3 * (size_t)i + 2]};
+        const float po[1] = {opacities_raw[i]};
+        k11_adam_row<3>(ad, 0, const_cast<float *>(means3D), i, px, z3);
+        k11_adam_row<3>(ad, 1, const_cast<float *>(scales), i, ps, z3);
+        k11_adam_row<4>(ad, 2, const_cast<float *>(rotations), i, pq, z);
+        k11_adam_row<3>(ad, 3, const_cast<float *>(shs), i, pd, z3);
+        k11_adam_row<1>(ad, 5, const_cast<float *>(opacities_raw), i, po, z1);
+        float *rp = rest_out;
+        for (int k = 0; k < (M - 1) * 3; k++) rp[k] = 0.f;
+        return;
+    }
     if (RAW && radii[i] <= 0) {
         dL_dmeans3D[3 * (size_t)i] = dL_dmeans3D[3 * (size_t)i + 1] = dL_dmeans3D[3 * (size_t)i + 2] = 0.f;
         dL_dscales[3 * (size_t)i] = dL_dscales[3 * (size_t)i + 1] = dL_dscales[3 * (size_t)i + 2] = 0.f;
@@ -330,7 +414,12 @@ preprocess_backward_body(const int i, const float *__restrict__ rest_in, float *
     const float p[3] = {means3D[3 * (size_t)i], means3D[3 * (size_t)i + 1], means3D[3 * (size_t)i + 2]};
     const float4 gco = grad_ld4(dL_dconic_opacity, i, gstride);
     const float gA = gco.x, gB = gco.y, gC = gco.z;
-    if (RAW) {
+    if (ADAM) {
+        const float oraw = opacities_raw[i];
+        const float so = 1.0f / (1.0f + expf(-oraw));
+        const float po[1] = {oraw}, go[1] = {gco.w * so * (1.0f - so)};
+        k11_adam_row<1>(ad, 5, const_cast<float *>(opacities_raw), i, po, go);
+    } else if (RAW) {
         const float so = 1.0f / (1.0f + expf(-opacities_raw[i]));
         dL_dopacities[i] = gco.w * so * (1.0f - so);
     } else {
@@ -484,9 +573,14 @@ preprocess_backward_body(const int i, const float *__restrict__ rest_in, float *
         dmean[1] += (ddir[1] - y * dot) / len;
         dmean[2] += (ddir[2] - z * dot) / len;
         if (RAW) {
-            dL_dshs[3 * (size_t)i] = dsh[0];
-            dL_dshs[3 * (size_t)i + 1] = dsh[1];
-            dL_dshs[3 * (size_t)i + 2] = dsh[2];
+            if (ADAM) {
+                const float pd[3] = {sh[0], sh[1], sh[2]}, gd[3] = {dsh[0], dsh[1], dsh[2]};
+                k11_adam_row<3>(ad, 3, const_cast<float *>(shs), i, pd, gd);
+            } else {
+                dL_dshs[3 * (size_t)i] = dsh[0];
+                dL_dshs[3 * (size_t)i + 1] = dsh[1];
+                dL_dshs[3 * (size_t)i + 2] = dsh[2];
+            }
             float *rp = rest_out;
 #pragma unroll
             for (int k = 3; k < NC * 3; k++) rp[k - 3] = dsh[k];
@@ -501,15 +595,21 @@ preprocess_backward_body(const int i, const float *__restrict__ rest_in, float *
             for (int k = NC * 3; k < M * 3; k++) dsh_out[k] = 0.f;
         }
     }
-    dL_dmeans3D[3 * (size_t)i] = dmean[0];
-    dL_dmeans3D[3 * (size_t)i + 1] = dmean[1];
-    dL_dmeans3D[3 * (size_t)i + 2] = dmean[2];
+    if (ADAM) {
+        k11_adam_row<3>(ad, 0, const_cast<float *>(means3D), i, p, dmean);
+    } else {
+        dL_dmeans3D[3 * (size_t)i] = dmean[0];
+        dL_dmeans3D[3 * (size_t)i + 1] = dmean[1];
+        dL_dmeans3D[3 * (size_t)i + 2] = dmean[2];
+    }
 
     // ---- cov3D -> scales, rotations.  Sigma = M^T M, M = S R^T
     {
         const float4 qraw = *reinterpret_cast<const float4 *>(rotations + 4 * (size_t)i);
         float4 q = qraw;
         float sc[3] = {scales[3 * (size_t)i], scales[3 * (size_t)i + 1], scales[3 * (size_t)i + 2]};
+        const float scraw[3] = {sc[0], sc[1], sc[2]};
+        float gsc[3];
         float qn = 1.f, qnr = 1.f;
         if (RAW) {
             qnr = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
@@ -539,11 +639,13 @@ preprocess_backward_body(const int i, const float *__restrict__ rest_in, float *
         float dR[3][3];
 #pragma unroll
         for (int r = 0; r < 3; r++) {
-            dL_dscales[3 * (size_t)i + r] = (RAW ? sc[r] : 1.f) *  // d exp(x) = exp(x) dx
+            gsc[r] = (RAW ? sc[r] : 1.f) *  // d exp(x) = exp(x) dx
                 scale_modifier * (R[0][r] * dM[r][0] + R[1][r] * dM[r][1] + R[2][r] * dM[r][2]);
+            if (!ADAM) dL_dscales[3 * (size_t)i + r] = gsc[r];
 #pragma unroll
             for (int j = 0; j < 3; j++) dR[j][r] = s[r] * dM[r][j];
         }
+        if (ADAM) k11_adam_row<3>(ad, 1, const_cast<float *>(scales), i, scraw, gsc);
         const float r_ = q.x, x = q.y, y = q.z, z = q.w;
         float4 dq;
         dq.x = 2.f * (-z * dR[0][1] + y * dR[0][2] + z * dR[1][0] - x * dR[1][2] - y * dR[2][0] + x * dR[2][1]);
@@ -558,7 +660,12 @@ preprocess_backward_body(const int i, const float *__restrict__ rest_in, float *
             dq = make_float4((dq.x - q.x * dot) / qn, (dq.y - q.y * dot) / qn, (dq.z - q.z * dot) / qn,
                              (dq.w - q.w * dot) / qn);
         }
-        dL_drotations[i] = dq;
+        if (ADAM) {
+            const float pq[4] = {qraw.x, qraw.y, qraw.z, qraw.w}, gq[4] = {dq.x, dq.y, dq.z, dq.w};
+            k11_adam_row<4>(ad, 2, const_cast<float *>(rotations), i, pq, gq);
+        } else {
+            dL_drotations[i] = dq;
+        }
     }
 }
 
@@ -580,13 +687,14 @@ preprocess_backward_kernel(int P, int M, const float *__restrict__ means3D, cons
                            float4 *__restrict__ dL_drotations, float *__restrict__ dL_dshs,
                            float *__restrict__ dL_dshs_rest, float *__restrict__ dL_dopacities) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const K11Adam ad{};
     if constexpr (RAW) {
         __shared__ float s_rest[K11_BLOCK * REST_W];
         if (M == 16) {  // block-uniform
             rest_stage_in(s_rest, shs_rest, P);
             __syncthreads();
             if (i < P)
-                preprocess_backward_body<DEG, RAW>(i, s_rest + threadIdx.x * REST_W, s_rest + threadIdx.x * REST_W, P, M,
+                preprocess_backward_body<DEG, RAW>(ad, i, s_rest + threadIdx.x * REST_W, s_rest + threadIdx.x * REST_W, P, M,
                                                    means3D, scales, scale_modifier, rotations, shs, shs_rest,
                                                    opacities_raw, view, proj, campos, W, H, tanfovx, tanfovy, radii,
                                                    cov3D, clamped, dL_dmeans2D, dL_dconic_opacity, dL_drgb, gstride,
@@ -598,12 +706,38 @@ preprocess_backward_kernel(int P, int M, const float *__restrict__ means3D, cons
         }
     }
     if (i >= P) return;
-    preprocess_backward_body<DEG, RAW>(i, RAW ? shs_rest + (size_t)i * (M - 1) * 3 : nullptr,
+    preprocess_backward_body<DEG, RAW>(ad, i, RAW ? shs_rest + (size_t)i * (M - 1) * 3 : nullptr,
                                        RAW ? dL_dshs_rest + (size_t)i * (M - 1) * 3 : nullptr, P, M, means3D, scales,
                                        scale_modifier, rotations, shs, shs_rest, opacities_raw, view, proj, campos, W, H,
                                        tanfovx, tanfovy, radii, cov3D, clamped, dL_dmeans2D, dL_dconic_opacity, dL_drgb,
                                        gstride, dL_dmeans3D, dL_dscales, dL_drotations, dL_dshs, dL_dshs_rest,
                                        dL_dopacities);
+}
+
+// K11 + Adam, one camera, 16-coefficient model (the launcher checks): the same body with the stores replaced by the
+// optimizer update (K11Adam above).  Own kernel name so that traces and counters tell the fused launch apart.
+template <int DEG>
+__global__ void __launch_bounds__(K11_BLOCK)
+preprocess_backward_adam_kernel(int P, float *__restrict__ xyz, float *__restrict__ scaling, float scale_modifier,
+                                float *__restrict__ rotation, float *__restrict__ f_dc, float *__restrict__ f_rest,
+                                float *__restrict__ opacity, const float *__restrict__ view,
+                                const float *__restrict__ proj, const float *__restrict__ campos, int W, int H,
+                                float tanfovx, float tanfovy, const int32_t *__restrict__ radii,
+                                const float *__restrict__ cov3D, const uint8_t *__restrict__ clamped,
+                                const float *__restrict__ dL_dmeans2D, const float *__restrict__ dL_dconic_opacity,
+                                const float *__restrict__ dL_drgb, int gstride, const K11Adam ad) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float s_rest[K11_BLOCK * REST_W];
+    rest_stage_in(s_rest, f_rest, P);
+    __syncthreads();
+    if (i < P)
+        preprocess_backward_body<DEG, true, true>(ad, i, s_rest + threadIdx.x * REST_W, s_rest + threadIdx.x * REST_W,
+                                                  P, 16, xyz, scaling, scale_modifier, rotation, f_dc, f_rest, opacity,
+                                                  view, proj, campos, W, H, tanfovx, tanfovy, radii, cov3D, clamped,
+                                                  dL_dmeans2D, dL_dconic_opacity, dL_drgb, gstride, nullptr, nullptr,
+                                                  nullptr, nullptr, nullptr, nullptr);
+    __syncthreads();
+    rest_adam_out(s_rest, f_rest, ad, P);
 }
 
 // ------------------------------------------------------------------------- K1 / K11, batched over cameras
@@ -748,9 +882,9 @@ preprocess_forward_batched_kernel(int P, int B, int M, const float *__restrict__
     }
 }
 
-template <int DEG>
-__global__ void __launch_bounds__(K11_BLOCK)
-preprocess_backward_batched_kernel(int P, int B, int M, const float *__restrict__ xyz,
+template <int DEG, bool ADAM>
+__device__ __forceinline__ void
+preprocess_backward_batched_body(int P, int B, int M, const float *__restrict__ xyz,
                                    const float *__restrict__ scaling, float scale_modifier,
                                    const float *__restrict__ rotation, const float *__restrict__ f_dc,
                                    const float *__restrict__ f_rest, const float *__restrict__ opacity,
@@ -761,10 +895,10 @@ preprocess_backward_batched_kernel(int P, int B, int M, const float *__restrict_
                                    int gstride,
                                    float *__restrict__ dL_dxyz, float *__restrict__ dL_dscaling,
                                    float4 *__restrict__ dL_drotation, float *__restrict__ dL_ddc,
-                                   float *__restrict__ dL_drest, float *__restrict__ dL_dopacity) {
+                                   float *__restrict__ dL_drest, float *__restrict__ dL_dopacity, const K11Adam &ad) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     __shared__ float s_rest[K11_BLOCK * REST_W];
-    const bool staged = M == 16;  // _features_rest in, its gradient out: coalesced through LDS
+    const bool staged = M == 16;  // _features_rest in, its gradient out: coalesced through LDS (ADAM: always)
     if (staged) {
         rest_stage_in(s_rest, f_rest, P);
         __syncthreads();
@@ -926,12 +1060,18 @@ preprocess_backward_batched_kernel(int P, int B, int M, const float *__restrict_
         }
     }
     // ---- stores + the camera-independent tail (cov3D -> scale / quaternion, activations), once
-    dL_dxyz[3 * (size_t)i] = dmean[0];
-    dL_dxyz[3 * (size_t)i + 1] = dmean[1];
-    dL_dxyz[3 * (size_t)i + 2] = dmean[2];
-    dL_ddc[3 * (size_t)i] = dsh[0];
-    dL_ddc[3 * (size_t)i + 1] = dsh[1];
-    dL_ddc[3 * (size_t)i + 2] = dsh[2];
+    if constexpr (ADAM) {
+        k11_adam_row<3>(ad, 0, const_cast<float *>(xyz), i, p, dmean);
+        const float pdc[3] = {sh[0], sh[1], sh[2]}, gdc[3] = {dsh[0], dsh[1], dsh[2]};
+        k11_adam_row<3>(ad, 3, const_cast<float *>(f_dc), i, pdc, gdc);
+    } else {
+        dL_dxyz[3 * (size_t)i] = dmean[0];
+        dL_dxyz[3 * (size_t)i + 1] = dmean[1];
+        dL_dxyz[3 * (size_t)i + 2] = dmean[2];
+        dL_ddc[3 * (size_t)i] = dsh[0];
+        dL_ddc[3 * (size_t)i + 1] = dsh[1];
+        dL_ddc[3 * (size_t)i + 2] = dsh[2];
+    }
     {
         float *rp = staged ? s_rest + threadIdx.x * REST_W : dL_drest + (size_t)i * (M - 1) * 3;
 #pragma unroll
@@ -939,15 +1079,23 @@ preprocess_backward_batched_kernel(int P, int B, int M, const float *__restrict_
         for (int k = NC * 3; k < M * 3; k++) rp[k - 3] = 0.f;
     }
     {
-        const float so = 1.0f / (1.0f + expf(-opacity[i]));
-        dL_dopacity[i] = dop * so * (1.0f - so);
+        const float oraw = opacity[i];
+        const float so = 1.0f / (1.0f + expf(-oraw));
+        if constexpr (ADAM) {
+            const float po[1] = {oraw}, go[1] = {dop * so * (1.0f - so)};
+            k11_adam_row<1>(ad, 5, const_cast<float *>(opacity), i, po, go);
+        } else {
+            dL_dopacity[i] = dop * so * (1.0f - so);
+        }
     }
     {
         const float4 qraw = *reinterpret_cast<const float4 *>(rotation + 4 * (size_t)i);
         const float qnr = sqrtf(qraw.x * qraw.x + qraw.y * qraw.y + qraw.z * qraw.z + qraw.w * qraw.w);
         const float qn = fmaxf(qnr, 1e-12f);
         const float4 q = make_float4(qraw.x / qn, qraw.y / qn, qraw.z / qn, qraw.w / qn);
-        const float sc[3] = {expf(scaling[3 * (size_t)i]), expf(scaling[3 * (size_t)i + 1]), expf(scaling[3 * (size_t)i + 2])};
+        const float scraw[3] = {scaling[3 * (size_t)i], scaling[3 * (size_t)i + 1], scaling[3 * (size_t)i + 2]};
+        const float sc[3] = {expf(scraw[0]), expf(scraw[1]), expf(scraw[2])};
+        float gsc[3];
         float R[3][3];
         quat_to_R(q, R);
         const float s[3] = {scale_modifier * sc[0], scale_modifier * sc[1], scale_modifier * sc[2]};
@@ -968,11 +1116,12 @@ preprocess_backward_batched_kernel(int P, int B, int M, const float *__restrict_
         float dR[3][3];
 #pragma unroll
         for (int r = 0; r < 3; r++) {
-            dL_dscaling[3 * (size_t)i + r] =
-                sc[r] * scale_modifier * (R[0][r] * dM[r][0] + R[1][r] * dM[r][1] + R[2][r] * dM[r][2]);
+            gsc[r] = sc[r] * scale_modifier * (R[0][r] * dM[r][0] + R[1][r] * dM[r][1] + R[2][r] * dM[r][2]);
+            if constexpr (!ADAM) dL_dscaling[3 * (size_t)i + r] = gsc[r];
 #pragma unroll
             for (int j = 0; j < 3; j++) dR[j][r] = s[r] * dM[r][j];
         }
+        if constexpr (ADAM) k11_adam_row<3>(ad, 1, const_cast<float *>(scaling), i, scraw, gsc);
         const float r_ = q.x, x = q.y, y = q.z, z = q.w;
         float4 dq;
         dq.x = 2.f * (-z * dR[0][1] + y * dR[0][2] + z * dR[1][0] - x * dR[1][2] - y * dR[2][0] + x * dR[2][1]);
@@ -983,14 +1132,58 @@ preprocess_backward_batched_kernel(int P, int B, int M, const float *__restrict_
         dq.w = 2.f * (-2.f * z * dR[0][0] - r_ * dR[0][1] + x * dR[0][2] + r_ * dR[1][0] - 2.f * z * dR[1][1] +
                       y * dR[1][2] + x * dR[2][0] + y * dR[2][1]);
         const float dot = qnr > 1e-12f ? (q.x * dq.x + q.y * dq.y + q.z * dq.z + q.w * dq.w) : 0.f;
-        dL_drotation[i] = make_float4((dq.x - q.x * dot) / qn, (dq.y - q.y * dot) / qn, (dq.z - q.z * dot) / qn,
+        const float4 gq = make_float4((dq.x - q.x * dot) / qn, (dq.y - q.y * dot) / qn, (dq.z - q.z * dot) / qn,
                                       (dq.w - q.w * dot) / qn);
+        if constexpr (ADAM) {
+            const float pq[4] = {qraw.x, qraw.y, qraw.z, qraw.w}, gqa[4] = {gq.x, gq.y, gq.z, gq.w};
+            k11_adam_row<4>(ad, 2, const_cast<float *>(rotation), i, pq, gqa);
+        } else {
+            dL_drotation[i] = gq;
+        }
     }
     }  // i < P
     if (staged) {
         __syncthreads();
-        rest_stage_out(s_rest, dL_drest, P);
+        if constexpr (ADAM)
+            rest_adam_out(s_rest, const_cast<float *>(f_rest), ad, P);
+        else
+            rest_stage_out(s_rest, dL_drest, P);
     }
+}
+
+template <int DEG>
+__global__ void __launch_bounds__(K11_BLOCK, 2)  // <= 256 registers: two workgroups per CU, not one
+preprocess_backward_batched_kernel(int P, int B, int M, const float *__restrict__ xyz,
+                                   const float *__restrict__ scaling, float scale_modifier,
+                                   const float *__restrict__ rotation, const float *__restrict__ f_dc,
+                                   const float *__restrict__ f_rest, const float *__restrict__ opacity,
+                                   const float *__restrict__ cams, int W, int H, const int32_t *__restrict__ radii,
+                                   const float *__restrict__ cov3D, const uint8_t *__restrict__ clamped,
+                                   const float *__restrict__ dL_dmeans2D,
+                                   const float *__restrict__ dL_dconic_opacity, const float *__restrict__ dL_drgb,
+                                   int gstride, float *__restrict__ dL_dxyz, float *__restrict__ dL_dscaling,
+                                   float4 *__restrict__ dL_drotation, float *__restrict__ dL_ddc,
+                                   float *__restrict__ dL_drest, float *__restrict__ dL_dopacity) {
+    preprocess_backward_batched_body<DEG, false>(P, B, M, xyz, scaling, scale_modifier, rotation, f_dc, f_rest, opacity,
+                                                 cams, W, H, radii, cov3D, clamped, dL_dmeans2D, dL_dconic_opacity,
+                                                 dL_drgb, gstride, dL_dxyz, dL_dscaling, dL_drotation, dL_ddc, dL_drest,
+                                                 dL_dopacity, K11Adam{});
+}
+
+template <int DEG>
+__global__ void __launch_bounds__(K11_BLOCK, 2)  // <= 256 registers: two workgroups per CU, not one
+preprocess_backward_adam_batched_kernel(int P, int B, float *__restrict__ xyz, float *__restrict__ scaling,
+                                        float scale_modifier, float *__restrict__ rotation,
+                                        float *__restrict__ f_dc, float *__restrict__ f_rest,
+                                        float *__restrict__ opacity, const float *__restrict__ cams, int W, int H,
+                                        const int32_t *__restrict__ radii, const float *__restrict__ cov3D,
+                                        const uint8_t *__restrict__ clamped, const float *__restrict__ dL_dmeans2D,
+                                        const float *__restrict__ dL_dconic_opacity,
+                                        const float *__restrict__ dL_drgb, int gstride, const K11Adam ad) {
+    preprocess_backward_batched_body<DEG, true>(P, B, 16, xyz, scaling, scale_modifier, rotation, f_dc, f_rest, opacity,
+                                                cams, W, H, radii, cov3D, clamped, dL_dmeans2D, dL_dconic_opacity,
+                                                dL_drgb, gstride, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                                ad);
 }
 
 // -------------------------------------------------------------------------------------------- K2
@@ -1138,6 +1331,63 @@ extern "C" int gsr_preprocess_backward_raw_batched(int P, int B, int sh_degree, 
                                         grad_row_stride, dL_dxyz,
                                         dL_dscaling, reinterpret_cast<float4 *>(dL_drotation), dL_dfeatures_dc,
                                         dL_dfeatures_rest, dL_dopacity));
+    GSR_LAUNCH_CHECK();
+    return 0;
+}
+
+// K11 for a batch of cameras fused with the optimizer step of the six tensors it differentiates (see K11Adam):
+// xyz .. opacity are read AND updated in place, exp_avgs / exp_avg_sqs are the moments in the tensor order
+// xyz, scaling, rotation, features_dc, features_rest, opacity; lrs .. steps as in gsr_adam_step_multi.  tanfov0: HOST
+// pointer to { tanfovx, tanfovy } of the camera when B == 1 (selects the one-camera kernel, as
+// gsr_preprocess_backward_raw does), or NULL.
+extern "C" int gsr_preprocess_backward_adam_raw_batched(
+    int P, int B, int sh_degree, int sh_coeffs, float *xyz, float *scaling, float scale_modifier, float *rotation,
+    float *features_dc, float *features_rest, float *opacity, const float *cams, int width, int height,
+    const int32_t *radii, const float *cov3D, const uint8_t *clamped, const float *dL_dmeans2D,
+    const float *dL_dconic_opacity, const float *dL_drgb, int grad_row_stride, float *const *exp_avgs,
+    float *const *exp_avg_sqs, const double *lrs, const double *beta1s, const double *beta2s, const double *epss,
+    const int64_t *steps, float grad_scale, const float *tanfov0, gsr_stream_t stream) {
+    if (P < 0 || B < 1 || sh_degree < 0 || sh_degree > 3 || sh_coeffs != 16 || width <= 0 || height <= 0)
+        return GSR_EINVAL;  // the fused step needs the LDS stage of a 16-coefficient model
+    if (P == 0) return 0;
+    if (!xyz || !scaling || !rotation || !features_dc || !features_rest || !opacity || !cams || !radii || !cov3D ||
+        !clamped || !dL_dmeans2D || !dL_dconic_opacity || !dL_drgb || !exp_avgs || !exp_avg_sqs || !lrs || !beta1s ||
+        !beta2s || !epss || !steps)
+        return GSR_EINVAL;
+    K11Adam ad{};
+    for (int t = 0; t < 6; t++) {
+        if (!exp_avgs[t] || !exp_avg_sqs[t] || steps[t] < 1) return GSR_EINVAL;
+        const double bc1 = 1.0 - pow(beta1s[t], (double)steps[t]);
+        const double bc2 = 1.0 - pow(beta2s[t], (double)steps[t]);
+        ad.m[t] = exp_avgs[t];
+        ad.v[t] = exp_avg_sqs[t];
+        ad.lr_c[t] = (float)(lrs[t] / bc1);
+        ad.b1[t] = (float)beta1s[t];
+        ad.b2[t] = (float)beta2s[t];
+        ad.omb1[t] = (float)(1.0 - beta1s[t]);
+        ad.omb2[t] = (float)(1.0 - beta2s[t]);
+        ad.inv_sqrt_bc2[t] = (float)(1.0 / sqrt(bc2));
+        ad.eps[t] = (float)epss[t];
+    }
+    if (((uintptr_t)features_rest | (uintptr_t)ad.m[4] | (uintptr_t)ad.v[4] | (uintptr_t)rotation) & 15)
+        return GSR_EINVAL;
+    ad.grad_scale = grad_scale;
+    const dim3 grid(gsr_div_up(P, K11_BLOCK)), block(K11_BLOCK);
+    if (B == 1 && tanfov0) {  // one camera: the leaner kernel without accumulators (160 registers instead of 270)
+        GSR_DISPATCH_DEG(sh_degree,
+                         hipLaunchKernelGGL(preprocess_backward_adam_kernel<DEG>, grid, block, 0,
+                                            reinterpret_cast<hipStream_t>(stream), P, xyz, scaling, scale_modifier,
+                                            rotation, features_dc, features_rest, opacity, cams, cams + 16, cams + 32,
+                                            width, height, tanfov0[0], tanfov0[1], radii, cov3D, clamped, dL_dmeans2D,
+                                            dL_dconic_opacity, dL_drgb, grad_row_stride, ad));
+        GSR_LAUNCH_CHECK();
+        return 0;
+    }
+    GSR_DISPATCH_DEG(sh_degree,
+                     hipLaunchKernelGGL(preprocess_backward_adam_batched_kernel<DEG>, grid, block, 0,
+                                        reinterpret_cast<hipStream_t>(stream), P, B, xyz, scaling, scale_modifier,
+                                        rotation, features_dc, features_rest, opacity, cams, width, height, radii,
+                                        cov3D, clamped, dL_dmeans2D, dL_dconic_opacity, dL_drgb, grad_row_stride, ad));
     GSR_LAUNCH_CHECK();
     return 0;
 }

@@ -399,6 +399,94 @@ def _batched_record(grads, B, P):
     return base.view(B * P, 9)
 
 
+# ---- deferred K11: the projection backward handed to an optimizer that fuses it with its step -------------------
+# A sink (fused_optim.FusedAdam(fuse_backward=True)) registers itself here.  When the six raw parameters of a
+# _PreprocessGaussiansRawBatched node are exactly the tensors the sink optimizes, the node's backward does not launch
+# K11: it returns no gradients (`.grad` stays None) and hands the sink everything K11 needs; the sink's step() then
+# runs K11 and Adam as ONE kernel (gsr_preprocess_backward_adam_raw_batched) -- or, whenever that is not possible,
+# materializes the gradients with the plain K11 and steps as usual.  Opt-in: nothing is deferred without a sink.
+_DEFERRED_SINK = [None]
+
+
+def set_deferred_backward_sink(sink):
+    """sink: object with accepts(params) -> bool and offer(PendingProjectionBackward), or None to switch deferral off"""
+    _DEFERRED_SINK[0] = sink
+
+
+class PendingProjectionBackward:
+    """K11's inputs of one backward pass, alive until the optimizer's step"""
+
+    def __init__(self, params, cams, radii, cov3D, clamped, g_means2D, g_conic_opacity, g_rgb, gstride, meta, tanfov0):
+        self.params = params  # xyz, scaling, rotation, features_dc, features_rest, opacity (the saved inputs)
+        self.versions = tuple(t._version for t in params)
+        self.cams, self.radii, self.cov3D, self.clamped = cams, radii, cov3D, clamped
+        self.g_means2D, self.g_conic_opacity, self.g_rgb, self.gstride = g_means2D, g_conic_opacity, g_rgb, gstride
+        self.meta, self.tanfov0 = meta, tanfov0
+        self.stream = torch.cuda.current_stream(params[0].device) if params[0].is_cuda else None
+
+    def join_stream(self):
+        """make the current stream wait for the stream the backward ran on (no-op when they are the same)"""
+        if self.stream is not None:
+            cur = torch.cuda.current_stream(self.params[0].device)
+            if cur != self.stream:
+                cur.wait_stream(self.stream)
+
+    def materialize(self):
+        """-> the six gradients, computed by the plain K11 (what the node's backward would have returned)"""
+        self.join_stream()
+        return _launch_k11(self.params, self.cams, self.radii, self.cov3D, self.clamped, self.g_means2D,
+                           self.g_conic_opacity, self.g_rgb, self.gstride, self.meta, self.tanfov0, None)
+
+    def fused_step(self, exp_avgs, exp_avg_sqs, lrs, beta1s, beta2s, epss, steps, grad_scale):
+        """K11 + Adam of the six tensors in one launch; arguments in the order of self.params"""
+        self.join_stream()
+        xyz, scaling, rotation, f_dc, f_rest, opacity = self.params
+        deg, smod, W, H, M = self.meta
+        P, B = xyz.shape[0], self.cams.shape[0]
+        VP, D, I64 = ctypes.c_void_p * 6, ctypes.c_double * 6, ctypes.c_int64 * 6
+        tf = (ctypes.c_float * 2)(float(self.tanfov0[0]), float(self.tanfov0[1])) \
+            if (B == 1 and self.tanfov0 is not None) else None
+        with _on(xyz.device), kernel_timer.range("preprocess_backward_adam", N=P, B=B, M=M):
+            check(lib.gsr_preprocess_backward_adam_raw_batched(
+                P, B, deg, M, _ptr(xyz), _ptr(scaling), smod, _ptr(rotation), _ptr(f_dc), _ptr(f_rest), _ptr(opacity),
+                _ptr(self.cams), W, H, _ptr(self.radii), _ptr(self.cov3D), _ptr(self.clamped), _ptr(self.g_means2D),
+                _ptr(self.g_conic_opacity), _ptr(self.g_rgb), self.gstride, VP(*[t.data_ptr() for t in exp_avgs]),
+                VP(*[t.data_ptr() for t in exp_avg_sqs]), D(*lrs), D(*beta1s), D(*beta2s), D(*epss), I64(*steps),
+                float(grad_scale), tf, _stream()), "gsr_preprocess_backward_adam_raw_batched")
+
+
+def _launch_k11(params, cams, radii, cov3D, clamped, g_means2D, g_conic_opacity, g_rgb, gstride, meta, tanfov0,
+                cuda_args_list):
+    xyz, scaling, rotation, f_dc, f_rest, opacity = params
+    deg, smod, W, H, M = meta
+    P, B = xyz.shape[0], cams.shape[0]
+    dev = xyz.device
+    d_xyz = torch.empty((P, 3), dtype=torch.float32, device=dev)
+    d_scaling = torch.empty((P, 3), dtype=torch.float32, device=dev)
+    d_rot = torch.empty((P, 4), dtype=torch.float32, device=dev)
+    d_dc = torch.empty((P, 1, 3), dtype=torch.float32, device=dev)
+    d_rest = torch.empty((P, M - 1, 3), dtype=torch.float32, device=dev)
+    d_opac = torch.empty((P, 1), dtype=torch.float32, device=dev)
+    with _on(dev), kernel_timer.range("preprocess_backward", N=P, B=B, M=M), \
+            zhx_range(cuda_args_list, "b20 preprocess time"):
+        if B == 1 and tanfov0 is not None:
+            # single camera: the leaner one-camera kernel (no accumulators); camera fields are slices of `cams`
+            base = cams.data_ptr()
+            check(lib.gsr_preprocess_backward_raw(
+                P, deg, M, _ptr(xyz), _ptr(scaling), smod, _ptr(rotation), _ptr(f_dc), _ptr(f_rest),
+                _ptr(opacity), ctypes.c_void_p(base), ctypes.c_void_p(base + 64), ctypes.c_void_p(base + 128), W,
+                H, float(tanfov0[0]), float(tanfov0[1]), _ptr(radii), _ptr(cov3D), _ptr(clamped),
+                _ptr(g_means2D), _ptr(g_conic_opacity), _ptr(g_rgb), gstride, _ptr(d_xyz), _ptr(d_scaling),
+                _ptr(d_rot), _ptr(d_dc), _ptr(d_rest), _ptr(d_opac), _stream()), "gsr_preprocess_backward_raw")
+        else:
+            check(lib.gsr_preprocess_backward_raw_batched(
+                P, B, deg, M, _ptr(xyz), _ptr(scaling), smod, _ptr(rotation), _ptr(f_dc), _ptr(f_rest),
+                _ptr(opacity), _ptr(cams), W, H, _ptr(radii), _ptr(cov3D), _ptr(clamped), _ptr(g_means2D),
+                _ptr(g_conic_opacity), _ptr(g_rgb), gstride, _ptr(d_xyz), _ptr(d_scaling), _ptr(d_rot),
+                _ptr(d_dc), _ptr(d_rest), _ptr(d_opac), _stream()), "gsr_preprocess_backward_raw_batched")
+    return d_xyz, d_scaling, d_rot, d_dc, d_rest, d_opac
+
+
 class _PreprocessGaussiansRawBatched(torch.autograd.Function):
     """K1 / K11 for a batch of B cameras in one launch each way (gsr_preprocess_*_raw_batched)."""
 
@@ -473,30 +561,15 @@ class _PreprocessGaussiansRawBatched(torch.autograd.Function):
                 g_means2D, g_rgb, g_conic_opacity, gstride = rec[:, 0:2], rec[:, 2:5], rec[:, 5:9], 9
             else:
                 g_means2D, g_rgb, g_conic_opacity, gstride = assemble(0, 2), assemble(1, 3), assemble(2, 4), 0
-        d_xyz = torch.empty((P, 3), dtype=torch.float32, device=dev)
-        d_scaling = torch.empty((P, 3), dtype=torch.float32, device=dev)
-        d_rot = torch.empty((P, 4), dtype=torch.float32, device=dev)
-        d_dc = torch.empty((P, 1, 3), dtype=torch.float32, device=dev)
-        d_rest = torch.empty((P, M - 1, 3), dtype=torch.float32, device=dev)
-        d_opac = torch.empty((P, 1), dtype=torch.float32, device=dev)
-        with _on(dev), kernel_timer.range("preprocess_backward", N=P, B=B, M=M), \
-                zhx_range(ctx.cuda_args_list, "b20 preprocess time"):
-            if B == 1 and ctx.tanfov0 is not None:
-                # single camera: the leaner one-camera kernel (no accumulators); camera fields are slices of `cams`
-                base = cams.data_ptr()
-                check(lib.gsr_preprocess_backward_raw(
-                    P, deg, M, _ptr(xyz), _ptr(scaling), smod, _ptr(rotation), _ptr(f_dc), _ptr(f_rest),
-                    _ptr(opacity), ctypes.c_void_p(base), ctypes.c_void_p(base + 64), ctypes.c_void_p(base + 128), W,
-                    H, float(ctx.tanfov0[0]), float(ctx.tanfov0[1]), _ptr(radii), _ptr(cov3D), _ptr(clamped),
-                    _ptr(g_means2D), _ptr(g_conic_opacity), _ptr(g_rgb), gstride, _ptr(d_xyz), _ptr(d_scaling),
-                    _ptr(d_rot), _ptr(d_dc), _ptr(d_rest), _ptr(d_opac), _stream()), "gsr_preprocess_backward_raw")
-            else:
-                check(lib.gsr_preprocess_backward_raw_batched(
-                    P, B, deg, M, _ptr(xyz), _ptr(scaling), smod, _ptr(rotation), _ptr(f_dc), _ptr(f_rest),
-                    _ptr(opacity), _ptr(cams), W, H, _ptr(radii), _ptr(cov3D), _ptr(clamped), _ptr(g_means2D),
-                    _ptr(g_conic_opacity), _ptr(g_rgb), gstride, _ptr(d_xyz), _ptr(d_scaling), _ptr(d_rot),
-                    _ptr(d_dc), _ptr(d_rest), _ptr(d_opac), _stream()), "gsr_preprocess_backward_raw_batched")
-        return d_xyz, d_scaling, d_rot, d_dc, d_rest, d_opac, None, None, None, None, None, None, None
+        params = (xyz, scaling, rotation, f_dc, f_rest, opacity)
+        sink = _DEFERRED_SINK[0]
+        if sink is not None and M == 16 and sink.accepts(params):
+            # K11 runs inside the optimizer's step (fused with Adam); `.grad` of the six parameters stays None
+            sink.offer(PendingProjectionBackward(params, cams, radii, cov3D, clamped, g_means2D, g_conic_opacity,
+                                                 g_rgb, gstride, ctx.meta, ctx.tanfov0))
+            return (None,) * 13
+        return _launch_k11(params, cams, radii, cov3D, clamped, g_means2D, g_conic_opacity, g_rgb, gstride, ctx.meta,
+                           ctx.tanfov0, ctx.cuda_args_list) + (None,) * 7
 
 
 def preprocess_gaussians_raw_batched(xyz, scaling, rotation, features_dc, features_rest, opacity, cams, sh_degree,

@@ -75,12 +75,15 @@ SIGNATURES = {
     "gsr_preprocess_backward_raw_batched": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float] +
                                             [c_void_p] * 5 + [c_int, c_int] + [c_void_p] * 6 + [c_int] +
                                             [c_void_p] * 7),
+    "gsr_preprocess_backward_adam_raw_batched": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float] +
+                                                 [c_void_p] * 5 + [c_int, c_int] + [c_void_p] * 6 + [c_int] +
+                                                 [c_void_p] * 7 + [c_float, c_void_p, c_void_p]),
     "gsr_activate_forward": (c_int, [c_int, c_int] + [c_void_p] * 10),
     "gsr_activate_backward": (c_int, [c_int, c_int] + [c_void_p] * 13),
     "gsr_render_backward": (c_int, [c_int, c_int, c_int] + [c_void_p] * 12),
 }
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 def _load():

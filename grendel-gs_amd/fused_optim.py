@@ -5,33 +5,154 @@ batch-size gradient scaling of train_internal.py:319-324 folded in.
 
 State layout (`state[p]["step" | "exp_avg" | "exp_avg_sq"]`) is the stock optimizer's, so
 `GaussianModel.capture()/restore()` checkpoints (scene/gaussian_model.py:70-107) stay interchangeable.
-There is no CPU fallback: parameters must live on the gfx950 device."""
+There is no CPU fallback: parameters must live on the gfx950 device.
+
+`fuse_backward=True` (opt-in) additionally fuses the projection backward K11 into the step: `loss.backward()`
+(train_internal.py:195) then stops in front of K11 -- the six raw parameters get NO `.grad` -- and `step()` runs K11 and
+the Adam update of those six tensors as one kernel, so their gradients (236 B per Gaussian, written by K11 and read back
+by the optimizer otherwise) never touch HBM.  The arithmetic is the unfused pair's, bit for bit.  Whatever happens
+between backward and step in the reference's loop keeps its meaning: densification replaces parameters (their pending
+gradient is dropped, exactly like the `.grad is None` skip of the stock optimizer, or -- for a partial replacement such
+as reset_opacity -- materialized for the tensors that are still current), `zero_grad()` without a step drops it, a second
+backward before the step materializes both.  What changes: code that READS `.grad` of the raw parameters between
+backward and step sees None -- the reference's own `param.grad /= bsz` loop (train_internal.py:319-324) would be such a
+reader and silently do nothing, so the scale has to be passed as `grad_scale` (constructor or step()), as bench.py
+does.  `means2D.grad` (densification statistics) is unaffected: it comes from K10, not K11."""
 import ctypes
 
 import torch
 
+import diff_gaussian_rasterization as _dgr
 from diff_gaussian_rasterization import _lib, _on, _stream, kernel_timer
 
 
 class FusedAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, fuse_backward=False, grad_scale=1.0):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self.grad_scale = float(grad_scale)
+        self._pending = None
+        self.fused_steps = 0         # steps in which K11 ran inside the optimizer kernel
+        self.materialized_steps = 0  # deferred backwards that had to fall back to the plain K11
+        self.fuse_backward = False
+        if fuse_backward:
+            self.set_fuse_backward(True)
+
+    # ------------------------------------------------------------------ deferred K11 (see the module docstring)
+    def set_fuse_backward(self, on):
+        """register / unregister this optimizer as the sink of the operator's deferred projection backward (one
+        optimizer per process can be the sink)"""
+        self.fuse_backward = bool(on)
+        if on:
+            _dgr.set_deferred_backward_sink(self)
+        elif _dgr._DEFERRED_SINK[0] is self:
+            self._flush_pending()
+            _dgr.set_deferred_backward_sink(None)
+
+    def _owner(self, t):
+        """(group, parameter) of this optimizer whose storage is tensor t, or None"""
+        ptr, shape = t.data_ptr(), t.shape
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.data_ptr() == ptr and p.shape == shape and p.dtype == t.dtype:
+                    return group, p
+        return None
+
+    def accepts(self, params):
+        """called by the operator's backward: True when all six raw parameters are optimized here and carry no other
+        gradient -- then offer() follows and the node returns no gradients"""
+        if not self.fuse_backward:
+            return False
+        for t in params:
+            o = self._owner(t)
+            if o is None or o[1].grad is not None or not o[1].requires_grad:
+                return False
+        return True
+
+    def offer(self, pending):
+        if self._pending is not None:  # a second backward before the step: both become ordinary gradients
+            self._flush_pending()
+            self._pending = pending
+            self._flush_pending()
+            return
+        self._pending = pending
+
+    def _flush_pending(self):
+        """materialize the pending projection backward into `.grad` of the parameters that are still the tensors it
+        was computed for (a replaced parameter has no gradient, as in the stock flow)"""
+        pend, self._pending = self._pending, None
+        if pend is None:
+            return
+        grads = None
+        for idx, t in enumerate(pend.params):
+            o = self._owner(t)
+            if o is None:
+                continue
+            if t._version != pend.versions[idx]:
+                raise RuntimeError("FusedAdam(fuse_backward=True): a parameter was modified in place between "
+                                   "backward() and step(); its deferred gradient would be computed from the new value")
+            if grads is None:
+                grads = pend.materialize()
+                self.materialized_steps += 1
+            p, g = o[1], grads[idx].view(o[1].shape)
+            p.grad = g if p.grad is None else p.grad.add_(g)
+
+    def zero_grad(self, set_to_none=True):
+        self._pending = None  # a pending projection backward is a gradient too
+        return super().zero_grad(set_to_none=set_to_none)
+
+    def _fused_backward_step(self, grad_scale):
+        """-> set of parameters updated by the fused K11 + Adam launch (empty when the pending backward had to be
+        materialized instead)"""
+        pend = self._pending
+        owners = [self._owner(t) for t in pend.params]
+        fusable = all(o is not None and o[1].grad is None and o[1].is_contiguous() for o in owners) and \
+            len({id(o[1]) for o in owners if o is not None}) == 6
+        if fusable:
+            for idx, t in enumerate(pend.params):
+                if t._version != pend.versions[idx]:
+                    raise RuntimeError("FusedAdam(fuse_backward=True): a parameter was modified in place between "
+                                       "backward() and step(); its deferred gradient would be computed from the new "
+                                       "value")
+        if not fusable:
+            self._flush_pending()
+            return set()
+        self._pending = None
+        sts = []
+        for group, p in owners:
+            st = self.state[p]
+            if len(st) == 0:
+                st["step"] = torch.tensor(0.0)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            sts.append(st)
+        torch._foreach_add_([st["step"] for st in sts], 1)
+        pend.fused_step([st["exp_avg"] for st in sts], [st["exp_avg_sq"] for st in sts],
+                        [g["lr"] for g, _ in owners], [g["betas"][0] for g, _ in owners],
+                        [g["betas"][1] for g, _ in owners], [g["eps"] for g, _ in owners],
+                        [int(st["step"]) for st in sts], grad_scale)
+        self.fused_steps += 1
+        return {id(p) for _, p in owners}
 
     @torch.no_grad()
-    def step(self, closure=None, grad_scale=1.0):
-        """`grad_scale` multiplies every gradient before the update (1 / bsz in the reference's loop).  All parameter
-        tensors that have a gradient are updated by ONE kernel launch (gsr_adam_step_multi)."""
+    def step(self, closure=None, grad_scale=None):
+        """`grad_scale` multiplies every gradient before the update (1 / bsz in the reference's loop; default: the
+        constructor's).  All parameter tensors that have a gradient are updated by ONE kernel launch
+        (gsr_adam_step_multi); with fuse_backward the six raw parameters of a pending projection backward are updated
+        by the fused K11 + Adam launch instead."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        if grad_scale is None:
+            grad_scale = self.grad_scale
+        done = self._fused_backward_step(grad_scale) if self._pending is not None else ()
         batch, steps = [], []
         for group in self.param_groups:
             b1, b2 = group["betas"]
             lr, eps = group["lr"], group["eps"]
             for p in group["params"]:
                 g = p.grad
-                if g is None:
+                if g is None or id(p) in done:
                     continue
                 if not p.is_cuda:
                     raise RuntimeError("FusedAdam: parameters must live on the gfx950 device (no CPU fallback)")

@@ -355,6 +355,26 @@ int gsr_preprocess_backward_raw_batched(int P, int B, int sh_degree, int sh_coef
                                         float *dL_dscaling, float *dL_drotation, float *dL_dfeatures_dc,
                                         float *dL_dfeatures_rest, float *dL_dopacity, gsr_stream_t stream);
 
+/* K11 of a batch FUSED with the optimizer step of the six tensors it differentiates (N3 inside a9's neighbour: the
+ * reference runs `loss.backward()` and then `gaussians.optimizer.step()` over the same 59 floats per Gaussian,
+ * train_internal.py:195 and :316-328, scene/gaussian_model.py:292).  A Gaussian's gradient is complete when its lane
+ * leaves the camera loop, so the dense Adam update (gsr_adam_step_multi's arithmetic, bit for bit) is applied there and
+ * the gradients never reach HBM: xyz .. opacity are read AND updated in place; exp_avgs / exp_avg_sqs are host arrays of
+ * the six device pointers of the moments in the order xyz, scaling, rotation, features_dc, features_rest, opacity; lrs ..
+ * steps host arrays of the six groups' hyper-parameters (steps = the 1-based count AFTER this update); grad_scale as
+ * in gsr_adam_step.  Needs sh_coeffs == 16 (GSR_EINVAL otherwise: run the two unfused calls).  tanfov0: HOST pointer
+ * to { tanfovx, tanfovy } when B == 1 (selects the one-camera kernel like gsr_preprocess_backward_raw), or NULL. */
+int gsr_preprocess_backward_adam_raw_batched(int P, int B, int sh_degree, int sh_coeffs, float *xyz, float *scaling,
+                                             float scale_modifier, float *rotation, float *features_dc,
+                                             float *features_rest, float *opacity, const float *cams, int width,
+                                             int height, const int32_t *radii, const float *cov3D,
+                                             const uint8_t *clamped, const float *dL_dmeans2D,
+                                             const float *dL_dconic_opacity, const float *dL_drgb,
+                                             int grad_row_stride, float *const *exp_avgs, float *const *exp_avg_sqs,
+                                             const double *lrs, const double *beta1s, const double *beta2s,
+                                             const double *epss, const int64_t *steps, float grad_scale,
+                                             const float *tanfov0, gsr_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * a19  fused parameter activations -- GaussianModel.get_scaling / get_rotation / get_opacity /
  * get_features (scene/gaussian_model.py:109-129): scales = exp(_scaling) [N,3], rotations =

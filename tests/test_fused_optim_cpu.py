@@ -1,0 +1,122 @@
+"""CPU: the bookkeeping of FusedAdam(fuse_backward=True) -- which backward passes are deferred, what step(),
+zero_grad(), a second backward and a replaced parameter do with a pending projection backward -- with a stand-in for
+the operator's PendingProjectionBackward (the kernels themselves: tests/test_gpu_loss_and_step.py)."""
+import pytest
+import torch
+
+import synthetic_scene as S
+
+NAMES = ("_xyz", "_scaling", "_rotation", "_features_dc", "_features_rest", "_opacity")
+
+
+@pytest.fixture(autouse=True)
+def _no_sink_left_behind():
+    import diff_gaussian_rasterization as dgr
+
+    yield
+    dgr.set_deferred_backward_sink(None)
+
+
+class FakePending:
+    def __init__(self, params):
+        self.params = params
+        self.versions = tuple(t._version for t in params)
+        self.fused_calls = []
+        self.materialized = 0
+
+    def materialize(self):
+        self.materialized += 1
+        return tuple(torch.full_like(t, float(i + 1)) for i, t in enumerate(self.params))
+
+    def fused_step(self, exp_avgs, exp_avg_sqs, lrs, b1, b2, eps, steps, grad_scale):
+        self.fused_calls.append((list(lrs), list(steps), grad_scale, [tuple(t.shape) for t in exp_avgs]))
+
+
+def make():
+    from fused_optim import FusedAdam
+
+    m = S.SyntheticGaussianModel(64, 64, 48, seed=1)
+    opt = FusedAdam(m.param_groups(), lr=0.0, eps=1e-15, fuse_backward=True, grad_scale=0.25)
+    return m, opt, tuple(getattr(m, n) for n in NAMES)
+
+
+def test_sink_registration_and_acceptance():
+    import diff_gaussian_rasterization as dgr
+    from fused_optim import FusedAdam
+
+    m, opt, params = make()
+    try:
+        assert dgr._DEFERRED_SINK[0] is opt and opt.accepts(params)
+        other = S.SyntheticGaussianModel(64, 64, 48, seed=2)
+        assert not opt.accepts(tuple(getattr(other, n) for n in NAMES))  # somebody else's parameters
+        m._xyz.grad = torch.zeros_like(m._xyz)
+        assert not opt.accepts(params)  # another gradient path already wrote .grad: do not defer
+        m._xyz.grad = None
+        plain = FusedAdam(other.param_groups(), lr=0.0, eps=1e-15)
+        assert dgr._DEFERRED_SINK[0] is opt and not plain.accepts(tuple(getattr(other, n) for n in NAMES))
+        opt.set_fuse_backward(False)
+        assert dgr._DEFERRED_SINK[0] is None and not opt.accepts(params)
+    finally:
+        opt.set_fuse_backward(False)
+
+
+def test_step_hands_the_six_groups_to_the_fused_launch():
+    m, opt, params = make()
+    try:
+        pend = FakePending(params)
+        opt.offer(pend)
+        opt.step()
+        assert opt._pending is None and opt.fused_steps == 1 and pend.materialized == 0
+        (lrs, steps, gs, shapes), = pend.fused_calls
+        # tensor order of the kernel (xyz, scaling, rotation, f_dc, f_rest, opacity) with each group's own lr
+        assert lrs == [0.00016, 0.005, 0.001, 0.0025, 0.0025 / 20.0, 0.05]
+        assert steps == [1] * 6 and gs == 0.25
+        assert shapes == [tuple(p.shape) for p in params]
+        assert all(float(opt.state[p]["step"]) == 1.0 for p in params)
+        opt.offer(FakePending(params))
+        opt.step(grad_scale=0.5)
+        assert all(float(opt.state[p]["step"]) == 2.0 for p in params)
+    finally:
+        opt.set_fuse_backward(False)
+
+
+def test_zero_grad_drops_and_second_backward_materializes():
+    m, opt, params = make()
+    try:
+        pend = FakePending(params)
+        opt.offer(pend)
+        opt.zero_grad(set_to_none=True)
+        assert opt._pending is None and pend.materialized == 0
+        a, b = FakePending(params), FakePending(params)
+        opt.offer(a)
+        opt.offer(b)  # gradient accumulation: both become ordinary, summed `.grad`s
+        assert opt._pending is None and a.materialized == 1 and b.materialized == 1
+        for i, p in enumerate(params):
+            assert torch.equal(p.grad, torch.full_like(p, 2.0 * (i + 1)))
+        assert not opt.accepts(params)  # .grad is set now: the next backward accumulates the stock way
+    finally:
+        opt.set_fuse_backward(False)
+
+
+def test_replaced_parameter_is_skipped_and_inplace_edit_is_refused():
+    m, opt, params = make()
+    try:
+        pend = FakePending(params)
+        opt.offer(pend)
+        new = torch.nn.Parameter(m._opacity.detach().clone())  # reset_opacity / densification: a new tensor in the group
+        for g in opt.param_groups:
+            if g["name"] == "opacity":
+                g["params"][0] = new
+        with pytest.raises(RuntimeError, match="gfx950"):  # five ordinary gradients on host tensors: no CPU optimizer
+            opt.step()
+        assert pend.materialized == 1 and not pend.fused_calls and new.grad is None
+        assert all(getattr(m, n).grad is not None for n in NAMES if n != "_opacity")
+
+        m2, opt2, params2 = make()
+        opt2.offer(FakePending(params2))
+        with torch.no_grad():
+            m2._xyz.add_(1.0)
+        with pytest.raises(RuntimeError, match="modified in place"):
+            opt2.step()
+    finally:
+        opt.set_fuse_backward(False)

@@ -450,6 +450,170 @@ def test_batched_camera_preprocess_equals_per_camera(device, deg):
         assert rel_err(pb.grad, pa.grad) < 1e-5
 
 
+@pytest.mark.parametrize("B,deg,N", [(1, 3, 30011), (1, 1, 4099), (3, 3, 30011), (2, 0, 777)])
+def test_fused_backward_step_equals_k11_then_adam(device, B, deg, N):
+    """FusedAdam(fuse_backward=True): K11 + Adam as ONE kernel == K11, then gsr_adam_step_multi, BIT FOR BIT --
+    parameters and both moments after every one of four steps, for the one-camera and the camera-batched kernel,
+    active SH degree below the stored one, a Gaussian count that is no multiple of the workgroup, invisible Gaussians
+    (zero gradient: the moments still decay).  The incoming gradients are dense tensors from autograd (deterministic);
+    in the fused mode the six parameters never get a `.grad`."""
+    import diff_gaussian_rasterization as dgr
+    from fused_optim import FusedAdam
+    from helpers import settings_from
+
+    W, H = 320, 208
+    cams = S.orbit_cameras(8, W, H, device=device)[:B]  # rotated by 0, 45, 90 degrees about (0, 0, 6)
+    rasts = [dgr.GaussianRasterizer(settings_from(c, torch.zeros(3), sh_degree=deg)) for c in cams]
+    packed = torch.stack([dgr.pack_camera(r.raster_settings) for r in rasts])
+    rs0 = rasts[0].raster_settings
+    gen = torch.Generator().manual_seed(5)
+    ws = [[torch.randn(s, generator=gen).to(device) for s in [(N, 2), (N, 3), (N, 4)]] for _ in range(B)]
+    names = ("_xyz", "_scaling", "_rotation", "_features_dc", "_features_rest", "_opacity")
+
+    def run(fuse):
+        m = S.SyntheticGaussianModel(N, W, H, seed=2, device=device, scale_coef=0.01)
+        with torch.no_grad():
+            m._xyz[::7] = torch.tensor([-50.0, 0.0, -44.0], device=device)  # behind all three cameras: zero gradient
+        opt = FusedAdam(m.param_groups(), lr=0.0, eps=1e-15, fuse_backward=fuse, grad_scale=1.0 / B)
+        snaps = []
+        try:
+            for it in range(4):
+                raw = [getattr(m, n) for n in names]
+                m2, rgb, co, radii, depths = dgr.preprocess_gaussians_raw_batched(
+                    *raw, packed, deg, 1.0, W, H, tanfov0=(rs0.tanfovx, rs0.tanfovy))
+                assert int((radii[0] > 0).sum()) > N // 4
+                assert int((torch.stack(list(radii)) <= 0).all(dim=0).sum()) >= N // 7
+                loss = sum((m2[k] * ws[k][0]).sum() + (rgb[k] * ws[k][1]).sum() + (co[k] * ws[k][2]).sum()
+                           for k in range(B)) * (1.0 + it)
+                loss.backward()
+                if fuse:
+                    assert all(getattr(m, n).grad is None for n in names)
+                else:
+                    assert all(getattr(m, n).grad is not None for n in names)
+                opt.step()
+                opt.zero_grad(set_to_none=True)
+                snaps.append([getattr(m, n).detach().clone() for n in names] +
+                             [opt.state[getattr(m, n)][k].clone() for n in names for k in ("exp_avg", "exp_avg_sq")] +
+                             [opt.state[getattr(m, n)]["step"].clone() for n in names])
+            assert opt.fused_steps == (4 if fuse else 0) and opt.materialized_steps == 0
+        finally:
+            opt.set_fuse_backward(False)
+        return snaps
+
+    a, b = run(False), run(True)
+    for it, (sa, sb) in enumerate(zip(a, b)):
+        for j, (x, y) in enumerate(zip(sa, sb)):
+            assert torch.equal(x.cpu(), y.cpu()), f"step {it}, tensor {j}: max |diff| {(x - y).abs().max().item():.3e}"
+    # ... and the update is not a no-op
+    assert not torch.equal(a[0][0], a[3][0]) and not torch.equal(a[0][4], a[3][4])
+
+
+def test_fused_backward_step_in_the_training_iteration(device):
+    """the whole iteration through the mirror with the fused K11 + Adam step: K10's [P,9] record goes into the fused
+    kernel through its row stride; the result equals the two-kernel form fed with the SAME record (K10's atomics make
+    two runs of the iteration differ in the last bits, so the second optimizer replays the first one's record);
+    what happens between backward and step keeps the stock meaning: a replaced parameter is skipped, zero_grad()
+    without a step drops the pending gradient, a second backward before the step materializes both."""
+    import diff_gaussian_rasterization as dgr
+    import utils.general_utils as utils
+    from fused_optim import FusedAdam
+    from gaussian_renderer import distributed_preprocess3dgs_and_all2all_final, render_final
+    from gaussian_renderer.loss_distribution import batched_loss_computation, load_camera_from_cpu_to_all_gpu
+    from gaussian_renderer.workload_division import DivisionStrategyHistoryFinal, start_strategy_final
+
+    N, W, H = 20000, 320, 208
+    utils.GLOBAL_RANK, utils.WORLD_SIZE = 0, 1
+    utils.DEFAULT_GROUP = utils.IN_NODE_GROUP = utils.SingleGPUGroup()
+    utils.set_args(utils.default_args(bsz=1))
+    utils.set_img_size(H, W)
+    utils.set_cur_iter(1)
+    cams = S.orbit_cameras(8, W, H, device=device)[:2]
+    for k, cam in enumerate(cams):
+        cam.original_image_backup = S.make_gt_image(W, H, seed=1 + k, device=device)
+    bg = torch.zeros(3, device=device)
+    pipe = type("P", (), {"debug": False})()
+    names = ("_xyz", "_scaling", "_rotation", "_features_dc", "_features_rest", "_opacity")
+    hist = DivisionStrategyHistoryFinal(S.SyntheticDataset(cams), 1, 0)
+    m = S.SyntheticGaussianModel(N, W, H, seed=3, device=device, scale_coef=0.012)
+    twin = S.SyntheticGaussianModel(N, W, H, seed=3, device=device, scale_coef=0.012)
+    opt = FusedAdam(m.param_groups(), lr=0.0, eps=1e-15, fuse_backward=True)
+    opt_twin = FusedAdam(twin.param_groups(), lr=0.0, eps=1e-15)
+
+    def backward_only(cam, it):
+        utils.set_cur_iter(it + 1)
+        st, tasks = start_strategy_final([cam], hist)
+        load_camera_from_cpu_to_all_gpu([cam], st, tasks)
+        pkg = distributed_preprocess3dgs_and_all2all_final([cam], m, pipe, bg, batched_strategies=st)
+        images, masks = render_final(pkg, st)
+        stats = [ca["stats_collector"] for ca in pkg["batched_cuda_args"]]
+        loss, _ = batched_loss_computation(images, [cam], masks, st, stats)
+        loss.backward()
+        return pkg
+
+    try:
+        for it in range(3):
+            pkg = backward_only(cams[it % 2], it)
+            pend = opt._pending
+            assert pend is not None and pend.gstride == 9 and all(getattr(m, n).grad is None for n in names)
+            assert pkg["batched_locally_preprocessed_mean2D"][0].grad is not None  # densification's statistic: from K10
+            # the twin: plain K11 on the SAME record, then the multi-tensor Adam
+            grads = dgr.PendingProjectionBackward(
+                tuple(getattr(twin, n) for n in names), pend.cams, pend.radii, pend.cov3D, pend.clamped, pend.g_means2D,
+                pend.g_conic_opacity, pend.g_rgb, pend.gstride, pend.meta, pend.tanfov0).materialize()
+            for n, g in zip(names, grads):
+                getattr(twin, n).grad = g.view(getattr(twin, n).shape)
+            opt.step()
+            opt_twin.step()
+            opt.zero_grad(set_to_none=True)
+            opt_twin.zero_grad(set_to_none=True)
+            for n in names:
+                assert torch.equal(getattr(m, n).detach(), getattr(twin, n).detach()), (it, n)
+                assert torch.equal(opt.state[getattr(m, n)]["exp_avg_sq"], opt_twin.state[getattr(twin, n)]["exp_avg_sq"])
+        assert opt.fused_steps == 3 and opt.materialized_steps == 0
+
+        # zero_grad() without a step drops the pending gradient
+        before = [getattr(m, n).detach().clone() for n in names]
+        backward_only(cams[0], 3)
+        opt.zero_grad(set_to_none=True)
+        assert opt._pending is None
+        opt.step()
+        assert all(torch.equal(getattr(m, n).detach(), b) for n, b in zip(names, before)) and opt.fused_steps == 3
+
+        # a parameter replaced between backward and step (reset_opacity / densification: a NEW tensor in the group) has
+        # no gradient and is skipped; the other five step on their materialized gradients
+        backward_only(cams[1], 4)
+        old_opacity = m._opacity
+        new_opacity = torch.nn.Parameter(old_opacity.detach().clone())
+        for g in opt.param_groups:
+            if g["name"] == "opacity":
+                st = opt.state.pop(g["params"][0])
+                g["params"][0] = new_opacity
+                opt.state[new_opacity] = st
+        m._opacity = new_opacity
+        kept = new_opacity.detach().clone()
+        xyz_before = m._xyz.detach().clone()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        assert opt.materialized_steps == 1 and opt.fused_steps == 3
+        assert torch.equal(new_opacity.detach(), kept) and not torch.equal(m._xyz.detach(), xyz_before)
+
+        # two backwards before one step: both become ordinary (summed) gradients
+        backward_only(cams[0], 5)
+        backward_only(cams[1], 6)
+        assert opt._pending is None and all(getattr(m, n).grad is not None for n in names)
+        assert opt.materialized_steps == 3
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        # and the next iteration is fused again
+        backward_only(cams[0], 7)
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        assert opt.fused_steps == 4
+        assert all(torch.isfinite(getattr(m, n)).all() for n in names)
+    finally:
+        opt.set_fuse_backward(False)
+
+
 def test_legacy_render_equals_render_final(device):
     """`gaussian_renderer.render()` (the legacy single-camera surface north_star names) == render_final, W = 1"""
     import gaussian_renderer as gr

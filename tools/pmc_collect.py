@@ -29,6 +29,7 @@ GROUPS = [  # (group, substrings of the kernel symbol, substring that marks ONE 
     ("composite_forward", ["composite_forward_kernel"], "composite_forward_kernel"),
     ("composite_backward", ["composite_backward_kernel"], "composite_backward_kernel"),
     ("preprocess_forward", ["preprocess_forward"], "preprocess_forward"),
+    ("preprocess_backward_adam", ["preprocess_backward_adam"], "preprocess_backward_adam"),  # fused K11 + Adam (first)
     ("preprocess_backward", ["preprocess_backward"], "preprocess_backward"),
     ("binning", ["touch_count_kernel", "radix_onesweep_kernel", "scan_gather_lookback_kernel", "emit_scatter_kernel",
                  "emit_pairs_kernel", "tile_ranges"], "touch_count_kernel"),
