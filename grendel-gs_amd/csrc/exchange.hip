@@ -62,42 +62,52 @@ exchange_need_kernel(int P, int B, int W, int gx, int gy, const float2 *__restri
 #endif
 constexpr int XCHUNK = GSR_XCHUNK;  // Gaussians per wave-chunk: XCHUNK / 64 rounds of 64 lanes
 
-// rows [miny, maxy) of the 3-sigma tile rect of Gaussian r (the K2 rule); false when it touches nothing
-__device__ __forceinline__ bool rect_rows(const float2 *__restrict__ means2D, const int32_t *__restrict__ radii, size_t r,
-                                          int gx, int gy, int &miny, int &maxy) {
-    const int rad = radii[r];
-    if (rad <= 0) return false;
-    const float2 xy = means2D[r];
-    int minx, maxx;
-    gsr_get_rect(xy.x, xy.y, rad, gx, gy, minx, miny, maxx, maxy);
-    return maxx > minx && maxy > miny;
+// rows [miny, maxy) of the 3-sigma tile rect of Gaussian r (the K2 rule) packed as miny | maxy << 16, or 0 when it
+// touches nothing (0 = the empty interval: no band test passes).  Both loads are unconditional, so that the loads of
+// several rounds can be in flight together (the radius no longer gates the load of the position).
+__device__ __forceinline__ uint32_t rect_rows_packed(int rad, float2 xy, int gx, int gy) {
+    int minx, miny, maxx, maxy;
+    gsr_get_rect(xy.x, xy.y, rad > 0 ? rad : 0, gx, gy, minx, miny, maxx, maxy);
+    const bool ok = rad > 0 && maxx > minx && maxy > miny;
+    return ok ? ((uint32_t)miny | ((uint32_t)maxy << 16)) : 0u;
+}
+__device__ __forceinline__ bool rows_hit(uint32_t rows, int lo, int hi) {
+    const int miny = (int)(rows & 0xffffu), maxy = (int)(rows >> 16);
+    return hi > lo && max(lo, miny) < min(hi, maxy);
 }
 
-// grid (chunks, cameras), 256 threads = 4 waves, one chunk per wave
+// grid (chunks, cameras), 256 threads = 4 waves, one chunk per wave.  One wave is a latency chain (a chunk is 16
+// rounds of 64 Gaussians and there is less than one wave per SIMD at 10^6 Gaussians), so ALL loads of the chunk are
+// issued first and the band tests run on registers; the counts stay in scalar registers (round 3: the per-round
+// dependent loads and an LDS counter per destination made this 33 us for 0.75 M Gaussians and 8 destinations).
 __global__ void __launch_bounds__(256)
 exchange_count_kernel(int P, int B, int W, int k0, int gx, int gy, int nchunk, const float2 *__restrict__ means2D,
                       const int32_t *__restrict__ radii, const int32_t *__restrict__ bands,
                       int32_t *__restrict__ chunkcnt, int32_t *__restrict__ counts) {
-    __shared__ int32_t s_cnt[4][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int kk = blockIdx.y, k = k0 + kk;  // kk: camera within the launch, k: camera of the batch
     const int chunk = blockIdx.x * 4 + wave;
-    for (int g = lane; g < W; g += 64) s_cnt[wave][g] = 0;
-    __builtin_amdgcn_wave_barrier();
-    if (chunk < nchunk) {
-        for (int r = 0; r < XCHUNK / 64; r++) {
-            const int i = chunk * XCHUNK + r * 64 + lane;
-            int miny = 0, maxy = 0;
-            const bool ok = i < P && rect_rows(means2D, radii, (size_t)k * P + i, gx, gy, miny, maxy);
-            for (int g = 0; g < W; g++) {
-                const int lo = bands[((size_t)k * W + g) * 2], hi = bands[((size_t)k * W + g) * 2 + 1];  // uniform
-                const unsigned long long m = __ballot(ok && hi > lo && max(lo, miny) < min(hi, maxy));
-                if (lane == 0 && m) s_cnt[wave][g] += (int32_t)__popcll(m);
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        for (int g = lane; g < W; g += 64) {
-            const int32_t c = s_cnt[wave][g];
+    if (chunk >= nchunk) return;
+    constexpr int R = XCHUNK / 64;
+    int32_t rad[R];
+    float2 xy[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int i = chunk * XCHUNK + r * 64 + lane;
+        const size_t row = (size_t)k * P + min(i, P - 1);  // clamped, not branched around: the loads stay together
+        rad[r] = radii[row];
+        xy[r] = means2D[row];
+        if (i >= P) rad[r] = 0;
+    }
+    uint32_t rows[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) rows[r] = rect_rows_packed(rad[r], xy[r], gx, gy);
+    for (int g = 0; g < W; g++) {
+        const int lo = bands[((size_t)k * W + g) * 2], hi = bands[((size_t)k * W + g) * 2 + 1];  // uniform
+        int32_t c = 0;
+#pragma unroll
+        for (int r = 0; r < R; r++) c += (int32_t)__popcll(__ballot(rows_hit(rows[r], lo, hi)));
+        if (lane == 0) {
             chunkcnt[((size_t)g * B + kk) * nchunk + chunk] = c;
             if (c) atomicAdd(&counts[(size_t)g * B + kk], c);
         }
@@ -113,6 +123,9 @@ struct SegOffsets {
 // SLAB = true : the segments are capacity slabs chosen BEFORE the counts were known (no read-back): a record whose
 //               position falls past its segment's end is not written (overflow -- the caller learns it from the counts
 //               later and repeats the exchange with the sized layout).
+// Same latency discipline as the count kernel: the records of FOUR rounds are loaded together (unconditionally: a
+// Gaussian that goes nowhere costs 44 bytes of reads), the running position of destination g lives in lane g & 63 of a
+// register (read with a wave-uniform lane index), not in LDS.
 template <bool SLAB>
 __global__ void __launch_bounds__(256)
 exchange_pack_kernel(int P, int B, int W, int k0, int cntB, int cnt0, int gx, int gy, int nchunk,
@@ -121,54 +134,84 @@ exchange_pack_kernel(int P, int B, int W, int k0, int cntB, int cnt0, int gx, in
                      const int32_t *__restrict__ radii, const float *__restrict__ depths,
                      const int32_t *__restrict__ bands, const int32_t *__restrict__ chunkcnt, SegOffsets seg,
                      float *__restrict__ msg, int32_t *__restrict__ send_idx) {
-    __shared__ int32_t s_base[4][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int kk = blockIdx.y, k = k0 + kk;
     const int chunk = blockIdx.x * 4 + wave;
     if (chunk >= nchunk) return;  // wave-uniform; no workgroup barrier below
-    // first row of this chunk in each segment: segment start + the counts of the chunks before it
-    for (int g = 0; g < W; g++) {
-        const int32_t *cc = chunkcnt + ((size_t)g * cntB + (cnt0 + kk)) * nchunk;  // layout of the count launch
-        int32_t part = 0;
-        for (int c = lane; c < chunk; c += 64) part += cc[c];
+    // first row of this chunk in each segment: segment start + the counts of the chunks before it.  Eight
+    // destinations at a time, so that their loads are in flight together; base[g >> 6] of lane g & 63 = destination g's.
+    int32_t base[4] = {0, 0, 0, 0};
+    for (int g0 = 0; g0 < W; g0 += 8) {
+        int32_t part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const int32_t *cc[8];
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
-        if (lane == 0) s_base[wave][g] = seg.off[g * B + kk] + part;
+        for (int j = 0; j < 8; j++)  // (rows past the last destination re-read the last one: no branch around a load)
+            cc[j] = chunkcnt + ((size_t)min(g0 + j, W - 1) * cntB + (cnt0 + kk)) * nchunk;
+#pragma unroll 2
+        for (int c = lane; c < chunk; c += 64) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) part[j] += cc[j][c];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int g = g0 + j;
+            if (g < W) {  // uniform
+                int32_t v = part[j];
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+                v += seg.off[g * B + kk];
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    if ((g >> 6) == q && lane == (g & 63)) base[q] = v;
+            }
+        }
     }
-    __builtin_amdgcn_wave_barrier();
     const unsigned long long lt = (1ull << lane) - 1ull;
-    for (int r = 0; r < XCHUNK / 64; r++) {
-        const int i = chunk * XCHUNK + r * 64 + lane;
-        const size_t row = (size_t)k * P + i;
-        int miny = 0, maxy = 0;
-        const bool ok = i < P && rect_rows(means2D, radii, row, gx, gy, miny, maxy);
-        if (__ballot(ok) == 0ull) continue;
-        float rec[11];
-        if (ok) {
+    constexpr int RB = 4;  // rounds whose records are in registers together
+    for (int rb = 0; rb < XCHUNK / 64; rb += RB) {
+        float rec[RB][11];
+        uint32_t rows[RB];
+#pragma unroll
+        for (int q = 0; q < RB; q++) {
+            const int i = chunk * XCHUNK + (rb + q) * 64 + lane;
+            const size_t row = (size_t)k * P + min(i, P - 1);  // clamped, not branched around (see the count kernel)
+            const int32_t rad = radii[row];
             const float2 xy = means2D[row];
             const float4 co = conic_opacity[row];
-            rec[0] = xy.x; rec[1] = xy.y;
-            rec[2] = rgb[3 * row]; rec[3] = rgb[3 * row + 1]; rec[4] = rgb[3 * row + 2];
-            rec[5] = co.x; rec[6] = co.y; rec[7] = co.z; rec[8] = co.w;
-            rec[9] = __int_as_float(radii[row]);
-            rec[10] = depths[row];
+            rec[q][0] = xy.x; rec[q][1] = xy.y;
+            rec[q][2] = rgb[3 * row]; rec[q][3] = rgb[3 * row + 1]; rec[q][4] = rgb[3 * row + 2];
+            rec[q][5] = co.x; rec[q][6] = co.y; rec[q][7] = co.z; rec[q][8] = co.w;
+            rec[q][9] = __int_as_float(rad);
+            rec[q][10] = depths[row];
         }
-        for (int g = 0; g < W; g++) {
-            const int lo = bands[((size_t)k * W + g) * 2], hi = bands[((size_t)k * W + g) * 2 + 1];  // uniform
-            const bool hit = ok && hi > lo && max(lo, miny) < min(hi, maxy);
-            const unsigned long long m = __ballot(hit);
-            if (m == 0ull) continue;
-            const int32_t base = s_base[wave][g];
-            const size_t pos = (size_t)base + __popcll(m & lt);
-            if (hit && (!SLAB || (int64_t)pos < (int64_t)seg.off[g * B + kk + 1])) {
-                float *dst = msg + pos * 11;
+        __builtin_amdgcn_sched_barrier(0);  // all twenty loads are issued before the first result is looked at
 #pragma unroll
-                for (int c = 0; c < 11; c++) dst[c] = rec[c];
-                send_idx[pos] = (int32_t)(kk * P + i);  // row of the [cameras of this launch, P] state
+        for (int q = 0; q < RB; q++) {
+            const int i = chunk * XCHUNK + (rb + q) * 64 + lane;
+            rows[q] = rect_rows_packed(i < P ? __float_as_int(rec[q][9]) : 0, make_float2(rec[q][0], rec[q][1]), gx, gy);
+        }
+#pragma unroll
+        for (int q = 0; q < RB; q++) {
+            if (__ballot(rows[q] != 0u) == 0ull) continue;
+            const int i = chunk * XCHUNK + (rb + q) * 64 + lane;
+#pragma unroll
+            for (int gb = 0; gb < 4; gb++) {
+                for (int g = gb * 64; g < min(W, gb * 64 + 64); g++) {
+                    const int lo = bands[((size_t)k * W + g) * 2], hi = bands[((size_t)k * W + g) * 2 + 1];  // uniform
+                    const bool hit = rows_hit(rows[q], lo, hi);
+                    const unsigned long long m = __ballot(hit);
+                    if (m == 0ull) continue;
+                    const int32_t b0 = __builtin_amdgcn_readlane(base[gb], g & 63);
+                    const size_t pos = (size_t)b0 + __popcll(m & lt);
+                    if (hit && (!SLAB || (int64_t)pos < (int64_t)seg.off[g * B + kk + 1])) {
+                        float *dst = msg + pos * 11;
+#pragma unroll
+                        for (int c = 0; c < 11; c++) dst[c] = rec[q][c];
+                        send_idx[pos] = (int32_t)(kk * P + i);  // row of the [cameras of this launch, P] state
+                    }
+                    if (lane == (g & 63)) base[gb] += (int32_t)__popcll(m);
+                }
             }
-            __builtin_amdgcn_wave_barrier();
-            if (lane == 0) s_base[wave][g] = base + (int32_t)__popcll(m);
-            __builtin_amdgcn_wave_barrier();
         }
     }
 }
@@ -189,22 +232,37 @@ exchange_slab_tail_kernel(int B, int cntB, int cnt0, const int32_t *__restrict__
         send_idx[r] = -1;
 }
 
-// The received slab [n][11] -> the five dense tensors the render op takes.  One lane per float of the slab: the reads
-// are one contiguous stream, the writes land in <= 5 short contiguous runs per wave.  (The generic row mover,
-// gsr_gather_rows, reads the width-1 columns with a 44-byte stride: 43 us for 0.65 M rows where this takes ~12.)
+// The received slab [n][11] -> the five dense tensors the render op takes.  A workgroup moves 256 rows through LDS:
+// the slab is read as one contiguous 16-byte-per-lane stream and every output array is written as one contiguous run
+// per workgroup (float2 / float4 stores), instead of the 24-92 byte runs per wave that one lane per float produced
+// (and of the 44-byte-stride column reads of the generic row mover, gsr_gather_rows: 43 us for 0.65 M rows).
+// Row stride 11 words in LDS: odd, the per-row reads below are conflict-free.
 __global__ void __launch_bounds__(256)
-exchange_unpack_kernel(long long n, const float *__restrict__ recv, float *__restrict__ means2D, float *__restrict__ rgb,
-                       float *__restrict__ conic_opacity, int32_t *__restrict__ radii, float *__restrict__ depths) {
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n * 11;
-         e += (long long)gridDim.x * blockDim.x) {
-        const long long r = e / 11;
-        const int c = (int)(e - r * 11);
-        const float v = recv[e];
-        if (c < 2) means2D[2 * r + c] = v;
-        else if (c < 5) rgb[3 * r + (c - 2)] = v;
-        else if (c < 9) conic_opacity[4 * r + (c - 5)] = v;
-        else if (c == 9) radii[r] = __float_as_int(v);
-        else depths[r] = v;
+exchange_unpack_kernel(long long n, int vec, const float *__restrict__ recv, float *__restrict__ means2D,
+                       float *__restrict__ rgb, float *__restrict__ conic_opacity, int32_t *__restrict__ radii,
+                       float *__restrict__ depths) {
+    __shared__ __attribute__((aligned(16))) float s[256 * 11];
+    const int t = threadIdx.x;
+    for (long long row0 = (long long)blockIdx.x * 256; row0 < n; row0 += (long long)gridDim.x * 256) {
+        const int rows = (int)min(256LL, n - row0);
+        const float *src = recv + row0 * 11;  // 11264-byte blocks: 16-byte aligned with the buffer
+        if (rows == 256 && vec) {  // (vec: the slab starts on a 16-byte boundary)
+            const float4 *s4 = reinterpret_cast<const float4 *>(src);
+            float4 *d4 = reinterpret_cast<float4 *>(s);
+            for (int e = t; e < 256 * 11 / 4; e += 256) d4[e] = s4[e];
+        } else {
+            for (int e = t; e < rows * 11; e += 256) s[e] = src[e];
+        }
+        __syncthreads();
+        if (t < rows) {
+            const float *r = s + t * 11;
+            reinterpret_cast<float2 *>(means2D)[row0 + t] = make_float2(r[0], r[1]);
+            reinterpret_cast<float4 *>(conic_opacity)[row0 + t] = make_float4(r[5], r[6], r[7], r[8]);
+            radii[row0 + t] = __float_as_int(r[9]);
+            depths[row0 + t] = r[10];
+        }
+        for (int e = t; e < rows * 3; e += 256) rgb[row0 * 3 + e] = s[(e / 3) * 11 + 2 + (e % 3)];
+        __syncthreads();
     }
 }
 
@@ -327,10 +385,11 @@ extern "C" int gsr_exchange_unpack(int64_t n, const float *recv, float *means2D,
     if (n < 0) return GSR_EINVAL;
     if (n == 0) return 0;
     if (!recv || !means2D || !rgb || !conic_opacity || !radii || !depths) return GSR_EINVAL;
-    long long blocks = (n * 11 + 255) / 256;
+    if (((uintptr_t)conic_opacity & 15) || ((uintptr_t)means2D & 7)) return GSR_EINVAL;
+    long long blocks = (n + 255) / 256;
     if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(exchange_unpack_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (long long)n, recv, means2D,
-                       rgb, conic_opacity, radii, depths);
+    hipLaunchKernelGGL(exchange_unpack_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (long long)n,
+                       (int)(((uintptr_t)recv & 15) == 0), recv, means2D, rgb, conic_opacity, radii, depths);
     GSR_LAUNCH_CHECK();
     return 0;
 }

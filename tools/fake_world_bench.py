@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--bsz", type=int, default=0)
+    ap.add_argument("--no-fuse-backward", action="store_true", help="K11 and Adam as two kernels")
     ap.add_argument("--profile", action="store_true", help="cProfile the host side of the steps (top functions by own time)")
     a0 = ap.parse_args()
 
@@ -95,7 +96,8 @@ def main():
         rank = W // 2  # a middle band
         # the fields run_workload reads
         a = argparse.Namespace(gaussians=0, width=0, height=0, bsz=a0.bsz, views=8, opacity_logit_mean=0.0,
-                               opacity_logit_std=2.0, device_scene=False, no_priming=False)
+                               opacity_logit_std=2.0, device_scene=False, no_priming=False,
+                               no_fuse_backward=a0.no_fuse_backward)
         os.environ["WORLD_SIZE"] = str(W)
         utils.GLOBAL_RANK, utils.LOCAL_RANK, utils.WORLD_SIZE = (rank if W > 1 else 0), 0, W
         utils.DEFAULT_GROUP = utils.IN_NODE_GROUP = FakeGroup(W, rank) if W > 1 else utils.SingleGPUGroup()
