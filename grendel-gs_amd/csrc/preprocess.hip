@@ -263,17 +263,53 @@ constexpr int REST_W = 45;  // (16 - 1) * 3 floats of _features_rest per Gaussia
 // workgroup size of K11 (one lane per Gaussian): the LDS stage below costs 180 B per lane whatever the size, so the
 // resident waves per CU are the same; smaller workgroups interleave their load / compute / store phases more finely
 #ifndef GSR_K11_BLOCK
-#define GSR_K11_BLOCK 256
+#define GSR_K11_BLOCK 128
 #endif
 constexpr int K11_BLOCK = GSR_K11_BLOCK;
-// workgroup-cooperative, coalesced copy of the block's rows of a [P, 45] array into / out of LDS
-__device__ __forceinline__ void rest_stage_in(float *__restrict__ s_rest, const float *__restrict__ g, int P) {
+constexpr int K11_WAVES_PER_EU = 3;  // (hipcc's second launch bound is WAVES PER SIMD) 180 B of LDS per lane admit
+                                     // 12 waves per CU whatever the block size: <= 168 registers
+#ifndef GSR_K11_UN
+#define GSR_K11_UN 4
+#endif
+// workgroup-cooperative, coalesced copy of the block's rows of a [P, 45] array into / out of LDS.  The way in is split
+// in two: ISSUE loads the lane's twelve 16-byte pieces into registers (clamped indices, no branches: all twelve loads
+// are in flight together -- a copy loop of load / wait / LDS-write iterations exposed the memory latency eleven times
+// per workgroup, and three workgroups of four waves per CU cannot hide that), COMMIT writes them to LDS; the caller
+// puts its own per-lane loads between the two.
+constexpr int REST_SLOTS = (REST_W + 3) / 4;  // 16-byte pieces per lane: ceil(45 / 4) whatever the block size
+struct RestStage {
+    float4 v[REST_SLOTS];
+};
+__device__ __forceinline__ RestStage rest_stage_issue(const float *__restrict__ g, int P) {
     const size_t row0 = (size_t)blockIdx.x * K11_BLOCK;
     const int nw = (int)min((size_t)K11_BLOCK, (size_t)P - row0) * REST_W;
     const float4 *src4 = reinterpret_cast<const float4 *>(g + row0 * REST_W);  // 46080-byte blocks: 16-byte aligned
+    const int n4 = nw / 4;  // >= 11
+    RestStage st;
+#pragma unroll
+    for (int u = 0; u < REST_SLOTS; u++) st.v[u] = src4[min((int)threadIdx.x + u * K11_BLOCK, n4 - 1)];
+    return st;
+}
+__device__ __forceinline__ void rest_stage_commit(float *__restrict__ s_rest, RestStage &st,
+                                                  const float *__restrict__ g, int P) {
+    const size_t row0 = (size_t)blockIdx.x * K11_BLOCK;
+    const int nw = (int)min((size_t)K11_BLOCK, (size_t)P - row0) * REST_W;
     float4 *s4 = reinterpret_cast<float4 *>(s_rest);
-    for (int k = threadIdx.x; k < nw / 4; k += K11_BLOCK) s4[k] = src4[k];
+    // the values are pinned in registers HERE (an empty asm that claims to modify them): without it the compiler sinks
+    // every load into the conditional LDS write that uses it -- load, wait, write, twelve times in a row
+#pragma unroll
+    for (int u = 0; u < REST_SLOTS; u++)
+        asm volatile("" : "+v"(st.v[u].x), "+v"(st.v[u].y), "+v"(st.v[u].z), "+v"(st.v[u].w));
+#pragma unroll
+    for (int u = 0; u < REST_SLOTS; u++) {
+        const int k = (int)threadIdx.x + u * K11_BLOCK;
+        if (k < nw / 4) s4[k] = st.v[u];
+    }
     for (int k = (nw & ~3) + threadIdx.x; k < nw; k += K11_BLOCK) s_rest[k] = g[row0 * REST_W + k];
+}
+__device__ __forceinline__ void rest_stage_in(float *__restrict__ s_rest, const float *__restrict__ g, int P) {
+    RestStage st = rest_stage_issue(g, P);
+    rest_stage_commit(s_rest, st, g, P);
 }
 __device__ __forceinline__ void rest_stage_out(const float *__restrict__ s_rest, float *__restrict__ g, int P) {
     const size_t row0 = (size_t)blockIdx.x * K11_BLOCK;
@@ -306,26 +342,45 @@ struct K11Adam {
     float grad_scale;
 };
 
-template <int K>
-__device__ __forceinline__ void k11_adam_row(const K11Adam &ad, int t, float *__restrict__ param, size_t row,
-                                             const float (&pv)[K], const float (&g)[K]) {
-    float *mp = ad.m[t] + row * K, *vp = ad.v[t] + row * K, *pp = param + row * K;
+// The 14 per-lane values (xyz 0-2, scaling 3-5, rotation 6-9, features_dc 10-12, opacity 13) are updated together at
+// the END of the lane's work: their 28 moment loads are then in flight at once (one exposed latency instead of five --
+// the first version updated each tensor where its gradient fell out and ran 0.50 ms against 0.355 ms for the two
+// kernels it replaces).  Plain (cacheable) accesses: a lane touches 4-byte pieces of 12 / 16 byte rows, neighbouring
+// lanes the rest of the line -- measured: streaming loads cost the kernel +0.027 ms (the line is fetched again for the
+// next piece), streaming stores alone +0.010 ms.
+__device__ __forceinline__ void k11_adam_small(const K11Adam &ad, size_t i, float *__restrict__ xyz,
+                                               float *__restrict__ scaling, float *__restrict__ rotation,
+                                               float *__restrict__ f_dc, float *__restrict__ opacity,
+                                               const float (&pv)[14], const float (&g)[14]) {
+    constexpr int T[14] = {0, 0, 0, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 5};
+    constexpr int K[14] = {3, 3, 3, 3, 3, 3, 4, 4, 4, 4, 3, 3, 3, 1};
+    constexpr int C[14] = {0, 1, 2, 0, 1, 2, 0, 1, 2, 3, 0, 1, 2, 0};
+    float *const base[6] = {xyz, scaling, rotation, f_dc, nullptr, opacity};
+    float m[14], v[14];
 #pragma unroll
-    for (int k = 0; k < K; k++) {
-        float p = pv[k], m = __builtin_nontemporal_load(mp + k), v = __builtin_nontemporal_load(vp + k);
-        gsr_adam1(p, __fmul_rn(g[k], ad.grad_scale), m, v, ad.lr_c[t], ad.b1[t], ad.b2[t], ad.omb1[t], ad.omb2[t],
-                  ad.inv_sqrt_bc2[t], ad.eps[t]);
-        pp[k] = p;
-        __builtin_nontemporal_store(m, mp + k);
-        __builtin_nontemporal_store(v, vp + k);
+    for (int e = 0; e < 14; e++) {
+        m[e] = ad.m[T[e]][i * K[e] + C[e]];
+        v[e] = ad.v[T[e]][i * K[e] + C[e]];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int e = 0; e < 14; e++) {
+        const int t = T[e];
+        float p = pv[e];
+        gsr_adam1(p, __fmul_rn(g[e], ad.grad_scale), m[e], v[e], ad.lr_c[t], ad.b1[t], ad.b2[t], ad.omb1[t],
+                  ad.omb2[t], ad.inv_sqrt_bc2[t], ad.eps[t]);
+        base[t][i * K[e] + C[e]] = p;
+        ad.m[t][i * K[e] + C[e]] = m[e];
+        ad.v[t][i * K[e] + C[e]] = v[e];
     }
 }
 
 // the workgroup's rows of _features_rest: gradient from LDS, parameter (just staged in by this workgroup: L2) and
-// both moments from HBM, 16 bytes per lane and access
+// both moments from HBM, 16 bytes per lane and access, FOUR accesses per lane in flight before the first is used
+// (three workgroups of four waves per CU do not cover the memory latency with one).
 __device__ __forceinline__ void rest_adam_out(const float *__restrict__ s_rest, float *__restrict__ param,
                                               const K11Adam &ad, int P) {
-    constexpr int t = 4;
+    constexpr int t = 4, UN = GSR_K11_UN;
     const size_t row0 = (size_t)blockIdx.x * K11_BLOCK;
     const int nw = (int)min((size_t)K11_BLOCK, (size_t)P - row0) * REST_W;
     typedef float vf4 __attribute__((ext_vector_type(4)));
@@ -335,17 +390,33 @@ __device__ __forceinline__ void rest_adam_out(const float *__restrict__ s_rest, 
     const float4 *s4 = reinterpret_cast<const float4 *>(s_rest);
     const float gs = ad.grad_scale, lr_c = ad.lr_c[t], b1 = ad.b1[t], b2 = ad.b2[t], omb1 = ad.omb1[t],
                 omb2 = ad.omb2[t], isb = ad.inv_sqrt_bc2[t], eps = ad.eps[t];
-    for (int k = threadIdx.x; k < nw / 4; k += K11_BLOCK) {
-        const float4 g = s4[k];
-        const vf4 pn = p4[k], mn = __builtin_nontemporal_load(m4 + k), vn = __builtin_nontemporal_load(v4 + k);
-        float pa[4] = {pn.x, pn.y, pn.z, pn.w}, ma[4] = {mn.x, mn.y, mn.z, mn.w}, va[4] = {vn.x, vn.y, vn.z, vn.w};
-        const float ga[4] = {g.x, g.y, g.z, g.w};
+    const int n4 = nw / 4;  // >= 11: a block holds at least one row of 45 words
+    for (int k0 = threadIdx.x; k0 < n4; k0 += K11_BLOCK * UN) {
+        vf4 pn[UN], mn[UN], vn[UN];
 #pragma unroll
-        for (int c = 0; c < 4; c++)
-            gsr_adam1(pa[c], __fmul_rn(ga[c], gs), ma[c], va[c], lr_c, b1, b2, omb1, omb2, isb, eps);
-        p4[k] = vf4{pa[0], pa[1], pa[2], pa[3]};
-        __builtin_nontemporal_store(vf4{ma[0], ma[1], ma[2], ma[3]}, m4 + k);
-        __builtin_nontemporal_store(vf4{va[0], va[1], va[2], va[3]}, v4 + k);
+        for (int u = 0; u < UN; u++) {  // clamped, not branched around: the loads stay together
+            const int k = min(k0 + u * K11_BLOCK, n4 - 1);
+            pn[u] = p4[k];
+            mn[u] = __builtin_nontemporal_load(m4 + k);
+            vn[u] = __builtin_nontemporal_load(v4 + k);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+            const int k = k0 + u * K11_BLOCK;
+            if (k < n4) {
+                const float4 g = s4[k];
+                float pa[4] = {pn[u].x, pn[u].y, pn[u].z, pn[u].w}, ma[4] = {mn[u].x, mn[u].y, mn[u].z, mn[u].w},
+                      va[4] = {vn[u].x, vn[u].y, vn[u].z, vn[u].w};
+                const float ga[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+                    gsr_adam1(pa[c], __fmul_rn(ga[c], gs), ma[c], va[c], lr_c, b1, b2, omb1, omb2, isb, eps);
+                p4[k] = vf4{pa[0], pa[1], pa[2], pa[3]};
+                __builtin_nontemporal_store(vf4{ma[0], ma[1], ma[2], ma[3]}, m4 + k);
+                __builtin_nontemporal_store(vf4{va[0], va[1], va[2], va[3]}, v4 + k);
+            }
+        }
     }
     for (int k = (nw & ~3) + threadIdx.x; k < nw; k += K11_BLOCK) {
         const size_t o = row0 * REST_W + k;
@@ -357,9 +428,50 @@ __device__ __forceinline__ void rest_adam_out(const float *__restrict__ s_rest, 
     }
 }
 
+// Everything one lane reads from HBM in the one-camera K11 besides its _features_rest row, loaded TOGETHER at the top of
+// the kernel (unconditionally: an invisible Gaussian costs its ~130 bytes of reads): the body used to fetch each piece
+// where it was first needed -- radius, then position and conic gradient, then the covariance, ... -- six dependent
+// waits per lane in a kernel whose occupancy (46 KB of LDS per workgroup) cannot hide them.
+struct K11In {
+    int32_t rad;
+    float p[3], sc[3], dc[3], op;
+    float4 q;
+    float cv[6];
+    float4 gco;
+    float2 g2;
+    float grgb[3];
+    uint8_t cl[3];
+};
+template <bool RAW>
+__device__ __forceinline__ K11In k11_load(size_t i, const float *__restrict__ means3D, const float *__restrict__ scales,
+                                          const float *__restrict__ rotations, const float *__restrict__ shs,
+                                          const float *__restrict__ opacities_raw, const int32_t *__restrict__ radii,
+                                          const float *__restrict__ cov3D, const uint8_t *__restrict__ clamped,
+                                          const float *__restrict__ dL_dmeans2D,
+                                          const float *__restrict__ dL_dconic_opacity,
+                                          const float *__restrict__ dL_drgb, int gstride) {
+    K11In in;
+    in.rad = radii[i];
+#pragma unroll
+    for (int e = 0; e < 3; e++) {
+        in.p[e] = means3D[3 * i + e];
+        in.sc[e] = scales[3 * i + e];
+        in.dc[e] = RAW ? shs[3 * i + e] : 0.f;
+        in.cl[e] = clamped[3 * i + e];
+        in.grgb[e] = dL_drgb[(gstride ? gstride : 3) * i + e];
+    }
+    in.op = RAW ? opacities_raw[i] : 0.f;
+    in.q = *reinterpret_cast<const float4 *>(rotations + 4 * i);
+#pragma unroll
+    for (int e = 0; e < 6; e++) in.cv[e] = cov3D[6 * i + e];
+    in.gco = grad_ld4(dL_dconic_opacity, i, gstride);
+    in.g2 = grad_ld2(dL_dmeans2D, i, gstride);
+    return in;
+}
+
 template <int DEG, bool RAW, bool ADAM = false>
 __device__ __forceinline__ void
-preprocess_backward_body(const K11Adam &ad, const int i, const float *__restrict__ rest_in, float *__restrict__ rest_out, int P, int M, const float *__restrict__ means3D, const float *__restrict__ scales,
+preprocess_backward_body(const K11In &in, float (&sp)[14], float (&sg)[14], const int i, const float *__restrict__ rest_in, float *__restrict__ rest_out, int P, int M, const float *__restrict__ means3D, const float *__restrict__ scales,
                            float scale_modifier, const float *__restrict__ rotations, const float *__restrict__ shs,
                            const float *__restrict__ shs_rest, const float *__restrict__ opacities_raw,
                            const float *__restrict__ view, const float *__restrict__ proj,
@@ -373,25 +485,22 @@ preprocess_backward_body(const K11Adam &ad, const int i, const float *__restrict
     constexpr int NC = (DEG + 1) * (DEG + 1);
     float *dsh_out = dL_dshs + (size_t)i * M * 3;
 
-    if (ADAM && radii[i] <= 0) {  // invisible: zero gradient, the moments still decay and still move the parameter
-        const float z[4] = {0.f, 0.f, 0.f, 0.f};
-        const float z3[3] = {0.f, 0.f, 0.f}, z1[1] = {0.f};
-        const float px[3] = {means3D[3 * (size_t)i], means3D[3 * (size_t)i + 1], means3D[3 * (size_t)i + 2]};
-        const float ps[3] = {scales[3 * (size_t)i], scales[3 * (size_t)i + 1], scales[3 * (size_t)i + 2]};
-        const float4 q4 = *reinterpret_cast<const float4 *>(rotations + 4 * (size_t)i);
-        const float pq[4] = {q4.x, q4.y, q4.z, q4.w};
-        const float pd[3] = {shs[3 * (size_t)i], shs[3 * (size_t)i + 1], shs[3 * (size_t)i + 2]};
-        const float po[1] = {opacities_raw[i]};
-        k11_adam_row<3>(ad, 0, const_cast<float *>(means3D), i, px, z3);
-        k11_adam_row<3>(ad, 1, const_cast<float *>(scales), i, ps, z3);
-        k11_adam_row<4>(ad, 2, const_cast<float *>(rotations), i, pq, z);
-        k11_adam_row<3>(ad, 3, const_cast<float *>(shs), i, pd, z3);
-        k11_adam_row<1>(ad, 5, const_cast<float *>(opacities_raw), i, po, z1);
+    if (ADAM && in.rad <= 0) {  // invisible: zero gradient, the moments still decay and still move the parameter
+#pragma unroll
+        for (int e = 0; e < 3; e++) {
+            sp[e] = in.p[e];
+            sp[3 + e] = in.sc[e];
+            sp[10 + e] = in.dc[e];
+        }
+        sp[6] = in.q.x; sp[7] = in.q.y; sp[8] = in.q.z; sp[9] = in.q.w;
+        sp[13] = in.op;
+#pragma unroll
+        for (int e = 0; e < 14; e++) sg[e] = 0.f;
         float *rp = rest_out;
         for (int k = 0; k < (M - 1) * 3; k++) rp[k] = 0.f;
         return;
     }
-    if (RAW && radii[i] <= 0) {
+    if (RAW && in.rad <= 0) {
         dL_dmeans3D[3 * (size_t)i] = dL_dmeans3D[3 * (size_t)i + 1] = dL_dmeans3D[3 * (size_t)i + 2] = 0.f;
         dL_dscales[3 * (size_t)i] = dL_dscales[3 * (size_t)i + 1] = dL_dscales[3 * (size_t)i + 2] = 0.f;
         dL_drotations[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -401,7 +510,7 @@ preprocess_backward_body(const K11Adam &ad, const int i, const float *__restrict
         for (int k = 0; k < (M - 1) * 3; k++) rp[k] = 0.f;
         return;
     }
-    if (radii[i] <= 0) {
+    if (in.rad <= 0) {
         dL_dmeans3D[3 * (size_t)i] = dL_dmeans3D[3 * (size_t)i + 1] = dL_dmeans3D[3 * (size_t)i + 2] = 0.f;
         dL_dscales[3 * (size_t)i] = dL_dscales[3 * (size_t)i + 1] = dL_dscales[3 * (size_t)i + 2] = 0.f;
         dL_drotations[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -411,16 +520,16 @@ preprocess_backward_body(const K11Adam &ad, const int i, const float *__restrict
     }
     const Cam cam = load_cam(view, proj, campos);
     const float fx = W / (2.0f * tanfovx), fy = H / (2.0f * tanfovy);
-    const float p[3] = {means3D[3 * (size_t)i], means3D[3 * (size_t)i + 1], means3D[3 * (size_t)i + 2]};
-    const float4 gco = grad_ld4(dL_dconic_opacity, i, gstride);
+    const float p[3] = {in.p[0], in.p[1], in.p[2]};
+    const float4 gco = in.gco;
     const float gA = gco.x, gB = gco.y, gC = gco.z;
     if (ADAM) {
-        const float oraw = opacities_raw[i];
+        const float oraw = in.op;
         const float so = 1.0f / (1.0f + expf(-oraw));
-        const float po[1] = {oraw}, go[1] = {gco.w * so * (1.0f - so)};
-        k11_adam_row<1>(ad, 5, const_cast<float *>(opacities_raw), i, po, go);
+        sp[13] = oraw;
+        sg[13] = gco.w * so * (1.0f - so);
     } else if (RAW) {
-        const float so = 1.0f / (1.0f + expf(-opacities_raw[i]));
+        const float so = 1.0f / (1.0f + expf(-in.op));
         dL_dopacities[i] = gco.w * so * (1.0f - so);
     } else {
         dL_dopacities[i] = gco.w;
@@ -434,7 +543,7 @@ preprocess_backward_body(const K11Adam &ad, const int i, const float *__restrict
     float T[2][3], tc[3];
     bool xin, yin;
     compute_T(t, cam.v, fx, fy, tanfovx, tanfovy, T, tc, xin, yin);
-    const float *cv = cov3D + 6 * (size_t)i;
+    const float *cv = in.cv;
     const float S[3][3] = {{cv[0], cv[1], cv[2]}, {cv[1], cv[3], cv[4]}, {cv[2], cv[4], cv[5]}};
     float ST0[3], ST1[3];
 #pragma unroll
@@ -490,7 +599,7 @@ preprocess_backward_body(const K11Adam &ad, const int i, const float *__restrict
         const float phw = cam.p[3] * p[0] + cam.p[7] * p[1] + cam.p[11] * p[2] + cam.p[15];
         const float mw = 1.0f / (phw + 0.0000001f);
         const float mul1 = phx * mw * mw, mul2 = phy * mw * mw;
-        const float2 g2 = grad_ld2(dL_dmeans2D, i, gstride);
+        const float2 g2 = in.g2;
 #pragma unroll
         for (int k = 0; k < 3; k++)
             dmean[k] += (cam.p[k * 4 + 0] * mw - cam.p[k * 4 + 3] * mul1) * g2.x +
@@ -501,9 +610,9 @@ preprocess_backward_body(const K11Adam &ad, const int i, const float *__restrict
     {
         float sh[NC * 3];
         if (RAW) {
-            sh[0] = shs[3 * (size_t)i];
-            sh[1] = shs[3 * (size_t)i + 1];
-            sh[2] = shs[3 * (size_t)i + 2];
+            sh[0] = in.dc[0];
+            sh[1] = in.dc[1];
+            sh[2] = in.dc[2];
             const float *rp = rest_in;
 #pragma unroll
             for (int k = 3; k < NC * 3; k++) sh[k] = rp[k - 3];
@@ -519,7 +628,7 @@ preprocess_backward_body(const K11Adam &ad, const int i, const float *__restrict
         float dsh[NC * 3];
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
-            const float g = clamped[3 * (size_t)i + ch] ? 0.f : dL_drgb[(gstride ? gstride : 3) * (size_t)i + ch];
+            const float g = in.cl[ch] ? 0.f : in.grgb[ch];
             float dx = 0.f, dy = 0.f, dz = 0.f;
             dsh[0 * 3 + ch] = SH_C0 * g;
             if (DEG > 0) {
@@ -574,8 +683,11 @@ preprocess_backward_body(const K11Adam &ad, const int i, const float *__restrict
         dmean[2] += (ddir[2] - z * dot) / len;
         if (RAW) {
             if (ADAM) {
-                const float pd[3] = {sh[0], sh[1], sh[2]}, gd[3] = {dsh[0], dsh[1], dsh[2]};
-                k11_adam_row<3>(ad, 3, const_cast<float *>(shs), i, pd, gd);
+#pragma unroll
+                for (int e = 0; e < 3; e++) {
+                    sp[10 + e] = sh[e];
+                    sg[10 + e] = dsh[e];
+                }
             } else {
                 dL_dshs[3 * (size_t)i] = dsh[0];
                 dL_dshs[3 * (size_t)i + 1] = dsh[1];
@@ -596,7 +708,11 @@ preprocess_backward_body(const K11Adam &ad, const int i, const float *__restrict
         }
     }
     if (ADAM) {
-        k11_adam_row<3>(ad, 0, const_cast<float *>(means3D), i, p, dmean);
+#pragma unroll
+        for (int e = 0; e < 3; e++) {
+            sp[e] = p[e];
+            sg[e] = dmean[e];
+        }
     } else {
         dL_dmeans3D[3 * (size_t)i] = dmean[0];
         dL_dmeans3D[3 * (size_t)i + 1] = dmean[1];
@@ -605,9 +721,9 @@ preprocess_backward_body(const K11Adam &ad, const int i, const float *__restrict
 
     // ---- cov3D -> scales, rotations.  Sigma = M^T M, M = S R^T
     {
-        const float4 qraw = *reinterpret_cast<const float4 *>(rotations + 4 * (size_t)i);
+        const float4 qraw = in.q;
         float4 q = qraw;
-        float sc[3] = {scales[3 * (size_t)i], scales[3 * (size_t)i + 1], scales[3 * (size_t)i + 2]};
+        float sc[3] = {in.sc[0], in.sc[1], in.sc[2]};
         const float scraw[3] = {sc[0], sc[1], sc[2]};
         float gsc[3];
         float qn = 1.f, qnr = 1.f;
@@ -645,7 +761,13 @@ preprocess_backward_body(const K11Adam &ad, const int i, const float *__restrict
 #pragma unroll
             for (int j = 0; j < 3; j++) dR[j][r] = s[r] * dM[r][j];
         }
-        if (ADAM) k11_adam_row<3>(ad, 1, const_cast<float *>(scales), i, scraw, gsc);
+        if (ADAM) {
+#pragma unroll
+            for (int e = 0; e < 3; e++) {
+                sp[3 + e] = scraw[e];
+                sg[3 + e] = gsc[e];
+            }
+        }
         const float r_ = q.x, x = q.y, y = q.z, z = q.w;
         float4 dq;
         dq.x = 2.f * (-z * dR[0][1] + y * dR[0][2] + z * dR[1][0] - x * dR[1][2] - y * dR[2][0] + x * dR[2][1]);
@@ -661,8 +783,8 @@ preprocess_backward_body(const K11Adam &ad, const int i, const float *__restrict
                              (dq.w - q.w * dot) / qn);
         }
         if (ADAM) {
-            const float pq[4] = {qraw.x, qraw.y, qraw.z, qraw.w}, gq[4] = {dq.x, dq.y, dq.z, dq.w};
-            k11_adam_row<4>(ad, 2, const_cast<float *>(rotations), i, pq, gq);
+            sp[6] = qraw.x; sp[7] = qraw.y; sp[8] = qraw.z; sp[9] = qraw.w;
+            sg[6] = dq.x; sg[7] = dq.y; sg[8] = dq.z; sg[9] = dq.w;
         } else {
             dL_drotations[i] = dq;
         }
@@ -674,7 +796,7 @@ preprocess_backward_body(const K11Adam &ad, const int i, const float *__restrict
 // lane by lane touches a different cache line in every lane of every load.  They are staged through LDS with
 // coalesced 16-byte accesses instead (row stride 45 words: conflict-free), both ways.
 template <int DEG, bool RAW>
-__global__ void __launch_bounds__(K11_BLOCK)
+__global__ void __launch_bounds__(K11_BLOCK, K11_WAVES_PER_EU)
 preprocess_backward_kernel(int P, int M, const float *__restrict__ means3D, const float *__restrict__ scales,
                            float scale_modifier, const float *__restrict__ rotations, const float *__restrict__ shs,
                            const float *__restrict__ shs_rest, const float *__restrict__ opacities_raw,
@@ -687,14 +809,19 @@ preprocess_backward_kernel(int P, int M, const float *__restrict__ means3D, cons
                            float4 *__restrict__ dL_drotations, float *__restrict__ dL_dshs,
                            float *__restrict__ dL_dshs_rest, float *__restrict__ dL_dopacities) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const K11Adam ad{};
+    float ad[14], ad2[14];  // (the fused kernel's per-lane parameter / gradient slots: unused here)
+    const size_t ic = (size_t)min(i, P - 1);  // lanes past the end load the last Gaussian's inputs and compute nothing
     if constexpr (RAW) {
         __shared__ float s_rest[K11_BLOCK * REST_W];
         if (M == 16) {  // block-uniform
-            rest_stage_in(s_rest, shs_rest, P);
+            RestStage st = rest_stage_issue(shs_rest, P);
+            const K11In in = k11_load<RAW>(ic, means3D, scales, rotations, shs, opacities_raw, radii, cov3D, clamped,
+                                           dL_dmeans2D, dL_dconic_opacity, dL_drgb, gstride);
+            __builtin_amdgcn_sched_barrier(0);  // every load of the lane is issued before the first result is used
+            rest_stage_commit(s_rest, st, shs_rest, P);
             __syncthreads();
             if (i < P)
-                preprocess_backward_body<DEG, RAW>(ad, i, s_rest + threadIdx.x * REST_W, s_rest + threadIdx.x * REST_W, P, M,
+                preprocess_backward_body<DEG, RAW>(in, ad, ad2, i, s_rest + threadIdx.x * REST_W, s_rest + threadIdx.x * REST_W, P, M,
                                                    means3D, scales, scale_modifier, rotations, shs, shs_rest,
                                                    opacities_raw, view, proj, campos, W, H, tanfovx, tanfovy, radii,
                                                    cov3D, clamped, dL_dmeans2D, dL_dconic_opacity, dL_drgb, gstride,
@@ -706,7 +833,9 @@ preprocess_backward_kernel(int P, int M, const float *__restrict__ means3D, cons
         }
     }
     if (i >= P) return;
-    preprocess_backward_body<DEG, RAW>(ad, i, RAW ? shs_rest + (size_t)i * (M - 1) * 3 : nullptr,
+    const K11In in = k11_load<RAW>(ic, means3D, scales, rotations, shs, opacities_raw, radii, cov3D, clamped, dL_dmeans2D,
+                                   dL_dconic_opacity, dL_drgb, gstride);
+    preprocess_backward_body<DEG, RAW>(in, ad, ad2, i, RAW ? shs_rest + (size_t)i * (M - 1) * 3 : nullptr,
                                        RAW ? dL_dshs_rest + (size_t)i * (M - 1) * 3 : nullptr, P, M, means3D, scales,
                                        scale_modifier, rotations, shs, shs_rest, opacities_raw, view, proj, campos, W, H,
                                        tanfovx, tanfovy, radii, cov3D, clamped, dL_dmeans2D, dL_dconic_opacity, dL_drgb,
@@ -717,7 +846,7 @@ preprocess_backward_kernel(int P, int M, const float *__restrict__ means3D, cons
 // K11 + Adam, one camera, 16-coefficient model (the launcher checks): the same body with the stores replaced by the
 // optimizer update (K11Adam above).  Own kernel name so that traces and counters tell the fused launch apart.
 template <int DEG>
-__global__ void __launch_bounds__(K11_BLOCK)
+__global__ void __launch_bounds__(K11_BLOCK, K11_WAVES_PER_EU)
 preprocess_backward_adam_kernel(int P, float *__restrict__ xyz, float *__restrict__ scaling, float scale_modifier,
                                 float *__restrict__ rotation, float *__restrict__ f_dc, float *__restrict__ f_rest,
                                 float *__restrict__ opacity, const float *__restrict__ view,
@@ -728,14 +857,23 @@ preprocess_backward_adam_kernel(int P, float *__restrict__ xyz, float *__restric
                                 const float *__restrict__ dL_drgb, int gstride, const K11Adam ad) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     __shared__ float s_rest[K11_BLOCK * REST_W];
-    rest_stage_in(s_rest, f_rest, P);
+    const size_t ic = (size_t)min(i, P - 1);
+    RestStage st = rest_stage_issue(f_rest, P);
+    const K11In in = k11_load<true>(ic, xyz, scaling, rotation, f_dc, opacity, radii, cov3D, clamped, dL_dmeans2D,
+                                    dL_dconic_opacity, dL_drgb, gstride);
+    __builtin_amdgcn_sched_barrier(0);  // every load of the lane is issued before the first result is used
+    rest_stage_commit(s_rest, st, f_rest, P);
     __syncthreads();
-    if (i < P)
-        preprocess_backward_body<DEG, true, true>(ad, i, s_rest + threadIdx.x * REST_W, s_rest + threadIdx.x * REST_W,
-                                                  P, 16, xyz, scaling, scale_modifier, rotation, f_dc, f_rest, opacity,
-                                                  view, proj, campos, W, H, tanfovx, tanfovy, radii, cov3D, clamped,
-                                                  dL_dmeans2D, dL_dconic_opacity, dL_drgb, gstride, nullptr, nullptr,
-                                                  nullptr, nullptr, nullptr, nullptr);
+    if (i < P) {
+        float sp[14], sg[14];
+        preprocess_backward_body<DEG, true, true>(in, sp, sg, i, s_rest + threadIdx.x * REST_W,
+                                                  s_rest + threadIdx.x * REST_W, P, 16, xyz, scaling, scale_modifier,
+                                                  rotation, f_dc, f_rest, opacity, view, proj, campos, W, H, tanfovx,
+                                                  tanfovy, radii, cov3D, clamped, dL_dmeans2D, dL_dconic_opacity,
+                                                  dL_drgb, gstride, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                                  nullptr);
+        k11_adam_small(ad, i, xyz, scaling, rotation, f_dc, opacity, sp, sg);
+    }
     __syncthreads();
     rest_adam_out(s_rest, f_rest, ad, P);
 }
@@ -1060,10 +1198,15 @@ preprocess_backward_batched_body(int P, int B, int M, const float *__restrict__ 
         }
     }
     // ---- stores + the camera-independent tail (cov3D -> scale / quaternion, activations), once
+    float sp[14], sg[14];  // ADAM: the per-lane parameters / gradients, updated together at the end
     if constexpr (ADAM) {
-        k11_adam_row<3>(ad, 0, const_cast<float *>(xyz), i, p, dmean);
-        const float pdc[3] = {sh[0], sh[1], sh[2]}, gdc[3] = {dsh[0], dsh[1], dsh[2]};
-        k11_adam_row<3>(ad, 3, const_cast<float *>(f_dc), i, pdc, gdc);
+#pragma unroll
+        for (int e = 0; e < 3; e++) {
+            sp[e] = p[e];
+            sg[e] = dmean[e];
+            sp[10 + e] = sh[e];
+            sg[10 + e] = dsh[e];
+        }
     } else {
         dL_dxyz[3 * (size_t)i] = dmean[0];
         dL_dxyz[3 * (size_t)i + 1] = dmean[1];
@@ -1082,8 +1225,8 @@ preprocess_backward_batched_body(int P, int B, int M, const float *__restrict__ 
         const float oraw = opacity[i];
         const float so = 1.0f / (1.0f + expf(-oraw));
         if constexpr (ADAM) {
-            const float po[1] = {oraw}, go[1] = {dop * so * (1.0f - so)};
-            k11_adam_row<1>(ad, 5, const_cast<float *>(opacity), i, po, go);
+            sp[13] = oraw;
+            sg[13] = dop * so * (1.0f - so);
         } else {
             dL_dopacity[i] = dop * so * (1.0f - so);
         }
@@ -1121,7 +1264,13 @@ preprocess_backward_batched_body(int P, int B, int M, const float *__restrict__ 
 #pragma unroll
             for (int j = 0; j < 3; j++) dR[j][r] = s[r] * dM[r][j];
         }
-        if constexpr (ADAM) k11_adam_row<3>(ad, 1, const_cast<float *>(scaling), i, scraw, gsc);
+        if constexpr (ADAM) {
+#pragma unroll
+            for (int e = 0; e < 3; e++) {
+                sp[3 + e] = scraw[e];
+                sg[3 + e] = gsc[e];
+            }
+        }
         const float r_ = q.x, x = q.y, y = q.z, z = q.w;
         float4 dq;
         dq.x = 2.f * (-z * dR[0][1] + y * dR[0][2] + z * dR[1][0] - x * dR[1][2] - y * dR[2][0] + x * dR[2][1]);
@@ -1135,12 +1284,15 @@ preprocess_backward_batched_body(int P, int B, int M, const float *__restrict__ 
         const float4 gq = make_float4((dq.x - q.x * dot) / qn, (dq.y - q.y * dot) / qn, (dq.z - q.z * dot) / qn,
                                       (dq.w - q.w * dot) / qn);
         if constexpr (ADAM) {
-            const float pq[4] = {qraw.x, qraw.y, qraw.z, qraw.w}, gqa[4] = {gq.x, gq.y, gq.z, gq.w};
-            k11_adam_row<4>(ad, 2, const_cast<float *>(rotation), i, pq, gqa);
+            sp[6] = qraw.x; sp[7] = qraw.y; sp[8] = qraw.z; sp[9] = qraw.w;
+            sg[6] = gq.x; sg[7] = gq.y; sg[8] = gq.z; sg[9] = gq.w;
         } else {
             dL_drotation[i] = gq;
         }
     }
+    if constexpr (ADAM)
+        k11_adam_small(ad, i, const_cast<float *>(xyz), const_cast<float *>(scaling), const_cast<float *>(rotation),
+                       const_cast<float *>(f_dc), const_cast<float *>(opacity), sp, sg);
     }  // i < P
     if (staged) {
         __syncthreads();
@@ -1152,7 +1304,7 @@ preprocess_backward_batched_body(int P, int B, int M, const float *__restrict__ 
 }
 
 template <int DEG>
-__global__ void __launch_bounds__(K11_BLOCK, 2)  // <= 256 registers: two workgroups per CU, not one
+__global__ void __launch_bounds__(K11_BLOCK, 2)  // two waves per SIMD (<= 256 registers), not one
 preprocess_backward_batched_kernel(int P, int B, int M, const float *__restrict__ xyz,
                                    const float *__restrict__ scaling, float scale_modifier,
                                    const float *__restrict__ rotation, const float *__restrict__ f_dc,
@@ -1171,7 +1323,7 @@ preprocess_backward_batched_kernel(int P, int B, int M, const float *__restrict_
 }
 
 template <int DEG>
-__global__ void __launch_bounds__(K11_BLOCK, 2)  // <= 256 registers: two workgroups per CU, not one
+__global__ void __launch_bounds__(K11_BLOCK, 2)  // two waves per SIMD (<= 256 registers), not one
 preprocess_backward_adam_batched_kernel(int P, int B, float *__restrict__ xyz, float *__restrict__ scaling,
                                         float scale_modifier, float *__restrict__ rotation,
                                         float *__restrict__ f_dc, float *__restrict__ f_rest,

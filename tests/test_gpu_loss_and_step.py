@@ -504,8 +504,9 @@ def test_fused_backward_step_equals_k11_then_adam(device, B, deg, N):
     for it, (sa, sb) in enumerate(zip(a, b)):
         for j, (x, y) in enumerate(zip(sa, sb)):
             assert torch.equal(x.cpu(), y.cpu()), f"step {it}, tensor {j}: max |diff| {(x - y).abs().max().item():.3e}"
-    # ... and the update is not a no-op
-    assert not torch.equal(a[0][0], a[3][0]) and not torch.equal(a[0][4], a[3][4])
+    # ... and the update is not a no-op (with active degree 0 the gradient of _features_rest IS zero and its moments
+    # start at zero: that tensor does not move)
+    assert not torch.equal(a[0][0], a[3][0]) and (deg == 0 or not torch.equal(a[0][4], a[3][4]))
 
 
 def test_fused_backward_step_in_the_training_iteration(device):

@@ -427,6 +427,48 @@ def test_fused_exchange_kernels_match_restatement(device):
     assert rel_err(pre - 1.0, ref) < 1e-5
 
 
+def test_exchange_kernels_many_destinations_many_chunks(device):
+    """the same kernels at 70 destinations (running positions in two registers, destinations taken eight at a time with
+    a ragged last block) and 69 chunks (the prefix over the preceding chunks loops twice), exact and slab layouts, and
+    the unpack of a slab that is neither a multiple of 256 rows nor 16-byte aligned"""
+    from oracle import exchange_oracle as XO
+
+    g = torch.Generator().manual_seed(13)
+    B, P, W, width, height = 1, 70000, 70, 800, 2000
+    gy = (height + 15) // 16
+    m2 = (torch.rand(B, P, 2, generator=g) * torch.tensor([width * 1.1, height * 1.1]) - 20.0)
+    radii = torch.randint(0, 40, (B, P), generator=g, dtype=torch.int32)
+    rgb, co, depths = torch.rand(B, P, 3, generator=g), torch.rand(B, P, 4, generator=g), torch.rand(B, P, generator=g)
+    cuts = sorted(set([0, gy] + torch.randperm(gy - 1, generator=g)[:W - 3].add(1).tolist()))  # W - 2 bands
+    bands = torch.zeros(B, W, 2, dtype=torch.int32)
+    for j in range(len(cuts) - 1):  # ranks 1 .. W - 2 render; ranks 0 and W - 1 render nothing of this camera
+        bands[0, j + 1, 0], bands[0, j + 1, 1] = cuts[j], cuts[j + 1]
+    dm2, drad, drgb, dco, ddep, dbands = [t.to(device) for t in (m2, radii, rgb, co, depths, bands)]
+    cc_ref, cnt_ref = XO.exchange_count(m2, radii, bands, 0, B, width, height)
+    cc, cnt = dgr.exchange_count(dm2, drad, dbands, 0, B, width, height)
+    assert torch.equal(cnt.cpu(), cnt_ref) and torch.equal(cc.cpu(), cc_ref)
+    assert int(cnt_ref[0, 0]) == 0 and int(cnt_ref[W - 1, 0]) == 0 and int(cnt_ref.sum()) > P
+    off, o = [], 0
+    for gdst in range(W):
+        off.append(o)
+        o += int(cnt_ref[gdst, 0])
+    msg_ref, idx_ref = XO.exchange_pack(m2, rgb, co, radii, depths, bands, None, off, o, 0, 1, width, height)
+    msg, idx = dgr.exchange_pack(dm2, drgb, dco, drad, ddep, dbands, cc, off, o, 0, 1, width, height)
+    assert torch.equal(idx.cpu(), idx_ref)
+    assert torch.equal(msg.cpu().view(torch.int32), msg_ref.view(torch.int32))
+    caps = [[n + 64, max(n - 3, 0), n][gdst % 3] for gdst, n in enumerate(cnt_ref[:, 0].tolist())]
+    msg_ref, idx_ref = XO.exchange_pack_slab(m2, rgb, co, radii, depths, bands, None, None, caps, 0, 1, width, height)
+    msg, idx = dgr.exchange_pack_slab(dm2, drgb, dco, drad, ddep, dbands, cc, cnt, caps, 0, 1, width, height)
+    assert torch.equal(idx.cpu(), idx_ref)
+    assert torch.equal(msg.cpu().view(torch.int32), msg_ref.view(torch.int32))
+    for first in (0, 1, 3):  # row offsets 0 / 44 / 132 bytes: the vector and the scalar staging path of the unpack
+        part = msg[first:first + 1000 + first]
+        outs = dgr.exchange_unpack(part)
+        refs = XO.exchange_unpack(msg_ref[first:first + 1000 + first])
+        for a, b in zip(outs, refs):
+            assert torch.equal(a.cpu().reshape(b.shape), b), first
+
+
 def test_slab_exchange_kernels_match_restatement(device):
     """gsr_exchange_pack_slab (capacity slabs: records at the front in the reference order, overflowing records dropped,
     zero padding with send index -1), gsr_exchange_unpack and the index -1 skip of gsr_scatter_add_rows against their
