@@ -308,9 +308,19 @@ __global__ void __launch_bounds__(256) l1_ssim_finalize_kernel(int nb, const flo
                                                                 float *__restrict__ out) {
     __shared__ double red[2][4];
     double a = 0.0, b = 0.0;
-    for (int i = threadIdx.x; i < nb; i += 256) {
-        a += (double)partials[2 * i];
-        b += (double)partials[2 * i + 1];
+    // eight independent 8-byte loads per trip (clamped index, masked value): one workgroup is a pure latency chain --
+    // 24 dependent load / add rounds for the 6120 partials of a 1080p image took 8 us
+    const float2 *p2 = reinterpret_cast<const float2 *>(partials);
+    for (int i0 = threadIdx.x; i0 < nb; i0 += 256 * 8) {
+        float2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = p2[min(i0 + 256 * u, nb - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (i0 + 256 * u < nb) {
+                a += (double)v[u].x;
+                b += (double)v[u].y;
+            }
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -388,7 +398,7 @@ extern "C" int gsr_l1_ssim_backward(int channels, int rows, int width, const flo
 
 extern "C" int gsr_l1_ssim_finalize(int num_partials, const float *partials, float c_l1, float c_ssim, float bias,
                                     float inv_n, float *out3, gsr_stream_t stream) {
-    if (num_partials < 0 || !out3 || (num_partials > 0 && !partials)) return GSR_EINVAL;
+    if (num_partials < 0 || !out3 || (num_partials > 0 && !partials) || !aligned_to(partials, 8)) return GSR_EINVAL;
     hipLaunchKernelGGL(l1_ssim_finalize_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        num_partials, partials, c_l1, c_ssim, bias, inv_n, out3);
     GSR_LAUNCH_CHECK();

@@ -375,6 +375,88 @@ __device__ __forceinline__ void k11_adam_small(const K11Adam &ad, size_t i, floa
     }
 }
 
+// The same update with the moments of the five small tensors moved through LDS (the one-camera fused kernel, after its
+// stage-out, when the _features_rest stage is free): every (tensor, moment) chunk of the workgroup -- K11_BLOCK rows of
+// 12 / 16 / 4 bytes, contiguous -- is read and written as ONE 16-byte streaming access per lane, and a lane picks its
+// 14 + 14 values out of LDS.  The per-lane 4-byte accesses of k11_adam_small have to stay cacheable (a streaming load
+// drops the line between a lane's pieces: +0.027 ms measured), and 224 MB of cacheable moment traffic per 10^6
+// Gaussians pushes the PARAMETERS out of the 256 MB memory-side cache -- the next iteration's K1 then reads them from
+// HBM (0.057 -> 0.075 ms).  Through LDS the moments stream past the cache like the optimizer kernel's.
+__device__ __forceinline__ void k11_adam_small_lds(float *__restrict__ lds, const K11Adam &ad, int P, int i,
+                                                   float *__restrict__ xyz, float *__restrict__ scaling,
+                                                   float *__restrict__ rotation, float *__restrict__ f_dc,
+                                                   float *__restrict__ opacity, const float (&pv)[14],
+                                                   const float (&g)[14]) {
+    constexpr int NT = 5;
+    constexpr int TT[NT] = {0, 1, 2, 3, 5}, KK[NT] = {3, 3, 4, 3, 1}, OFF[NT] = {0, 3, 6, 10, 13};  // x K11_BLOCK words
+    constexpr int MV = 14 * K11_BLOCK;  // words of one moment of the five tensors
+    typedef float vf4 __attribute__((ext_vector_type(4)));
+    const size_t row0 = (size_t)blockIdx.x * K11_BLOCK;
+    const int rows = (int)min((size_t)K11_BLOCK, (size_t)P - row0);
+    const int e4 = 4 * (int)threadIdx.x;
+    // ---- in: one 16-byte piece per lane, tensor and moment -- ten independent loads, clamped instead of branched
+    // around so that they stay together (a ragged last block takes the scalar loop)
+    if (rows == K11_BLOCK) {
+        vf4 in[NT][2];
+#pragma unroll
+        for (int j = 0; j < NT; j++)
+#pragma unroll
+            for (int mv = 0; mv < 2; mv++) {
+                const float *src = (mv ? ad.v[TT[j]] : ad.m[TT[j]]) + row0 * KK[j];
+                in[j][mv] = __builtin_nontemporal_load(reinterpret_cast<const vf4 *>(src + min(e4, K11_BLOCK * KK[j] - 4)));
+            }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NT; j++)
+#pragma unroll
+            for (int mv = 0; mv < 2; mv++)
+                if (e4 < K11_BLOCK * KK[j])
+                    *reinterpret_cast<vf4 *>(lds + mv * MV + OFF[j] * K11_BLOCK + e4) = in[j][mv];
+    } else {
+#pragma unroll
+        for (int j = 0; j < NT; j++)
+#pragma unroll
+            for (int mv = 0; mv < 2; mv++) {
+                const float *src = (mv ? ad.v[TT[j]] : ad.m[TT[j]]) + row0 * KK[j];
+                for (int e = threadIdx.x; e < rows * KK[j]; e += K11_BLOCK) lds[mv * MV + OFF[j] * K11_BLOCK + e] = src[e];
+            }
+    }
+    __syncthreads();
+    // ---- the lane's 14 values
+    if (i < P) {
+        constexpr int T[14] = {0, 0, 0, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 5};
+        constexpr int J[14] = {0, 0, 0, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4};
+        constexpr int C[14] = {0, 1, 2, 0, 1, 2, 0, 1, 2, 3, 0, 1, 2, 0};
+        float *const base[6] = {xyz, scaling, rotation, f_dc, nullptr, opacity};
+#pragma unroll
+        for (int e = 0; e < 14; e++) {
+            const int t = T[e], k = KK[J[e]];
+            float *lm = lds + OFF[J[e]] * K11_BLOCK + (int)threadIdx.x * k + C[e];
+            float p = pv[e], m = lm[0], v = lm[MV];
+            gsr_adam1(p, __fmul_rn(g[e], ad.grad_scale), m, v, ad.lr_c[t], ad.b1[t], ad.b2[t], ad.omb1[t], ad.omb2[t],
+                      ad.inv_sqrt_bc2[t], ad.eps[t]);
+            base[t][(size_t)i * k + C[e]] = p;
+            lm[0] = m;
+            lm[MV] = v;
+        }
+    }
+    __syncthreads();
+    // ---- out
+#pragma unroll
+    for (int j = 0; j < NT; j++)
+#pragma unroll
+        for (int mv = 0; mv < 2; mv++) {
+            float *dst = (mv ? ad.v[TT[j]] : ad.m[TT[j]]) + row0 * KK[j];
+            if (rows == K11_BLOCK) {
+                if (e4 < K11_BLOCK * KK[j])
+                    __builtin_nontemporal_store(*reinterpret_cast<const vf4 *>(lds + mv * MV + OFF[j] * K11_BLOCK + e4),
+                                                reinterpret_cast<vf4 *>(dst + e4));
+            } else {
+                for (int e = threadIdx.x; e < rows * KK[j]; e += K11_BLOCK) dst[e] = lds[mv * MV + OFF[j] * K11_BLOCK + e];
+            }
+        }
+}
+
 // the workgroup's rows of _features_rest: gradient from LDS, parameter (just staged in by this workgroup: L2) and
 // both moments from HBM, 16 bytes per lane and access, FOUR accesses per lane in flight before the first is used
 // (three workgroups of four waves per CU do not cover the memory latency with one).
@@ -864,18 +946,24 @@ preprocess_backward_adam_kernel(int P, float *__restrict__ xyz, float *__restric
     __builtin_amdgcn_sched_barrier(0);  // every load of the lane is issued before the first result is used
     rest_stage_commit(s_rest, st, f_rest, P);
     __syncthreads();
-    if (i < P) {
-        float sp[14], sg[14];
+    float sp[14], sg[14];
+    if (i < P)
         preprocess_backward_body<DEG, true, true>(in, sp, sg, i, s_rest + threadIdx.x * REST_W,
                                                   s_rest + threadIdx.x * REST_W, P, 16, xyz, scaling, scale_modifier,
                                                   rotation, f_dc, f_rest, opacity, view, proj, campos, W, H, tanfovx,
                                                   tanfovy, radii, cov3D, clamped, dL_dmeans2D, dL_dconic_opacity,
                                                   dL_drgb, gstride, nullptr, nullptr, nullptr, nullptr, nullptr,
                                                   nullptr);
-        k11_adam_small(ad, i, xyz, scaling, rotation, f_dc, opacity, sp, sg);
-    }
+#ifdef GSR_K11_SMALL_DIRECT
+    if (i < P) k11_adam_small(ad, i, xyz, scaling, rotation, f_dc, opacity, sp, sg);
     __syncthreads();
     rest_adam_out(s_rest, f_rest, ad, P);
+#else
+    __syncthreads();
+    rest_adam_out(s_rest, f_rest, ad, P);
+    __syncthreads();  // the stage is free: the moments of the small tensors go through it
+    k11_adam_small_lds(s_rest, ad, P, i, xyz, scaling, rotation, f_dc, opacity, sp, sg);
+#endif
 }
 
 // ------------------------------------------------------------------------- K1 / K11, batched over cameras
@@ -1521,8 +1609,9 @@ extern "C" int gsr_preprocess_backward_adam_raw_batched(
         ad.inv_sqrt_bc2[t] = (float)(1.0 / sqrt(bc2));
         ad.eps[t] = (float)epss[t];
     }
-    if (((uintptr_t)features_rest | (uintptr_t)ad.m[4] | (uintptr_t)ad.v[4] | (uintptr_t)rotation) & 15)
-        return GSR_EINVAL;
+    uintptr_t al = (uintptr_t)features_rest | (uintptr_t)rotation;
+    for (int t = 0; t < 6; t++) al |= (uintptr_t)ad.m[t] | (uintptr_t)ad.v[t];
+    if (al & 15) return GSR_EINVAL;  // 16-byte accesses on the moments and the _features_rest block
     ad.grad_scale = grad_scale;
     const dim3 grid(gsr_div_up(P, K11_BLOCK)), block(K11_BLOCK);
     if (B == 1 && tanfov0) {  // one camera: the leaner kernel without accumulators (160 registers instead of 270)
