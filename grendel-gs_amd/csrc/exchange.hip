@@ -107,11 +107,32 @@ exchange_count_kernel(int P, int B, int W, int k0, int gx, int gy, int nchunk, c
         int32_t c = 0;
 #pragma unroll
         for (int r = 0; r < R; r++) c += (int32_t)__popcll(__ballot(rows_hit(rows[r], lo, hi)));
-        if (lane == 0) {
-            chunkcnt[((size_t)g * B + kk) * nchunk + chunk] = c;
-            if (c) atomicAdd(&counts[(size_t)g * B + kk], c);
-        }
+        if (lane == 0) chunkcnt[((size_t)g * B + kk) * nchunk + chunk] = c;
     }
+}
+
+// counts[segment] = sum of the segment's per-chunk counts; one workgroup per (destination, camera) segment.  (The count
+// kernel used to add every chunk's count to its segment's total with a global atomic: W x B words of ONE cache line
+// hammered by every wave of the launch -- 5 900 same-line atomics for 0.75 M Gaussians and 8 destinations, which an L2
+// channel retires at ~100 per microsecond.  Once the loads no longer hid it that WAS the kernel: 71 us.)
+__global__ void __launch_bounds__(256)
+exchange_sum_kernel(int nchunk, const int32_t *__restrict__ chunkcnt, int32_t *__restrict__ counts) {
+    __shared__ int32_t red[4];
+    const int32_t *row = chunkcnt + (size_t)blockIdx.x * nchunk;
+    int32_t acc = 0;
+    for (int c0 = threadIdx.x; c0 < nchunk; c0 += 256 * 4) {
+        int32_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = row[min(c0 + 256 * u, nchunk - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (c0 + 256 * u < nchunk) acc += v[u];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
 struct SegOffsets {
@@ -290,13 +311,16 @@ extern "C" int gsr_exchange_count(int P, int B_total, int k0, int B, int W, int 
     if (P < 0 || B < 1 || B > 65535 || k0 < 0 || k0 + B > B_total || W < 1 || W > 256 || W * B > 512 ||
         width <= 0 || height <= 0 || !counts)
         return GSR_EINVAL;
-    GSR_HIP(hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)W * B, stream));
-    if (P == 0) return 0;
+    if (P == 0) {
+        GSR_HIP(hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)W * B, stream));
+        return 0;
+    }
     if (!means2D || !radii || !bands || !chunkcnt) return GSR_EINVAL;
     const int gx = (width + GSR_BLOCK_X - 1) / GSR_BLOCK_X, gy = (height + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y;
     const int nchunk = gsr_div_up(P, XCHUNK);
     hipLaunchKernelGGL(exchange_count_kernel, dim3(gsr_div_up(nchunk, 4), B), dim3(256), 0, stream, P, B, W, k0, gx, gy,
                        nchunk, reinterpret_cast<const float2 *>(means2D), radii, bands, chunkcnt, counts);
+    hipLaunchKernelGGL(exchange_sum_kernel, dim3(W * B), dim3(256), 0, stream, nchunk, chunkcnt, counts);
     GSR_LAUNCH_CHECK();
     return 0;
 }

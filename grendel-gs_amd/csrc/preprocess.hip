@@ -999,8 +999,8 @@ preprocess_forward_batched_kernel(int P, int B, int M, const float *__restrict__
                                   float4 *__restrict__ conic_opacity, float *__restrict__ rgb,
                                   uint8_t *__restrict__ clamped) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
     constexpr int NC = (DEG + 1) * (DEG + 1);
+    if (i >= P) return;
     const int gx = (W + GSR_BLOCK_X - 1) / GSR_BLOCK_X, gy = (H + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y;
     // ---- camera-independent part, once
     const float p[3] = {xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2]};
@@ -1028,8 +1028,9 @@ preprocess_forward_batched_kernel(int P, int B, int M, const float *__restrict__
     shl[1] = f_dc[3 * (size_t)i + 1];
     shl[2] = f_dc[3 * (size_t)i + 2];
     {
-        // (staging these 180-byte rows through LDS as K11 does was measured SLOWER here: 78 -> 96 us; the forward
-        // is light enough that the 46 KB of LDS cost more occupancy than the coalescing returns)
+        // (staging these 180-byte rows through LDS as K11 does does not pay here: with a copy loop 78 -> 96 us in round 2,
+        // with K11's issue / commit split and 128-lane workgroups 60.5 -> 60.0 us at 10^6 and 342 -> 343 us at 6 10^6
+        // Gaussians in round 3 -- the forward has the occupancy to hide the strided rows)
         const float *rp = f_rest + (size_t)i * (M - 1) * 3;
 #pragma unroll
         for (int k = 3; k < NC * 3; k++) shl[k] = rp[k - 3];
@@ -1129,6 +1130,7 @@ preprocess_backward_batched_body(int P, int B, int M, const float *__restrict__ 
         rest_stage_in(s_rest, f_rest, P);
         __syncthreads();
     }
+    float sp[14], sg[14];  // ADAM: the per-lane parameters / gradients, updated after the stage-out (below)
     if (i < P) {
     constexpr int NC = (DEG + 1) * (DEG + 1);
     const float p[3] = {xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2]};
@@ -1286,7 +1288,6 @@ preprocess_backward_batched_body(int P, int B, int M, const float *__restrict__ 
         }
     }
     // ---- stores + the camera-independent tail (cov3D -> scale / quaternion, activations), once
-    float sp[14], sg[14];  // ADAM: the per-lane parameters / gradients, updated together at the end
     if constexpr (ADAM) {
 #pragma unroll
         for (int e = 0; e < 3; e++) {
@@ -1378,16 +1379,18 @@ preprocess_backward_batched_body(int P, int B, int M, const float *__restrict__ 
             dL_drotation[i] = gq;
         }
     }
-    if constexpr (ADAM)
-        k11_adam_small(ad, i, const_cast<float *>(xyz), const_cast<float *>(scaling), const_cast<float *>(rotation),
-                       const_cast<float *>(f_dc), const_cast<float *>(opacity), sp, sg);
     }  // i < P
     if (staged) {
         __syncthreads();
-        if constexpr (ADAM)
+        if constexpr (ADAM) {
             rest_adam_out(s_rest, const_cast<float *>(f_rest), ad, P);
-        else
+            __syncthreads();  // the stage is free: the moments of the small tensors go through it
+            k11_adam_small_lds(s_rest, ad, P, i, const_cast<float *>(xyz), const_cast<float *>(scaling),
+                               const_cast<float *>(rotation), const_cast<float *>(f_dc), const_cast<float *>(opacity),
+                               sp, sg);
+        } else {
             rest_stage_out(s_rest, dL_drest, P);
+        }
     }
 }
 

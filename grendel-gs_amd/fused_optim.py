@@ -31,6 +31,7 @@ class FusedAdam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self.grad_scale = float(grad_scale)
         self._pending = None
+        self._owners_cache = None
         self.fused_steps = 0         # steps in which K11 ran inside the optimizer kernel
         self.materialized_steps = 0  # deferred backwards that had to fall back to the plain K11
         self.fuse_backward = False
@@ -57,16 +58,28 @@ class FusedAdam(torch.optim.Optimizer):
                     return group, p
         return None
 
+    def _owners_of(self, params):
+        """[(group, parameter)] x 6 for the six tensors of a projection backward, or None when one of them is not
+        optimized here (or two share a parameter); cached per set of addresses -- the lookup runs every iteration"""
+        key = tuple(t.data_ptr() for t in params)
+        cached = self._owners_cache
+        if cached is not None and cached[0] == key and \
+                all(any(q is p for q in g["params"]) and p.data_ptr() == k for (g, p), k in zip(cached[1], key)):
+            return cached[1]
+        owners = [self._owner(t) for t in params]
+        if any(o is None for o in owners) or len({id(o[1]) for o in owners}) != len(owners):
+            self._owners_cache = None
+            return None
+        self._owners_cache = (key, owners)
+        return owners
+
     def accepts(self, params):
         """called by the operator's backward: True when all six raw parameters are optimized here and carry no other
         gradient -- then offer() follows and the node returns no gradients"""
         if not self.fuse_backward:
             return False
-        for t in params:
-            o = self._owner(t)
-            if o is None or o[1].grad is not None or not o[1].requires_grad:
-                return False
-        return True
+        owners = self._owners_of(params)
+        return owners is not None and all(p.grad is None and p.requires_grad for _, p in owners)
 
     def offer(self, pending):
         if self._pending is not None:  # a second backward before the step: both become ordinary gradients
@@ -104,9 +117,8 @@ class FusedAdam(torch.optim.Optimizer):
         """-> set of parameters updated by the fused K11 + Adam launch (empty when the pending backward had to be
         materialized instead)"""
         pend = self._pending
-        owners = [self._owner(t) for t in pend.params]
-        fusable = all(o is not None and o[1].grad is None and o[1].is_contiguous() for o in owners) and \
-            len({id(o[1]) for o in owners if o is not None}) == 6
+        owners = self._owners_of(pend.params)  # None: a parameter was replaced since the backward
+        fusable = owners is not None and all(p.grad is None and p.is_contiguous() for _, p in owners)
         if fusable:
             for idx, t in enumerate(pend.params):
                 if t._version != pend.versions[idx]:
