@@ -38,6 +38,14 @@ class FusedAdam(torch.optim.Optimizer):
         if fuse_backward:
             self.set_fuse_backward(True)
 
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        # an unpickled optimizer never is the sink of a pending backward: re-arm with set_fuse_backward(True)
+        self.__dict__.setdefault("grad_scale", 1.0)
+        self._pending, self._owners_cache, self.fuse_backward = None, None, False
+        self.__dict__.setdefault("fused_steps", 0)
+        self.__dict__.setdefault("materialized_steps", 0)
+
     # ------------------------------------------------------------------ deferred K11 (see the module docstring)
     def set_fuse_backward(self, on):
         """register / unregister this optimizer as the sink of the operator's deferred projection backward (one

@@ -120,3 +120,13 @@ def test_replaced_parameter_is_skipped_and_inplace_edit_is_refused():
             opt2.step()
     finally:
         opt.set_fuse_backward(False)
+
+
+def test_unpickled_optimizer_comes_back_disarmed():
+    """__setstate__ (what unpickling / copy.deepcopy of an optimizer runs): no pending backward, not the sink"""
+    m, opt, params = make()
+    opt.offer(FakePending(params))
+    fresh = opt.__class__.__new__(opt.__class__)
+    fresh.__setstate__({"defaults": opt.defaults, "state": {}, "param_groups": opt.param_groups})
+    assert fresh._pending is None and fresh.fuse_backward is False and fresh.grad_scale == 1.0
+    assert not fresh.accepts(params)

@@ -615,6 +615,46 @@ def test_fused_backward_step_in_the_training_iteration(device):
         opt.set_fuse_backward(False)
 
 
+def test_fused_backward_is_not_offered_a_model_without_sixteen_coefficients(device):
+    """the fused K11 + Adam kernel exists for 16-coefficient models (its LDS stage is sized for 45 floats of
+    _features_rest per Gaussian); any other model keeps the two-kernel path: ordinary `.grad`s, ordinary step -- and the
+    C entry point refuses such a call instead of misreading the rows"""
+    import ctypes
+
+    import diff_gaussian_rasterization as dgr
+    from fused_optim import FusedAdam
+    from helpers import settings_from
+
+    N, W, H = 5000, 240, 160
+    m = S.SyntheticGaussianModel(N, W, H, seed=6, device=device, scale_coef=0.012)
+    m._features_rest = torch.nn.Parameter(m._features_rest.detach()[:, :8].contiguous())  # 9 coefficients: degree 2
+    m.active_sh_degree = 2
+    names = ("_xyz", "_scaling", "_rotation", "_features_dc", "_features_rest", "_opacity")
+    opt = FusedAdam(m.param_groups(), lr=0.0, eps=1e-15, fuse_backward=True)
+    try:
+        cam = S.orbit_cameras(8, W, H, device=device)[0]
+        rs = dgr.GaussianRasterizer(settings_from(cam, torch.zeros(3), sh_degree=2)).raster_settings
+        packed = dgr.pack_camera(rs).view(1, -1)
+        before = m._features_rest.detach().clone()
+        m2, rgb, co, radii, depths = dgr.preprocess_gaussians_raw_batched(
+            *[getattr(m, n) for n in names], packed, 2, 1.0, W, H, tanfov0=(rs.tanfovx, rs.tanfovy))
+        (m2[0].sum() + rgb[0].sum() + co[0].sum()).backward()
+        assert opt._pending is None and all(getattr(m, n).grad is not None for n in names)
+        opt.step()
+        assert opt.fused_steps == 0 and not torch.equal(m._features_rest.detach(), before)
+        st = opt.state
+        VP, D, I64 = ctypes.c_void_p * 6, ctypes.c_double * 6, ctypes.c_int64 * 6
+        rc = dgr.lib.gsr_preprocess_backward_adam_raw_batched(
+            N, 1, 2, 9, *[getattr(m, n).data_ptr() for n in names[:2]], 1.0, *[getattr(m, n).data_ptr() for n in names[2:]],
+            packed.data_ptr(), W, H, radii[0].data_ptr(), m2[0].data_ptr(), m2[0].data_ptr(), m2[0].data_ptr(),
+            co[0].data_ptr(), rgb[0].data_ptr(), 0, VP(*[st[getattr(m, n)]["exp_avg"].data_ptr() for n in names]),
+            VP(*[st[getattr(m, n)]["exp_avg_sq"].data_ptr() for n in names]), D(*[0.0] * 6), D(*[0.9] * 6), D(*[0.999] * 6),
+            D(*[1e-15] * 6), I64(*[2] * 6), 1.0, None, None)
+        assert rc != 0 and b"invalid" in dgr.lib.gsr_error_string(rc).lower()
+    finally:
+        opt.set_fuse_backward(False)
+
+
 def test_legacy_render_equals_render_final(device):
     """`gaussian_renderer.render()` (the legacy single-camera surface north_star names) == render_final, W = 1"""
     import gaussian_renderer as gr
