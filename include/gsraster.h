@@ -226,8 +226,9 @@ int gsr_exchange_need(int P, int B, int W, int width, int height, const float *m
  * all_to_all_communication_final (gaussian_renderer/__init__.py:542-698) runs K2, then nonzero() per (camera, band),
  * index_select + cat per destination; its autograd backward is an index_put with accumulate.  Here, for the cameras
  * [k0, k0 + B) of a batch of B_total whose state is camera-major ([B_total,P,.] arrays):
- *   gsr_exchange_count : counts int32 [W][B] (zeroed here) = number of Gaussians rank g needs of camera k0 + kk, and
- *       chunkcnt int32 [W * B][gsr_exchange_chunks(P)] = the same per 1024-Gaussian chunk (a workspace for pack);
+ *   gsr_exchange_count : counts int32 [W][B] (every entry written here) = number of Gaussians rank g needs of camera
+ *       k0 + kk, and chunkcnt int32 [W * B][gsr_exchange_chunks(P)] = the same per 1024-Gaussian chunk (a workspace for
+ *       pack; counts is its row sums, formed by a second launch -- no atomics);
  *   gsr_exchange_pack  : after the caller has turned the counts of all ranks into the layout of its send buffer --
  *       segment_offsets[g * B + kk] (HOST array, W * B <= 512 entries) = first row of the (destination g, camera
  *       k0 + kk) segment -- writes the 11-float records (means2D 2, rgb 3, conic_opacity 4, radius bits, depth) into
