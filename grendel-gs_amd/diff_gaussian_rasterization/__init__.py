@@ -437,22 +437,30 @@ class PendingProjectionBackward:
         return _launch_k11(self.params, self.cams, self.radii, self.cov3D, self.clamped, self.g_means2D,
                            self.g_conic_opacity, self.g_rgb, self.gstride, self.meta, self.tanfov0, None)
 
-    def fused_step(self, exp_avgs, exp_avg_sqs, lrs, beta1s, beta2s, epss, steps, grad_scale):
-        """K11 + Adam of the six tensors in one launch; arguments in the order of self.params"""
+    def fused_step(self, exp_avgs, exp_avg_sqs, lrs, beta1s, beta2s, epss, steps, grad_scale, cache=None):
+        """K11 + Adam of the six tensors in one launch; arguments in the order of self.params.  `cache`: a dict the
+        caller keeps between steps -- the ctypes tables of the moments' addresses and of the betas / eps only change
+        when the model is rebuilt, and this call sits on the host's critical path in front of the launch."""
         self.join_stream()
         xyz, scaling, rotation, f_dc, f_rest, opacity = self.params
         deg, smod, W, H, M = self.meta
         P, B = xyz.shape[0], self.cams.shape[0]
         VP, D, I64 = ctypes.c_void_p * 6, ctypes.c_double * 6, ctypes.c_int64 * 6
+        key = (tuple(t.data_ptr() for t in exp_avgs), tuple(t.data_ptr() for t in exp_avg_sqs), tuple(beta1s),
+               tuple(beta2s), tuple(epss))
+        tabs = cache.get("tabs") if cache is not None else None
+        if tabs is None or tabs[0] != key:
+            tabs = (key, VP(*key[0]), VP(*key[1]), D(*beta1s), D(*beta2s), D(*epss))
+            if cache is not None:
+                cache["tabs"] = tabs
         tf = (ctypes.c_float * 2)(float(self.tanfov0[0]), float(self.tanfov0[1])) \
             if (B == 1 and self.tanfov0 is not None) else None
         with _on(xyz.device), kernel_timer.range("preprocess_backward_adam", N=P, B=B, M=M):
             check(lib.gsr_preprocess_backward_adam_raw_batched(
                 P, B, deg, M, _ptr(xyz), _ptr(scaling), smod, _ptr(rotation), _ptr(f_dc), _ptr(f_rest), _ptr(opacity),
                 _ptr(self.cams), W, H, _ptr(self.radii), _ptr(self.cov3D), _ptr(self.clamped), _ptr(self.g_means2D),
-                _ptr(self.g_conic_opacity), _ptr(self.g_rgb), self.gstride, VP(*[t.data_ptr() for t in exp_avgs]),
-                VP(*[t.data_ptr() for t in exp_avg_sqs]), D(*lrs), D(*beta1s), D(*beta2s), D(*epss), I64(*steps),
-                float(grad_scale), tf, _stream()), "gsr_preprocess_backward_adam_raw_batched")
+                _ptr(self.g_conic_opacity), _ptr(self.g_rgb), self.gstride, tabs[1], tabs[2], D(*lrs), tabs[3], tabs[4],
+                tabs[5], I64(*steps), float(grad_scale), tf, _stream()), "gsr_preprocess_backward_adam_raw_batched")
 
 
 def _launch_k11(params, cams, radii, cov3D, clamped, g_means2D, g_conic_opacity, g_rgb, gstride, meta, tanfov0,

@@ -32,6 +32,7 @@ class FusedAdam(torch.optim.Optimizer):
         self.grad_scale = float(grad_scale)
         self._pending = None
         self._owners_cache = None
+        self._launch_cache = {}
         self.fused_steps = 0         # steps in which K11 ran inside the optimizer kernel
         self.materialized_steps = 0  # deferred backwards that had to fall back to the plain K11
         self.fuse_backward = False
@@ -42,7 +43,7 @@ class FusedAdam(torch.optim.Optimizer):
         super().__setstate__(state)
         # an unpickled optimizer never is the sink of a pending backward: re-arm with set_fuse_backward(True)
         self.__dict__.setdefault("grad_scale", 1.0)
-        self._pending, self._owners_cache, self.fuse_backward = None, None, False
+        self._pending, self._owners_cache, self._launch_cache, self.fuse_backward = None, None, {}, False
         self.__dict__.setdefault("fused_steps", 0)
         self.__dict__.setdefault("materialized_steps", 0)
 
@@ -145,11 +146,13 @@ class FusedAdam(torch.optim.Optimizer):
                 st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
             sts.append(st)
-        torch._foreach_add_([st["step"] for st in sts], 1)
+        # (the launch first, the host-side step counters after it: at world size > 1 the host is the bottleneck and
+        # everything in front of this launch is time the GPU idles)
         pend.fused_step([st["exp_avg"] for st in sts], [st["exp_avg_sq"] for st in sts],
                         [g["lr"] for g, _ in owners], [g["betas"][0] for g, _ in owners],
                         [g["betas"][1] for g, _ in owners], [g["eps"] for g, _ in owners],
-                        [int(st["step"]) for st in sts], grad_scale)
+                        [int(st["step"]) + 1 for st in sts], grad_scale, cache=self._launch_cache)
+        torch._foreach_add_([st["step"] for st in sts], 1)
         self.fused_steps += 1
         return {id(p) for _, p in owners}
 

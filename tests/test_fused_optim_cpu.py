@@ -28,7 +28,7 @@ class FakePending:
         self.materialized += 1
         return tuple(torch.full_like(t, float(i + 1)) for i, t in enumerate(self.params))
 
-    def fused_step(self, exp_avgs, exp_avg_sqs, lrs, b1, b2, eps, steps, grad_scale):
+    def fused_step(self, exp_avgs, exp_avg_sqs, lrs, b1, b2, eps, steps, grad_scale, cache=None):
         self.fused_calls.append((list(lrs), list(steps), grad_scale, [tuple(t.shape) for t in exp_avgs]))
 
 

@@ -1,5 +1,6 @@
 """Where does the GPU idle inside a training iteration?  From a rocprofv3 kernel trace (rocpd sqlite) of bench.py:
-take the steady-state iterations (delimited by adam_multi_kernel), and for every kernel print its mean duration and
+take the steady-state iterations (delimited by the optimizer kernel: adam_multi_kernel, or the fused
+preprocess_backward_adam kernel when K11 runs inside the step), and for every kernel print its mean duration and
 the mean idle gap on the device BEFORE it (start - previous kernel's end, all queues merged).
 Usage: python tools/gap_analysis.py results.db [skip_iterations]"""
 import sqlite3
@@ -23,11 +24,11 @@ def main():
     s_col = "start" if "start" in cols else "start_timestamp"
     e_col = "end" if "end" in cols else "end_timestamp"
     rows = c.execute(f"select name, {s_col}, {e_col} from kernels order by {s_col}").fetchall()
-    # iterations: from the end of one adam kernel to the end of the next
+    # iterations: from the end of one optimizer kernel to the end of the next
     its, cur = [], []
     for name, s, e in rows:
         cur.append((short(name), s, e))
-        if "adam_multi_kernel" in name:
+        if "adam_multi_kernel" in name or "preprocess_backward_adam" in name:
             its.append(cur)
             cur = []
     its = its[skip:]
