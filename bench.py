@@ -330,7 +330,11 @@ def run_workload(a, name, world, rank, dev, steps, warmup, repeats, render_steps
            "kernels_region_ms_per_step": (1e3 * dt_instr / steps) if dt_instr else None,
            "optimizer": {"fuse_backward": bool(opt.fuse_backward), "fused_steps": fused_steps,
                          "materialized_steps": opt.materialized_steps,
-                         "ms_per_step_two_kernels": round(1e3 * dt_unfused / steps, 4) if dt_unfused else None},
+                         "ms_per_step_two_kernels": round(1e3 * dt_unfused / steps, 4) if dt_unfused else None,
+                         "images_per_s_two_kernels": round(bsz * steps / dt_unfused, 3) if dt_unfused else None,
+                         "note": "fuse_backward: K11 runs inside the optimizer kernel (same arithmetic bit for bit, "
+                                 "tests/test_gpu_loss_and_step.py); *_two_kernels = the same steps with K11 and Adam "
+                                 "as separate launches, best of two regions timed after the contract's regions"},
            "timing": {"repeats": len(per_step), "ms_per_step_median": round(percentile(per_step, 0.5), 4),
                       "ms_per_step_p10": round(percentile(per_step, 0.1), 4),
                       "ms_per_step_p90": round(percentile(per_step, 0.9), 4),
