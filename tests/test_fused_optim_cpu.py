@@ -130,3 +130,78 @@ def test_unpickled_optimizer_comes_back_disarmed():
     fresh.__setstate__({"defaults": opt.defaults, "state": {}, "param_groups": opt.param_groups})
     assert fresh._pending is None and fresh.fuse_backward is False and fresh.grad_scale == 1.0
     assert not fresh.accepts(params)
+
+
+@pytest.fixture
+def fake_library(monkeypatch):
+    """the operator's Python plumbing on HOST tensors: every C-ABI entry point is replaced by a ctypes callback with the
+    real prototype (include/gsraster.h via _lib.SIGNATURES), so argument counts and types are checked exactly as on
+    the GPU box while nothing is computed; -> list of (entry point, number of arguments) in call order"""
+    import contextlib
+    import ctypes
+
+    import diff_gaussian_rasterization as dgr
+    import fused_optim
+    from diff_gaussian_rasterization import _lib
+
+    calls = []
+
+    class Fake:
+        def __getattr__(self, name):
+            res, args = _lib.SIGNATURES[name]
+
+            def cb(*a):
+                calls.append((name, len(a)))
+                return 0
+
+            f = ctypes.CFUNCTYPE(res, *args)(cb)
+            setattr(self, name, f)
+            return f
+
+    fake = Fake()
+    monkeypatch.setattr(dgr, "lib", fake)
+    monkeypatch.setattr(fused_optim._lib, "lib", fake)
+    monkeypatch.setattr(dgr, "_f32c", lambda t, n: t.float().contiguous())
+    monkeypatch.setattr(dgr, "_on", lambda dev: contextlib.nullcontext())
+    monkeypatch.setattr(dgr, "_stream", lambda: None)
+    return calls
+
+
+@pytest.mark.parametrize("B", [1, 3])
+def test_operator_hands_the_projection_backward_to_the_optimizer(fake_library, B):
+    """_PreprocessGaussiansRawBatched.backward with a sink: no K11 launch, no `.grad`, ONE fused launch at step();
+    without a sink (or after set_fuse_backward(False)): the plain K11 of that batch size; two backwards before one
+    step: two plain K11 launches, summed gradients"""
+    import diff_gaussian_rasterization as dgr
+    from fused_optim import FusedAdam
+
+    calls = fake_library
+    m = S.SyntheticGaussianModel(500, 64, 48, seed=1)
+    opt = FusedAdam(m.param_groups(), lr=0.0, eps=1e-15, fuse_backward=True, grad_scale=1.0 / B)
+    raw = [getattr(m, n) for n in NAMES]
+    cams = torch.zeros(B, 40)
+
+    def backward_once():
+        m2, rgb, co, radii, depths = dgr.preprocess_gaussians_raw_batched(*raw, cams, 3, 1.0, 64, 48, tanfov0=(0.5, 0.4))
+        sum((m2[k] ** 2).sum() + rgb[k].sum() + co[k].sum() for k in range(B)).backward()
+
+    backward_once()
+    assert all(p.grad is None for p in raw) and opt._pending is not None
+    assert [c[0] for c in calls] == ["gsr_preprocess_forward_raw_batched"]
+    opt.step()
+    opt.zero_grad()
+    assert [c[0] for c in calls][-1] == "gsr_preprocess_backward_adam_raw_batched" and opt.fused_steps == 1
+    assert all(float(opt.state[p]["step"]) == 1.0 for p in raw)
+    calls.clear()
+    opt.set_fuse_backward(False)
+    backward_once()
+    plain = "gsr_preprocess_backward_raw" if B == 1 else "gsr_preprocess_backward_raw_batched"
+    assert [c[0] for c in calls] == ["gsr_preprocess_forward_raw_batched", plain]
+    assert all(p.grad is not None for p in raw)
+    opt.zero_grad()
+    calls.clear()
+    opt.set_fuse_backward(True)
+    backward_once()
+    backward_once()
+    assert [c[0] for c in calls].count(plain) == 2 and opt._pending is None and opt.materialized_steps == 2
+    assert all(p.grad is not None for p in raw)
