@@ -126,3 +126,31 @@ def test_band_aware_xcd_map_is_a_balanced_bijection():
             assert abs(len(bt) - hull / 8) < 1 + 1e-9
         if hull == T:
             assert m == [span(b, T) for b in range(T)]
+
+
+def test_bench_accounting_knows_the_fused_step():
+    """bench.py's algorithmic bytes of the fused K11 + Adam launch = K11's + Adam's minus the gradient round trip and
+    the optimizer's parameter read; tools/pmc_collect.py files the fused kernels under their own group"""
+    import importlib.util
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for B in (1, 4):
+        m = {"N": 1000, "B": B, "M": 16}
+        k11 = bench.algorithmic_bytes("preprocess_backward", m)
+        adam = bench.algorithmic_bytes("adam", {"numel": 1000 * 59})
+        fused = bench.algorithmic_bytes("preprocess_backward_adam", m)
+        assert fused == k11 + adam - 1000 * 3 * 236 == 1000 * (1416 + 80 * B)
+    spec = importlib.util.spec_from_file_location("pmc_collect", os.path.join(root, "tools", "pmc_collect.py"))
+    pc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pc)
+    assert pc.group_of("void (anonymous namespace)::preprocess_backward_adam_kernel<3>(int, float*)") == \
+        "preprocess_backward_adam"
+    assert pc.group_of("void (anonymous namespace)::preprocess_backward_adam_batched_kernel<3>(int, int)") == \
+        "preprocess_backward_adam"
+    assert pc.group_of("void (anonymous namespace)::preprocess_backward_kernel<3, true>(int, int)") == \
+        "preprocess_backward"
+    assert pc.group_of("(anonymous namespace)::adam_multi_kernel((anonymous namespace)::AdamBatch, float)") == "adam"
