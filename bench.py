@@ -179,6 +179,19 @@ class _SingleRankView:
         u.GLOBAL_RANK, u.WORLD_SIZE, u.DEFAULT_GROUP, u.IN_NODE_GROUP = self.saved
 
 
+def self_launch_command(n, argv):
+    """argv of `python -m torch.distributed.run` that runs this file with one rank per GPU on this node (rendezvous on
+    127.0.0.1: the container's hostname may not resolve)"""
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
 def percentile(xs, q):
     xs = sorted(xs)
     k = (len(xs) - 1) * q
@@ -423,8 +436,13 @@ def main():
     import utils.general_utils as utils
 
     world = int(os.environ.get("WORLD_SIZE", 1))
-    if world != a.gpus and world == 1 and a.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: become the launcher the reference's README uses (torchrun --standalone
+        # --nproc-per-node N, README.md:199-202) -- one process per GPU over RCCL; rank 0 prints the JSON line
+        sys.stdout.flush()
+        os.execv(sys.executable, self_launch_command(a.gpus, sys.argv[1:]))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     if local_rank >= torch.cuda.device_count():  # several ranks sharing one device (tools/, tests): not a bench mode
         local_rank = 0
@@ -606,6 +624,12 @@ def main():
         out["extra_workloads"] = ews
     if world > 1:
         out["config"]["balance_timing"] = a.balance_timing
+        try:
+            rccl = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception as e:  # noqa: BLE001
+            rccl = f"unknown ({type(e).__name__})"
+        out["distributed"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "rccl_version": rccl,
+                              "devices_visible": torch.cuda.device_count(), "launcher": "torch.distributed.run"}
         import gaussian_renderer as gr
 
         out["exchange_layouts"] = dict(gr.exchange_stats)

@@ -197,7 +197,10 @@ class FusedAdam(torch.optim.Optimizer):
             dev = part[0][0].device
             # the pointer tables of parameters and moments only change when the model is rebuilt (densification,
             # restore): cached per launch group, keyed by the parameters' addresses
-            key = tuple(b[0].data_ptr() for b in part) + tuple(b[2]["exp_avg"].data_ptr() for b in part)
+            # AND by everything else the plan holds (sizes, both moments): densification replaces every tensor several
+            # times between two steps and the caching allocator may hand an old address back with a different size
+            key = tuple((b[0].data_ptr(), b[0].numel(), b[2]["exp_avg"].data_ptr(), b[2]["exp_avg_sq"].data_ptr())
+                        for b in part)
             plan = self._plans.get(i) if hasattr(self, "_plans") else None
             if plan is None or plan[0] != key:
                 for b in part:

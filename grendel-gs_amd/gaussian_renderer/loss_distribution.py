@@ -53,7 +53,7 @@ def _band_of(camera, l, r, device):
         return src[:, y0:y1, :].to(device, non_blocking=True).contiguous()
     cache = getattr(camera, "_gsr_bands", None)
     key = (y0, y1, src.data_ptr(), src._version)
-    if cache is None or cache[0][2:] != key[2:]:
+    if cache is None or (cache and cache[0][0][2:] != key[2:]):  # entries are (key, band): another image / new contents
         cache = []
     for k_, band in cache:
         if k_ == key:

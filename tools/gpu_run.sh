@@ -1,0 +1,89 @@
+#!/bin/bash
+# One GPU session, stages chosen on the command line:  tools/gpu_run.sh <tag> <stage> [<stage> ...]
+#   fw        tests/test_gpu_fake_world.py (asynchronous multi-rank iteration on one device)
+#   test      the whole -m gpu suite
+#   quick     the parity / loss-and-step / golden tests only
+#   bench     bench.py, default flags (the contract's N = 1 line)          -> bench.json
+#   benchq    bench.py --no-extra --no-cpu-baseline (headline workload only) -> benchq.json
+#   ab        benchq for the production library and every variants/libgsraster_*.so
+#   fake      tools/fake_world_bench.py --workload c2 --worlds 1 2 4 8      -> fake_world_c2.txt
+#   fake8     the same, W = 1 and 8 only
+#   gaps8     kernel trace of one rank of the fake 8-rank world + idle gaps  -> fake_world_w8_gaps.txt
+#   pmc       kernel trace + PMC passes of the bench command (tools/pmc_collect.py) -> pmc.json / pmc.txt
+# Everything lands in gpurun_out/<tag>/.
+set -u
+TAG=${1:-r04}; shift || true
+STAGES=${*:-fw benchq}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+export TMPDIR=/tmp
+has() { [[ " $STAGES " == *" $1 "* ]]; }
+cd $R
+summ() {  # json file -> one line
+  python - "$1" "$2" <<'PY'
+import json, sys
+try:
+    d = json.load(open(sys.argv[1]))
+    k = d["kernels"]
+    print("%-14s %7.1f img/s  %.3f ms  views %7.1f | " % (sys.argv[2], d["value"], d["ms_per_step"], d["rendered_views_per_sec"]) +
+          "  ".join("%s %.4f" % (n[:16], v["avg_ms"]) for n, v in k.items()))
+except Exception as e:
+    print(sys.argv[2], "FAILED", e)
+PY
+}
+if has fw; then
+  timeout 900 python -m pytest tests/test_gpu_fake_world.py -q -m gpu -x -s -p no:cacheprovider > $O/fw.log 2>&1
+  echo "fw pytest exit $?" | tee -a $O/fw.log
+  grep -E "fake world|passed|failed|Error|error" $O/fw.log | tail -15
+fi
+if has quick; then
+  timeout 1200 python -m pytest tests/test_gpu_loss_and_step.py tests/test_gpu_parity.py tests/test_gpu_golden.py -q -m gpu -x -p no:cacheprovider > $O/quick.log 2>&1
+  echo "quick pytest exit $?" | tee -a $O/quick.log
+  tail -4 $O/quick.log
+fi
+if has test; then
+  timeout 1500 python -m pytest tests -q -m gpu -x -p no:cacheprovider > $O/gputest.log 2>&1
+  echo "pytest exit $?" | tee -a $O/gputest.log
+  tail -6 $O/gputest.log
+fi
+if has bench; then
+  timeout 900 python bench.py > $O/bench.json 2> $O/bench.err
+  echo "bench exit $?"
+  summ $O/bench.json bench
+fi
+if has benchq; then
+  timeout 300 python bench.py --no-cpu-baseline --no-extra --steps 30 --warmup 6 --repeats 3 --render-steps 10 > $O/benchq.json 2> $O/benchq.err
+  summ $O/benchq.json benchq | tee -a $O/ab.txt
+fi
+if has ab; then
+  for lib in $(ls variants/libgsraster_*.so 2>/dev/null); do
+    [[ $lib == *stats* ]] && continue
+    n=$(basename $lib .so); n=${n#libgsraster_}
+    GSRASTER_LIB=$R/$lib timeout 300 python bench.py --no-cpu-baseline --no-extra --steps 30 --warmup 6 --repeats 3 --render-steps 10 > $O/ab_$n.json 2> $O/ab_$n.err
+    summ $O/ab_$n.json $n | tee -a $O/ab.txt
+  done
+  timeout 300 python bench.py --no-cpu-baseline --no-extra --steps 30 --warmup 6 --repeats 3 --render-steps 10 > $O/ab_production2.json 2> $O/ab_production2.err
+  summ $O/ab_production2.json production2 | tee -a $O/ab.txt
+fi
+if has fake; then
+  timeout 600 python tools/fake_world_bench.py --workload c2 --worlds 1 2 4 8 --steps 20 > $O/fake_world_c2.txt 2> $O/fake_world_c2.err
+  cut -c1-400 $O/fake_world_c2.txt
+fi
+if has fake8; then
+  timeout 400 python tools/fake_world_bench.py --workload c2 --worlds 1 8 --steps 20 > $O/fake_world_c2.txt 2> $O/fake_world_c2.err
+  cut -c1-400 $O/fake_world_c2.txt
+fi
+if has gaps8; then
+  cd /tmp
+  timeout 400 rocprofv3 --kernel-trace -d $O/prof_fw -- python $R/tools/fake_world_bench.py --workload c2 --worlds 8 --steps 24 --warmup 6 > $O/fake_world_c2_w8.txt 2> $O/fake_world_c2_w8.err
+  cd $R
+  DB=$(find $O/prof_fw -name "*.db" | head -1)
+  python tools/gap_analysis.py $DB 12 > $O/fake_world_w8_gaps.txt 2>&1
+  find $O -name "*.db" -size +8M -delete
+  cut -c1-110 $O/fake_world_w8_gaps.txt
+fi
+if has pmc; then
+  bash tools/gpu_session.sh $TAG trace sq fetch write > $O/pmc_session.log 2>&1
+  tail -5 $O/pmc_session.log
+fi
