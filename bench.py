@@ -251,10 +251,9 @@ def run_workload(a, name, world, rank, dev, steps, warmup, repeats, render_steps
         state["it"] += 1
         return [cameras[(s + j) % n_views] for j in range(bsz)]
 
-    def train_step():
-        cams = batch()
-        utils.set_cur_iter(utils.get_cur_iter() + bsz)
-        strategies, tasks = start_strategy_final(cams, history)
+    def iteration(cams, strategies, tasks, between=None):
+        """GT staging .. optimizer step of one batch (train_internal.py:134-208, 316-329); `between` runs where the
+        reference calls finish_strategy_final, between backward and step"""
         load_camera_from_cpu_to_all_gpu(cams, strategies, tasks)
         pkg = distributed_preprocess3dgs_and_all2all_final(cams, model, pipe, bg, batched_strategies=strategies,
                                                            mode="train")
@@ -262,13 +261,44 @@ def run_workload(a, name, world, rank, dev, steps, warmup, repeats, render_steps
         stats = [ca["stats_collector"] for ca in pkg["batched_cuda_args"]]
         loss, _ = batched_loss_computation(images, cams, masks, strategies, stats)
         loss.backward()
-        finish_strategy_final(cams, history, strategies, stats)
+        if between is not None:
+            between(stats)
         opt.step()
         opt.zero_grad(set_to_none=True)
         for cam in cams:
             cam.original_image = None
         state["sizes"] = pkg["gpui_to_gpuj_imgk_size"]
+        state["loss"] = loss
+        return loss
+
+    # --graph: the iteration replayed as ONE hipGraph (graphed_step.py) whenever nothing consumes per-iteration timings
+    # (frozen load-balancer heuristics); with live heuristics, `--balance-every R` makes every R-th iteration an eager,
+    # timed one that feeds the balancer and freezes the partition in between
+    from gaussian_renderer.workload_division import timings_have_consumer
+    graphed = None
+    if getattr(a, "graph", "off") == "on" and opt.fuse_backward:
+        from graphed_step import GraphedIteration
+        graphed = GraphedIteration(opt, iteration)
+    state["graph"] = graphed
+    every = max(int(getattr(a, "balance_every", 0) or 0), 0)
+    args_ns = utils.get_args()
+    live_default = not args_ns.no_heuristics_update
+
+    def train_step():
+        cams = batch()
+        utils.set_cur_iter(utils.get_cur_iter() + bsz)
+        if graphed is not None and every and live_default:
+            args_ns.no_heuristics_update = (state["it"] % every) != 1  # probe iterations keep the reference's mode
+        strategies, tasks = start_strategy_final(cams, history)
         state["bands"] = [(s.gpu_ids, s.division_pos) for s in strategies]
+        if graphed is not None and not timings_have_consumer():
+            graphed(cams, strategies, tasks)
+            idle = {"forward_render_time": 0.0, "backward_render_time": 0.0, "forward_loss_time": 0.0}
+            finish_strategy_final(cams, history, strategies, [dict(idle) for _ in cams])  # frozen: nothing to gather
+            return
+        if graphed is not None:
+            graphed.validate()
+        iteration(cams, strategies, tasks, between=lambda stats: finish_strategy_final(cams, history, strategies, stats))
 
     def render_step():
         with torch.no_grad():
@@ -280,6 +310,8 @@ def run_workload(a, name, world, rank, dev, steps, warmup, repeats, render_steps
         return images
 
     def fence():
+        if graphed is not None:
+            graphed.validate()  # the replay in flight counted (or has been repeated eagerly) before the clock stops
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -319,9 +351,14 @@ def run_workload(a, name, world, rank, dev, steps, warmup, repeats, render_steps
     launches = {}
     if collect_kernels:
         state["it"] = it0
+        if graphed is not None:  # per-kernel events need the eager launches
+            graphed.validate()
+            graphed.enabled = False
         dgr.kernel_timer.enabled = True
         dt_instr = timed(train_step, steps)
         dgr.kernel_timer.enabled = False
+        if graphed is not None:
+            graphed.enabled = graphed.stats["disabled"] is None
         torch.cuda.synchronize()
         launches = dgr.kernel_timer.launches()
         dgr.kernel_timer.reset()
@@ -331,6 +368,9 @@ def run_workload(a, name, world, rank, dev, steps, warmup, repeats, render_steps
     dt_unfused = None
     if two_kernel_leg is None:
         two_kernel_leg = repeats > 1
+    if graphed is not None:
+        graphed.validate()
+        graphed.enabled = False  # the legs below (two-kernel step, forward-only render) are eager
     if opt.fuse_backward and two_kernel_leg:  # the same steps with K11 and Adam as two kernels (gradients through HBM)
         opt.set_fuse_backward(False)
         timed(train_step, min(steps, 5))  # the gradient tensors are new to the caching allocator
@@ -348,6 +388,7 @@ def run_workload(a, name, world, rank, dev, steps, warmup, repeats, render_steps
                          "note": "fuse_backward: K11 runs inside the optimizer kernel (same arithmetic bit for bit, "
                                  "tests/test_gpu_loss_and_step.py); *_two_kernels = the same steps with K11 and Adam "
                                  "as separate launches, best of two regions timed after the contract's regions"},
+           "graph": (dict(graphed.stats) if graphed is not None else None),
            "timing": {"repeats": len(per_step), "ms_per_step_median": round(percentile(per_step, 0.5), 4),
                       "ms_per_step_p10": round(percentile(per_step, 0.1), 4),
                       "ms_per_step_p90": round(percentile(per_step, 0.9), 4),
@@ -428,6 +469,12 @@ def main():
     ap.add_argument("--no-fuse-backward", action="store_true",
                     help="run K11 and Adam as two kernels (the parameter gradients go through HBM) instead of the fused "
                          "K11 + Adam launch")
+    ap.add_argument("--graph", default="off", choices=["off", "on"],
+                    help="replay the training iteration as ONE hipGraph (graphed_step.py) whenever the load balancer's "
+                         "heuristics are frozen; results are the eager loop's (capacity overflows are repeated eagerly)")
+    ap.add_argument("--balance-every", type=int, default=0,
+                    help="with --graph on and live heuristics: every R-th iteration is an eager, timed one that feeds "
+                         "the load balancer; the partition is frozen in between (0: never freeze -> no graph)")
     ap.add_argument("--no-1gpu-leg", action="store_true", help="N > 1: skip the same-workload single-GPU leg")
     ap.add_argument("--render-steps", type=int, default=20, help="forward-only views/sec leg (untimed by driver)")
     ap.add_argument("--pmc-calib", action="store_true", help="also run a 256 MiB streaming multiply (PMC calibration)")

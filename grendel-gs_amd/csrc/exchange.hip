@@ -418,6 +418,77 @@ extern "C" int gsr_exchange_unpack(int64_t n, const float *recv, float *means2D,
     return 0;
 }
 
+// ---- capacity checks of a captured (hipGraph) iteration: nothing reaches the host inside a replay, so the kernels
+// that depend on a capacity chosen at capture time raise bits of ONE device word when it does not hold; the fused
+// K11 + Adam launch of the same replay then changes nothing (preprocess.hip: K11Adam::skip) and the host, which looks
+// at the word after the replay, repeats the iteration eagerly.
+namespace {
+__global__ void flag_if_greater_kernel(const uint32_t *__restrict__ value, uint32_t limit, uint32_t *__restrict__ flag,
+                                       uint32_t bit) {
+    if (threadIdx.x == 0 && *value > limit) atomicOr(flag, bit);
+}
+// all_counts [W][W][B] (rows rank i sends rank j of camera k, all-gathered), caps the same shape: bit_over when a
+// count exceeds its slab; bit_few when a band this rank renders (bit k of rendered_mask) receives fewer than `few`
+// rows in total (the reference's stand-in rule needs the true count, gaussian_renderer/__init__.py:1260-1269)
+__global__ void exchange_check_kernel(const int32_t *__restrict__ all_counts, const int32_t *__restrict__ caps, int W,
+                                      int B, int me, unsigned long long rendered_mask, int few,
+                                      uint32_t *__restrict__ flag, uint32_t bit_over, uint32_t bit_few) {
+    const int n = W * W * B;
+    bool over = false;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) over |= all_counts[i] > caps[i];
+    bool lack = false;
+    for (int k = threadIdx.x; k < B; k += blockDim.x) {
+        if (!((rendered_mask >> k) & 1ull)) continue;
+        long long rows = 0;
+        for (int i = 0; i < W; i++) rows += all_counts[((size_t)i * W + me) * B + k];
+        lack |= rows < few;
+    }
+    if (__any(over) && (threadIdx.x & 63) == 0) atomicOr(flag, bit_over);
+    if (__any(lack) && (threadIdx.x & 63) == 0) atomicOr(flag, bit_few);
+}
+// end of a captured iteration: the flag word and the replay's sequence number (a device word the host refreshes in
+// front of every replay) go to slot seq % slots of a pinned, device-mapped ring; the host polls the stamp (as it polls
+// the pair count, binning.hip) and so learns EXACTLY which replay was the first one that did not count
+__global__ void publish_flag_kernel(const uint32_t *__restrict__ flag, const uint32_t *__restrict__ seq,
+                                    uint32_t *__restrict__ host_ring, uint32_t slots) {
+    if (threadIdx.x == 0) {
+        const uint32_t s = *seq;
+        uint32_t *w = host_ring + 2 * (size_t)(s % slots);
+        __hip_atomic_store(w, *flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(w + 1, s, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+}  // namespace
+
+extern "C" int gsr_publish_flag(const uint32_t *flag_dev, const uint32_t *seq_dev, uint32_t *host_ring_pinned,
+                                uint32_t slots, gsr_stream_t stream_) {
+    if (!flag_dev || !seq_dev || !host_ring_pinned || slots == 0) return GSR_EINVAL;
+    hipLaunchKernelGGL(publish_flag_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream_), flag_dev,
+                       seq_dev, host_ring_pinned, slots);
+    GSR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gsr_flag_if_greater(const uint32_t *value_dev, uint32_t limit, uint32_t *flag_dev, uint32_t bit,
+                                   gsr_stream_t stream_) {
+    if (!value_dev || !flag_dev) return GSR_EINVAL;
+    hipLaunchKernelGGL(flag_if_greater_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream_), value_dev,
+                       limit, flag_dev, bit);
+    GSR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gsr_exchange_check(const int32_t *all_counts_dev, const int32_t *caps_dev, int W, int B, int me,
+                                  uint64_t rendered_mask, int few, uint32_t *flag_dev, uint32_t bit_over,
+                                  uint32_t bit_few, gsr_stream_t stream_) {
+    if (!all_counts_dev || !caps_dev || !flag_dev || W < 1 || B < 1 || B > 64 || me < 0 || me >= W) return GSR_EINVAL;
+    hipLaunchKernelGGL(exchange_check_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_),
+                       all_counts_dev, caps_dev, W, B, me, (unsigned long long)rendered_mask, few, flag_dev, bit_over,
+                       bit_few);
+    GSR_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int gsr_zero_async(void *ptr, size_t bytes, gsr_stream_t stream_) {
     if (bytes == 0) return 0;
     if (!ptr) return GSR_EINVAL;

@@ -340,7 +340,27 @@ struct K11Adam {
     float *m[6], *v[6];
     float lr_c[6], b1[6], b2[6], omb1[6], omb2[6], inv_sqrt_bc2[6], eps[6];
     float grad_scale;
+    // hipGraph mode (gsr_preprocess_backward_adam_raw_batched_dyn): what changes from step to step is read from DEVICE
+    // memory instead of the kernel arguments, so that one captured launch serves every replay --
+    //   dyn[0..5] = lr / (1 - beta1^t), dyn[6..11] = 1 / sqrt(1 - beta2^t) per tensor (the host refreshes them with an
+    //   asynchronous copy in front of the replay);  skip: a word that is non-zero when an earlier kernel of the SAME
+    //   replay found a capacity exceeded (tile sort / exchange slab): the step then changes nothing and the host
+    //   repeats the iteration eagerly.
+    const float *dyn;
+    const uint32_t *skip;
 };
+// the per-step constants of the captured launch (wave-uniform scalar loads, once per workgroup)
+__device__ __forceinline__ K11Adam k11_adam_resolve(const K11Adam &in) {
+    K11Adam ad = in;
+    if (in.dyn) {
+#pragma unroll
+        for (int t = 0; t < 6; t++) {
+            ad.lr_c[t] = in.dyn[t];
+            ad.inv_sqrt_bc2[t] = in.dyn[6 + t];
+        }
+    }
+    return ad;
+}
 
 // The 14 per-lane values (xyz 0-2, scaling 3-5, rotation 6-9, features_dc 10-12, opacity 13) are updated together at
 // the END of the lane's work: their 28 moment loads are then in flight at once (one exposed latency instead of five --
@@ -936,7 +956,9 @@ preprocess_backward_adam_kernel(int P, float *__restrict__ xyz, float *__restric
                                 float tanfovx, float tanfovy, const int32_t *__restrict__ radii,
                                 const float *__restrict__ cov3D, const uint8_t *__restrict__ clamped,
                                 const float *__restrict__ dL_dmeans2D, const float *__restrict__ dL_dconic_opacity,
-                                const float *__restrict__ dL_drgb, int gstride, const K11Adam ad) {
+                                const float *__restrict__ dL_drgb, int gstride, const K11Adam ad_in) {
+    if (ad_in.skip && *ad_in.skip) return;  // wave-uniform: a capacity overflowed earlier in this replay
+    const K11Adam ad = k11_adam_resolve(ad_in);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     __shared__ float s_rest[K11_BLOCK * REST_W];
     const size_t ic = (size_t)min(i, P - 1);
@@ -1422,7 +1444,9 @@ preprocess_backward_adam_batched_kernel(int P, int B, float *__restrict__ xyz, f
                                         const int32_t *__restrict__ radii, const float *__restrict__ cov3D,
                                         const uint8_t *__restrict__ clamped, const float *__restrict__ dL_dmeans2D,
                                         const float *__restrict__ dL_dconic_opacity,
-                                        const float *__restrict__ dL_drgb, int gstride, const K11Adam ad) {
+                                        const float *__restrict__ dL_drgb, int gstride, const K11Adam ad_in) {
+    if (ad_in.skip && *ad_in.skip) return;
+    const K11Adam ad = k11_adam_resolve(ad_in);
     preprocess_backward_batched_body<DEG, true>(P, B, 16, xyz, scaling, scale_modifier, rotation, f_dc, f_rest, opacity,
                                                 cams, W, H, radii, cov3D, clamped, dL_dmeans2D, dL_dconic_opacity,
                                                 dL_drgb, gstride, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
@@ -1590,21 +1614,41 @@ extern "C" int gsr_preprocess_backward_adam_raw_batched(
     const float *dL_dconic_opacity, const float *dL_drgb, int grad_row_stride, float *const *exp_avgs,
     float *const *exp_avg_sqs, const double *lrs, const double *beta1s, const double *beta2s, const double *epss,
     const int64_t *steps, float grad_scale, const float *tanfov0, gsr_stream_t stream) {
+    return gsr_preprocess_backward_adam_raw_batched_dyn(
+        P, B, sh_degree, sh_coeffs, xyz, scaling, scale_modifier, rotation, features_dc, features_rest, opacity, cams,
+        width, height, radii, cov3D, clamped, dL_dmeans2D, dL_dconic_opacity, dL_drgb, grad_row_stride, exp_avgs,
+        exp_avg_sqs, lrs, beta1s, beta2s, epss, steps, grad_scale, tanfov0, nullptr, nullptr, stream);
+}
+
+// The same launch for a captured (hipGraph) iteration: `dyn_dev` (DEVICE, 12 floats: lr / (1 - beta1^t) and
+// 1 / sqrt(1 - beta2^t) of the six tensors, in the tensor order above) replaces what `lrs` / `steps` would give -- both
+// may then be NULL -- and `skip_flag_dev` (DEVICE word, may be NULL) turns the whole launch into a no-op when it is
+// non-zero at execution time.  With both NULL this is gsr_preprocess_backward_adam_raw_batched.
+extern "C" int gsr_preprocess_backward_adam_raw_batched_dyn(
+    int P, int B, int sh_degree, int sh_coeffs, float *xyz, float *scaling, float scale_modifier, float *rotation,
+    float *features_dc, float *features_rest, float *opacity, const float *cams, int width, int height,
+    const int32_t *radii, const float *cov3D, const uint8_t *clamped, const float *dL_dmeans2D,
+    const float *dL_dconic_opacity, const float *dL_drgb, int grad_row_stride, float *const *exp_avgs,
+    float *const *exp_avg_sqs, const double *lrs, const double *beta1s, const double *beta2s, const double *epss,
+    const int64_t *steps, float grad_scale, const float *tanfov0, const float *dyn_dev, const uint32_t *skip_flag_dev,
+    gsr_stream_t stream) {
     if (P < 0 || B < 1 || sh_degree < 0 || sh_degree > 3 || sh_coeffs != 16 || width <= 0 || height <= 0)
         return GSR_EINVAL;  // the fused step needs the LDS stage of a 16-coefficient model
     if (P == 0) return 0;
     if (!xyz || !scaling || !rotation || !features_dc || !features_rest || !opacity || !cams || !radii || !cov3D ||
-        !clamped || !dL_dmeans2D || !dL_dconic_opacity || !dL_drgb || !exp_avgs || !exp_avg_sqs || !lrs || !beta1s ||
-        !beta2s || !epss || !steps)
+        !clamped || !dL_dmeans2D || !dL_dconic_opacity || !dL_drgb || !exp_avgs || !exp_avg_sqs || !beta1s ||
+        !beta2s || !epss || (!dyn_dev && (!lrs || !steps)))
         return GSR_EINVAL;
     K11Adam ad{};
+    ad.dyn = dyn_dev;
+    ad.skip = skip_flag_dev;
     for (int t = 0; t < 6; t++) {
-        if (!exp_avgs[t] || !exp_avg_sqs[t] || steps[t] < 1) return GSR_EINVAL;
-        const double bc1 = 1.0 - pow(beta1s[t], (double)steps[t]);
-        const double bc2 = 1.0 - pow(beta2s[t], (double)steps[t]);
+        if (!exp_avgs[t] || !exp_avg_sqs[t] || (!dyn_dev && steps[t] < 1)) return GSR_EINVAL;
+        const double bc1 = dyn_dev ? 1.0 : 1.0 - pow(beta1s[t], (double)steps[t]);
+        const double bc2 = dyn_dev ? 1.0 : 1.0 - pow(beta2s[t], (double)steps[t]);
         ad.m[t] = exp_avgs[t];
         ad.v[t] = exp_avg_sqs[t];
-        ad.lr_c[t] = (float)(lrs[t] / bc1);
+        ad.lr_c[t] = dyn_dev ? 0.f : (float)(lrs[t] / bc1);
         ad.b1[t] = (float)beta1s[t];
         ad.b2[t] = (float)beta2s[t];
         ad.omb1[t] = (float)(1.0 - beta1s[t]);

@@ -30,7 +30,7 @@ __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "_C", "load_im
            "merge_image_tiles_by_pos", "set_timing_mode", "fused_l1_ssim_band", "fused_band_loss", "fused_activations", "pack_camera",
            "preprocess_gaussians_raw_batched", "knn_mean_dist2", "group_rows", "gather_rows", "exchange_need",
            "exchange_count", "exchange_pack", "exchange_pack_slab", "exchange_unpack", "zeros_async", "scatter_add_rows",
-           "set_tie_order", "scatter_rows", "local_pixels"]
+           "set_tie_order", "scatter_rows", "local_pixels", "GraphCapture", "capturing"]
 
 BLOCK_X, BLOCK_Y, ONE_DIM_BLOCK_SIZE = 16, 16, 256
 
@@ -455,6 +455,18 @@ class PendingProjectionBackward:
                 cache["tabs"] = tabs
         tf = (ctypes.c_float * 2)(float(self.tanfov0[0]), float(self.tanfov0[1])) \
             if (B == 1 and self.tanfov0 is not None) else None
+        cap_ctx = _CAPTURE[0]
+        if cap_ctx is not None:
+            # captured launch: lr / bias corrections come from the capture's device block at execution time, and the
+            # launch is a no-op when a capacity check of the same replay has raised the flag word
+            with _on(xyz.device):
+                check(lib.gsr_preprocess_backward_adam_raw_batched_dyn(
+                    P, B, deg, M, _ptr(xyz), _ptr(scaling), smod, _ptr(rotation), _ptr(f_dc), _ptr(f_rest),
+                    _ptr(opacity), _ptr(self.cams), W, H, _ptr(self.radii), _ptr(self.cov3D), _ptr(self.clamped),
+                    _ptr(self.g_means2D), _ptr(self.g_conic_opacity), _ptr(self.g_rgb), self.gstride, tabs[1], tabs[2],
+                    None, tabs[3], tabs[4], tabs[5], None, float(grad_scale), tf, _ptr(cap_ctx.dyn), _ptr(cap_ctx.flag),
+                    _stream()), "gsr_preprocess_backward_adam_raw_batched_dyn")
+            return
         with _on(xyz.device), kernel_timer.range("preprocess_backward_adam", N=P, B=B, M=M):
             check(lib.gsr_preprocess_backward_adam_raw_batched(
                 P, B, deg, M, _ptr(xyz), _ptr(scaling), smod, _ptr(rotation), _ptr(f_dc), _ptr(f_rest), _ptr(opacity),
@@ -646,6 +658,77 @@ def set_tie_order(order):
     check(lib.gsr_set_depth_tie_order(1 if order == "position" else 0), "gsr_set_depth_tie_order")
 
 
+# ---- an iteration captured in a hipGraph (graphed_step.GraphedIteration) --------------------------------------------
+# Inside a capture nothing may reach the host: the pair count is not polled, buffers are sized from the counts of earlier
+# (eager) iterations, and the kernels whose capacity may not hold raise bits of the capture's device flag word
+# (include/gsraster.h: gsr_flag_if_greater), which turns the optimizer launch of the same replay into a no-op.
+FLAG_PAIRS, FLAG_SLAB, FLAG_FEW = 1, 2, 4
+_CAPTURE = [None]
+
+
+class GraphCapture:
+    """what the ops need to know while an iteration is being captured (set by graphed_step.GraphedIteration)"""
+
+    def __init__(self, flag, dyn, pair_slack=1.25):
+        self.flag, self.dyn, self.pair_slack = flag, dyn, pair_slack  # device uint32 [1], device float32 [12]
+        self.pairs = []     # per render op of the iteration: (pinned int32 [1] that receives D, capacity)
+        self.counts = None  # (pinned int32 [W*W*B] that receives the exchange's all-gathered counts, caps numpy, shape)
+        self.slab_caps_dev = None  # device int32 [W*W*B]: the exchange planner's capacities, uploaded before the capture
+        # pinned memory is allocated BEFORE the capture starts (hipHostMalloc is not a capturable call)
+        self._words, self._next = torch.zeros((8192,), dtype=torch.int32).pin_memory(), 0
+
+    def take_pinned(self, n):
+        """-> a pinned int32 view of n words (from the block allocated before the capture)"""
+        if self._next + n > self._words.numel():
+            raise RuntimeError("graph capture: out of pinned result words")
+        v = self._words[self._next:self._next + n]
+        self._next += n
+        return v
+
+    def pair_capacity(self, dev):
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        seen = max([v for (d, _s), v in _MAX_PAIRS.items() if d == idx], default=0)
+        if seen <= 0:
+            raise RuntimeError("graph capture: no eager iteration has sorted a view on this device yet")
+        return _bucket(4 * int(seen * self.pair_slack + 4096)) // 4
+
+
+def capturing():
+    return _CAPTURE[0]
+
+
+def _bin_gaussians_captured(cap_ctx, means2D, depths, radii, conic_opacity, compute_locally, width, height):
+    """K3-K7 inside a hipGraph capture: the tile sort is launched for a CAPACITY taken from earlier iterations, the pair
+    count stays on the device (copied to a pinned word the host reads after the replay) and a count above the capacity
+    raises FLAG_PAIRS instead of a re-sort.  Returns the capacity as D."""
+    P = means2D.shape[0]
+    dev = means2D.device
+    gx, gy = (width + BLOCK_X - 1) // BLOCK_X, (height + BLOCK_Y - 1) // BLOCK_Y
+    ranges = torch.empty((gx * gy + 1, 2), dtype=torch.int32, device=dev)[:gx * gy]
+    prep_bytes = lib.gsr_bin_prepare_bytes(P, width, height)
+    prep = torch.empty((max(prep_bytes, 4),), dtype=torch.uint8, device=dev)
+    stream = _stream()
+    ticket = ctypes.c_uint32(0)
+    check(lib.gsr_bin_prepare_async(P, width, height, _ptr(means2D), _ptr(depths), _ptr(radii), _ptr(conic_opacity),
+                                    _ptr(compute_locally), _ptr(prep), prep_bytes, ctypes.byref(ticket), stream),
+          "gsr_bin_prepare_async")
+    cap = cap_ctx.pair_capacity(dev)
+    if int(lib.gsr_bin_sort_capacity(P, lib.gsr_bin_sort_bytes(P, cap, width, height), width, height)) < cap:
+        raise RuntimeError("graph capture: frames above 256 x 256 tiles have no bounded tile sort")
+    sort_bytes = lib.gsr_bin_sort_bytes(P, cap, width, height)
+    scratch = torch.empty((max(sort_bytes, 4),), dtype=torch.uint8, device=dev)
+    point_list = torch.empty((cap,), dtype=torch.int32, device=dev)
+    check(lib.gsr_bin_sort_bounded(P, width, height, _ptr(compute_locally), _ptr(prep), cap, _ptr(scratch), sort_bytes,
+                                   _ptr(point_list), _ptr(ranges), stream), "gsr_bin_sort_bounded")
+    off = int(lib.gsr_bin_total_offset(P, width, height))
+    check(lib.gsr_flag_if_greater(prep.data_ptr() + off, cap, _ptr(cap_ctx.flag), FLAG_PAIRS, stream),
+          "gsr_flag_if_greater")
+    host = cap_ctx.take_pinned(1)
+    host.copy_(prep[off:off + 4].view(torch.int32), non_blocking=True)
+    cap_ctx.pairs.append((host, cap))
+    return point_list, ranges, cap
+
+
 def bin_gaussians(means2D, depths, radii, conic_opacity, compute_locally, width, height, cuda_args=None):
     """K3-K7: returns (point_list uint32-as-int32 [D], ranges int32 [tiles,2], D).  One host read-back (the pair count
     D, like the reference's own num_rendered) -- but the GPU does not wait for it: once a view of this size has been
@@ -653,6 +736,8 @@ def bin_gaussians(means2D, depths, radii, conic_opacity, compute_locally, width,
     memory, and the host reads D while they run (it only re-sorts if D outgrew the capacity).
     Per tile the list is the reference's (depth, then index) order restricted to the Gaussians that
     can reach alpha >= 1/255 somewhere in the tile's neighbourhood (see include/gsraster.h)."""
+    if _CAPTURE[0] is not None:
+        return _bin_gaussians_captured(_CAPTURE[0], means2D, depths, radii, conic_opacity, compute_locally, width, height)
     P = means2D.shape[0]
     dev = means2D.device
     gx, gy = (width + BLOCK_X - 1) // BLOCK_X, (height + BLOCK_Y - 1) // BLOCK_Y
@@ -724,6 +809,8 @@ class _RenderGaussians(torch.autograd.Function):
         # per call (the mirror asks through cuda_args, so a module-wide mode a user chose is never overridden), else
         # the module-wide mode
         timing = (cuda_args.get("_gsr_timing") if isinstance(cuda_args, dict) else None) or _timing_mode()
+        if _CAPTURE[0] is not None:
+            timing = "off"  # events recorded inside a capture cannot be read
         stats = cuda_args.get("stats_collector") if isinstance(cuda_args, dict) else None
         with _on(dev):
             if timing != "off":
@@ -1122,6 +1209,17 @@ def exchange_unpack(recv):
         check(lib.gsr_exchange_unpack(n, _ptr(recv), _ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2]), _ptr(radii),
                                       _ptr(depths), _stream()), "gsr_exchange_unpack")
     return outs[0], outs[1], outs[2], radii, depths
+
+
+def exchange_check(all_counts, caps_dev, W, B, me, rendered_mask, few, flag):
+    """capacity check of a captured exchange (include/gsraster.h: gsr_exchange_check): raises FLAG_SLAB / FLAG_FEW in
+    the device word `flag`"""
+    if all_counts.dtype != torch.int32 or caps_dev.dtype != torch.int32 or all_counts.numel() != W * W * B or \
+            caps_dev.numel() != W * W * B or not all_counts.is_contiguous() or not caps_dev.is_contiguous():
+        raise ValueError("all_counts / caps_dev must be contiguous int32 [W*W*B]")
+    with _on(all_counts.device):
+        check(lib.gsr_exchange_check(_ptr(all_counts), _ptr(caps_dev), W, B, me, int(rendered_mask), int(few),
+                                     _ptr(flag), FLAG_SLAB, FLAG_FEW, _stream()), "gsr_exchange_check")
 
 
 def zeros_async(shape, dtype, device):

@@ -152,9 +152,32 @@ class FusedAdam(torch.optim.Optimizer):
                         [g["lr"] for g, _ in owners], [g["betas"][0] for g, _ in owners],
                         [g["betas"][1] for g, _ in owners], [g["eps"] for g, _ in owners],
                         [int(st["step"]) + 1 for st in sts], grad_scale, cache=self._launch_cache)
+        if _dgr.capturing() is not None:
+            # the launch was recorded into a hipGraph, not executed: the step counters move when a replay is launched
+            # (graph_advance); the graph's owner finds the six (group, parameter) pairs here
+            self._graph_owners = owners
+            return {id(p) for _, p in owners}
         torch._foreach_add_([st["step"] for st in sts], 1)
         self.fused_steps += 1
         return {id(p) for _, p in owners}
+
+    # ------------------------------------------------------------------ a captured iteration (graphed_step.py)
+    def graph_hyper(self):
+        """the 12 per-step constants of the captured fused launch for the NEXT step, from the param groups' current
+        learning rates and the step counters: lr / (1 - beta1^t) x 6, then 1 / sqrt(1 - beta2^t) x 6, in the order of
+        the six tensors of the projection backward (include/gsraster.h: gsr_preprocess_backward_adam_raw_batched_dyn)"""
+        out = [0.0] * 12
+        for t, (group, p) in enumerate(self._graph_owners):
+            step = int(self.state[p]["step"]) + 1
+            b1, b2 = group["betas"]
+            out[t] = group["lr"] / (1.0 - b1 ** step)
+            out[6 + t] = 1.0 / (1.0 - b2 ** step) ** 0.5
+        return out
+
+    def graph_advance(self, n=1):
+        """a replay of the captured iteration has been launched (n > 0) / n replays turned out to be no-ops (n < 0)"""
+        torch._foreach_add_([self.state[p]["step"] for _, p in self._graph_owners], float(n))
+        self.fused_steps += n
 
     @torch.no_grad()
     def step(self, closure=None, grad_scale=None):
@@ -189,6 +212,9 @@ class FusedAdam(torch.optim.Optimizer):
                     raise RuntimeError("FusedAdam: dense fp32 parameters and gradients expected")
                 steps.append(st["step"])
                 batch.append((p, g, st, lr, b1, b2, eps))
+        if batch and _dgr.capturing() is not None:
+            raise RuntimeError("FusedAdam: a captured iteration supports the fused K11 + Adam launch only (parameters "
+                               "outside the projection backward carry gradients)")
         if steps:
             torch._foreach_add_(steps, 1)  # host tensors, as in the stock optimizer's state
         for i in range(0, len(batch), 16):

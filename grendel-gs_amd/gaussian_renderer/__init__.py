@@ -460,7 +460,30 @@ def _batched_exchange_final(m2_views, rgb_views, co_views, radii_views, depths_v
                                "set_exchange_speculation(False)")
     speculate = _EXCHANGE_OPTIONS["speculate"] if speculate is None else speculate
     gather_work = None
-    if _known is not None:   # the repeat of an overflowed speculative exchange: counts already on the host
+    cap_ctx = _dgr.capturing()
+    if cap_ctx is not None:
+        # the iteration is being captured in a hipGraph (graphed_step.py): capacity slabs are the only layout that needs
+        # nothing from the host; the verification happens ON THE DEVICE -- gsr_exchange_check raises the capture's flag
+        # word when a count exceeds its slab or a rendered band receives fewer than 10 rows, which makes the optimizer
+        # launch of the same replay a no-op -- and the host looks at the counts (copied to pinned memory by the graph)
+        # after the replay
+        if planner.caps is None or _known is not None or cap_ctx.slab_caps_dev is None:
+            raise RuntimeError("graph capture: the exchange needs slab capacities from earlier eager iterations")
+        speculate = True
+        chunkcnt, counts = _dgr.exchange_count(bases[0], radii_all, bands, 0, B, width, height)
+        all_counts = torch.empty((W * W, B), dtype=torch.int32, device=dev)
+        dist.all_gather_into_tensor(all_counts, counts, group=group)
+        rendered = 0
+        for k, st in enumerate(batched_strategies):
+            if me in st.gpu_ids:
+                rendered |= 1 << k
+        _dgr.exchange_check(all_counts, cap_ctx.slab_caps_dev, W, B, me, rendered, 10, cap_ctx.flag)
+        host = cap_ctx.take_pinned(W * W * B)
+        host.copy_(all_counts.view(-1), non_blocking=True)
+        cap_ctx.counts = (host, planner.caps.copy(), (W, W, B))
+        sizes = _LazySizes()
+        sizes._resolver = lambda h=host, z=sizes: setattr(z, "_v", h.view(W, W, B).tolist())
+    elif _known is not None:   # the repeat of an overflowed speculative exchange: counts already on the host
         chunkcnt, counts, sizes = _known
         speculate = False
     else:
@@ -486,7 +509,10 @@ def _batched_exchange_final(m2_views, rgb_views, co_views, radii_views, depths_v
 
     pipeline = _EXCHANGE_OPTIONS["overlap"] if pipeline is None else pipeline
     pipelined = (pipeline or speculate) and B > 1         # one exchange per camera ...
-    overlap = pipelined and pipeline and dev.type == "cuda"  # ... on the side stream
+    # ... on the side stream -- not inside a hipGraph capture: the process group's watchdog thread polls the events of
+    # collectives issued from a stream that has not joined the capture yet, which HIP forbids (measured: the capture
+    # aborts with hipErrorCapturedEvent); a captured iteration keeps its exchanges on the capturing stream
+    overlap = pipelined and pipeline and dev.type == "cuda" and cap_ctx is None
     groups = [(k, 1) for k in range(B)] if pipelined else [(0, B)]
     cur = torch.cuda.current_stream() if dev.type == "cuda" else None
     side = _side_stream(dev) if overlap else None
@@ -552,7 +578,7 @@ def _batched_exchange_final(m2_views, rgb_views, co_views, radii_views, depths_v
     if gather_work is not None:
         gather_work.wait()          # stream-level join with the (long finished) size all-gather; the host does not wait
         planner.stage(all_counts)   # asynchronous copy to pinned memory + event, behind the unpack in stream order
-    pending = (planner, chunkcnt, counts, sizes) if speculate else None
+    pending = (planner, chunkcnt, counts, sizes) if (speculate and cap_ctx is None) else None
     return out[0], out[1], out[2], out[3], out[4], sizes, (events, token), pending
 
 

@@ -1,0 +1,259 @@
+"""GraphedIteration -- one training iteration of the hot path replayed as ONE hipGraph.
+
+Why: behind the pixel partition a rank's iteration is ~50 kernels of 3-200 us (0.8 ms in all at 8 ranks on
+BASELINE configs[2]'s shape) and the Python / autograd work between two C-ABI calls costs more than the kernels do --
+the W > 1 step is HOST-bound (profiles/r03s2_fake_world_w8_gaps.txt: 0.94 ms of kernels, 0.7-0.95 ms of launch gaps).
+The reference's loop is eager too (train_internal.py:134-208, 316-329), but it is not sub-millisecond.  Capturing the
+iteration -- GT band staging, K1, the exchange (count, pack into capacity slabs, all-to-all-v, unpack), K3-K8, the band
+loss, K10, the mirror exchange, the fused K11 + Adam launch -- into a hipGraph leaves ONE launch per iteration on the host.
+
+What made the iteration capturable (every item is a host dependency the eager path has):
+  * pair count D (the reference reads `num_rendered` back to size its sort): the tile sort runs at a CAPACITY taken
+    from earlier iterations (gsr_bin_sort_bounded), D stays on the device; D > capacity raises a bit of a device flag word;
+  * exchange sizes (gaussian_renderer/__init__.py:572-585 reads the i2j counts back): capacity slabs from the planner;
+    gsr_exchange_check raises the flag when a count exceeds its slab or a rendered band receives < 10 rows;
+  * Adam's step count / learning rates (kernel arguments in the eager launch): read from a 12-float device block that
+    the host refreshes with an asynchronous copy in front of every replay (gsr_preprocess_backward_adam_raw_batched_dyn);
+  * per-iteration inputs (camera, ground truth): static proxies refreshed by device copies in front of the replay.
+A raised flag makes the optimizer launch of that replay -- and, the flag being sticky, of every later one -- a no-op; the
+host looks at the flag one iteration late (so it never waits for the replay it has just launched), and on a raised flag
+repeats the affected iterations EAGERLY, in order: results are those of the eager loop, iteration by iteration.
+
+One graph per (partition, image size, camera intrinsics, shard size, capacities); a key's first `warmup` sights run
+eagerly (they teach the capacities).  Usable when nothing consumes per-iteration timings (frozen load-balancer
+heuristics: events recorded inside a capture cannot be read).
+
+    step = GraphedIteration(optimizer, body)      # body(cameras, strategies, tasks) -> loss: GT staging ... opt.step()
+    loss = step(cameras, strategies, tasks)       # replays when it can, runs `body` eagerly when it cannot
+    step.validate()                               # before READING results (loss.item(), means2D.grad, ...)
+"""
+import copy
+import math
+from types import SimpleNamespace
+
+import torch
+
+import diff_gaussian_rasterization as _dgr
+
+
+class _Entry:
+    __slots__ = ("graph", "proxies", "out", "ctx", "caps_key", "pair_cap")
+
+
+class GraphedIteration:
+    def __init__(self, optimizer, body, warmup=3, max_graphs=8, enabled=True):
+        self.opt, self.body, self.warmup, self.max_graphs = optimizer, body, int(warmup), int(max_graphs)
+        self.enabled = bool(enabled)
+        self.entries, self._seen = {}, {}
+        self._inflight = None       # (event, cameras, strategies, tasks) of the replay nobody has validated yet
+        self._flag = self._dyn = None
+        self._hyper_host = None
+        self.stats = {"replayed": 0, "eager": 0, "captured": 0, "redone": 0, "disabled": None}
+
+    # ------------------------------------------------------------------ keys and static inputs
+    def _planner_caps(self, B):
+        """(planner, capacities int64 numpy [W,W,B]) of the exchange this rank takes part in, or (None, None)"""
+        import gaussian_renderer as gr
+        import torch.distributed as dist
+        import utils.general_utils as utils
+
+        group = utils.DEFAULT_GROUP
+        if group.size() == 1:
+            if not (gr._EXCHANGE_OPTIONS["forced"] and dist.is_initialized()):
+                return None, None
+            if not isinstance(group, dist.ProcessGroup):
+                group = dist.group.WORLD
+        planner = gr._planner(group, group.size(), B)
+        return planner, planner.caps
+
+    def _key(self, cameras, strategies):
+        import utils.general_utils as utils
+
+        p0 = self.opt.param_groups[0]["params"][0]
+        _, caps = self._planner_caps(len(cameras))
+        return (tuple((tuple(s.gpu_ids), tuple(s.division_pos)) for s in strategies), utils.get_img_size(),
+                tuple((float(c.FoVx), float(c.FoVy), int(c.image_height), int(c.image_width)) for c in cameras),
+                p0.data_ptr(), tuple(p0.shape), None if caps is None else caps.tobytes())
+
+    @staticmethod
+    def _packed(camera):
+        """the [40] record K1 / K11 read (diff_gaussian_rasterization.pack_camera), cached on the camera under the key
+        the mirror checks (gaussian_renderer/__init__.py: distributed_preprocess3dgs_and_all2all_final)"""
+        tf = (math.tan(camera.FoVx * 0.5), math.tan(camera.FoVy * 0.5))
+        mats = (camera.world_view_transform, camera.full_proj_transform, camera.camera_center)
+        key = (float(tf[0]), float(tf[1])) + tuple((t.data_ptr(), t._version) for t in mats)
+        cached = getattr(camera, "_gsr_packed", None)
+        if cached is None or cached[0] != key:
+            rs = SimpleNamespace(viewmatrix=mats[0], projmatrix=mats[1], campos=mats[2], tanfovx=tf[0], tanfovy=tf[1])
+            cached = (key, _dgr.pack_camera(rs))
+            camera._gsr_packed = cached
+        return cached[1]
+
+    def _make_proxies(self, cameras):
+        """static stand-ins of the batch's cameras: the captured kernels read THEIR buffers, which are refreshed from
+        the real cameras in front of every replay"""
+        proxies = []
+        for cam in cameras:
+            px = copy.copy(cam)
+            for name in ("world_view_transform", "full_proj_transform", "camera_center"):
+                setattr(px, name, getattr(cam, name).detach().clone())
+            px._gsr_packed = None
+            packed = self._packed(px).clone()
+            mats = (px.world_view_transform, px.full_proj_transform, px.camera_center)
+            key = (float(math.tan(px.FoVx * 0.5)), float(math.tan(px.FoVy * 0.5))) + tuple(
+                (t.data_ptr(), t._version) for t in mats)
+            px._gsr_packed = (key, packed)
+            gt = cam.original_image_backup
+            px.original_image_backup = torch.empty(gt.shape, dtype=gt.dtype, device=packed.device)
+            px.original_image = None
+            px._gsr_bands = None
+            proxies.append(px)
+        return proxies
+
+    def _refresh(self, proxies, cameras):
+        for px, cam in zip(proxies, cameras):
+            px._gsr_packed[1].copy_(self._packed(cam), non_blocking=True)
+            px.original_image_backup.copy_(cam.original_image_backup, non_blocking=True)
+            px.uid = getattr(cam, "uid", None)
+
+    # ------------------------------------------------------------------ capture
+    RING = 16  # replays whose result slots / hyper-parameter blocks may be outstanding (two ever are)
+
+    def _ensure_buffers(self, dev):
+        if self._flag is None:
+            self._flag = torch.zeros((1,), dtype=torch.int32, device=dev)
+            # device block the captured launches read at execution time: 12 Adam constants + the replay's sequence number
+            self._dyn = torch.zeros((16,), dtype=torch.float32, device=dev)
+            self._hyper_host = torch.zeros((self.RING, 16), dtype=torch.float32).pin_memory()
+            self._hyper_np = self._hyper_host.numpy()
+            self._hyper_seq = self._hyper_host.view(torch.int32).numpy()
+            # pinned, device-mapped ring the LAST launch of every replay stores { flag, sequence number } into
+            self._ring = torch.zeros((2 * self.RING,), dtype=torch.int32).pin_memory()
+            self._ring_np = self._ring.numpy()
+            self._seq = 0
+
+    def _capture(self, key, cameras, strategies, tasks):
+        dev = self.opt.param_groups[0]["params"][0].device
+        self._ensure_buffers(dev)
+        e = _Entry()
+        e.proxies = self._make_proxies(cameras)
+        self._refresh(e.proxies, cameras)
+        e.ctx = _dgr.GraphCapture(self._flag, self._dyn)
+        planner, caps = self._planner_caps(len(cameras))
+        if caps is not None:
+            e.ctx.slab_caps_dev = torch.tensor(caps.reshape(-1), dtype=torch.int32).to(dev)
+        torch.cuda.synchronize(dev)
+        e.graph = torch.cuda.CUDAGraph()
+        _dgr._CAPTURE[0] = e.ctx
+        try:
+            # thread_local: the process group's watchdog thread keeps polling the events of EARLIER (eager) collectives
+            # while this thread captures; in the default (global) mode HIP fails those polls and the watchdog aborts the
+            # process (measured on RCCL 2.26 / ROCm 7.0)
+            with torch.cuda.graph(e.graph, capture_error_mode="thread_local"):
+                e.out = self.body(e.proxies, strategies, tasks)
+                _dgr.check(_dgr.lib.gsr_publish_flag(self._flag.data_ptr(), self._dyn.data_ptr() + 48,
+                                                     self._ring.data_ptr(), self.RING, _dgr._stream()),
+                           "gsr_publish_flag")
+        finally:
+            _dgr._CAPTURE[0] = None
+        if len(self.entries) >= self.max_graphs:
+            self.entries.pop(next(iter(self.entries)))
+        self.entries[key] = e
+        self.stats["captured"] += 1
+        return e
+
+    # ------------------------------------------------------------------ validation (one iteration late)
+    def _observe(self, entry):
+        """feed what the replay measured to the planners of the eager path (capacities keep tracking the scene)"""
+        if entry.ctx.counts is not None:
+            planner, _ = self._planner_caps(entry.ctx.counts[2][2])
+            host, _caps, shape = entry.ctx.counts
+            if planner is not None:
+                import numpy as np
+
+                planner.observe(host.numpy().reshape(shape).astype(np.int64))
+
+    def _check_inflight(self):
+        """-> None when the replay in flight (if any) was fine; otherwise the result of repeating it eagerly"""
+        infl, self._inflight = self._inflight, None
+        if infl is None:
+            return None
+        entry, seq, ev, queue = infl
+        slot = 2 * (seq % self.RING)
+        ring = self._ring_np
+        spins = 0
+        while int(ring[slot + 1]) != seq:  # the stamp lands a few microseconds after the replay's last kernel
+            spins += 1
+            if spins > 2000:
+                ev.synchronize()  # (also surfaces a faulted kernel)
+                if int(ring[slot + 1]) != seq:
+                    raise RuntimeError("graphed iteration: the replay finished without publishing its flag word")
+        if int(ring[slot]) == 0:
+            self._observe(entry)
+            return None
+        # a capacity did not hold in THAT replay: it and every later one were no-ops on the parameters (the flag is
+        # sticky).  Let the device drain, clear the flag, drop the graphs (their capacities are stale) and repeat the
+        # iterations eagerly, in order
+        torch.cuda.current_stream().synchronize()
+        self._flag.zero_()
+        self.opt.graph_advance(-len(queue))
+        self.entries.clear()
+        self._seen.clear()
+        out = None
+        for (cameras, strategies, tasks) in queue:
+            out = self.body(cameras, strategies, tasks)
+            self.stats["redone"] += 1
+        return out
+
+    def validate(self):
+        """wait for the iteration in flight and make sure it counted (repeating it eagerly if a capacity overflowed);
+        call before reading results on the host.  -> the repeated iteration's result, or None"""
+        return self._check_inflight()
+
+    # ------------------------------------------------------------------ the step
+    def __call__(self, cameras, strategies, tasks):
+        if not self.enabled:
+            self.stats["eager"] += 1
+            return self.body(cameras, strategies, tasks)
+        key = self._key(cameras, strategies)
+        entry = self.entries.get(key)
+        if entry is None:
+            redo = self._check_inflight()
+            del redo
+            self.stats["eager"] += 1
+            out = self.body(cameras, strategies, tasks)
+            n = self._seen[key] = self._seen.get(key, 0) + 1
+            if n >= self.warmup:
+                try:
+                    self._capture(self._key(cameras, strategies), cameras, strategies, tasks)
+                except Exception as exc:  # noqa: BLE001
+                    # no graph for this process from here on: every rank fails the same way (the capture is
+                    # deterministic), so the ranks stay in step
+                    _dgr._CAPTURE[0] = None
+                    self.enabled = False
+                    self.stats["disabled"] = f"{type(exc).__name__}: {exc}"
+            return out
+        # replay: inputs, hyper-parameters, ONE launch
+        self._refresh(entry.proxies, cameras)
+        self._seq = seq = (self._seq + 1) & 0x3FFFFFFF or 1
+        slot = seq % self.RING
+        self._hyper_np[slot, :12] = self.opt.graph_hyper()
+        self._hyper_seq[slot, 12] = seq
+        self._dyn.copy_(self._hyper_host[slot], non_blocking=True)
+        entry.graph.replay()
+        ev = torch.cuda.Event()
+        ev.record()
+        self.opt.graph_advance(1)
+        self.stats["replayed"] += 1
+        prev = self._inflight
+        if prev is None:
+            self._inflight = (entry, seq, ev, [(cameras, strategies, tasks)])
+            return entry.out
+        # look at the PREVIOUS replay now that this one keeps the device busy
+        p_entry, p_seq, p_ev, p_queue = prev
+        self._inflight = (p_entry, p_seq, p_ev, p_queue + [(cameras, strategies, tasks)])
+        redo = self._check_inflight()
+        if redo is not None:
+            return redo
+        self._inflight = (entry, seq, ev, [(cameras, strategies, tasks)])
+        return entry.out

@@ -137,6 +137,33 @@ int gsr_bin_prepare_async(int P, int width, int height, const float *means2D, co
                           uint32_t *ticket, gsr_stream_t stream);
 int gsr_bin_count_wait(uint32_t ticket, int64_t *num_rendered_host, gsr_stream_t stream);
 int64_t gsr_bin_sort_capacity(int P, size_t scratch_bytes, int width, int height);
+/* Byte offset, inside the prep workspace of gsr_bin_prepare*, of the uint32 pair count D that K4 leaves on the DEVICE
+ * (what gsr_bin_sort_bounded's kernels read).  For callers that capture the iteration in a hipGraph and therefore
+ * cannot take D through gsr_bin_count_wait inside a replay: they copy the word out / test it with
+ * gsr_flag_if_greater.  Stands where the reference reads `num_rendered` back (its rasterizer's forward). */
+size_t gsr_bin_total_offset(int P, int width, int height);
+
+/* Capacity checks of a captured (hipGraph) training iteration -- the reference sizes everything from counts it reads
+ * back (num_rendered; the exchange's i2j sizes, gaussian_renderer/__init__.py:572-585), a replayed graph cannot.
+ * Buffers are sized from earlier iterations instead and these launches raise bits of ONE device word when a capacity
+ * does not hold; gsr_preprocess_backward_adam_raw_batched_dyn skips its update when the word is non-zero and the host,
+ * which reads the word after the replay, repeats the iteration eagerly.
+ *   gsr_flag_if_greater : *flag_dev |= bit  when  *value_dev > limit  (e.g. the pair count against the sort capacity)
+ *   gsr_exchange_check  : all_counts_dev / caps_dev int32 [W][W][B] (rows rank i sends rank j of camera k, and the
+ *                         slab reserved for them): bit_over when a count exceeds its slab; bit_few when a band this
+ *                         rank (`me`) renders -- bit k of rendered_mask -- receives fewer than `few` rows in total
+ *                         (the reference's < 10-Gaussian stand-in rule, gaussian_renderer/__init__.py:1260-1269). */
+/*   gsr_publish_flag    : last launch of a captured iteration: { *flag_dev, *seq_dev } are stored (system scope, the
+ *                         stamp last) into words 2 s, 2 s + 1 of a pinned, device-accessible ring of `slots` pairs,
+ *                         s = *seq_dev % slots; seq_dev is a device word the host refreshes in front of every replay.
+ *                         The host polls the stamp instead of synchronising the stream. */
+int gsr_publish_flag(const uint32_t *flag_dev, const uint32_t *seq_dev, uint32_t *host_ring_pinned, uint32_t slots,
+                     gsr_stream_t stream);
+int gsr_flag_if_greater(const uint32_t *value_dev, uint32_t limit, uint32_t *flag_dev, uint32_t bit,
+                        gsr_stream_t stream);
+int gsr_exchange_check(const int32_t *all_counts_dev, const int32_t *caps_dev, int W, int B, int me,
+                       uint64_t rendered_mask, int few, uint32_t *flag_dev, uint32_t bit_over, uint32_t bit_few,
+                       gsr_stream_t stream);
 int gsr_bin_sort_bounded(int P, int width, int height, const uint8_t *compute_locally, const void *prep,
                          int64_t capacity, void *scratch, size_t scratch_bytes, uint32_t *point_list, int32_t *ranges,
                          gsr_stream_t stream);
@@ -375,6 +402,22 @@ int gsr_preprocess_backward_adam_raw_batched(int P, int B, int sh_degree, int sh
                                              const double *lrs, const double *beta1s, const double *beta2s,
                                              const double *epss, const int64_t *steps, float grad_scale,
                                              const float *tanfov0, gsr_stream_t stream);
+/* The same launch for an iteration captured in a hipGraph (train_internal.py:134-208,316-329 replayed as one graph):
+ * what changes from step to step is read from DEVICE memory at execution time -- dyn_dev: 12 floats, lr / (1 - beta1^t)
+ * of the six tensors then 1 / sqrt(1 - beta2^t) of the six tensors (lrs / steps may then be NULL) -- and skip_flag_dev
+ * (DEVICE uint32, may be NULL) makes the launch a no-op when non-zero (a capacity check of the same replay failed, see
+ * gsr_flag_if_greater).  With both NULL this is gsr_preprocess_backward_adam_raw_batched. */
+int gsr_preprocess_backward_adam_raw_batched_dyn(int P, int B, int sh_degree, int sh_coeffs, float *xyz, float *scaling,
+                                                 float scale_modifier, float *rotation, float *features_dc,
+                                                 float *features_rest, float *opacity, const float *cams, int width,
+                                                 int height, const int32_t *radii, const float *cov3D,
+                                                 const uint8_t *clamped, const float *dL_dmeans2D,
+                                                 const float *dL_dconic_opacity, const float *dL_drgb,
+                                                 int grad_row_stride, float *const *exp_avgs,
+                                                 float *const *exp_avg_sqs, const double *lrs, const double *beta1s,
+                                                 const double *beta2s, const double *epss, const int64_t *steps,
+                                                 float grad_scale, const float *tanfov0, const float *dyn_dev,
+                                                 const uint32_t *skip_flag_dev, gsr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * a19  fused parameter activations -- GaussianModel.get_scaling / get_rotation / get_opacity /

@@ -1,0 +1,158 @@
+"""GraphedIteration (grendel-gs_amd/graphed_step.py): the training iteration replayed as ONE hipGraph gives the eager
+loop's results -- with the real learning rates (the captured fused K11 + Adam launch reads its step-dependent constants
+from device memory), with the exchange in the graph (a one-rank RCCL group: pack into capacity slabs, all-to-all-v,
+unpack, mirror all-to-all-v, all captured), and when a capacity overflows (the flagged replays change nothing and are
+repeated eagerly, in order)."""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+pytestmark = pytest.mark.gpu
+
+NAMES = ["_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"]
+
+
+def _setup(device, bsz, forced):
+    import gaussian_renderer as gr
+    import synthetic_scene as S
+    import utils.general_utils as utils
+
+    N, W, H = 60_000, 640, 368
+    utils.GLOBAL_RANK, utils.LOCAL_RANK, utils.WORLD_SIZE = 0, 0, 1
+    utils.DEFAULT_GROUP = utils.IN_NODE_GROUP = utils.SingleGPUGroup()
+    utils.set_args(utils.default_args(bsz=bsz))
+    utils.set_img_size(H, W)
+    utils.set_cur_iter(1)
+    gr._PLANNERS.clear()
+    gr.set_exchange_forced(forced)
+    cams = S.orbit_cameras(4, W, H, device=device)
+    for k, c in enumerate(cams):
+        c.original_image_backup = S.make_gt_image(W, H, seed=30 + k, device=device)
+    return N, W, H, cams
+
+
+def _train(device, steps, bsz, graph, forced=False, shrink_pairs=None):
+    """-> (losses per step, final parameters, moments, GraphedIteration stats)"""
+    import diff_gaussian_rasterization as dgr
+    import synthetic_scene as S
+    import utils.general_utils as utils
+    from fused_optim import FusedAdam
+    from gaussian_renderer import distributed_preprocess3dgs_and_all2all_final, render_final
+    from gaussian_renderer.loss_distribution import batched_loss_computation, load_camera_from_cpu_to_all_gpu
+    from gaussian_renderer.workload_division import DivisionStrategyHistoryFinal, start_strategy_final
+    from graphed_step import GraphedIteration
+
+    N, W, H, cams = _setup(device, bsz, forced)
+    model = S.SyntheticGaussianModel(N, W, H, seed=9, device=device, scale_coef=0.008)
+    hist = DivisionStrategyHistoryFinal(S.SyntheticDataset(cams), 1, 0)
+    bg = torch.tensor([0.1, 0.2, 0.3], device=device)
+    pipe = type("P", (), {"debug": False})()
+    opt = FusedAdam(model.param_groups(), lr=0.0, eps=1e-15, fuse_backward=True, grad_scale=1.0 / bsz)
+
+    def body(batch, strategies, tasks):
+        load_camera_from_cpu_to_all_gpu(batch, strategies, tasks)
+        pkg = distributed_preprocess3dgs_and_all2all_final(batch, model, pipe, bg, batched_strategies=strategies,
+                                                           mode="train")
+        images, masks = render_final(pkg, strategies)
+        stats = [ca["stats_collector"] for ca in pkg["batched_cuda_args"]]
+        loss, _ = batched_loss_computation(images, batch, masks, strategies, stats)
+        loss.backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        return loss
+
+    step = GraphedIteration(opt, body, warmup=2, enabled=graph)
+    saved_cap = dgr.GraphCapture.pair_capacity
+    if shrink_pairs is not None:  # a tile-sort capacity that cannot hold: every replay must be flagged and repeated
+        dgr.GraphCapture.pair_capacity = lambda self, dev: max(int(saved_cap(self, dev) * shrink_pairs) // 1024 * 1024, 1024)
+    losses = []
+    try:
+        for it in range(steps):
+            batch = [cams[(it * bsz + j) % len(cams)] for j in range(bsz)]
+            utils.set_cur_iter(utils.get_cur_iter() + bsz)
+            for g in opt.param_groups:  # a learning-rate schedule: the replays must follow it
+                if g["name"] == "xyz":
+                    g["lr"] = 0.00016 * (0.97 ** it)
+            strategies, tasks = start_strategy_final(batch, hist)
+            loss = step(batch, strategies, tasks)
+            redo = step.validate()  # (per step here: the test reads every loss)
+            losses.append(float(redo if redo is not None else loss))
+    finally:
+        dgr.GraphCapture.pair_capacity = saved_cap
+    torch.cuda.synchronize()
+    params = {n: getattr(model, n).detach().clone() for n in NAMES}
+    moments = {n: (opt.state[getattr(model, n)]["exp_avg"].clone(), opt.state[getattr(model, n)]["exp_avg_sq"].clone(),
+                   float(opt.state[getattr(model, n)]["step"])) for n in NAMES}
+    init = S.SyntheticGaussianModel(N, W, H, seed=9, device=device, scale_coef=0.008)
+    delta = {n: params[n] - getattr(init, n).detach() for n in NAMES}
+    opt.set_fuse_backward(False)
+    return losses, delta, moments, dict(step.stats)
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+
+def _compare(run, ref, steps):
+    losses, delta, moments, _ = run
+    losses_r, delta_r, moments_r, _ = ref
+    for a, b in zip(losses, losses_r):
+        assert abs(a - b) <= 2e-4 * abs(b), (losses, losses_r)
+    for n in NAMES:
+        assert moments[n][2] == moments_r[n][2] == float(steps), (n, moments[n][2], moments_r[n][2])
+        e = _rel(delta[n], delta_r[n])
+        assert e < 5e-3, f"{n}: the parameters moved differently under the graph: rel {e:.2e}"
+        e1, e2 = _rel(moments[n][0], moments_r[n][0]), _rel(moments[n][1], moments_r[n][1])
+        assert e1 < 5e-3 and e2 < 5e-3, f"{n}: moments differ: {e1:.2e} / {e2:.2e}"
+
+
+@pytest.mark.parametrize("bsz", [1, 2])
+def test_graphed_iteration_equals_the_eager_loop(device, bsz):
+    steps = 7
+    ref = _train(device, steps, bsz, graph=False)
+    run = _train(device, steps, bsz, graph=True)
+    st = run[3]
+    assert st["disabled"] is None, st
+    assert st["captured"] == 1 and st["eager"] == 2 and st["replayed"] == steps - 2 and st["redone"] == 0, st
+    _compare(run, ref, steps)
+
+
+def test_graphed_iteration_with_the_exchange_over_rccl(device):
+    """the exchange inside the graph: pack into capacity slabs, all-to-all-v and its mirror over a ONE-rank RCCL group
+    (every visible row is sent to the rank itself), the capacity check on the device"""
+    import torch.distributed as dist
+
+    import gaussian_renderer as gr
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29543")
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    steps = 10
+    try:
+        ref = _train(device, steps, 2, graph=False, forced=False)
+        before = dict(gr.exchange_stats)
+        run = _train(device, steps, 2, graph=True, forced=True)
+        st = run[3]
+        assert st["disabled"] is None, st
+        # (the slab capacities settle during the first iterations: a changed capacity is a new graph key)
+        assert st["captured"] >= 1 and st["replayed"] >= 3 and st["redone"] == 0, st
+        assert gr.exchange_stats["speculative"] > before["speculative"]
+        _compare(run, ref, steps)
+    finally:
+        gr.set_exchange_forced(False)
+        gr._PLANNERS.clear()
+
+
+def test_overflowing_replays_change_nothing_and_are_repeated_eagerly(device):
+    steps = 7
+    ref = _train(device, steps, 1, graph=False)
+    run = _train(device, steps, 1, graph=True, shrink_pairs=0.5)
+    st = run[3]
+    assert st["disabled"] is None, st
+    assert st["redone"] >= 1 and st["captured"] >= 1, st
+    _compare(run, ref, steps)

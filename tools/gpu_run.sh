@@ -8,6 +8,7 @@
 #   ab        benchq for the production library and every variants/libgsraster_*.so
 #   fake      tools/fake_world_bench.py --workload c2 --worlds 1 2 4 8      -> fake_world_c2.txt
 #   fake8     the same, W = 1 and 8 only
+#   gtest     tests/test_gpu_graphed_step.py;  fakeg: the fake world with --graph on
 #   gaps8     kernel trace of one rank of the fake 8-rank world + idle gaps  -> fake_world_w8_gaps.txt
 #   pmc       kernel trace + PMC passes of the bench command (tools/pmc_collect.py) -> pmc.json / pmc.txt
 # Everything lands in gpurun_out/<tag>/.
@@ -36,6 +37,27 @@ if has fw; then
   timeout 900 python -m pytest tests/test_gpu_fake_world.py -q -m gpu -x -s -p no:cacheprovider > $O/fw.log 2>&1
   echo "fw pytest exit $?" | tee -a $O/fw.log
   grep -E "fake world|passed|failed|Error|error" $O/fw.log | tail -15
+fi
+if has probe; then
+  for w in a2a a2a_uneven allgather allreduce; do
+    timeout 120 python tools/probes/rccl_capture_probe.py $w > $O/probe_$w.log 2>&1
+    echo "probe $w exit $?"; grep -v amdgpu.ids $O/probe_$w.log | tail -3 | cut -c1-200
+  done
+fi
+if has xprobe; then
+  for cfg in "2 0" "2 1" "1 0"; do
+    timeout 100 python tools/probes/graph_exchange_probe.py $cfg > "$O/xprobe_${cfg// /_}.log" 2>&1
+    echo "xprobe $cfg exit $?"; grep -v amdgpu.ids "$O/xprobe_${cfg// /_}.log" | grep -E "stats|equals|Error|error|Fatal|File \"/(root|tmp)" | tail -6 | cut -c1-250
+  done
+fi
+if has gtest; then
+  timeout 900 python -m pytest tests/test_gpu_graphed_step.py -q -m gpu -x -s -p no:cacheprovider > $O/gtest.log 2>&1
+  echo "gtest pytest exit $?" | tee -a $O/gtest.log
+  tail -25 $O/gtest.log | cut -c1-400
+fi
+if has fakeg; then
+  timeout 600 python tools/fake_world_bench.py --workload c2 --worlds 1 2 4 8 --steps 20 --graph on > $O/fake_world_c2_graph.txt 2> $O/fake_world_c2_graph.err
+  cut -c1-700 $O/fake_world_c2_graph.txt; tail -5 $O/fake_world_c2_graph.err
 fi
 if has quick; then
   timeout 1200 python -m pytest tests/test_gpu_loss_and_step.py tests/test_gpu_parity.py tests/test_gpu_golden.py -q -m gpu -x -p no:cacheprovider > $O/quick.log 2>&1
