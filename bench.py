@@ -349,14 +349,17 @@ def run_workload(a, name, world, rank, dev, steps, warmup, repeats, render_steps
     # replay's own step time is reported as `kernels_region_ms_per_step`.
     dt_instr = None
     launches = {}
+    walked = (0, 0)
     if collect_kernels:
         state["it"] = it0
         if graphed is not None:  # per-kernel events need the eager launches
             graphed.validate()
             graphed.enabled = False
+        dgr.composite_walked(reset=True)
         dgr.kernel_timer.enabled = True
         dt_instr = timed(train_step, steps)
         dgr.kernel_timer.enabled = False
+        walked = dgr.composite_walked(reset=True)  # list entries K8 / K10 went through in exactly these launches
         if graphed is not None:
             graphed.enabled = graphed.stats["disabled"] is None
         torch.cuda.synchronize()
@@ -377,7 +380,8 @@ def run_workload(a, name, world, rank, dev, steps, warmup, repeats, render_steps
         dt_unfused = min(timed(train_step, steps), timed(train_step, steps))
         opt.set_fuse_backward(True)
 
-    out = {"name": name, "desc": desc, "gaussians_total": n_total, "gaussians_this_rank": int(model._xyz.shape[0]),
+    lrs = {g.get("name", str(i)): g["lr"] for i, g in enumerate(opt.param_groups)}
+    out = {"name": name, "desc": desc, "learning_rates": lrs, "gaussians_total": n_total, "gaussians_this_rank": int(model._xyz.shape[0]),
            "image": [W, H], "bsz": bsz, "world": world, "scene": scene, "dt": dt, "steps": steps,
            "ms_per_step": 1e3 * dt / steps, "images_per_s": bsz * steps / dt, "priming_steps": priming,
            "kernels_region_ms_per_step": (1e3 * dt_instr / steps) if dt_instr else None,
@@ -403,7 +407,7 @@ def run_workload(a, name, world, rank, dev, steps, warmup, repeats, render_steps
     kern = {}
     px_cache = {}
     for kname, recs in launches.items():
-        tot_ms, tot_b, D_sum = 0.0, 0, 0
+        tot_ms, tot_b, D_sum, px_sum = 0.0, 0, 0, 0
         for ms, meta in recs:
             m = dict(meta)
             if "mask" in m:
@@ -414,19 +418,41 @@ def run_workload(a, name, world, rank, dev, steps, warmup, repeats, render_steps
             tot_ms += ms
             tot_b += algorithmic_bytes(kname, m)
             D_sum += m.get("D", 0) or 0
+            px_sum += m.get("Px", 0) or 0
         n = len(recs)
-        kern[kname] = {"launches": n, "avg_ms": round(tot_ms / n, 5), "algo_MB": round(tot_b / n / 1e6, 3),
-                       "GBps": round(tot_b / (tot_ms * 1e-3) / 1e9, 1) if tot_ms > 0 and tot_b else None}
-        if kern[kname]["GBps"]:
-            kern[kname]["frac_hbm_peak"] = round(kern[kname]["GBps"] / HBM_PEAK_GBS, 4)
+        k = kern[kname] = {"launches": n, "avg_ms": round(tot_ms / n, 5)}
+        gbps = (tot_b / (tot_ms * 1e-3) / 1e9) if tot_ms > 0 and tot_b else None
         if D_sum:
-            kern[kname]["mean_pairs_D"] = D_sum // n
-        if kname == "binning" and tot_ms > 0:
+            k["mean_pairs_D"] = D_sum // n
+        if kname in ("composite_forward", "composite_backward"):
+            # The D-based formula (40 / 76 B per pair + 20 B per pixel) credits the WHOLE tile lists;
+            # early termination leaves most of every list unread, so it is no roofline (it exceeded 1.0 "of peak" on
+            # the 6 M-Gaussian shape).  What the kernel can have asked memory for follows from the entries it WALKED
+            # (counted by the kernels themselves, gsr_composite_walked): 40 B (K8) / 76 B (K10: + the 36-byte gradient
+            # record) per walked entry of a tile + 20 B per pixel.  The kernels are bound by VALU issue (`bound`).
+            w_entries = walked[0 if kname == "composite_forward" else 1] / n
+            per = 40 if kname == "composite_forward" else 76
+            wb = per * w_entries + 20 * px_sum / n
+            k.update({"bound": "valu", "hbm_formula_MB": round(tot_b / n / 1e6, 3),
+                      "hbm_formula_note": "whole-list formula of SURVEY.md 8(d), credits bytes the kernel never touches: "
+                                          "no roofline",
+                      "walked_entries": int(w_entries),
+                      "walked_frac_of_D": round(w_entries / (D_sum / n), 4) if D_sum else None,
+                      "hbm_walked_MB": round(wb / 1e6, 3),
+                      "hbm_walked_frac": round(wb / (tot_ms / n * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if tot_ms > 0 else None})
+        elif kname == "binning":
+            # bytes THIS build's split-key binning moves by construction; the reference's 64-bit-key
+            # algorithm would move `reference_algorithm_MB` -- a speed-up statement, not a roofline
             own = sum(algorithmic_bytes("binning_own", dict(meta)) for _, meta in recs)
-            kern[kname].update({"algo_MB_note": "the REFERENCE's algorithm (64-bit keys, 6 LSD passes over 12-byte pairs)",
-                                "own_MB": round(own / n / 1e6, 3), "own_GBps": round(own / (tot_ms * 1e-3) / 1e9, 1),
-                                "own_frac_hbm_peak": round(own / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                "own_note": "64 B x P + 40 B x D: what this build's split-key binning moves"})
+            k.update({"bound": "hbm / launch latency", "algo_MB": round(own / n / 1e6, 3),
+                      "algo_note": "64 B x P + 40 B x D: what this build's split-key binning moves",
+                      "GBps": round(own / (tot_ms * 1e-3) / 1e9, 1) if tot_ms > 0 else None,
+                      "frac_hbm_peak": round(own / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if tot_ms > 0 else None,
+                      "reference_algorithm_MB": round(tot_b / n / 1e6, 3)})
+        else:
+            k.update({"bound": "hbm", "algo_MB": round(tot_b / n / 1e6, 3), "GBps": round(gbps, 1) if gbps else None})
+            if gbps:
+                k["frac_hbm_peak"] = round(gbps / HBM_PEAK_GBS, 4)
     out["kernels"] = kern
     if world > 1 and state["sizes"] is not None:
         sizes = state["sizes"]  # sizes[i][j][k]: rows rank i sends to rank j for camera k (last step)
@@ -585,7 +611,7 @@ def main():
         if pk_.get("valu_busy_frac") is not None:
             kv["valu_busy"] = pk_.get("valu_busy_frac")
     if dom:
-        ach = kern[dom]["GBps"]
+        dk = kern[dom]
         pk = (pmc or {}).get("kernels", {}).get(dom, {})
         valu = None
         if pk.get("SQ_INSTS_VALU"):
@@ -594,20 +620,38 @@ def main():
             # were busy; a wave64 VALU instruction occupies its SIMD ~4.1-4.2 cycles on this chip (same counters)
             valu = {"insts_per_launch": pk["SQ_INSTS_VALU"], "active_quad_cycles_per_launch": pk.get("SQ_ACTIVE_INST_VALU"),
                     "busy_cycles_per_launch": pk.get("SQ_BUSY_CYCLES"), "profiled_avg_ms": pk.get("avg_ms"),
-                    "frac": pk.get("valu_busy_frac"), "cycles_per_inst": pk.get("cycles_per_valu_inst"),
-                    "derivation": "frac = 4 * SQ_ACTIVE_INST_VALU / (SQ_BUSY_CYCLES / 32 * 1024 SIMDs)"}
-        roofline = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4) if ach else None,
-                    "traffic": pk.get("hbm_bytes_per_launch"),
-                    "traffic_frac": round(pk["hbm_bytes_per_launch"] / (pk["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-                    if pk.get("hbm_bytes_per_launch") and pk.get("avg_ms") else None,
-                    "avg_ms": kern[dom]["avg_ms"], "algorithmic_bytes": int(kern[dom]["algo_MB"] * 1e6),
-                    "valu": valu, "pmc_source": pmc_note, "source_hash": src,
-                    "note": "achieved = algorithmic bytes of the launches / their HIP-event time, taken in the instrumented "
-                            "replay of the timed steps (same launches, kernels_region_ms_per_step); the composite "
-                            "kernels stop early on saturated pixels, so they MOVE fewer bytes than the formula "
-                            "credits (traffic_frac is the measured-bytes fraction) and are bound by VALU issue "
-                            "(valu.frac), see DESIGN.md"}
+                    "frac": pk.get("valu_busy_frac"), "mfma_frac": pk.get("mfma_busy_frac"),
+                    "cycles_per_inst": pk.get("cycles_per_valu_inst"),
+                    "derivation": "frac = 4 * SQ_ACTIVE_INST_VALU / (SQ_BUSY_CYCLES / 32 * 1024 SIMDs); mfma_frac = "
+                                  "SQ_VALU_MFMA_BUSY_CYCLES / the same cycles (fp32 MFMA and VALU do not co-issue)"}
+        traffic = pk.get("hbm_bytes_per_launch")
+        traffic_frac = (round(traffic / (pk["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                        if traffic and pk.get("avg_ms") else None)
+        if dk.get("bound") == "valu":
+            # the dominant kernel is bound by instruction issue, not by HBM: the roofline is the SIMDs' issue capacity
+            # (VALU-busy + MFMA-busy fraction of the SIMD cycles, PMC of THIS build or null); the HBM views sit beside it
+            issue = (round((pk.get("valu_busy_frac") or 0.0) + (pk.get("mfma_busy_frac") or 0.0), 4)
+                     if pk.get("valu_busy_frac") is not None else None)
+            roofline = {"kernel": dom, "bound": "valu", "achieved": issue, "peak": 1.0,
+                        "unit": "fraction of SIMD issue cycles busy (VALU + fp32 MFMA)", "frac": issue,
+                        "hbm_walked_frac": dk.get("hbm_walked_frac"), "hbm_walked_bytes": int(dk["hbm_walked_MB"] * 1e6),
+                        "hbm_formula_bytes": int(dk["hbm_formula_MB"] * 1e6),
+                        "hbm_formula_frac": round(dk["hbm_formula_MB"] * 1e6 / (dk["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        "hbm_formula_note": dk["hbm_formula_note"], "hbm_peak_GBps": HBM_PEAK_GBS,
+                        "traffic": traffic, "traffic_frac": traffic_frac, "avg_ms": dk["avg_ms"], "valu": valu,
+                        "pmc_source": pmc_note, "source_hash": src,
+                        "note": "K10 walks " + str(dk.get("walked_frac_of_D")) + " of the pair entries (early "
+                                "termination); hbm_walked_frac = (76 B x walked entries + 20 B x pixels) / HIP-event "
+                                "time / 8 TB/s, traffic = PMC FETCH_SIZE + WRITE_SIZE of the same command"}
+        else:
+            ach = dk.get("GBps")
+            roofline = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(ach / HBM_PEAK_GBS, 4) if ach else None, "traffic": traffic,
+                        "traffic_frac": traffic_frac, "avg_ms": dk["avg_ms"],
+                        "algorithmic_bytes": int(dk["algo_MB"] * 1e6), "valu": valu, "pmc_source": pmc_note,
+                        "source_hash": src,
+                        "note": "achieved = algorithmic bytes of the launches / their HIP-event time, taken in the "
+                                "instrumented replay of the timed steps (same launches, kernels_region_ms_per_step)"}
     n_total, W, H = main_res["gaussians_total"], main_res["image"][0], main_res["image"][1]
     out = {
         "metric": "training iters/sec (fwd+bwd)",
@@ -629,6 +673,10 @@ def main():
                    "bsz": main_res["bsz"],
                    "parallelism": f"pixel-partition x{world} (row bands), Gaussian-sharded x{world}",
                    "scene": main_res["scene"], "opacity_logit": [a.opacity_logit_mean, a.opacity_logit_std], "seed": 0,
+                   "learning_rates": main_res["learning_rates"],
+                   "learning_rates_note": "per parameter group, the reference's (arguments/__init__.py:109-118); the "
+                                          "constructor default lr=0.0 (scene/gaussian_model.py:292) is overridden by "
+                                          "every group, so the parameters DO move in the timed steps",
                    "optimizer": ("FusedAdam, K11 fused into the step (gsr_preprocess_backward_adam_raw_batched): same "
                                  "arithmetic as K11 + Adam, parameter gradients never written to HBM"
                                  if main_res["optimizer"]["fuse_backward"] else "FusedAdam after K11 (two kernels)")},
@@ -665,9 +713,11 @@ def main():
                         "ms_per_step": round(r["ms_per_step"], 4), "steps": r["steps"],
                         "rendered_views_per_sec": round(r.get("rendered_views_per_sec", 0.0), 3),
                         "ms_per_step_two_kernels": r["optimizer"]["ms_per_step_two_kernels"],
-                        "dominant_kernels": {k_: {"avg_ms": v_["avg_ms"], "frac_hbm_peak": v_.get("frac_hbm_peak"),
-                                                  **({"own_frac_hbm_peak": v_["own_frac_hbm_peak"]}
-                                                     if "own_frac_hbm_peak" in v_ else {})} for k_, v_ in top}})
+                        "dominant_kernels": {k_: {"avg_ms": v_["avg_ms"], "bound": v_.get("bound"),
+                                                  **({"frac_hbm_peak": v_["frac_hbm_peak"]}
+                                                     if "frac_hbm_peak" in v_ else {}),
+                                                  **({"hbm_walked_frac": v_["hbm_walked_frac"]}
+                                                     if "hbm_walked_frac" in v_ else {})} for k_, v_ in top}})
         out["extra_workloads"] = ews
     if world > 1:
         out["config"]["balance_timing"] = a.balance_timing

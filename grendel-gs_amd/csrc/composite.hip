@@ -25,6 +25,12 @@ constexpr float LOG2E = 1.4426950408889634f;
 constexpr float ALPHA_MIN = 1.0f / 255.0f;
 constexpr float T_STOP = 0.0001f;
 
+// list entries WALKED per launch group (always on; one atomic per workgroup): [0] K8, [1] K10 -- per tile, the entries
+// of the tile's list that its longest-walking quadrant wave went through (rounded up to the 64-entry chunks the walk
+// loads).  bench.py turns them into the bytes the kernels can have asked HBM for: early termination leaves most of
+// every list untouched, so the formula that credits the WHOLE list (40 / 76 B x D) is not a roofline.
+__device__ unsigned long long g_walked[2];
+
 #ifdef GSR_STATS
 __device__ unsigned long long g_stats[8];
 #define GSR_STAT(i, v) do { const unsigned long long sv__ = (unsigned long long)(v); if (lane == 0) atomicAdd(&g_stats[i], sv__); } while (0)
@@ -176,11 +182,16 @@ composite_forward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
     int last = 0;
     bool done = !inside;
     __shared__ __attribute__((aligned(16))) float slab[4][32 * PREC];
+    __shared__ int s_walk[2];  // [0] longest walk of the four waves, [1] waves that have finished
+    if (threadIdx.x < 2) s_walk[threadIdx.x] = 0;
+    __syncthreads();  // the only workgroup barrier of the kernel: all four waves are at their first instructions
     v2f A0 = {0.f, 0.f}, A1 = {0.f, 0.f}, A2 = {0.f, 0.f};  // colour sums of the even / odd pair slots (added at the end)
     float *wslab = slab[wave];
+    int walked = 0;
 
     for (int c = 0; c < n; c += 64) {
         if (__all(done)) break;
+        walked = c + 64;
         const bool have = c + lane < n;
         const uint32_t id = have ? point_list[range.x + c + lane] : 0u;
         const Entry e = load_entry(have, id, means2D, conic_opacity, (float)qx0, (float)qy0);
@@ -251,6 +262,10 @@ composite_forward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
             }
             if (__all(done)) break;
         }
+    }
+    if (lane == 0) {  // the last wave to get here adds the tile's longest walk to the launch counter
+        atomicMax(&s_walk[0], walked < n ? walked : n);
+        if (atomicAdd(&s_walk[1], 1) == 3) atomicAdd(&g_walked[0], (unsigned long long)s_walk[0]);
     }
     C0 = A0.x + A0.y;
     C1 = A1.x + A1.y;
@@ -367,6 +382,7 @@ composite_backward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
     __syncthreads();
     const int bmax = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
     if (bmax == 0) return;
+    if (threadIdx.x == 0) atomicAdd(&g_walked[1], (unsigned long long)bmax);  // entries the tile's walk goes through
     // the wave that walks the longest list has every entry of every chunk in its slab: the flush reads from it
     int wbest = 0;
 #pragma unroll
@@ -583,6 +599,16 @@ composite_backward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
 }
 
 }  // namespace
+
+extern "C" int gsr_composite_walked(unsigned long long *out2, int reset) {
+    if (!out2) return GSR_EINVAL;
+    GSR_HIP(hipMemcpyFromSymbol(out2, HIP_SYMBOL(g_walked), sizeof(unsigned long long) * 2));
+    if (reset) {
+        const unsigned long long z[2] = {0ull, 0ull};
+        GSR_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_walked), z, sizeof(z)));
+    }
+    return 0;
+}
 
 #ifdef GSR_STATS
 extern "C" int gsr_debug_stats(unsigned long long *out8, int reset) {

@@ -171,6 +171,13 @@ def _zhx_flush(ca):
             f.write(f"{label}: {ms[label]:.6f} ms\n")
 
 
+def composite_walked(reset=False):
+    """-> (K8, K10) list entries walked since the last reset (include/gsraster.h: gsr_composite_walked); synchronous"""
+    out = (ctypes.c_ulonglong * 2)()
+    check(lib.gsr_composite_walked(out, 1 if reset else 0), "gsr_composite_walked")
+    return int(out[0]), int(out[1])
+
+
 def local_pixels(mask, W, H):
     """number of image pixels inside the tiles marked in `mask` (uint8/bool [TILE_Y*TILE_X]); host-syncing helper for
     bench bookkeeping, called after the timed region"""

@@ -189,6 +189,12 @@ int gsr_render_backward(int P, int width, int height, const int32_t *ranges, con
                         const float *means2D, const float *conic_opacity, const float *rgb,
                         const uint8_t *compute_locally, const float *bg, const float *final_T,
                         const int32_t *n_contrib, const float *dL_dpixels, float *dL_record, gsr_stream_t stream);
+/* Measurement aid (bench.py's roofline leg; the reference has nothing to bind here): list entries the composite kernels
+ * WALKED since the last reset, summed over launches -- out2[0] K8, out2[1] K10; per tile the entries its longest-walking
+ * quadrant goes through (K8: up to the chunk in which the last pixel saturates; K10: the largest n_contrib of the
+ * tile).  Early termination leaves most of every list untouched, so D-based byte formulas over-credit these kernels.
+ * Synchronous (a device-to-host copy of two words); reset != 0 zeroes the counters afterwards. */
+int gsr_composite_walked(unsigned long long *out2, int reset);
 
 /* ---------------------------------------------------------------------------------------------
  * N1  fused band-local L1 + SSIM loss -- the arithmetic of final_system_loss_computation,

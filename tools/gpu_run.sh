@@ -105,6 +105,15 @@ if has gaps8; then
   find $O -name "*.db" -size +8M -delete
   cut -c1-110 $O/fake_world_w8_gaps.txt
 fi
+if has gapsg; then
+  cd /tmp
+  timeout 400 rocprofv3 --kernel-trace -d $O/prof_fwg -- python $R/tools/fake_world_bench.py --workload c2 --worlds 8 --steps 24 --warmup 6 --graph on > $O/fake_world_c2_w8_graph.txt 2> $O/fake_world_c2_w8_graph.err
+  cd $R
+  DB=$(find $O/prof_fwg -name "*.db" | head -1)
+  python tools/gap_analysis.py $DB 12 > $O/fake_world_w8_graph_gaps.txt 2>&1
+  find $O -name "*.db" -size +8M -delete
+  cut -c1-110 $O/fake_world_w8_graph_gaps.txt
+fi
 if has pmc; then
   bash tools/gpu_session.sh $TAG trace sq fetch write > $O/pmc_session.log 2>&1
   tail -5 $O/pmc_session.log

@@ -25,7 +25,7 @@ for st in trace sq fetch write; do
   has $st || continue
   case $st in
     trace) PMC="";;
-    sq)    PMC="--pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_SALU SQ_WAVES";;
+    sq)    PMC="--pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVES";;
     fetch) PMC="--pmc FETCH_SIZE";;
     write) PMC="--pmc WRITE_SIZE";;
   esac

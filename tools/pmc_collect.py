@@ -135,6 +135,10 @@ def main():
             d["avg_ms"] = round(sum(v[anyc][2] for v in members.values()) / calls / 1e6, 5)  # duration in the PMC run
             if d.get("SQ_ACTIVE_INST_VALU") and d.get("SQ_BUSY_CYCLES"):
                 d["valu_busy_frac"] = round(4.0 * d["SQ_ACTIVE_INST_VALU"] / (d["SQ_BUSY_CYCLES"] / 32.0 * 1024.0), 4)
+            if d.get("SQ_VALU_MFMA_BUSY_CYCLES") is not None and d.get("SQ_BUSY_CYCLES"):
+                # cycles the matrix pipe is busy, summed over the SIMDs (fp32 MFMA does not co-issue with the VALU on
+                # this chip: SQ_VALU_MFMA_COEXEC_CYCLES = 0, profiles/r02_composite_sq_counters.txt)
+                d["mfma_busy_frac"] = round(d["SQ_VALU_MFMA_BUSY_CYCLES"] / (d["SQ_BUSY_CYCLES"] / 32.0 * 1024.0), 4)
             if d.get("SQ_ACTIVE_INST_VALU") and d.get("SQ_INSTS_VALU"):
                 d["cycles_per_valu_inst"] = round(4.0 * d["SQ_ACTIVE_INST_VALU"] / d["SQ_INSTS_VALU"], 3)
             print(f"{g:22s} calls {calls:4d}  avg {d['avg_ms']:.4f} ms  " +
