@@ -424,18 +424,27 @@ extern "C" int gsr_exchange_unpack(int64_t n, const float *recv, float *means2D,
 // at the word after the replay, repeats the iteration eagerly.
 namespace {
 __global__ void flag_if_greater_kernel(const uint32_t *__restrict__ value, uint32_t limit, uint32_t *__restrict__ flag,
-                                       uint32_t bit) {
-    if (threadIdx.x == 0 && *value > limit) atomicOr(flag, bit);
+                                       uint32_t bit, uint32_t *__restrict__ host_copy) {
+    if (threadIdx.x == 0) {
+        const uint32_t v = *value;
+        if (v > limit) atomicOr(flag, bit);
+        if (host_copy) __hip_atomic_store(host_copy, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 // all_counts [W][W][B] (rows rank i sends rank j of camera k, all-gathered), caps the same shape: bit_over when a
 // count exceeds its slab; bit_few when a band this rank renders (bit k of rendered_mask) receives fewer than `few`
 // rows in total (the reference's stand-in rule needs the true count, gaussian_renderer/__init__.py:1260-1269)
 __global__ void exchange_check_kernel(const int32_t *__restrict__ all_counts, const int32_t *__restrict__ caps, int W,
                                       int B, int me, unsigned long long rendered_mask, int few,
-                                      uint32_t *__restrict__ flag, uint32_t bit_over, uint32_t bit_few) {
+                                      uint32_t *__restrict__ flag, uint32_t bit_over, uint32_t bit_few,
+                                      int32_t *__restrict__ host_copy) {
     const int n = W * W * B;
     bool over = false;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) over |= all_counts[i] > caps[i];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int32_t c = all_counts[i];
+        over |= c > caps[i];
+        if (host_copy) __hip_atomic_store(host_copy + i, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     bool lack = false;
     for (int k = threadIdx.x; k < B; k += blockDim.x) {
         if (!((rendered_mask >> k) & 1ull)) continue;
@@ -470,21 +479,21 @@ extern "C" int gsr_publish_flag(const uint32_t *flag_dev, const uint32_t *seq_de
 }
 
 extern "C" int gsr_flag_if_greater(const uint32_t *value_dev, uint32_t limit, uint32_t *flag_dev, uint32_t bit,
-                                   gsr_stream_t stream_) {
+                                   uint32_t *host_copy_pinned, gsr_stream_t stream_) {
     if (!value_dev || !flag_dev) return GSR_EINVAL;
     hipLaunchKernelGGL(flag_if_greater_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream_), value_dev,
-                       limit, flag_dev, bit);
+                       limit, flag_dev, bit, host_copy_pinned);
     GSR_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int gsr_exchange_check(const int32_t *all_counts_dev, const int32_t *caps_dev, int W, int B, int me,
                                   uint64_t rendered_mask, int few, uint32_t *flag_dev, uint32_t bit_over,
-                                  uint32_t bit_few, gsr_stream_t stream_) {
+                                  uint32_t bit_few, int32_t *host_copy_pinned, gsr_stream_t stream_) {
     if (!all_counts_dev || !caps_dev || !flag_dev || W < 1 || B < 1 || B > 64 || me < 0 || me >= W) return GSR_EINVAL;
     hipLaunchKernelGGL(exchange_check_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_),
                        all_counts_dev, caps_dev, W, B, me, (unsigned long long)rendered_mask, few, flag_dev, bit_over,
-                       bit_few);
+                       bit_few, host_copy_pinned);
     GSR_LAUNCH_CHECK();
     return 0;
 }

@@ -728,10 +728,9 @@ def _bin_gaussians_captured(cap_ctx, means2D, depths, radii, conic_opacity, comp
     check(lib.gsr_bin_sort_bounded(P, width, height, _ptr(compute_locally), _ptr(prep), cap, _ptr(scratch), sort_bytes,
                                    _ptr(point_list), _ptr(ranges), stream), "gsr_bin_sort_bounded")
     off = int(lib.gsr_bin_total_offset(P, width, height))
-    check(lib.gsr_flag_if_greater(prep.data_ptr() + off, cap, _ptr(cap_ctx.flag), FLAG_PAIRS, stream),
+    host = cap_ctx.take_pinned(1)  # the kernel leaves the pair count there (pinned, device-accessible)
+    check(lib.gsr_flag_if_greater(prep.data_ptr() + off, cap, _ptr(cap_ctx.flag), FLAG_PAIRS, host.data_ptr(), stream),
           "gsr_flag_if_greater")
-    host = cap_ctx.take_pinned(1)
-    host.copy_(prep[off:off + 4].view(torch.int32), non_blocking=True)
     cap_ctx.pairs.append((host, cap))
     return point_list, ranges, cap
 
@@ -1218,7 +1217,7 @@ def exchange_unpack(recv):
     return outs[0], outs[1], outs[2], radii, depths
 
 
-def exchange_check(all_counts, caps_dev, W, B, me, rendered_mask, few, flag):
+def exchange_check(all_counts, caps_dev, W, B, me, rendered_mask, few, flag, host_copy=None):
     """capacity check of a captured exchange (include/gsraster.h: gsr_exchange_check): raises FLAG_SLAB / FLAG_FEW in
     the device word `flag`"""
     if all_counts.dtype != torch.int32 or caps_dev.dtype != torch.int32 or all_counts.numel() != W * W * B or \
@@ -1226,7 +1225,9 @@ def exchange_check(all_counts, caps_dev, W, B, me, rendered_mask, few, flag):
         raise ValueError("all_counts / caps_dev must be contiguous int32 [W*W*B]")
     with _on(all_counts.device):
         check(lib.gsr_exchange_check(_ptr(all_counts), _ptr(caps_dev), W, B, me, int(rendered_mask), int(few),
-                                     _ptr(flag), FLAG_SLAB, FLAG_FEW, _stream()), "gsr_exchange_check")
+                                     _ptr(flag), FLAG_SLAB, FLAG_FEW,
+                                     host_copy.data_ptr() if host_copy is not None else None, _stream()),
+              "gsr_exchange_check")
 
 
 def zeros_async(shape, dtype, device):

@@ -477,9 +477,8 @@ def _batched_exchange_final(m2_views, rgb_views, co_views, radii_views, depths_v
         for k, st in enumerate(batched_strategies):
             if me in st.gpu_ids:
                 rendered |= 1 << k
-        _dgr.exchange_check(all_counts, cap_ctx.slab_caps_dev, W, B, me, rendered, 10, cap_ctx.flag)
-        host = cap_ctx.take_pinned(W * W * B)
-        host.copy_(all_counts.view(-1), non_blocking=True)
+        host = cap_ctx.take_pinned(W * W * B)  # the check kernel leaves the counts there (pinned, device-accessible)
+        _dgr.exchange_check(all_counts, cap_ctx.slab_caps_dev, W, B, me, rendered, 10, cap_ctx.flag, host_copy=host)
         cap_ctx.counts = (host, planner.caps.copy(), (W, W, B))
         sizes = _LazySizes()
         sizes._resolver = lambda h=host, z=sizes: setattr(z, "_v", h.view(W, W, B).tolist())

@@ -89,31 +89,60 @@ class GraphedIteration:
             camera._gsr_packed = cached
         return cached[1]
 
-    def _make_proxies(self, cameras):
-        """static stand-ins of the batch's cameras: the captured kernels read THEIR buffers, which are refreshed from
-        the real cameras in front of every replay"""
+    MAXB = 16  # cameras per batch whose packed records live in the device block (larger batches: not graphed)
+
+    @staticmethod
+    def _packed_host(camera):
+        """numpy copy of the camera's [40] record (one device read-back per camera, ever: cameras are static)"""
+        dev = GraphedIteration._packed(camera)
+        key = camera._gsr_packed[0]
+        cached = getattr(camera, "_gsr_packed_host", None)
+        if cached is None or cached[0] != key:
+            cached = (key, dev.detach().cpu().numpy().copy())
+            camera._gsr_packed_host = cached
+        return cached[1]
+
+    def _make_proxies(self, cameras, tasks):
+        """static stand-ins of the batch's cameras: the captured kernels read THEIR buffers -- the [40] camera record
+        (a slice of the device block that also carries Adam's constants: ONE host-to-device copy refreshes both) and
+        the uint8 ground-truth band of the rows this rank renders (refreshed by one strided copy per camera)"""
+        import utils.general_utils as utils
+        from gaussian_renderer.loss_distribution import get_coverage_y_min_max
+
+        mine = {k: (l, r) for (k, l, r) in tasks[utils.GLOBAL_RANK]} if tasks is not None else {}
         proxies = []
-        for cam in cameras:
+        for k, cam in enumerate(cameras):
             px = copy.copy(cam)
             for name in ("world_view_transform", "full_proj_transform", "camera_center"):
                 setattr(px, name, getattr(cam, name).detach().clone())
-            px._gsr_packed = None
-            packed = self._packed(px).clone()
             mats = (px.world_view_transform, px.full_proj_transform, px.camera_center)
             key = (float(math.tan(px.FoVx * 0.5)), float(math.tan(px.FoVy * 0.5))) + tuple(
                 (t.data_ptr(), t._version) for t in mats)
-            px._gsr_packed = (key, packed)
-            gt = cam.original_image_backup
-            px.original_image_backup = torch.empty(gt.shape, dtype=gt.dtype, device=packed.device)
+            px._gsr_packed = (key, self._dyn[16 + 40 * k:16 + 40 * (k + 1)])
+            # the ground truth: only the band this rank renders, in a static buffer that the mirror's band cache
+            # (gaussian_renderer/loss_distribution.py: _band_of) finds under the placeholder's key -- no copy is captured
             px.original_image = None
-            px._gsr_bands = None
+            px._gsr_band = None
+            dev = self._dyn.device
+            px.original_image_backup = torch.empty((3, 1, 1), dtype=torch.uint8, device=dev)  # placeholder (cache key)
+            px._gsr_bands = []
+            if k in mine:
+                y0, y1 = get_coverage_y_min_max(*mine[k])
+                band = torch.empty((3, y1 - y0, int(cam.image_width)), dtype=torch.uint8, device=dev)
+                src = px.original_image_backup
+                px._gsr_bands = [((y0, y1, src.data_ptr(), src._version), band)]
+                px._gsr_band = (y0, y1, band)
             proxies.append(px)
         return proxies
 
-    def _refresh(self, proxies, cameras):
-        for px, cam in zip(proxies, cameras):
-            px._gsr_packed[1].copy_(self._packed(cam), non_blocking=True)
-            px.original_image_backup.copy_(cam.original_image_backup, non_blocking=True)
+    def _refresh(self, proxies, cameras, slot):
+        """stage this iteration's inputs: camera records into the pinned block of `slot` (they travel with Adam's
+        constants), ground-truth bands by one strided copy each"""
+        for k, (px, cam) in enumerate(zip(proxies, cameras)):
+            self._hyper_np[slot, 16 + 40 * k:16 + 40 * (k + 1)] = self._packed_host(cam)
+            if px._gsr_band is not None:
+                y0, y1, band = px._gsr_band
+                band.copy_(cam.original_image_backup[:, y0:y1, :], non_blocking=True)
             px.uid = getattr(cam, "uid", None)
 
     # ------------------------------------------------------------------ capture
@@ -122,9 +151,10 @@ class GraphedIteration:
     def _ensure_buffers(self, dev):
         if self._flag is None:
             self._flag = torch.zeros((1,), dtype=torch.int32, device=dev)
-            # device block the captured launches read at execution time: 12 Adam constants + the replay's sequence number
-            self._dyn = torch.zeros((16,), dtype=torch.float32, device=dev)
-            self._hyper_host = torch.zeros((self.RING, 16), dtype=torch.float32).pin_memory()
+            # device block the captured launches read at execution time: 12 Adam constants, the replay's sequence number
+            # (word 12) and the batch's camera records (40 floats each, from word 16)
+            self._dyn = torch.zeros((16 + 40 * self.MAXB,), dtype=torch.float32, device=dev)
+            self._hyper_host = torch.zeros((self.RING, 16 + 40 * self.MAXB), dtype=torch.float32).pin_memory()
             self._hyper_np = self._hyper_host.numpy()
             self._hyper_seq = self._hyper_host.view(torch.int32).numpy()
             # pinned, device-mapped ring the LAST launch of every replay stores { flag, sequence number } into
@@ -136,8 +166,14 @@ class GraphedIteration:
         dev = self.opt.param_groups[0]["params"][0].device
         self._ensure_buffers(dev)
         e = _Entry()
-        e.proxies = self._make_proxies(cameras)
-        self._refresh(e.proxies, cameras)
+        if len(cameras) > self.MAXB:
+            raise RuntimeError(f"batches above {self.MAXB} cameras are not graphed")
+        import utils.general_utils as utils
+
+        if getattr(utils.get_args(), "distributed_dataset_storage", False) and utils.DEFAULT_GROUP.size() > 1:
+            raise RuntimeError("distributed dataset storage stages its ground truth with point-to-point sends: not graphed")
+        e.proxies = self._make_proxies(cameras, tasks)
+        self._stage(e, cameras)
         e.ctx = _dgr.GraphCapture(self._flag, self._dyn)
         planner, caps = self._planner_caps(len(cameras))
         if caps is not None:
@@ -161,6 +197,19 @@ class GraphedIteration:
         self.entries[key] = e
         self.stats["captured"] += 1
         return e
+
+    def _stage(self, entry, cameras):
+        """-> sequence number of the replay these inputs are staged for"""
+        self._seq = seq = (self._seq + 1) & 0x3FFFFFFF or 1
+        slot = seq % self.RING
+        B = len(cameras)
+        self._refresh(entry.proxies, cameras, slot)
+        if self.opt.__dict__.get("_graph_owners") is not None:
+            self._hyper_np[slot, :12] = self.opt.graph_hyper()
+        self._hyper_seq[slot, 12] = seq
+        n = 16 + 40 * B
+        self._dyn[:n].copy_(self._hyper_host[slot, :n], non_blocking=True)
+        return seq
 
     # ------------------------------------------------------------------ validation (one iteration late)
     def _observe(self, entry):
@@ -233,13 +282,8 @@ class GraphedIteration:
                     self.enabled = False
                     self.stats["disabled"] = f"{type(exc).__name__}: {exc}"
             return out
-        # replay: inputs, hyper-parameters, ONE launch
-        self._refresh(entry.proxies, cameras)
-        self._seq = seq = (self._seq + 1) & 0x3FFFFFFF or 1
-        slot = seq % self.RING
-        self._hyper_np[slot, :12] = self.opt.graph_hyper()
-        self._hyper_seq[slot, 12] = seq
-        self._dyn.copy_(self._hyper_host[slot], non_blocking=True)
+        # replay: inputs + hyper-parameters (one host-to-device copy, one band copy per camera), then ONE launch
+        seq = self._stage(entry, cameras)
         entry.graph.replay()
         ev = torch.cuda.Event()
         ev.record()

@@ -152,18 +152,20 @@ size_t gsr_bin_total_offset(int P, int width, int height);
  *   gsr_exchange_check  : all_counts_dev / caps_dev int32 [W][W][B] (rows rank i sends rank j of camera k, and the
  *                         slab reserved for them): bit_over when a count exceeds its slab; bit_few when a band this
  *                         rank (`me`) renders -- bit k of rendered_mask -- receives fewer than `few` rows in total
- *                         (the reference's < 10-Gaussian stand-in rule, gaussian_renderer/__init__.py:1260-1269). */
-/*   gsr_publish_flag    : last launch of a captured iteration: { *flag_dev, *seq_dev } are stored (system scope, the
+ *                         (the reference's < 10-Gaussian stand-in rule, gaussian_renderer/__init__.py:1260-1269).
+ *   Both also leave what they looked at in PINNED, device-accessible host memory when host_copy_pinned is not NULL
+ *   (the value / the W*W*B counts, system-scope stores): the host reads them after the replay, no copy node needed.
+ *   gsr_publish_flag    : last launch of a captured iteration: { *flag_dev, *seq_dev } are stored (system scope, the
  *                         stamp last) into words 2 s, 2 s + 1 of a pinned, device-accessible ring of `slots` pairs,
  *                         s = *seq_dev % slots; seq_dev is a device word the host refreshes in front of every replay.
  *                         The host polls the stamp instead of synchronising the stream. */
 int gsr_publish_flag(const uint32_t *flag_dev, const uint32_t *seq_dev, uint32_t *host_ring_pinned, uint32_t slots,
                      gsr_stream_t stream);
 int gsr_flag_if_greater(const uint32_t *value_dev, uint32_t limit, uint32_t *flag_dev, uint32_t bit,
-                        gsr_stream_t stream);
+                        uint32_t *host_copy_pinned, gsr_stream_t stream);
 int gsr_exchange_check(const int32_t *all_counts_dev, const int32_t *caps_dev, int W, int B, int me,
                        uint64_t rendered_mask, int few, uint32_t *flag_dev, uint32_t bit_over, uint32_t bit_few,
-                       gsr_stream_t stream);
+                       int32_t *host_copy_pinned, gsr_stream_t stream);
 int gsr_bin_sort_bounded(int P, int width, int height, const uint8_t *compute_locally, const void *prep,
                          int64_t capacity, void *scratch, size_t scratch_bytes, uint32_t *point_list, int32_t *ranges,
                          gsr_stream_t stream);

@@ -20,14 +20,15 @@ import harness  # noqa: E402
 import scenes  # noqa: E402
 
 FULL = ["c0", "w2"]          # inputs + every output
-SUMMARY = ["hd", "hdw2"]     # inputs regenerated from the seed (checksum stored), outputs summarised
+SUMMARY = ["hd", "hdw2", "w2b2", "w4b2", "w8b4"]  # inputs regenerated from the seed (checksum stored), outputs summarised
 
 
 def main():
     out_dir = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
     assert harness.reference_staged(), "stage the reference first: python tools/stage_reference.py"
-    for name in FULL + SUMMARY:
+    only = sys.argv[2:]
+    for name in [n for n in FULL + SUMMARY if not only or n in only]:
         scene = scenes.build_case(name)
         outs = harness.run_side("ref", scene)
         blob = {}

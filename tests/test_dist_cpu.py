@@ -451,3 +451,40 @@ def test_pipelined_load_balancer_lags_one_step_and_needs_no_device_sync():
         p.join(timeout=60)
     for rank, msg in results:
         assert msg == "ok", f"rank {rank}:\n{msg}"
+
+
+def test_local_sampling_strategy_equals_the_reference():
+    """a13, `--local_sampling` branch (gaussian_renderer/workload_division.py:858-877 of the reference): every camera
+    of the batch is rendered whole by the rank that sampled it.  tests/golden/reference_local_sampling.json holds what
+    the REFERENCE's start_strategy_final returned (tests/golden/make_local_sampling_golden.py imports it); the mirror
+    must return the same task lists and strategy fields."""
+    import json
+    from types import SimpleNamespace
+
+    for p in (os.path.join(ROOT, "grendel-gs_amd"), ROOT):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import utils.general_utils as utils
+    from gaussian_renderer.workload_division import start_strategy_final
+
+    saved = (utils.ARGS, utils.WORLD_SIZE, utils.GLOBAL_RANK, utils.DEFAULT_GROUP, utils.IMG_H, utils.IMG_W,
+             utils.TILE_Y, utils.TILE_X)
+    cases = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_local_sampling.json")))
+    assert len(cases) >= 5
+    try:
+        for c in cases:
+            world, bsz, rank = c["world"], c["bsz"], c["rank"]
+            utils.set_args(utils.default_args(bsz=bsz, local_sampling=True, distributed_dataset_storage=True))
+            utils.WORLD_SIZE, utils.GLOBAL_RANK = world, rank
+            utils.DEFAULT_GROUP = SimpleNamespace(size=lambda w=world: w, rank=lambda r=rank: r)
+            utils.set_img_size(1080, 1920)
+            assert utils.TILE_Y == c["tile_y"]
+            cams = [SimpleNamespace(uid=100 + k) for k in range(bsz)]
+            strategies, tasks = start_strategy_final(cams, None)
+            assert [[list(t) for t in g] for g in tasks] == c["tasks"], c
+            got = [{"uid": s.camera.uid, "world_size": s.world_size, "gpu_ids": list(s.gpu_ids),
+                    "division_pos": list(s.division_pos), "rank": s.rank} for s in strategies]
+            assert got == c["strategies"], (c, got)
+    finally:
+        (utils.ARGS, utils.WORLD_SIZE, utils.GLOBAL_RANK, utils.DEFAULT_GROUP, utils.IMG_H, utils.IMG_W, utils.TILE_Y,
+         utils.TILE_X) = saved

@@ -59,7 +59,7 @@ def test_mirror_matches_frozen_reference_run(device, name):
     _report(f"mirror vs frozen reference run [{name}]", harness.compare(ref, mir, tol=TOL.get(name, 1e-5)))
 
 
-@pytest.mark.parametrize("name", ["hd", "hdw2"])
+@pytest.mark.parametrize("name", ["hd", "hdw2", "w2b2", "w4b2", "w8b4"])
 def test_mirror_matches_frozen_reference_summary(device, name):
     z, _, summ = _load_fixture(name)
     scene = scenes.build_case(name)

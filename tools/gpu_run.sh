@@ -50,6 +50,15 @@ if has xprobe; then
     echo "xprobe $cfg exit $?"; grep -v amdgpu.ids "$O/xprobe_${cfg// /_}.log" | grep -E "stats|equals|Error|error|Fatal|File \"/(root|tmp)" | tail -6 | cut -c1-250
   done
 fi
+if has golden; then
+  mkdir -p $O/golden
+  timeout 900 python tests/golden/make_reference_b1_golden.py $O/golden w2b2 w4b2 w8b4 > $O/golden.log 2>&1
+  echo "golden exit $?"; tail -5 $O/golden.log | cut -c1-300
+fi
+if has b1; then
+  timeout 900 python -m pytest tests/test_gpu_reference_b1.py -q -m gpu -x -p no:cacheprovider > $O/b1.log 2>&1
+  echo "b1 pytest exit $?"; tail -4 $O/b1.log | cut -c1-300
+fi
 if has gtest; then
   timeout 900 python -m pytest tests/test_gpu_graphed_step.py -q -m gpu -x -s -p no:cacheprovider > $O/gtest.log 2>&1
   echo "gtest pytest exit $?" | tee -a $O/gtest.log
