@@ -148,6 +148,28 @@ __device__ __forceinline__ int composite_tile_of_block(const int2 *__restrict__ 
     return gsr_xcd_span_of_block_band(blockIdx.x, tiles, hull.x * gx, (hull.y - hull.x) * gx);
 }
 
+// what a lane holds of one list entry between the load and the chunk that consumes it (software prefetch)
+struct RawEntry {
+    float2 xy;
+    float4 co;
+    float r, g, b;
+};
+__device__ __forceinline__ RawEntry load_raw(bool have, uint32_t id, const float2 *__restrict__ means2D,
+                                             const float4 *__restrict__ conic_opacity, const float *__restrict__ rgb) {
+    RawEntry e;
+    e.xy = make_float2(0.f, 0.f);
+    e.co = make_float4(0.f, 0.f, 0.f, 0.f);
+    e.r = e.g = e.b = 0.f;
+    if (have) {
+        e.xy = means2D[id];
+        e.co = conic_opacity[id];
+        e.r = rgb[3 * (size_t)id];
+        e.g = rgb[3 * (size_t)id + 1];
+        e.b = rgb[3 * (size_t)id + 2];
+    }
+    return e;
+}
+
 // ------------------------------------------------------------------------------------------- K8
 __global__ void __launch_bounds__(256)
 composite_forward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
@@ -189,6 +211,9 @@ composite_forward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
     float *wslab = slab[wave];
     int walked = 0;
 
+    // (measured, round 4: loading a chunk's entries one chunk ahead -- K10's software prefetch -- does NOT help here: 78
+    // instead of 64 VGPRs, 0.146 -> 0.152 ms at 1 M Gaussians / 1080p and no change on a 1/8 row band; the walk of a
+    // thin band is bound by the imbalance of ONE round of resident workgroups, not by memory latency)
     for (int c = 0; c < n; c += 64) {
         if (__all(done)) break;
         walked = c + 64;
@@ -315,28 +340,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int MB = 8;      // entries per MFMA batch: rows 0-7 of the 16 x 16 result are their q-rows, rows 8-15 their w-rows
 constexpr int MSTR = 66;   // row stride of the (q, w) matrix in 8-byte elements: phase A writes and phase B reads conflict-free
-
-// what a lane holds of one list entry between the load and the chunk that consumes it (software prefetch)
-struct RawEntry {
-    float2 xy;
-    float4 co;
-    float r, g, b;
-};
-__device__ __forceinline__ RawEntry load_raw(bool have, uint32_t id, const float2 *__restrict__ means2D,
-                                             const float4 *__restrict__ conic_opacity, const float *__restrict__ rgb) {
-    RawEntry e;
-    e.xy = make_float2(0.f, 0.f);
-    e.co = make_float4(0.f, 0.f, 0.f, 0.f);
-    e.r = e.g = e.b = 0.f;
-    if (have) {
-        e.xy = means2D[id];
-        e.co = conic_opacity[id];
-        e.r = rgb[3 * (size_t)id];
-        e.g = rgb[3 * (size_t)id + 1];
-        e.b = rgb[3 * (size_t)id + 2];
-    }
-    return e;
-}
 
 __global__ void __launch_bounds__(256, 4)  // 4 waves per SIMD: <= 128 VGPRs (LDS admits 4 workgroups per CU)
 composite_backward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,

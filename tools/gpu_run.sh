@@ -97,6 +97,14 @@ if has ab; then
   timeout 300 python bench.py --no-cpu-baseline --no-extra --steps 30 --warmup 6 --repeats 3 --render-steps 10 > $O/ab_production2.json 2> $O/ab_production2.err
   summ $O/ab_production2.json production2 | tee -a $O/ab.txt
 fi
+if has abfake8; then
+  for lib in "" $(ls variants/libgsraster_*.so 2>/dev/null); do
+    [[ $lib == *stats* ]] && continue
+    n=production; [ -n "$lib" ] && { n=$(basename $lib .so); n=${n#libgsraster_}; }
+    GSRASTER_LIB=${lib:+$R/$lib} timeout 300 python tools/fake_world_bench.py --workload c2 --worlds 8 --steps 20 --graph on > $O/abfake8_$n.txt 2> $O/abfake8_$n.err
+    echo "$n: $(cut -c1-420 $O/abfake8_$n.txt | head -1)"
+  done
+fi
 if has fake; then
   timeout 600 python tools/fake_world_bench.py --workload c2 --worlds 1 2 4 8 --steps 20 > $O/fake_world_c2.txt 2> $O/fake_world_c2.err
   cut -c1-400 $O/fake_world_c2.txt
