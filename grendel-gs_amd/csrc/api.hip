@@ -12,7 +12,7 @@ const char *gsr_error_string(int code) {
     return "gsraster: unknown error";
 }
 
-int gsr_abi_version(void) { return 9; }
+int gsr_abi_version(void) { return 10; }
 
 int gsr_get_block_xy(int *block_x, int *block_y, int *one_dim_block) {
     if (!block_x || !block_y || !one_dim_block) return GSR_EINVAL;
@@ -123,8 +123,42 @@ int gsr_render_forward(int P, int width, int height, const int32_t *ranges, cons
     if (!ranges || !compute_locally || !bg || !out_color || !final_T || !n_contrib) return GSR_EINVAL;
     if (P > 0 && (!means2D || !conic_opacity || !rgb)) return GSR_EINVAL;
     return gsr_launch_composite_forward(P, width, height, ranges, point_list, means2D, conic_opacity, rgb,
-                                        compute_locally, bg, out_color, final_T, n_contrib,
+                                        compute_locally, bg, out_color, final_T, n_contrib, nullptr, 0, 0, 0,
                                         reinterpret_cast<hipStream_t>(stream));
+}
+
+size_t gsr_render_seg_bytes(int width, int height) {
+    if (width <= 0 || height <= 0) return 0;
+    return gsr_composite_seg_bytes(width, height);
+}
+
+int gsr_render_forward_seg(int P, int width, int height, const int32_t *ranges, const uint32_t *point_list,
+                           const float *means2D, const float *conic_opacity, const float *rgb,
+                           const uint8_t *compute_locally, const float *bg, float *out_color, float *final_T,
+                           int32_t *n_contrib, void *seg_ws, size_t seg_bytes, int row_lo, int row_hi,
+                           gsr_stream_t stream) {
+    if (P < 0 || width <= 0 || height <= 0) return GSR_EINVAL;
+    if (!ranges || !compute_locally || !bg || !out_color || !final_T || !n_contrib) return GSR_EINVAL;
+    if (P > 0 && (!means2D || !conic_opacity || !rgb)) return GSR_EINVAL;
+    return gsr_launch_composite_forward(P, width, height, ranges, point_list, means2D, conic_opacity, rgb,
+                                        compute_locally, bg, out_color, final_T, n_contrib, seg_ws, seg_bytes, row_lo,
+                                        row_hi, reinterpret_cast<hipStream_t>(stream));
+}
+
+int gsr_render_backward_seg(int P, int width, int height, const int32_t *ranges, const uint32_t *point_list,
+                            const float *means2D, const float *conic_opacity, const float *rgb,
+                            const uint8_t *compute_locally, const float *bg, const float *final_T,
+                            const int32_t *n_contrib, const float *dL_dpixels, float *dL_record,
+                            const float *out_color, void *seg_ws, size_t seg_bytes, int row_lo, int row_hi,
+                            gsr_stream_t stream) {
+    if (P < 0 || width <= 0 || height <= 0) return GSR_EINVAL;
+    if (P == 0) return 0;
+    if (!ranges || !compute_locally || !bg || !final_T || !n_contrib || !dL_dpixels || !means2D || !conic_opacity ||
+        !rgb || !dL_record)
+        return GSR_EINVAL;
+    return gsr_launch_composite_backward(P, width, height, ranges, point_list, means2D, conic_opacity, rgb,
+                                         compute_locally, bg, final_T, n_contrib, dL_dpixels, dL_record, out_color,
+                                         seg_ws, seg_bytes, row_lo, row_hi, reinterpret_cast<hipStream_t>(stream));
 }
 
 int gsr_render_backward(int P, int width, int height, const int32_t *ranges, const uint32_t *point_list,
@@ -137,8 +171,8 @@ int gsr_render_backward(int P, int width, int height, const int32_t *ranges, con
         !rgb || !dL_record)
         return GSR_EINVAL;
     return gsr_launch_composite_backward(P, width, height, ranges, point_list, means2D, conic_opacity, rgb,
-                                         compute_locally, bg, final_T, n_contrib, dL_dpixels, dL_record,
-                                         reinterpret_cast<hipStream_t>(stream));
+                                         compute_locally, bg, final_T, n_contrib, dL_dpixels, dL_record, nullptr,
+                                         nullptr, 0, 0, 0, reinterpret_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

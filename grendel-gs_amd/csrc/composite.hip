@@ -140,8 +140,7 @@ __device__ __forceinline__ v2f pair_exponent(const PairRec &p, float pxf, float 
 // block -> tile: XCD-contiguous spans of the BAND this rank renders.  The binning leaves the band (the row hull of the
 // mask, [lo, hi) tile rows) in row `tiles` of the range table (include/gsraster.h: gsr_bin_sort); anything implausible
 // there falls back to spans of the whole grid.
-__device__ __forceinline__ int composite_tile_of_block(const int2 *__restrict__ ranges, int gx) {
-    const int tiles = (int)gridDim.x;
+__device__ __forceinline__ int composite_tile_of_block(const int2 *__restrict__ ranges, int gx, int tiles) {
     const int2 hull = ranges[tiles];
     const int gy = tiles / gx;
     if (hull.x < 0 || hull.y > gy || hull.x >= hull.y) return gsr_xcd_span_of_block(blockIdx.x, tiles);
@@ -170,21 +169,124 @@ __device__ __forceinline__ RawEntry load_raw(bool have, uint32_t id, const float
     return e;
 }
 
+// ---- list SEGMENTS for the backward (round 4).  One workgroup per tile walks the tile's list serially, so the kernel
+// lasts at least as long as its longest list takes ONE wave -- on a thin row band (one round of resident workgroups,
+// world size 8) that IS the kernel time (measured: K8 / K10 of a 1/8 band take 1/2.8 of the full image's time, and
+// neither a software prefetch nor another block -> tile map changes it, profiles/r04_ab_*).  The backward can be cut
+// exactly: K10 needs, per pixel, the transmittance T and the colour accumulated IN FRONT of a list position, both of
+// which the forward knows when it passes that position.  So K8 leaves a CHECKPOINT (T, C.rgb per pixel) every SEG_LEN
+// entries it really walks and queues the segment that starts there; K10 runs segment 0 of every tile in its usual
+// workgroups and hands the queued segments to persistent worker workgroups (atomic ticket).  Work is only ever created
+// for entries the forward walked: early termination is untouched, nothing is recomputed.
+#ifndef GSR_SEG_LEN
+#define GSR_SEG_LEN 256
+#endif
+#ifndef GSR_SEG_MAXJ
+#define GSR_SEG_MAXJ 16
+#endif
+constexpr int SEG_LEN = GSR_SEG_LEN;    // list entries per segment (a multiple of the 64-entry chunk)
+constexpr int SEG_MAXJ = GSR_SEG_MAXJ;  // boundaries per tile that can carry a checkpoint (<= 31; a list walked deeper keeps a long tail)
+static_assert(SEG_LEN % 64 == 0 && SEG_MAXJ <= 31, "segment geometry");
+constexpr int SEG_WORKERS = 1024;
+struct SegWs {
+    uint32_t *hdr;      // [0] segments queued by K8 (may exceed cap: only the first cap exist), [1] K10's ticket
+    uint32_t *queue;    // [cap]: tile * 32 + segment index (>= 1)
+    int32_t *seg_slot;  // [tiles][SEG_MAXJ]: checkpoint slot of the boundary at entry (j + 1) * SEG_LEN, -1: none
+    float *ckpt;        // [cap][4][256]: T, C.r, C.g, C.b of the tile's 256 pixels (quadrant-major: wave * 64 + lane)
+    uint32_t cap;
+};
+__host__ __device__ inline size_t seg_ws_bytes(int tiles, uint32_t cap) {
+    return 64 + sizeof(uint32_t) * (size_t)cap + sizeof(int32_t) * (size_t)tiles * SEG_MAXJ + sizeof(float) * 1024 * (size_t)cap;
+}
+inline SegWs seg_ws_of(void *ws, int tiles, uint32_t cap) {
+    SegWs w{};
+    if (!ws) return w;
+    char *b = reinterpret_cast<char *>(ws);
+    w.hdr = reinterpret_cast<uint32_t *>(b);
+    w.queue = reinterpret_cast<uint32_t *>(b + 64);
+    w.seg_slot = reinterpret_cast<int32_t *>(b + 64 + sizeof(uint32_t) * (size_t)cap);
+    w.ckpt = reinterpret_cast<float *>(b + 64 + sizeof(uint32_t) * (size_t)cap + sizeof(int32_t) * (size_t)tiles * SEG_MAXJ);
+    w.cap = cap;
+    return w;
+}
+constexpr uint32_t SEG_CAP = 8192;
+
+// A segment boundary the calling wave really crosses (every SEG_LEN walked entries): the first wave of the tile to get here claims a checkpoint slot and queues the
+// segment for the backward; every wave that gets here leaves its pixels' state (T, colour in front of the boundary).
+__device__ __forceinline__ void k8_checkpoint(const SegWs &seg, int *s_slot, int tile, int c, int lane,
+                                                        int wave, float T, float c0, float c1, float c2) {
+    const int j = c / SEG_LEN - 1;
+    int slot = 0;
+    if (lane == 0) {
+        int v = atomicCAS(&s_slot[j], -1, -2);
+        if (v == -1) {
+            const uint32_t k = atomicAdd(seg.hdr, 1u);
+            v = k < seg.cap ? (int)k : -3;
+            if (v >= 0) {
+                seg.queue[k] = (uint32_t)tile * 32u + (uint32_t)(j + 1);
+                seg.seg_slot[(size_t)tile * SEG_MAXJ + j] = v;
+            }
+            __hip_atomic_store(&s_slot[j], v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+            while (v == -2) v = __hip_atomic_load(&s_slot[j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        slot = v;
+    }
+    slot = __builtin_amdgcn_readfirstlane(slot);
+    if (slot >= 0) {
+        float *ck = seg.ckpt + (size_t)slot * 1024 + wave * 64 + lane;
+        ck[0] = T;
+        ck[256] = c0;
+        ck[512] = c1;
+        ck[768] = c2;
+    }
+}
+
 // ------------------------------------------------------------------------------------------- K8
+template <bool SEG, bool BAND>  // SEG: leave checkpoints for the backward's list segments; BAND: the grid covers the
+                                // band's tiles only (each costs registers: the whole-image launch keeps its 64)
 __global__ void __launch_bounds__(256)
 composite_forward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
                          const uint32_t *__restrict__ point_list, const float2 *__restrict__ means2D,
                          const float4 *__restrict__ conic_opacity, const float *__restrict__ rgb,
                          const uint8_t *__restrict__ compute_locally, const float *__restrict__ bg,
-                         float *__restrict__ out_color, float *__restrict__ final_T, int32_t *__restrict__ n_contrib) {
-    const int tile = composite_tile_of_block(ranges, gx);
+                         float *__restrict__ out_color, float *__restrict__ final_T, int32_t *__restrict__ n_contrib,
+                         const SegWs seg, int band_first, int band_tiles) {
+    const size_t HW = (size_t)H * W;
+    int tile;
+    if (BAND) {
+        // The caller knows the rows of its band on the HOST (Grendel's strategies do): the grid covers the band's tiles
+        // only.  With a grid over all tiles the 7/8 of the workgroups that are not ours on a 1/8 band still have to be
+        // dispatched one by one behind the resident ones -- measured as a CONSTANT ~30 us (K8) / ~60 us (K10) of the
+        // launch whatever the band (K10: 0.388 / 0.224 / 0.154 / 0.117 ms for 1 / 2 / 4 / 8 bands = 0.06 + 0.33 / W).
+        // The pixels outside the band must still be exactly 0 (SUM assembly): the band's workgroups clear them together,
+        // with coalesced stores, before they start on their tiles.
+        tile = band_first + gsr_xcd_span_of_block(blockIdx.x, band_tiles);
+    } else {
+        tile = composite_tile_of_block(ranges, gx, (int)gridDim.x);
+    }
+    // (every workgroup clears its share of the pixels outside the band when it is done with its tile: workgroups with
+    // short lists do it while the long ones still walk)
+    auto clear_outside = [&]() {
+        if (!BAND) return;
+        const size_t n0 = (size_t)min(H, (band_first / gx) * GSR_BLOCK_Y) * W;
+        const size_t p1 = (size_t)min(H, ((band_first + band_tiles) / gx) * GSR_BLOCK_Y) * W;
+        const size_t nout = n0 + (HW - p1);
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nout; i += (size_t)gridDim.x * 256) {
+            const size_t q = i < n0 ? i : p1 + (i - n0);
+            out_color[q] = 0.f;
+            out_color[HW + q] = 0.f;
+            out_color[2 * HW + q] = 0.f;
+            final_T[q] = 1.f;
+            n_contrib[q] = 0;
+        }
+    };
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tx = tile % gx, ty = tile / gx;
     const int qx0 = tx * GSR_BLOCK_X + (wave & 1) * 8, qy0 = ty * GSR_BLOCK_Y + (wave >> 1) * 8;
     const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
     const bool inside = px < W && py < H;
     const size_t pid = (size_t)py * W + px;
-    const size_t HW = (size_t)H * W;
 
     if (!compute_locally[tile]) {  // not ours: pixels must be exactly 0 (SUM all-reduce assembly)
         if (inside) {
@@ -194,6 +296,7 @@ composite_forward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
             final_T[pid] = 1.f;
             n_contrib[pid] = 0;
         }
+        clear_outside();
         return;
     }
     const int2 range = ranges[tile];
@@ -205,7 +308,12 @@ composite_forward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
     bool done = !inside;
     __shared__ __attribute__((aligned(16))) float slab[4][32 * PREC];
     __shared__ int s_walk[2];  // [0] longest walk of the four waves, [1] waves that have finished
+    __shared__ int s_slot[SEG_MAXJ];  // checkpoint slot of boundary j: -1 nobody got there yet, -2 being claimed, -3 none
     if (threadIdx.x < 2) s_walk[threadIdx.x] = 0;
+    if (SEG && threadIdx.x < SEG_MAXJ) {
+        s_slot[threadIdx.x] = -1;
+        if (seg.seg_slot) seg.seg_slot[(size_t)tile * SEG_MAXJ + threadIdx.x] = -1;
+    }
     __syncthreads();  // the only workgroup barrier of the kernel: all four waves are at their first instructions
     v2f A0 = {0.f, 0.f}, A1 = {0.f, 0.f}, A2 = {0.f, 0.f};  // colour sums of the even / odd pair slots (added at the end)
     float *wslab = slab[wave];
@@ -216,6 +324,8 @@ composite_forward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
     // thin band is bound by the imbalance of ONE round of resident workgroups, not by memory latency)
     for (int c = 0; c < n; c += 64) {
         if (__all(done)) break;
+        if (SEG && seg.seg_slot && c > 0 && (c & (SEG_LEN - 1)) == 0 && c <= SEG_LEN * SEG_MAXJ)
+            k8_checkpoint(seg, s_slot, tile, c, lane, wave, T, A0.x + A0.y, A1.x + A1.y, A2.x + A2.y);
         walked = c + 64;
         const bool have = c + lane < n;
         const uint32_t id = have ? point_list[range.x + c + lane] : 0u;
@@ -302,6 +412,7 @@ composite_forward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
         final_T[pid] = T;
         n_contrib[pid] = last;
     }
+    clear_outside();
 }
 
 // ------------------------------------------------------------------------------------------ K10
@@ -341,14 +452,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int MB = 8;      // entries per MFMA batch: rows 0-7 of the 16 x 16 result are their q-rows, rows 8-15 their w-rows
 constexpr int MSTR = 66;   // row stride of the (q, w) matrix in 8-byte elements: phase A writes and phase B reads conflict-free
 
-__global__ void __launch_bounds__(256, 4)  // 4 waves per SIMD: <= 128 VGPRs (LDS admits 4 workgroups per CU)
-composite_backward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
-                          const uint32_t *__restrict__ point_list, const float2 *__restrict__ means2D,
-                          const float4 *__restrict__ conic_opacity, const float *__restrict__ rgb,
-                          const uint8_t *__restrict__ compute_locally, const float *__restrict__ bg,
-                          const float *__restrict__ final_T, const int32_t *__restrict__ n_contrib,
-                          const float *__restrict__ dL_dpixels, float *__restrict__ dL_record) {
-    const int tile = composite_tile_of_block(ranges, gx);
+// segment `sidx` of tile `tile`: the list entries [sidx * SEG_LEN, next boundary with a checkpoint or the end)
+__device__ __forceinline__ void
+composite_backward_segment(const int tile, const int sidx, int W, int H, int gx, const int2 *__restrict__ ranges,
+                           const uint32_t *__restrict__ point_list, const float2 *__restrict__ means2D,
+                           const float4 *__restrict__ conic_opacity, const float *__restrict__ rgb,
+                           const uint8_t *__restrict__ compute_locally, const float *__restrict__ bg,
+                           const float *__restrict__ final_T, const int32_t *__restrict__ n_contrib,
+                           const float *__restrict__ dL_dpixels, float *__restrict__ dL_record,
+                           const float *__restrict__ out_color, const SegWs &seg) {
     if (!compute_locally[tile]) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tx = tile % gx, ty = tile / gx;
@@ -360,6 +472,12 @@ composite_backward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
     const int2 range = ranges[tile];
     const float pxf = (float)px, pyf = (float)py;
 
+    // the segment's end: the next boundary that carries a checkpoint (then every pixel that blends beyond it starts
+    // from the checkpointed state), or the end of the list
+    const int c_lo = sidx * SEG_LEN;
+    int end_slot = -1;
+    if (seg.seg_slot && sidx < SEG_MAXJ) end_slot = seg.seg_slot[(size_t)tile * SEG_MAXJ + sidx];
+    const int c_hi = end_slot >= 0 ? c_lo + SEG_LEN : 0x7fffffff;
     const float T_final = inside ? final_T[pid] : 0.f;
     const int last = inside ? n_contrib[pid] : 0;
     float g0 = 0.f, g1 = 0.f, g2 = 0.f;
@@ -377,15 +495,16 @@ composite_backward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
     __shared__ float fslab[64 * 7];         // [entry of the chunk][x, y, a2, b2, c2, id, o]: what the flush needs
     __shared__ float sout[64 * 10];         // [entry][9 gradient values, id]: mapped by ONE wave, added by all (see the flush)
     __shared__ int s_wmax[4];
-    int wmax = last;
+    int wmax = min(last, c_hi);  // entries of THIS segment a pixel of the wave still contributes to end here
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) wmax = max(wmax, __shfl_xor(wmax, d, 64));
+    if (wmax <= c_lo) wmax = 0;  // nothing of the wave in this segment
     if (lane == 0) s_wmax[wave] = wmax;
     for (int i = threadIdx.x; i < 4 * 64 * 9; i += 256) (&sacc[0][0])[i] = 0.f;
     __syncthreads();
     const int bmax = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
     if (bmax == 0) return;
-    if (threadIdx.x == 0) atomicAdd(&g_walked[1], (unsigned long long)bmax);  // entries the tile's walk goes through
+    if (threadIdx.x == 0) atomicAdd(&g_walked[1], (unsigned long long)(bmax - c_lo));  // entries this walk goes through
     // the wave that walks the longest list has every entry of every chunk in its slab: the flush reads from it
     int wbest = 0;
 #pragma unroll
@@ -416,20 +535,31 @@ composite_backward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
 
     float T = T_final;
     float rho = 0.f;  // (colour accumulated BEHIND the current position) . g
+    if (end_slot >= 0 && last > c_hi) {
+        // this pixel blends entries beyond the segment: start from the forward's state at the boundary.  T = the
+        // transmittance in front of entry c_hi; the colour behind it is what the pixel ended with (without the
+        // background's share) minus what it had accumulated in front of the boundary, normalised by T
+        const float *ck = seg.ckpt + (size_t)end_slot * 1024 + wave * 64 + lane;
+        T = ck[0];
+        const float r0 = out_color[pid] - T_final * bg[0] - ck[256];
+        const float r1 = out_color[HW + pid] - T_final * bg[1] - ck[512];
+        const float r2 = out_color[2 * HW + pid] - T_final * bg[2] - ck[768];
+        rho = (r0 * g0 + r1 * g1 + r2 * g2) * __builtin_amdgcn_rcpf(T);
+    }
 
     // software prefetch: the list entries of a chunk are loaded one chunk ahead, their indices two chunks ahead (three
     // dependent gathers otherwise sit in front of every chunk, and only 4 waves per SIMD are there to hide them)
-    const int c0 = ((bmax - 1) / 64) * 64;
+    const int c0 = ((bmax - 1) / 64) * 64;  // (>= c_lo: bmax > c_lo and c_lo is a multiple of 64)
     uint32_t id_cur = (c0 + lane < wmax) ? point_list[range.x + c0 + lane] : 0u;
-    uint32_t id_nxt = (c0 >= 64 && c0 - 64 + lane < wmax) ? point_list[range.x + c0 - 64 + lane] : 0u;
+    uint32_t id_nxt = (c0 >= c_lo + 64 && c0 - 64 + lane < wmax) ? point_list[range.x + c0 - 64 + lane] : 0u;
     RawEntry raw = load_raw(c0 + lane < wmax, id_cur, means2D, conic_opacity, rgb);
 
-    for (int c = c0; c >= 0; c -= 64) {
+    for (int c = c0; c >= c_lo; c -= 64) {
         float *acc_tab = sacc[wave];
         // issue the loads of the NEXT chunk now; they are consumed at the top of the next iteration
-        const bool have_nxt = c >= 64 && c - 64 + lane < wmax;
+        const bool have_nxt = c >= c_lo + 64 && c - 64 + lane < wmax;
         const RawEntry raw_nxt = load_raw(have_nxt, id_nxt, means2D, conic_opacity, rgb);
-        const uint32_t id_nxt2 = (c >= 128 && c - 128 + lane < wmax) ? point_list[range.x + c - 128 + lane] : 0u;
+        const uint32_t id_nxt2 = (c >= c_lo + 128 && c - 128 + lane < wmax) ? point_list[range.x + c - 128 + lane] : 0u;
         if (c < wmax) {  // wave-uniform
             const bool have = c + lane < wmax;
             Entry e;
@@ -601,6 +731,42 @@ composite_backward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
     }
 }
 
+__global__ void __launch_bounds__(256, 4)  // 4 waves per SIMD: <= 128 VGPRs (LDS admits 4 workgroups per CU)
+composite_backward_kernel(int W, int H, int gx, int tiles, const int2 *__restrict__ ranges,
+                          const uint32_t *__restrict__ point_list, const float2 *__restrict__ means2D,
+                          const float4 *__restrict__ conic_opacity, const float *__restrict__ rgb,
+                          const uint8_t *__restrict__ compute_locally, const float *__restrict__ bg,
+                          const float *__restrict__ final_T, const int32_t *__restrict__ n_contrib,
+                          const float *__restrict__ dL_dpixels, float *__restrict__ dL_record,
+                          const float *__restrict__ out_color, const SegWs seg, int band_first, int band_tiles) {
+    // workgroups [0, nstatic): segment 0 of every tile (of the band, when the caller named it: see K8), XCD-contiguous
+    // spans.  The others are persistent workers: they take the segments K8 queued (their number is only known on the
+    // device) by atomic ticket.
+    const int nstatic = band_tiles > 0 ? band_tiles : tiles;
+    const bool worker = (int)blockIdx.x >= nstatic;
+    __shared__ uint32_t s_item;
+    const uint32_t count = worker ? min(seg.hdr[0], seg.cap) : 0u;
+    for (;;) {
+        int tile, sidx = 0;
+        if (worker) {
+            __syncthreads();  // (also: the previous segment's LDS is no longer read)
+            if (threadIdx.x == 0) s_item = atomicAdd(&seg.hdr[1], 1u);
+            __syncthreads();
+            const uint32_t t = s_item;
+            if (t >= count) return;
+            const uint32_t item = seg.queue[t];
+            tile = (int)(item >> 5);
+            sidx = (int)(item & 31u);
+        } else {
+            tile = band_tiles > 0 ? band_first + gsr_xcd_span_of_block(blockIdx.x, band_tiles)
+                                  : composite_tile_of_block(ranges, gx, tiles);
+        }
+        composite_backward_segment(tile, sidx, W, H, gx, ranges, point_list, means2D, conic_opacity, rgb,
+                                   compute_locally, bg, final_T, n_contrib, dL_dpixels, dL_record, out_color, seg);
+        if (!worker) return;
+    }
+}
+
 }  // namespace
 
 extern "C" int gsr_composite_walked(unsigned long long *out2, int reset) {
@@ -624,16 +790,33 @@ extern "C" int gsr_debug_stats(unsigned long long *out8, int reset) {
 }
 #endif
 
+size_t gsr_composite_seg_bytes(int W, int H) {
+    const int gx = (W + GSR_BLOCK_X - 1) / GSR_BLOCK_X, gy = (H + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y;
+    return seg_ws_bytes(gx * gy, SEG_CAP);
+}
+
 int gsr_launch_composite_forward(int P, int W, int H, const int32_t *ranges, const uint32_t *point_list,
                                  const float *means2D, const float *conic_opacity, const float *rgb,
                                  const uint8_t *compute_locally, const float *bg, float *out_color, float *final_T,
-                                 int32_t *n_contrib, hipStream_t stream) {
+                                 int32_t *n_contrib, void *seg_ws, size_t seg_bytes, int row_lo, int row_hi,
+                                 hipStream_t stream) {
     (void)P;
     const int gx = (W + GSR_BLOCK_X - 1) / GSR_BLOCK_X, gy = (H + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y;
-    hipLaunchKernelGGL(composite_forward_kernel, dim3(gx * gy), dim3(256), 0, stream, W, H, gx,
-                       reinterpret_cast<const int2 *>(ranges), point_list, reinterpret_cast<const float2 *>(means2D),
-                       reinterpret_cast<const float4 *>(conic_opacity), rgb, compute_locally, bg, out_color, final_T,
-                       n_contrib);
+    const bool band = row_lo >= 0 && row_lo < row_hi && row_hi <= gy && !(row_lo == 0 && row_hi == gy);
+    const int band_first = band ? row_lo * gx : 0, band_tiles = band ? (row_hi - row_lo) * gx : 0;
+    if (seg_ws && seg_bytes < seg_ws_bytes(gx * gy, SEG_CAP)) return GSR_ENOSPACE;
+    const SegWs seg = seg_ws_of(seg_ws, gx * gy, SEG_CAP);
+    if (seg_ws) GSR_HIP(hipMemsetAsync(seg_ws, 0, 64, stream));  // { segments queued, the backward's ticket }
+    auto launch = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3(band ? band_tiles : gx * gy), dim3(256), 0, stream, W, H, gx,
+                           reinterpret_cast<const int2 *>(ranges), point_list, reinterpret_cast<const float2 *>(means2D),
+                           reinterpret_cast<const float4 *>(conic_opacity), rgb, compute_locally, bg, out_color, final_T,
+                           n_contrib, seg, band_first, band_tiles);
+    };
+    if (seg_ws && band) launch(composite_forward_kernel<true, true>);
+    else if (seg_ws) launch(composite_forward_kernel<true, false>);
+    else if (band) launch(composite_forward_kernel<false, true>);
+    else launch(composite_forward_kernel<false, false>);
     GSR_LAUNCH_CHECK();
     return 0;
 }
@@ -642,14 +825,20 @@ int gsr_launch_composite_backward(int P, int W, int H, const int32_t *ranges, co
                                   const float *means2D, const float *conic_opacity, const float *rgb,
                                   const uint8_t *compute_locally, const float *bg, const float *final_T,
                                   const int32_t *n_contrib, const float *dL_dpixels, float *dL_record,
+                                  const float *out_color, void *seg_ws, size_t seg_bytes, int row_lo, int row_hi,
                                   hipStream_t stream) {
     GSR_HIP(hipMemsetAsync(dL_record, 0, sizeof(float) * 9 * (size_t)P, stream));
     if (P == 0) return 0;
     const int gx = (W + GSR_BLOCK_X - 1) / GSR_BLOCK_X, gy = (H + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y;
-    hipLaunchKernelGGL(composite_backward_kernel, dim3(gx * gy), dim3(256), 0, stream, W, H, gx,
-                       reinterpret_cast<const int2 *>(ranges), point_list, reinterpret_cast<const float2 *>(means2D),
-                       reinterpret_cast<const float4 *>(conic_opacity), rgb, compute_locally, bg, final_T, n_contrib,
-                       dL_dpixels, dL_record);
+    const bool band = row_lo >= 0 && row_lo < row_hi && row_hi <= gy && !(row_lo == 0 && row_hi == gy);
+    const int band_first = band ? row_lo * gx : 0, band_tiles = band ? (row_hi - row_lo) * gx : 0;
+    if (seg_ws && (seg_bytes < seg_ws_bytes(gx * gy, SEG_CAP) || !out_color)) return GSR_EINVAL;
+    const SegWs seg = seg_ws_of(seg_ws, gx * gy, SEG_CAP);
+    hipLaunchKernelGGL(composite_backward_kernel, dim3((band ? band_tiles : gx * gy) + (seg_ws ? SEG_WORKERS : 0)),
+                       dim3(256), 0, stream, W, H, gx, gx * gy, reinterpret_cast<const int2 *>(ranges), point_list,
+                       reinterpret_cast<const float2 *>(means2D), reinterpret_cast<const float4 *>(conic_opacity), rgb,
+                       compute_locally, bg, final_T, n_contrib, dL_dpixels, dL_record, out_color, seg, band_first,
+                       band_tiles);
     GSR_LAUNCH_CHECK();
     return 0;
 }

@@ -647,6 +647,15 @@ def release_workspaces():
 
 
 _SPECULATIVE_SORT = [os.environ.get("GSR_SPECULATIVE_SORT", "1") != "0"]  # env: A/B measurements only
+_SEGMENTS = [{"0": False, "always": "always"}.get(os.environ.get("GSR_SEGMENTS", "1"), True)]  # env: A/B only
+_BAND_GRID = [os.environ.get("GSR_BAND_GRID", "1") != "0"]  # env: A/B measurements only
+
+
+def set_list_segments(on):
+    """True (default): on THIN bands (<= 2048 tiles, named by the caller through cuda_args["_gsr_band"]) the composite
+    forward leaves checkpoints every 256 walked list entries and the backward runs the segments in parallel workgroups
+    (gsr_render_*_seg); "always": on every launch; False: one workgroup walks a tile's whole list"""
+    _SEGMENTS[0] = "always" if on == "always" else bool(on)
 
 
 def set_speculative_sort(on):
@@ -832,10 +841,24 @@ class _RenderGaussians(torch.autograd.Function):
             # bench bookkeeping: the launch's local pixel count is derived from the mask AFTER the run (no sync here)
             ctx.px_meta = dict(mask=mask, W=W, H=H) if kernel_timer.enabled else {}
             ctx.cuda_args = cuda_args
+            # the tile rows of the caller's band, when it names them (the mirror does: cuda_args["_gsr_band"]; the
+            # mask must be false outside): the launches then cover the band's tiles only
+            band = cuda_args.get("_gsr_band") if (isinstance(cuda_args, dict) and _BAND_GRID[0]) else None
+            row_lo, row_hi = (int(band[0]), int(band[1])) if band else (0, 0)
+            thin = 0 < (row_hi - row_lo) * gx <= 2048  # at most two rounds of resident workgroups
+            # list segments for the backward (include/gsraster.h: gsr_render_forward_seg) when a backward can follow and
+            # the band is THIN: measured (profiles/r04_ab_segments.txt) -9 us net on a 1/8 band, nothing on a whole image
+            # (its lists finish in staggered rounds anyway) where the checkpoints only cost the forward 4-9 us
+            seg_ws, seg_bytes = None, 0
+            if any(ctx.needs_input_grad[:3]) and (_SEGMENTS[0] == "always" or (_SEGMENTS[0] and thin)):
+                seg_bytes = int(lib.gsr_render_seg_bytes(W, H))
+                seg_ws = torch.empty((seg_bytes,), dtype=torch.uint8, device=dev)
             with kernel_timer.range("composite_forward", P=P, D=D, **ctx.px_meta), zhx_range(cuda_args, "70 render time"):
-                check(lib.gsr_render_forward(P, W, H, _ptr(ranges), _ptr(point_list), _ptr(means2D),
-                                             _ptr(conic_opacity), _ptr(rgb), _ptr(mask), _ptr(bg), _ptr(out),
-                                             _ptr(final_T), _ptr(n_contrib), _stream()), "gsr_render_forward")
+                check(lib.gsr_render_forward_seg(P, W, H, _ptr(ranges), _ptr(point_list), _ptr(means2D),
+                                                 _ptr(conic_opacity), _ptr(rgb), _ptr(mask), _ptr(bg), _ptr(out),
+                                                 _ptr(final_T), _ptr(n_contrib), _ptr(seg_ws), seg_bytes, row_lo, row_hi,
+                                                 _stream()), "gsr_render_forward_seg")
+            ctx.seg = (seg_ws, seg_bytes, out if seg_ws is not None else None, row_lo, row_hi)
             if timing != "off":
                 ev1.record()
                 ctx.fwd_events = (ev0, ev1)
@@ -876,10 +899,12 @@ class _RenderGaussians(torch.autograd.Function):
                 ev0.record()
             with kernel_timer.range("composite_backward", P=P, D=ctx.num_rendered, **ctx.px_meta), \
                     zhx_range(ctx.cuda_args, "b10 render time"):
-                check(lib.gsr_render_backward(P, W, H, _ptr(ranges), _ptr(point_list), _ptr(means2D),
-                                              _ptr(conic_opacity), _ptr(rgb), _ptr(mask), _ptr(bg), _ptr(final_T),
-                                              _ptr(n_contrib), _ptr(g_out), _ptr(record), _stream()),
-                      "gsr_render_backward")
+                seg_ws, seg_bytes, out_img, row_lo, row_hi = ctx.seg
+                check(lib.gsr_render_backward_seg(P, W, H, _ptr(ranges), _ptr(point_list), _ptr(means2D),
+                                                  _ptr(conic_opacity), _ptr(rgb), _ptr(mask), _ptr(bg), _ptr(final_T),
+                                                  _ptr(n_contrib), _ptr(g_out), _ptr(record), _ptr(out_img),
+                                                  _ptr(seg_ws), seg_bytes, row_lo, row_hi, _stream()),
+                      "gsr_render_backward_seg")
             if timing != "off":
                 ev1.record()
         stats = ctx.cuda_args.get("stats_collector") if isinstance(ctx.cuda_args, dict) else None

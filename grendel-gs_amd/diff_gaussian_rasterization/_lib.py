@@ -83,6 +83,11 @@ SIGNATURES = {
                                                      [c_void_p] * 7 + [c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gsr_bin_total_offset": (c_size_t, [c_int, c_int, c_int]),
     "gsr_flag_if_greater": (c_int, [c_void_p, ctypes.c_uint32, c_void_p, ctypes.c_uint32, c_void_p, c_void_p]),
+    "gsr_render_seg_bytes": (c_size_t, [c_int, c_int]),
+    "gsr_render_forward_seg": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int,
+                                       c_void_p]),
+    "gsr_render_backward_seg": (c_int, [c_int, c_int, c_int] + [c_void_p] * 13 + [c_size_t, c_int, c_int, c_void_p]),
     "gsr_composite_walked": (c_int, [ctypes.POINTER(ctypes.c_ulonglong), c_int]),
     "gsr_publish_flag": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_uint32, c_void_p]),
     "gsr_exchange_check": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, ctypes.c_uint64, c_int, c_void_p,
@@ -92,7 +97,7 @@ SIGNATURES = {
     "gsr_render_backward": (c_int, [c_int, c_int, c_int] + [c_void_p] * 12),
 }
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 def _load():

@@ -758,6 +758,8 @@ def _render_cameras(pkg, batched_strategies):
             st = cuda_args["stats_collector"]
             st["forward_render_time"] = st["backward_render_time"] = st["forward_loss_time"] = 0.0
         else:
+            rows_of = getattr(strategy, "_my_rows", None)  # host-known tile rows of this rank's band (the mask's rows)
+            cuda_args["_gsr_band"] = rows_of() if rows_of is not None else None
             image, _, _, _ = pkg["batched_rasterizers"][k].render_gaussians(
                 means2D=means2D, conic_opacity=conic_opacity, rgb=rgb,
                 depths=pkg["batched_depths_redistributed"][k], radii=pkg["batched_radii_redistributed"][k],

@@ -191,6 +191,35 @@ int gsr_render_backward(int P, int width, int height, const int32_t *ranges, con
                         const float *means2D, const float *conic_opacity, const float *rgb,
                         const uint8_t *compute_locally, const float *bg, const float *final_T,
                         const int32_t *n_contrib, const float *dL_dpixels, float *dL_record, gsr_stream_t stream);
+/* K8 / K10 with list SEGMENTS (round 4).  One workgroup per tile walks the tile's list serially, so a launch lasts at
+ * least as long as its longest list takes one wave -- which is the whole kernel on a thin row band (one round of
+ * resident workgroups at world size 8).  The backward can be cut exactly: per pixel it needs the transmittance and the
+ * colour accumulated IN FRONT of a list position, which the forward knows when it passes that position.  With a
+ * workspace (gsr_render_seg_bytes(width, height) bytes, caller-allocated, alive until the backward has run)
+ *   gsr_render_forward_seg  leaves a checkpoint (T, C.rgb per pixel) every 256 list entries it really walks and queues
+ *                           the segment that starts there;
+ *   gsr_render_backward_seg runs segment 0 of every tile in its usual workgroups and hands the queued segments to
+ *                           persistent worker workgroups.  out_color = the forward's image (the colour BEHIND a
+ *                           boundary is the final colour minus the checkpointed one).
+ * Early termination is untouched (segments exist only for entries the forward walked); gradients equal the one-segment
+ * kernel's up to fp32 rounding (the checkpointed T replaces a chain of divisions).  seg_ws == NULL: exactly
+ * gsr_render_forward / gsr_render_backward.  Same call sites as those (gaussian_renderer/__init__.py:1271-1282).
+ * [row_lo, row_hi): the TILE ROWS of the caller's band when it knows them on the host (Grendel's strategies do:
+ * compute_locally must then be false outside these rows), else 0, 0.  The launches then cover the band's tiles only; a
+ * grid over all tiles costs a constant ~30 us (forward) / ~60 us (backward) of workgroup dispatch for tiles that are not
+ * ours, whatever the band.  The forward still leaves every pixel outside the band exactly 0. */
+size_t gsr_render_seg_bytes(int width, int height);
+int gsr_render_forward_seg(int P, int width, int height, const int32_t *ranges, const uint32_t *point_list,
+                           const float *means2D, const float *conic_opacity, const float *rgb,
+                           const uint8_t *compute_locally, const float *bg, float *out_color, float *final_T,
+                           int32_t *n_contrib, void *seg_ws, size_t seg_bytes, int row_lo, int row_hi,
+                           gsr_stream_t stream);
+int gsr_render_backward_seg(int P, int width, int height, const int32_t *ranges, const uint32_t *point_list,
+                            const float *means2D, const float *conic_opacity, const float *rgb,
+                            const uint8_t *compute_locally, const float *bg, const float *final_T,
+                            const int32_t *n_contrib, const float *dL_dpixels, float *dL_record,
+                            const float *out_color, void *seg_ws, size_t seg_bytes, int row_lo, int row_hi,
+                            gsr_stream_t stream);
 /* Measurement aid (bench.py's roofline leg; the reference has nothing to bind here): list entries the composite kernels
  * WALKED since the last reset, summed over launches -- out2[0] K8, out2[1] K10; per tile the entries its longest-walking
  * quadrant goes through (K8: up to the chunk in which the last pixel saturates; K10: the largest n_contrib of the

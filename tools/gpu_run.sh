@@ -59,6 +59,10 @@ if has b1; then
   timeout 900 python -m pytest tests/test_gpu_reference_b1.py -q -m gpu -x -p no:cacheprovider > $O/b1.log 2>&1
   echo "b1 pytest exit $?"; tail -4 $O/b1.log | cut -c1-300
 fi
+if has seg; then
+  timeout 900 python -m pytest tests/test_gpu_segments.py -q -m gpu -x -p no:cacheprovider > $O/seg.log 2>&1
+  echo "seg pytest exit $?"; tail -25 $O/seg.log | cut -c1-300
+fi
 if has gtest; then
   timeout 900 python -m pytest tests/test_gpu_graphed_step.py -q -m gpu -x -s -p no:cacheprovider > $O/gtest.log 2>&1
   echo "gtest pytest exit $?" | tee -a $O/gtest.log
@@ -104,6 +108,27 @@ if has abfake8; then
     GSRASTER_LIB=${lib:+$R/$lib} timeout 300 python tools/fake_world_bench.py --workload c2 --worlds 8 --steps 20 --graph on > $O/abfake8_$n.txt 2> $O/abfake8_$n.err
     echo "$n: $(cut -c1-420 $O/abfake8_$n.txt | head -1)"
   done
+fi
+if has abseg; then
+  for v in 1 0 1 0; do
+    GSR_SEGMENTS=$v timeout 300 python bench.py --no-cpu-baseline --no-extra --steps 30 --warmup 6 --repeats 3 --render-steps 10 > $O/abseg_$v.json 2> $O/abseg_$v.err
+    summ $O/abseg_$v.json "segments=$v" | tee -a $O/abseg.txt
+    GSR_SEGMENTS=$v timeout 300 python tools/fake_world_bench.py --workload c2 --worlds 8 --steps 20 --graph on > $O/abseg_fake8_$v.txt 2> $O/abseg_fake8_$v.err
+    echo "segments=$v fake8: $(cut -c1-400 $O/abseg_fake8_$v.txt | head -1)" | tee -a $O/abseg.txt
+  done
+fi
+if has ablow; then
+  for v in "1 1" "0 1" "1 0" "0 0"; do
+    set -- $v
+    GSR_SEGMENTS=$1 GSR_BAND_GRID=$2 timeout 300 python bench.py --no-cpu-baseline --no-extra --steps 20 --warmup 5 --repeats 2 --render-steps 5 --opacity-logit-mean -2 --opacity-logit-std 1 > $O/ablow_$1$2.json 2> $O/ablow_$1$2.err
+    summ $O/ablow_$1$2.json "lowop seg=$1 band=$2" | tee -a $O/ablow.txt
+    GSR_SEGMENTS=$1 GSR_BAND_GRID=$2 timeout 300 python tools/fake_world_bench.py --workload c2 --worlds 4 8 --steps 20 --graph on > $O/ablow_fake_$1$2.txt 2> $O/ablow_fake_$1$2.err
+    cut -c1-330 $O/ablow_fake_$1$2.txt | sed "s/^/seg=$1 band=$2 /" | tee -a $O/ablow.txt
+  done
+fi
+if has fake48; then
+  timeout 400 python tools/fake_world_bench.py --workload c2 --worlds 4 8 --steps 20 --graph on > $O/fake_world_c2_48.txt 2> $O/fake_world_c2_48.err
+  cut -c1-400 $O/fake_world_c2_48.txt
 fi
 if has fake; then
   timeout 600 python tools/fake_world_bench.py --workload c2 --worlds 1 2 4 8 --steps 20 > $O/fake_world_c2.txt 2> $O/fake_world_c2.err
