@@ -51,6 +51,11 @@ for p in (PKG, ROOT):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+# hipGraph replays (--graph on): the HIP runtime's "graph packet capture" leaves a graph's pre-built packets stale once a
+# few hundred ordinary launches have run between two replays -- the next replay faults (measured on ROCm 7.0.2,
+# tools/probes/graph_bench_probe2.py).  The flag is read when libamdhip64 is loaded: before torch.
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -681,6 +686,7 @@ def main():
                                  "arithmetic as K11 + Adam, parameter gradients never written to HBM"
                                  if main_res["optimizer"]["fuse_backward"] else "FusedAdam after K11 (two kernels)")},
         "optimizer": main_res["optimizer"],
+        "graph": main_res.get("graph"),
         "timing": main_res["timing"],
         "setup": {"priming_steps": main_res["priming_steps"],
                   "note": "untimed pass over the distinct synthetic cameras before the W warmup steps (large / multi-rank "

@@ -713,6 +713,17 @@ def capturing():
     return _CAPTURE[0]
 
 
+_DEBUG_RANGES = []  # (GSR_GRAPH_DEBUG=1) buffers of captured iterations: eager allocations must never overlap them
+
+
+def _debug_overlap(name, t):
+    a0, a1 = t.data_ptr(), t.data_ptr() + t.numel() * t.element_size()
+    for n, p, sz in _DEBUG_RANGES:
+        if a0 < p + sz and p < a1:
+            print(f"[graphed] OVERLAP: eager {name} [{a0:#x}, {a1:#x}) with captured {n} [{p:#x}, {p + sz:#x})",
+                  file=__import__("sys").stderr, flush=True)
+
+
 def _bin_gaussians_captured(cap_ctx, means2D, depths, radii, conic_opacity, compute_locally, width, height):
     """K3-K7 inside a hipGraph capture: the tile sort is launched for a CAPACITY taken from earlier iterations, the pair
     count stays on the device (copied to a pinned word the host reads after the replay) and a count above the capacity
@@ -741,6 +752,9 @@ def _bin_gaussians_captured(cap_ctx, means2D, depths, radii, conic_opacity, comp
     check(lib.gsr_flag_if_greater(prep.data_ptr() + off, cap, _ptr(cap_ctx.flag), FLAG_PAIRS, host.data_ptr(), stream),
           "gsr_flag_if_greater")
     cap_ctx.pairs.append((host, cap))
+    if os.environ.get("GSR_GRAPH_DEBUG") == "1":
+        _DEBUG_RANGES.extend([("prep", prep.data_ptr(), prep.numel()), ("scratch", scratch.data_ptr(), scratch.numel()),
+                              ("point_list", point_list.data_ptr(), 4 * point_list.numel())])
     return point_list, ranges, cap
 
 
@@ -761,6 +775,9 @@ def bin_gaussians(means2D, depths, radii, conic_opacity, compute_locally, width,
     ranges = torch.empty((gx * gy + 1, 2), dtype=torch.int32, device=dev)[:gx * gy]
     prep_bytes = lib.gsr_bin_prepare_bytes(P, width, height)
     prep = torch.empty((max(prep_bytes, 4),), dtype=torch.uint8, device=dev)
+    if _DEBUG_RANGES:
+        _debug_overlap("prep", prep)
+        _debug_overlap("means2D", means2D)
     stream = _stream()
     ticket = ctypes.c_uint32(0)
     with zhx_range(cuda_args, "24 updateDistributedStatLocally.updateTileTouched time"):

@@ -36,6 +36,17 @@ import torch
 import diff_gaussian_rasterization as _dgr
 
 
+import os as _os
+import sys as _sys
+
+_DEBUG = _os.environ.get("GSR_GRAPH_DEBUG") == "1"
+
+
+def _dbg(*a):
+    if _DEBUG:
+        print("[graphed]", *a, file=_sys.stderr, flush=True)
+
+
 class _Entry:
     __slots__ = ("graph", "proxies", "out", "ctx", "caps_key", "pair_cap")
 
@@ -163,6 +174,14 @@ class GraphedIteration:
             self._seq = 0
 
     def _capture(self, key, cameras, strategies, tasks):
+        if _os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") != "0" and _os.environ.get("GSR_GRAPH_ANYWAY") != "1":
+            # Measured on ROCm 7.0.2 (tools/probes/graph_bench_probe2.py): with the runtime's graph packet capture on, a
+            # graph's pre-built packets go stale once a few hundred ordinary launches have run between two replays
+            # (400 trivial elementwise launches are enough) and the next replay dies with a memory access fault.  With
+            # the flag off replays cost ~3 % more and survive.  The runtime reads the flag when libamdhip64 is loaded:
+            # it has to be in the environment before torch is imported (bench.py, tests/conftest.py set it).
+            raise RuntimeError("hipGraph replays need DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in the environment BEFORE torch is "
+                               "imported (HIP runtime issue with replays after eager launches); iteration stays eager")
         dev = self.opt.param_groups[0]["params"][0].device
         self._ensure_buffers(dev)
         e = _Entry()
@@ -180,6 +199,7 @@ class GraphedIteration:
             e.ctx.slab_caps_dev = torch.tensor(caps.reshape(-1), dtype=torch.int32).to(dev)
         torch.cuda.synchronize(dev)
         e.graph = torch.cuda.CUDAGraph()
+        _dbg("capture begins")
         _dgr._CAPTURE[0] = e.ctx
         try:
             # thread_local: the process group's watchdog thread keeps polling the events of EARLIER (eager) collectives
@@ -196,6 +216,7 @@ class GraphedIteration:
             self.entries.pop(next(iter(self.entries)))
         self.entries[key] = e
         self.stats["captured"] += 1
+        _dbg("captured; pair capacities", [c for _, c in e.ctx.pairs])
         return e
 
     def _stage(self, entry, cameras):
@@ -245,7 +266,8 @@ class GraphedIteration:
         # iterations eagerly, in order
         torch.cuda.current_stream().synchronize()
         self._flag.zero_()
-        self.opt.graph_advance(-len(queue))
+        if self.opt.__dict__.get("_graph_owners") is not None:
+            self.opt.graph_advance(-len(queue))
         self.entries.clear()
         self._seen.clear()
         out = None
@@ -284,10 +306,16 @@ class GraphedIteration:
             return out
         # replay: inputs + hyper-parameters (one host-to-device copy, one band copy per camera), then ONE launch
         seq = self._stage(entry, cameras)
+        _dbg("replay", seq)
         entry.graph.replay()
+        if _DEBUG:
+            torch.cuda.synchronize()
+            _dbg("replay done", seq, "flag", int(self._ring_np[2 * (seq % self.RING)]), "pairs",
+                 [(int(h[0]), c) for h, c in entry.ctx.pairs])
         ev = torch.cuda.Event()
         ev.record()
-        self.opt.graph_advance(1)
+        if self.opt.__dict__.get("_graph_owners") is not None:  # (a body without an optimizer step: nothing to count)
+            self.opt.graph_advance(1)
         self.stats["replayed"] += 1
         prev = self._inflight
         if prev is None:

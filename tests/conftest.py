@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# hipGraph replays (grendel-gs_amd/graphed_step.py) need the HIP runtime's graph packet capture off; the flag is read when
+# libamdhip64 is loaded, i.e. before the first `import torch` of the test session (bench.py explains what was measured)
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "grendel-gs_amd")
 for p in (PKG, ROOT):

@@ -24,6 +24,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (os.path.join(ROOT, "grendel-gs_amd"), ROOT):
     sys.path.insert(0, p)
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")  # (see bench.py: must precede the import of torch)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 

@@ -91,6 +91,11 @@ if has benchq; then
   timeout 300 python bench.py --no-cpu-baseline --no-extra --steps 30 --warmup 6 --repeats 3 --render-steps 10 > $O/benchq.json 2> $O/benchq.err
   summ $O/benchq.json benchq | tee -a $O/ab.txt
 fi
+if has benchg; then
+  timeout 300 python bench.py --graph on --no-cpu-baseline --no-extra --steps 30 --warmup 6 --repeats 3 --render-steps 10 > $O/benchg.json 2> $O/benchg.err
+  summ $O/benchg.json "graph=on" | tee -a $O/ab.txt
+  python -c "import json; d=json.load(open('$O/benchg.json')); print(d.get('graph'), d['timing'])"
+fi
 if has ab; then
   for lib in $(ls variants/libgsraster_*.so 2>/dev/null); do
     [[ $lib == *stats* ]] && continue
