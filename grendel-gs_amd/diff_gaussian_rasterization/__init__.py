@@ -412,12 +412,20 @@ def _batched_record(grads, B, P):
 # K11: it returns no gradients (`.grad` stays None) and hands the sink everything K11 needs; the sink's step() then
 # runs K11 and Adam as ONE kernel (gsr_preprocess_backward_adam_raw_batched) -- or, whenever that is not possible,
 # materializes the gradients with the plain K11 and steps as usual.  Opt-in: nothing is deferred without a sink.
-_DEFERRED_SINK = [None]
+_DEFERRED_SINK = [None]  # a weak reference: an optimizer that is dropped stops being the sink
 
 
 def set_deferred_backward_sink(sink):
-    """sink: object with accepts(params) -> bool and offer(PendingProjectionBackward), or None to switch deferral off"""
-    _DEFERRED_SINK[0] = sink
+    """sink: object with accepts(params) -> bool and offer(PendingProjectionBackward), or None to switch deferral off.
+    Held weakly -- a superseded optimizer that nobody references any more cannot swallow a backward."""
+    import weakref
+
+    _DEFERRED_SINK[0] = weakref.ref(sink) if sink is not None else None
+
+
+def deferred_backward_sink():
+    ref = _DEFERRED_SINK[0]
+    return ref() if ref is not None else None
 
 
 class PendingProjectionBackward:
@@ -589,7 +597,7 @@ class _PreprocessGaussiansRawBatched(torch.autograd.Function):
             else:
                 g_means2D, g_rgb, g_conic_opacity, gstride = assemble(0, 2), assemble(1, 3), assemble(2, 4), 0
         params = (xyz, scaling, rotation, f_dc, f_rest, opacity)
-        sink = _DEFERRED_SINK[0]
+        sink = deferred_backward_sink()
         if sink is not None and M == 16 and sink.accepts(params):
             # K11 runs inside the optimizer's step (fused with Adam); `.grad` of the six parameters stays None
             sink.offer(PendingProjectionBackward(params, cams, radii, cov3D, clamped, g_means2D, g_conic_opacity,

@@ -33,6 +33,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._pending = None
         self._owners_cache = None
         self._launch_cache = {}
+        self._warned_replicated = False
         self.fused_steps = 0         # steps in which K11 ran inside the optimizer kernel
         self.materialized_steps = 0  # deferred backwards that had to fall back to the plain K11
         self.fuse_backward = False
@@ -44,6 +45,7 @@ class FusedAdam(torch.optim.Optimizer):
         # an unpickled optimizer never is the sink of a pending backward: re-arm with set_fuse_backward(True)
         self.__dict__.setdefault("grad_scale", 1.0)
         self._pending, self._owners_cache, self._launch_cache, self.fuse_backward = None, None, {}, False
+        self._warned_replicated = False
         self.__dict__.setdefault("fused_steps", 0)
         self.__dict__.setdefault("materialized_steps", 0)
 
@@ -54,7 +56,7 @@ class FusedAdam(torch.optim.Optimizer):
         self.fuse_backward = bool(on)
         if on:
             _dgr.set_deferred_backward_sink(self)
-        elif _dgr._DEFERRED_SINK[0] is self:
+        elif _dgr.deferred_backward_sink() is self:
             self._flush_pending()
             _dgr.set_deferred_backward_sink(None)
 
@@ -88,7 +90,26 @@ class FusedAdam(torch.optim.Optimizer):
         if not self.fuse_backward:
             return False
         owners = self._owners_of(params)
-        return owners is not None and all(p.grad is None and p.requires_grad for _, p in owners)
+        if owners is None or not all(p.grad is None and p.requires_grad for _, p in owners):
+            return False
+        if not self._warned_replicated:
+            # replicated storage (world > 1 without --gaussians_distribution) all-reduces `.grad` between backward and
+            # step (scene/gaussian_model.py: sync_gradients_for_replicated_3dgs_storage): a deferred backward leaves
+            # `.grad` None and that sync would silently do nothing
+            try:
+                import utils.general_utils as utils
+
+                args = utils.get_args()
+                if utils.DEFAULT_GROUP is not None and utils.DEFAULT_GROUP.size() > 1 and args is not None and \
+                        not getattr(args, "gaussians_distribution", True):
+                    import warnings
+
+                    warnings.warn("FusedAdam(fuse_backward=True) with replicated Gaussian storage: the gradient "
+                                  "all-reduce between backward and step sees no `.grad`; use fuse_backward=False")
+            except Exception:  # noqa: BLE001  (no mirror `utils` on the path: nothing to check)
+                pass
+            self._warned_replicated = True
+        return True
 
     def offer(self, pending):
         if self._pending is not None:  # a second backward before the step: both become ordinary gradients

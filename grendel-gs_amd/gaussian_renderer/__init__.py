@@ -235,6 +235,19 @@ class _SlabPlanner:
         self.caps_list = None   # the same as nested python lists
         self.pending = None     # (event | None, host matrix, caps it was packed with) of an unverified iteration
         self._ring, self._slot = [], 0
+        self.redo_streak = 0    # consecutive speculative exchanges that had to be repeated ...
+        self.backoff = 0        # ... after REDO_LIMIT of them: this many iterations with the exact layout
+
+    REDO_LIMIT, BACKOFF = 3, 32
+
+    def note(self, redone):
+        """a scene / partition where a rendered band keeps receiving < 10 rows (an empty sky band, early training) or the
+        counts keep outgrowing their slabs would pay two exchanges and two renders every iteration: after REDO_LIMIT
+        repeats in a row the next BACKOFF iterations use the exact layout (one read-back, the reference's schedule).  The
+        same decision on every rank: `redone` is a function of the all-gathered counts."""
+        self.redo_streak = self.redo_streak + 1 if redone else 0
+        if self.redo_streak >= self.REDO_LIMIT:
+            self.redo_streak, self.backoff = 0, self.BACKOFF
 
     def observe(self, m):
         """m: int64 numpy array [W, W, B]"""
@@ -262,11 +275,17 @@ class _SlabPlanner:
         else:
             host, ev = all_counts.clone(), None
         self.pending = (ev, host, self.caps)
+        return self.pending
 
-    def resolve(self):
-        """-> (count matrix int64 numpy [W, W, B] of the pending iteration, True when every count fitted its slab)"""
-        ev, host, caps = self.pending
-        self.pending = None
+    def resolve(self, pending=None):
+        """-> (count matrix int64 numpy [W, W, B] of `pending` (default: the latest staged iteration), True when every
+        count fitted its slab).  A package keeps ITS pending tuple, so a second package created before the first one is
+        verified cannot be mistaken for it."""
+        if pending is None:
+            pending = self.pending
+        if pending is self.pending:
+            self.pending = None
+        ev, host, caps = pending
         if ev is not None:
             ev.synchronize()  # the copy was queued before the all-to-all: long complete when a render has polled D
         m = host.numpy().reshape(self.W, self.W, self.B).astype(np.int64)  # (a copy: the pinned buffer is reused)
@@ -488,6 +507,9 @@ def _batched_exchange_final(m2_views, rgb_views, co_views, radii_views, depths_v
     else:
         chunkcnt, counts = _dgr.exchange_count(bases[0], radii_all, bands, 0, B, width, height)
         all_counts = torch.empty((W * W, B), dtype=torch.int32, device=dev)
+        if planner.backoff > 0:  # repeated redos: exact layout for a while (see _SlabPlanner.note)
+            planner.backoff -= 1
+            speculate = False
         speculate = speculate and planner.caps is not None
         if speculate and dev.type == "cuda":
             # nothing the pack / all-to-all / unpack below need depends on the gathered matrix (the pack works from the
@@ -577,7 +599,7 @@ def _batched_exchange_final(m2_views, rgb_views, co_views, radii_views, depths_v
     if gather_work is not None:
         gather_work.wait()          # stream-level join with the (long finished) size all-gather; the host does not wait
         planner.stage(all_counts)   # asynchronous copy to pinned memory + event, behind the unpack in stream order
-    pending = (planner, chunkcnt, counts, sizes) if (speculate and cap_ctx is None) else None
+    pending = (planner, chunkcnt, counts, sizes, planner.pending) if (speculate and cap_ctx is None) else None
     return out[0], out[1], out[2], out[3], out[4], sizes, (events, token), pending
 
 
@@ -697,7 +719,7 @@ def distributed_preprocess3dgs_and_all2all_final(batched_viewpoint_cameras, pc, 
         pkg["_exchange_token"] = token
         pkg.pop("_exchange_pending", None)
         if pending is not None:
-            planner, chunkcnt, counts, lazy = pending
+            planner, chunkcnt, counts, lazy, staged = pending
             rendered = [(g, k) for k, st in enumerate(batched_strategies) for g in st.gpu_ids]
 
             def verify():
@@ -708,10 +730,12 @@ def distributed_preprocess3dgs_and_all2all_final(batched_viewpoint_cameras, pc, 
                 if pkg.get("_exchange_pending") is None:
                     return True
                 pkg.pop("_exchange_pending")
-                m, fitted = planner.resolve()
+                m, fitted = planner.resolve(staged)
                 lazy._v = m.tolist()
                 recv_rows = m.sum(axis=0).tolist()  # [destination][camera]: rows a band receives
-                if fitted and all(recv_rows[g][k] >= 10 for (g, k) in rendered):
+                ok = fitted and all(recv_rows[g][k] >= 10 for (g, k) in rendered)
+                planner.note(redone=not ok)
+                if ok:
                     return True
                 exchange_stats["redone"] += 1
                 exchange(known=(chunkcnt, counts, lazy._v))

@@ -128,8 +128,8 @@ def _worker(rank, world, port, bsz, q):
                 m2s, rgbs, cos, radiis, depthss, sizes, (events, token), pending = run()
                 assert (pending is not None) == spec
                 if spec:  # what render_final does after the renders: look at the counts, repeat if a slab overflowed
-                    pl, chunkcnt, counts, lazy = pending
-                    m, fitted = pl.resolve()
+                    pl, chunkcnt, counts, lazy, staged = pending
+                    m, fitted = pl.resolve(staged)
                     assert m.tolist() == sizes_ref
                     assert fitted == (mode == "speculative")
                     if not fitted:
@@ -488,3 +488,32 @@ def test_local_sampling_strategy_equals_the_reference():
     finally:
         (utils.ARGS, utils.WORLD_SIZE, utils.GLOBAL_RANK, utils.DEFAULT_GROUP, utils.IMG_H, utils.IMG_W, utils.TILE_Y,
          utils.TILE_X) = saved
+
+
+def test_slab_planner_backs_off_after_repeated_redos_and_keeps_pending_per_package():
+    """the exchange's capacity planner (host logic): three speculative exchanges in a row that had to be repeated switch
+    the next 32 iterations to the exact layout; a package resolves ITS staged counts, whatever was staged after it"""
+    import numpy as np
+
+    for p in (os.path.join(ROOT, "grendel-gs_amd"), ROOT):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import gaussian_renderer as gr
+
+    pl = gr._SlabPlanner(2, 1)
+    pl.observe(np.full((2, 2, 1), 100, dtype=np.int64))
+    assert pl.backoff == 0
+    pl.note(True)
+    pl.note(True)
+    pl.note(False)          # a success in between resets the streak
+    pl.note(True)
+    pl.note(True)
+    assert pl.backoff == 0
+    pl.note(True)
+    assert pl.backoff == pl.BACKOFF and pl.redo_streak == 0
+    first = pl.stage(torch.full((4, 1), 7, dtype=torch.int32))
+    second = pl.stage(torch.full((4, 1), 9, dtype=torch.int32))
+    m1, fit1 = pl.resolve(first)       # the older package, resolved after a newer one was staged
+    assert int(m1[0, 0, 0]) == 7 and fit1 and pl.pending is second
+    m2, _ = pl.resolve(second)
+    assert int(m2[0, 0, 0]) == 9 and pl.pending is None

@@ -46,16 +46,25 @@ def test_sink_registration_and_acceptance():
 
     m, opt, params = make()
     try:
-        assert dgr._DEFERRED_SINK[0] is opt and opt.accepts(params)
+        assert dgr.deferred_backward_sink() is opt and opt.accepts(params)
         other = S.SyntheticGaussianModel(64, 64, 48, seed=2)
         assert not opt.accepts(tuple(getattr(other, n) for n in NAMES))  # somebody else's parameters
         m._xyz.grad = torch.zeros_like(m._xyz)
         assert not opt.accepts(params)  # another gradient path already wrote .grad: do not defer
         m._xyz.grad = None
         plain = FusedAdam(other.param_groups(), lr=0.0, eps=1e-15)
-        assert dgr._DEFERRED_SINK[0] is opt and not plain.accepts(tuple(getattr(other, n) for n in NAMES))
+        assert dgr.deferred_backward_sink() is opt and not plain.accepts(tuple(getattr(other, n) for n in NAMES))
         opt.set_fuse_backward(False)
-        assert dgr._DEFERRED_SINK[0] is None and not opt.accepts(params)
+        assert dgr.deferred_backward_sink() is None and not opt.accepts(params)
+        # the sink is held weakly: an optimizer nobody references any more cannot swallow a backward
+        opt.set_fuse_backward(True)
+        assert dgr.deferred_backward_sink() is opt
+        import gc
+
+        del opt
+        gc.collect()
+        assert dgr.deferred_backward_sink() is None
+        opt = FusedAdam(m.param_groups(), lr=0.0, eps=1e-15)
     finally:
         opt.set_fuse_backward(False)
 
