@@ -221,8 +221,9 @@ def run_workload(a, name, world, rank, dev, steps, warmup, repeats, render_steps
     n_total, W, H, bsz, desc = WORKLOADS[name]
     n_total = a.gaussians or n_total
     W, H = a.width or W, a.height or H
-    bsz = a.bsz or (bsz if bsz is not None else max(1, world))
     real_world = int(os.environ.get("WORLD_SIZE", 1))
+    # (`weak`: one image per GPU of the run -- also in the same-workload leg on ONE GPU, which then steps over N images)
+    bsz = a.bsz or (bsz if bsz is not None else max(1, real_world if single_view else world))
     utils.set_args(utils.default_args(bsz=bsz))
     utils.set_img_size(H, W)
     utils.set_cur_iter(1)
@@ -573,10 +574,17 @@ def main():
         if not a.no_1gpu_leg:
             one_gpu = same_workload_1gpu(name)
         if a.workload == "auto" and not a.no_extra:
-            ex = run_workload(a, "c4", world, rank, dev, max(a.steps // 3, 5), min(a.warmup, 3), 1, 0,
-                              collect_kernels=False)
-            ex1 = None if a.no_1gpu_leg else same_workload_1gpu("c4")
-            extras.append((ex, ex1))
+            # configs[4]'s shape (strong scaling of one 4K image over a 40 M-Gaussian scene) and the weak-scaling leg:
+            # bsz = N whole images per step on the configs[1] scene sharded N ways (Grendel's batched multi-view mode,
+            # configs[3]) -- its `value` is directly comparable with the N = 1 line (same scene, one image per GPU)
+            for wname, st in (("c4", max(a.steps // 3, 5)), ("weak", a.steps)):
+                try:
+                    ex = run_workload(a, wname, world, rank, dev, st, min(a.warmup, 3), 1, 0, collect_kernels=False)
+                except Exception as e:  # noqa: BLE001  (every rank fails alike: sizes are a function of (N, workload))
+                    ex = {"name": wname, "error": f"{type(e).__name__}: {e}"}
+                    torch.cuda.empty_cache()
+                ex1 = None if (a.no_1gpu_leg or "error" in ex) else same_workload_1gpu(wname)
+                extras.append((ex, ex1))
 
     if a.pmc_calib:
         x = torch.rand(64 * 1024 * 1024, device=dev)  # 256 MiB
@@ -589,6 +597,8 @@ def main():
         return
 
     def brief(res, res1):
+        if "error" in res:
+            return {"workload": res["name"], "error": res["error"]}
         d = {"workload": f"{res['name']}: {res['desc']}", "gaussians_total": res["gaussians_total"],
              "image": res["image"], "bsz": res["bsz"], "value": round(res["images_per_s"], 3), "unit": "images/s",
              "ms_per_step": round(res["ms_per_step"], 4), "steps": res["steps"], "timing": res["timing"]}

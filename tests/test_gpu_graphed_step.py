@@ -47,6 +47,7 @@ def _train(device, steps, bsz, graph, forced=False, shrink_pairs=None, eager_at=
     from graphed_step import GraphedIteration
 
     N, W, H, cams = _setup(device, bsz, forced)
+    dgr.release_workspaces()  # (pair counts other tests' scenes left behind would size this scene's capacities)
     model = S.SyntheticGaussianModel(N, W, H, seed=9, device=device, scale_coef=0.008)
     hist = DivisionStrategyHistoryFinal(S.SyntheticDataset(cams), 1, 0)
     bg = torch.tensor([0.1, 0.2, 0.3], device=device)
