@@ -164,4 +164,13 @@ fi
 if has pmc; then
   bash tools/gpu_session.sh $TAG trace sq fetch write > $O/pmc_session.log 2>&1
   tail -5 $O/pmc_session.log
+  # bench.py quotes the PMC figures of the build it runs on: put them where it looks (the session's copy comes home in
+  # gpurun_out/<tag>/pmc.json and is committed as profiles/<round>_pmc.json)
+  [ -s $O/pmc.json ] && cp $O/pmc.json $R/profiles/${PMC_NAME:-r04_pmc}.json && cp $O/pmc.txt $R/profiles/${PMC_NAME:-r04_pmc}.txt
+fi
+if has benchfull; then
+  timeout 1200 python bench.py > $O/bench.json 2> $O/bench.err
+  echo "bench exit $?"
+  summ $O/bench.json bench
+  python -c "import json; d=json.load(open('$O/bench.json')); print(json.dumps(d['roofline'])[:900]); print([ (w['workload'][:30], w.get('value')) for w in d.get('extra_workloads', [])]); print(d['cpu_baseline'])"
 fi
