@@ -70,6 +70,71 @@ def install_fake_collectives():
     dist.all_reduce = lambda *a, **k: None
 
 
+# ---- a BALANCED partition for the fake world (round 4).  With the even partition the instrument's middle rank renders
+# the densest band of the image: 1 / 5.3 of the composite work instead of 1 / 8 on configs[2]'s shape
+# (tools/diag/wg_timeline.py) -- a real run's load balancer shrinks that band.  Grendel's balancer is a fixed-point
+# iteration on per-row costs (new cost of a band's rows = the band's measured time / its rows, workload_division.py:
+# 953-998); it is run here round by round: in a round every rank position r = 0 .. W-1 is measured in turn on the
+# CURRENT partition (heuristics frozen inside the round), then the per-row costs are updated from all ranks' times with
+# the reference's formula.  The final measurement (optionally as a hipGraph) uses the converged partition, frozen.
+_SHARED = {"heur": {}, "round": {}}
+
+
+def _install_balancer_hooks(wd, utils):
+    import torch as _torch
+
+    init0 = wd.DivisionStrategyHistoryFinal.__init__
+
+    def init(self, dataset, world_size, rank):
+        init0(self, dataset, world_size, rank)
+        for cam in dataset.cameras:
+            if cam.uid in _SHARED["heur"]:
+                self.accum_heuristic[cam.uid] = _SHARED["heur"][cam.uid].clone()
+
+    wd.DivisionStrategyHistoryFinal.__init__ = init
+    my0 = wd._my_times
+
+    def my_times(batched_strategies, batched_statistic_collector):
+        mine = my0(batched_strategies, batched_statistic_collector)
+        for k, st in enumerate(batched_strategies):
+            if mine[k] >= 0:
+                rec = _SHARED["round"].setdefault(st.camera.uid, {})
+                rec.setdefault(utils.GLOBAL_RANK, []).append((mine[k], tuple(st.gpu_ids), tuple(st.division_pos)))
+        return mine
+
+    wd._my_times = my_times
+    _SHARED["torch"] = _torch
+
+
+def _end_of_round(tile_y):
+    """per-row costs of every camera from the round's measurements (all rank positions), the reference's update rule"""
+    torch_ = _SHARED["torch"]
+    spread = []
+    for uid, per_rank in _SHARED["round"].items():
+        any_rec = next(iter(per_rank.values()))[-1]
+        gpu_ids, div = any_rec[1], any_rec[2]
+        new = torch_.ones((tile_y,), dtype=torch_.float32)
+        times = []
+        for j, g in enumerate(gpu_ids):
+            recs = [t for (t, gi, dv) in per_rank.get(g, []) if dv == div]
+            if not recs:
+                continue
+            t = sorted(recs)[len(recs) // 2]  # median over the round's visits of this camera
+            times.append(t)
+            new[div[j]:div[j + 1]] = t / (div[j + 1] - div[j])
+        _SHARED["heur"][uid] = new
+        if times:
+            spread.append(max(times) / (sum(times) / len(times)))
+    # ONE partition for all cameras: the mean of the per-camera row costs.  A captured iteration bakes its partition in
+    # (grid sizes, band rows of the loss), so per-camera cut points would need one graph per camera; the cameras'
+    # profiles differ by a few percent only (printed: max / mean band time of the per-camera partitions)
+    mean = sum(_SHARED["heur"].values()) / max(len(_SHARED["heur"]), 1)
+    for uid in list(_SHARED["heur"]):
+        _SHARED["heur"][uid] = mean.clone()
+    _SHARED["round"] = {}
+    return sum(spread) / max(len(spread), 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="c2")
@@ -79,6 +144,9 @@ def main():
     ap.add_argument("--bsz", type=int, default=0)
     ap.add_argument("--no-fuse-backward", action="store_true", help="K11 and Adam as two kernels")
     ap.add_argument("--graph", default="off", choices=["off", "on"], help="replay the iteration as one hipGraph")
+    ap.add_argument("--balanced", type=int, default=0, metavar="ROUNDS",
+                    help="balance the row partition with Grendel's own rule over ROUNDS rounds (every rank position "
+                         "measured in turn), then measure EVERY rank position on the converged partition")
     ap.add_argument("--profile", action="store_true", help="cProfile the host side of the steps (top functions by own time)")
     a0 = ap.parse_args()
 
@@ -88,12 +156,65 @@ def main():
 
     install_fake_collectives()
     wd._gather_times_on_host = lambda mine: [list(mine) for _ in range(utils.DEFAULT_GROUP.size())]
+    utils.our_allgather_among_cpu_processes_float_list = lambda data, group: [list(data) for _ in range(group.size())]
     # identical ranks report identical times whatever their band: fed back, that drives the partition to a degenerate
-    # one (time / rows rises as a band shrinks).  Keep the even partition: the gather and its bookkeeping still run.
+    # one (time / rows rises as a band shrinks).  The product's per-iteration update is therefore switched off; the
+    # even partition stays unless --balanced runs the same rule round by round over all rank positions (above).
     wd._update_heuristics = lambda *a, **k: None
+    if a0.balanced:
+        _install_balancer_hooks(wd, utils)
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     results = []
+    def one_run(W, rank, graph, steps, warmup, frozen, timed_probe=False, collect=True):
+        a = argparse.Namespace(gaussians=0, width=0, height=0, bsz=a0.bsz, views=8, opacity_logit_mean=0.0,
+                               opacity_logit_std=2.0, device_scene=False, no_priming=False,
+                               no_fuse_backward=a0.no_fuse_backward, graph=graph, balance_every=0)
+        os.environ["WORLD_SIZE"] = str(W)
+        utils.GLOBAL_RANK, utils.LOCAL_RANK, utils.WORLD_SIZE = (rank if W > 1 else 0), 0, W
+        utils.DEFAULT_GROUP = utils.IN_NODE_GROUP = FakeGroup(W, rank) if W > 1 else utils.SingleGPUGroup()
+        wd._BALANCE["mode"] = "exact"
+        import gaussian_renderer as gr
+
+        gr._PLANNERS.clear()
+        _default_args = utils.default_args
+        # frozen: nothing consumes timings (graph-capable); timed_probe: the ops record their render / loss events
+        utils.default_args = lambda **kw: _default_args(**{**kw, "no_heuristics_update": frozen,
+                                                           "save_strategy_history": timed_probe})
+        try:
+            return bench.run_workload(a, a0.workload, W, rank if W > 1 else 0, dev, steps, warmup, 1, 0,
+                                      single_view=(W == 1), collect_kernels=collect)
+        finally:
+            utils.default_args = _default_args
+
+    def bench_bands(res):
+        ex = res.get("exchange") or {}
+        return ex.get("bands_last_step")
+
+    if a0.balanced:
+        base = one_run(1, 0, a0.graph, a0.steps, a0.warmup, True)
+        print(json.dumps({"world": 1, "ms_per_step": round(base["ms_per_step"], 4)}), flush=True)
+        for W in [w for w in a0.worlds if w > 1]:
+            _SHARED["heur"].clear()
+            for rnd in range(a0.balanced):
+                for r in range(W):
+                    one_run(W, r, "off", 8, 2, True, timed_probe=True, collect=False)
+                imb = _end_of_round(utils.TILE_Y)
+                print(f"# W={W} round {rnd}: max / mean band time of the measured partition {imb:.3f}", flush=True)
+            per_rank = []
+            for r in range(W):
+                res = one_run(W, r, a0.graph, a0.steps, a0.warmup, True)
+                per_rank.append({"rank": r, "ms_per_step": round(res["ms_per_step"], 4), "graph": res.get("graph"),
+                                 "bands": bench_bands(res),
+                                 "kernel_sum_ms": round(sum(v["avg_ms"] for v in res["kernels"].values()), 4),
+                                 "render_ms": round(sum(v["avg_ms"] for k, v in res["kernels"].items()
+                                                        if k.startswith(("binning", "composite", "l1_ssim"))), 4)})
+            worst = max(p_["ms_per_step"] for p_ in per_rank)
+            print(json.dumps({"world": W, "balanced_rounds": a0.balanced, "graph": a0.graph, "per_rank": per_rank,
+                              "step_ms_max_over_ranks": worst,
+                              "speedup_bound": round(base["ms_per_step"] / worst, 3)}), flush=True)
+        return
+
     for W in a0.worlds:
         rank = W // 2  # a middle band
         # the fields run_workload reads

@@ -135,6 +135,10 @@ if has fake48; then
   timeout 400 python tools/fake_world_bench.py --workload c2 --worlds 4 8 --steps 20 --graph on > $O/fake_world_c2_48.txt 2> $O/fake_world_c2_48.err
   cut -c1-400 $O/fake_world_c2_48.txt
 fi
+if has fakebal; then
+  timeout 900 python tools/fake_world_bench.py --workload c2 --worlds 8 --steps 20 --graph on --balanced 2 > $O/fake_world_c2_balanced.txt 2> $O/fake_world_c2_balanced.err
+  cut -c1-900 $O/fake_world_c2_balanced.txt; grep -v amdgpu $O/fake_world_c2_balanced.err | tail -3
+fi
 if has fake; then
   timeout 600 python tools/fake_world_bench.py --workload c2 --worlds 1 2 4 8 --steps 20 > $O/fake_world_c2.txt 2> $O/fake_world_c2.err
   cut -c1-400 $O/fake_world_c2.txt
