@@ -154,3 +154,21 @@ def test_bench_accounting_knows_the_fused_step():
     assert pc.group_of("void (anonymous namespace)::preprocess_backward_kernel<3, true>(int, int)") == \
         "preprocess_backward"
     assert pc.group_of("(anonymous namespace)::adam_multi_kernel((anonymous namespace)::AdamBatch, float)") == "adam"
+
+
+def test_bench_launches_itself_for_more_than_one_gpu():
+    """`python bench.py --gpus N` without a launcher becomes `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...` (the reference's start-up, README.md:199-202)"""
+    import importlib.util
+    import sys
+
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    argv = bench.self_launch_command(4, ["--gpus", "4", "--steps", "7"])
+    assert argv[0] == sys.executable and argv[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nnodes=1" in argv and "--nproc-per-node=4" in argv
+    assert argv[argv.index("--master-addr") + 1] == "127.0.0.1" and int(argv[argv.index("--master-port") + 1]) > 0
+    i = argv.index(os.path.join(ROOT, "bench.py"))
+    assert argv[i + 1:] == ["--gpus", "4", "--steps", "7"]
+    assert os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0"  # set before torch is imported (graph replays)

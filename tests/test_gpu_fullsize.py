@@ -99,9 +99,11 @@ def test_fullsize_band_union_and_permutation(device, N, W, H):
             img, _, _, _ = rast.render_gaussians(m2, co, rgb, depths, radii, mask, None, {})
             total = total + img
         (total * wgt).sum().backward()
+        run.last = (m2.detach(), radii.detach(), depths.detach())
         return total.detach(), {k: gg[k].grad for k in KEYS}
 
     img1, gr1 = run([(0, gy)])
+    m2_1, radii_1, depths_1 = run.last
     assert torch.isfinite(img1).all()
     cuts = [0, gy // 8, gy // 4, gy // 2, gy - 3, gy]
     img8, gr8 = run(list(zip(cuts[:-1], cuts[1:])))
@@ -123,6 +125,43 @@ def test_fullsize_band_union_and_permutation(device, N, W, H):
     print(f"[permutation {N} {W}x{H}] {ties} exact depth ties; image rel {e_img:.1e}, d_means3D rel {e_g:.1e}")
     assert e_img < 1e-3
     assert e_g < 1e-2
+    # The structural statement behind those two numbers (round-3 verdict): a pixel may differ ONLY where BOTH Gaussians
+    # of an exactly depth-tied pair can contribute -- in the intersection of their 3-sigma rects.  Everywhere else the
+    # permuted render is bitwise the original (the lists there are the same sequences).
+    import numpy as np
+
+    dz = depths_1.cpu().numpy()
+    vis = radii_1.cpu().numpy() > 0
+    order = np.argsort(dz, kind="stable")
+    ds = dz[order]
+    xy, rr = m2_1.cpu().numpy(), radii_1.cpu().numpy()
+
+    def rect(i):
+        # every pixel of every TILE the 3-sigma rect touches (the tile rect; inside a touched tile a
+        # Gaussian contributes wherever its alpha reaches 1/255, which can be beyond 3 sigma)
+        x, y, r = float(xy[i, 0]), float(xy[i, 1]), float(rr[i])
+        tx0, tx1 = max(int((x - r) / 16), 0), min(int((x + r + 15) / 16), gx)
+        ty0, ty1 = max(int((y - r) / 16), 0), min(int((y + r + 15) / 16), gy)
+        return 16 * tx0, min(16 * tx1, W), 16 * ty0, min(16 * ty1, H)
+
+    foot = np.zeros((H, W), dtype=bool)
+    starts = np.flatnonzero(np.concatenate([[True], ds[1:] != ds[:-1]]))
+    ends = np.concatenate([starts[1:], [len(ds)]])
+    tied_pairs = 0
+    for a, b in zip(starts[ends - starts > 1], ends[ends - starts > 1]):  # runs of exactly equal depth
+        ids = [i for i in order[a:b] if vis[i]]
+        for u in range(len(ids)):
+            for v in range(u + 1, len(ids)):
+                ra, rb = rect(ids[u]), rect(ids[v])
+                x0, x1, y0, y1 = max(ra[0], rb[0]), min(ra[1], rb[1]), max(ra[2], rb[2]), min(ra[3], rb[3])
+                if x1 > x0 and y1 > y0:  # the two can meet on these pixels: swapping them may change them
+                    foot[y0:y1, x0:x1] = True
+                    tied_pairs += 1
+    differs = (imgp != img1).any(dim=0).cpu().numpy()
+    print(f"[permutation {N} {W}x{H}] {tied_pairs} depth-tied pairs overlap on screen, on {int(foot.sum())} pixels; "
+          f"{int(differs.sum())} pixels differ, {int((differs & ~foot).sum())} of them outside those footprints")
+    assert not (differs & ~foot).any(), "a permutation changed a pixel that no depth-tied PAIR can reach"
+    assert int(differs.sum()) <= int(foot.sum())
     # with depth ties broken by screen position (set_tie_order("position"): not by the index in the input arrays) the
     # render does not depend on the order of the Gaussians at all: the image bitwise, the gradients up to the order of
     # K10's float atomics
