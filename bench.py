@@ -340,6 +340,14 @@ def run_workload(a, name, world, rank, dev, steps, warmup, repeats, render_steps
     # the caching allocator a hipMalloc (multi-GB at the 40 M / 4K shape) and the speculative tile sort a fall-back --
     # first-epoch effects that would dominate the few steps those legs run.  Not used for the headline workload c1
     # (measured there: no effect).  Reported as `setup.priming_steps`.
+    # The step of a multi-rank run is host-bound: keep the cyclic garbage collector from walking the (large, static)
+    # object graph of the imported libraries every few hundred allocations -- everything alive now moves to the
+    # permanent generation (measured on one rank of a fake 8-rank world at bsz 8: 12.7 -> see profiles/r04_gc_freeze.txt)
+    if os.environ.get("GSR_GC_FREEZE", "1") != "0":
+        import gc
+
+        gc.collect()
+        gc.freeze()
     priming = -(-n_views // bsz) if (name != "c1" and not a.no_priming) else 0  # (c1_4k etc.: primed)
     for _ in range(priming):
         train_step()
