@@ -260,6 +260,7 @@ def main():
             st = pstats.Stats(pr, stream=sio)
             st.sort_stats("tottime").print_stats(30)
             st.sort_stats("cumulative").print_stats("grendel-gs_amd|bench.py|fake_world", 60)
+            st.sort_stats("tottime").print_callers("contiguous|run_backward", 12)
             print(f"# host profile, W={W}: {a0.steps + a0.warmup + 8} steps (incl. priming / warmup)")
             print(sio.getvalue()[:16000], flush=True)
         kern = {k: v["avg_ms"] for k, v in res["kernels"].items()}
