@@ -32,6 +32,24 @@ from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianR
 
 import diff_gaussian_rasterization as _dgr
 
+
+def _keep_grad_view(t):
+    """What the reference's `means2D.retain_grad()` (gaussian_renderer/__init__.py:953) is there for -- densification
+    reads `means2D.grad[:, :2]` (scene/gaussian_model.py:1046-1052) -- without the copy: retain_grad() CLONES the
+    incoming gradient, which here is a column view of K10's [P,9] record (a strided 8-of-36-byte read: 9 us per
+    iteration at 1 M Gaussians, 51 us at 6 M).  Nobody writes the record after K10 (K11 and the mirror exchange read
+    it), so the view itself is kept as `.grad`.  Accumulates like retain_grad() if the tensor is used twice."""
+    import weakref
+    ref, first = weakref.ref(t), [True]
+
+    def hook(g):
+        x = ref()
+        if x is not None:  # (reading .grad of a non-leaf that has none warns: the first call is remembered instead)
+            x.grad = g if first[0] else x.grad + g
+            first[0] = False
+
+    t.register_hook(hook)
+
 N_DIFF = 9  # means2D (2) + rgb (3) + conic_opacity (4): columns that carry gradients
 N_AUX = 2   # radius (as float) + depth: no gradient
 
@@ -680,7 +698,7 @@ def distributed_preprocess3dgs_and_all2all_final(batched_viewpoint_cameras, pc, 
     for k in range(len(rasterizers)):
         means2D = m2_all[k]
         if mode == "train":
-            means2D.retain_grad()  # densification reads means2D.grad (scene/gaussian_model.py:1046-1052)
+            _keep_grad_view(means2D)  # densification reads means2D.grad (scene/gaussian_model.py:1046-1052)
         params.append([means2D, rgb_all[k], co_all[k], radii_all[k], depths_all[k]])
     if timers is not None:
         timers.stop("forward_preprocess_gaussians")
