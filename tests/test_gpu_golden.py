@@ -87,7 +87,7 @@ def test_det_zero_cull_matches_fp32_restatement(device):
     gg = {k: v.to(device).requires_grad_(True) for k, v in g.items()}
     m2, rgb, co, radii, depths = rast.preprocess_gaussians(*[gg[k] for k in KEYS], {})
     assert torch.equal(radii.cpu(), ref[3]), "radii incl. the det == 0 culls are bit-identical to the fp32 restatement"
-    assert float(co[det0.to(device)].abs().sum()) == 0.0 and float(m2[det0.to(device)].abs().sum()) == 0.0
+    assert float(co.detach()[det0.to(device)].abs().sum()) == 0.0 and float(m2.detach()[det0.to(device)].abs().sum()) == 0.0
     img, _, _, _ = rast.render_gaussians(m2, co, rgb, depths, radii, None, None, {})
     img.sum().backward()
     assert torch.isfinite(img).all()
