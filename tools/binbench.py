@@ -55,7 +55,7 @@ def main():
         lib = load(path)
         ranges = torch.empty((gx * gy + 1, 2), dtype=torch.int32, device=dev)
         nb = lib.gsr_bin_prepare_bytes(P, W, H)
-        prep = torch.empty(nb, dtype=torch.uint8, device=dev)
+        prep = torch.zeros(nb, dtype=torch.uint8, device=dev)  # (zeros: timing probes with wrong lists must still read valid indices)
         D = ctypes.c_int64(0)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         t_prep = t_sort = 0.0
@@ -67,7 +67,7 @@ def main():
             ev[1].record()
             sb = lib.gsr_bin_sort_bytes(P, D.value, W, H)
             if it == 0:
-                scratch = torch.empty(sb, dtype=torch.uint8, device=dev)
+                scratch = torch.zeros(sb, dtype=torch.uint8, device=dev)
                 plist = torch.empty(D.value, dtype=torch.int32, device=dev)
             rc = lib.gsr_bin_sort(P, W, H, ptr(mask), ptr(prep), D.value, ptr(scratch), sb, ptr(plist), ptr(ranges),
                                   stream)

@@ -21,8 +21,10 @@ def _sub(src, old, new, count=1):
     return src.replace(old, new)
 
 
-def build():
+def build(window=None):
     rx = open(os.path.join(CSRC, "radix.h")).read()
+    if window:  # (look-back window experiment: python tools/diag/radix_timeline.py build 8)
+        rx = _sub(rx, "constexpr int LB_WINDOW = 4;", f"constexpr int LB_WINDOW = {int(window)};")
     rx = _sub(rx, "// LDS of one radix pass workgroup\n",
               f"__device__ unsigned long long g_rxt[{NREC}][{NW}];\n__device__ unsigned int g_rxt_n;\n"
               "// LDS of one radix pass workgroup\n")
@@ -176,6 +178,6 @@ def run(n):
 
 if __name__ == "__main__":
     if sys.argv[1] == "build":
-        build()
+        build(sys.argv[2] if len(sys.argv) > 2 else None)
     else:
         run(int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 1_000_000)
