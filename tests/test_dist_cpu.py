@@ -517,3 +517,37 @@ def test_slab_planner_backs_off_after_repeated_redos_and_keeps_pending_per_packa
     assert int(m1[0, 0, 0]) == 7 and fit1 and pl.pending is second
     m2, _ = pl.resolve(second)
     assert int(m2[0, 0, 0]) == 9 and pl.pending is None
+
+
+def test_kept_gradient_view_of_a_non_leaf():
+    """gaussian_renderer._keep_grad_view: what means2D.retain_grad() is there for (densification reads means2D.grad) minus
+    its clone -- the incoming gradient (a column view of K10's [P,9] record) is kept as it is; a tensor used twice
+    accumulates like retain_grad(); reading never warns"""
+    import warnings
+
+    import torch
+
+    import gaussian_renderer as gr
+
+    class FromRecord(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, a):
+            return a.sum()
+
+        @staticmethod
+        def backward(ctx, g):
+            rec = torch.arange(45.0).view(5, 9)
+            return rec[:, 0:2]
+
+    p = torch.randn(5, 2, requires_grad=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        t = p * 2.0
+        gr._keep_grad_view(t)
+        FromRecord.apply(t).backward()
+        assert t.grad.stride() == (9, 1) and t.grad._base is not None  # the view, not a copy
+        assert torch.equal(t.grad, torch.arange(45.0).view(5, 9)[:, 0:2])
+        t2 = p * 3.0
+        gr._keep_grad_view(t2)
+        (FromRecord.apply(t2) + FromRecord.apply(t2)).backward()
+        assert torch.equal(t2.grad, 2 * torch.arange(45.0).view(5, 9)[:, 0:2])
