@@ -29,17 +29,15 @@ heuristics: events recorded inside a capture cannot be read).
 """
 import copy
 import math
+import os as _os
+import sys as _sys
 from types import SimpleNamespace
 
 import torch
 
 import diff_gaussian_rasterization as _dgr
 
-
-import os as _os
-import sys as _sys
-
-_DEBUG = _os.environ.get("GSR_GRAPH_DEBUG") == "1"
+_DEBUG = _os.environ.get("GSR_GRAPH_DEBUG") == "1"  # every replay synchronised and logged to stderr
 
 
 def _dbg(*a):
@@ -289,8 +287,7 @@ class GraphedIteration:
         key = self._key(cameras, strategies)
         entry = self.entries.get(key)
         if entry is None:
-            redo = self._check_inflight()
-            del redo
+            self._check_inflight()  # (a flagged replay is repeated here, before this iteration runs eagerly)
             self.stats["eager"] += 1
             out = self.body(cameras, strategies, tasks)
             n = self._seen[key] = self._seen.get(key, 0) + 1
