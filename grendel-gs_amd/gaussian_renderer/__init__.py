@@ -22,6 +22,7 @@ the 9 gradient columns followed by a scatter-add into the owners' per-camera buf
 mode there is no gradient all-reduce at all.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -171,7 +172,9 @@ def all_to_all_communication_final(batched_rasterizers, batched_screenspace_para
 #   overlap   : pipeline the per-camera exchanges on a side HIP stream
 #   speculate : pack into capacity slabs chosen from earlier iterations, so that this iteration's counts never have to
 #               reach the host before the all-to-all is launched (no `.cpu()` between K1 and the render)
-_EXCHANGE_OPTIONS = {"overlap": True, "speculate": True, "forced": False}
+#   group     : ONE exchange for the whole batch when every rank renders (a band of) at most one of its cameras
+_EXCHANGE_OPTIONS = {"overlap": True, "speculate": True, "forced": False,
+                     "group": os.environ.get("GSR_EXCHANGE_GROUP", "1") != "0"}  # (env: A/B measurements only)
 _SIDE_STREAMS = {}
 _BANDS_CACHE = {}
 _PLANNERS = {}
@@ -183,6 +186,18 @@ def set_exchange_overlap(enabled):
     runs beside camera k-1's K3-K8 in the forward and beside camera k+1's K10 in the backward (north_star); off: one
     exchange for the whole batch on the current stream"""
     _EXCHANGE_OPTIONS["overlap"] = bool(enabled)
+
+
+def set_exchange_grouping(enabled):
+    """True (default): when every rank renders a band of AT MOST ONE camera of the batch (bsz <= world size, the
+    reference's usual batched mode: train_internal.py with bsz 4 or 8 on 4-8 GPUs), the capacity-slab exchange of the
+    whole batch is ONE pack, ONE all-to-all-v and ONE unpack each way instead of one per camera.  Nothing needs
+    regrouping then: the rows a rank receives for the cameras it renders no part of are the all-zero padding records of
+    their slabs (radius 0: K3 culls them), so the whole message IS its camera's input, in the reference's (source,
+    index) order.  Per-camera exchanges cannot overlap anything on such a rank (its one render needs its one camera's
+    rows, its K10 produces that camera's gradients), they only multiply the launches of a host-bound step by bsz.
+    False, or a rank that renders two cameras: one exchange per camera, pipelined on the side stream."""
+    _EXCHANGE_OPTIONS["group"] = bool(enabled)
 
 
 def set_exchange_speculation(enabled):
@@ -547,7 +562,14 @@ def _batched_exchange_final(m2_views, rgb_views, co_views, radii_views, depths_v
     layout_sizes = planner.caps_list if speculate else sizes  # rows per (source, destination, camera) of the buffers
 
     pipeline = _EXCHANGE_OPTIONS["overlap"] if pipeline is None else pipeline
-    pipelined = (pipeline or speculate) and B > 1         # one exchange per camera ...
+    # one exchange for the whole batch (set_exchange_grouping): the same decision on every rank -- it is a function of
+    # the strategies, which every rank derives from the same heuristics
+    renders = [0] * W
+    for st in batched_strategies:
+        for g in st.gpu_ids:
+            renders[g % W] += 1
+    grouped = bool(speculate and B > 1 and _EXCHANGE_OPTIONS["group"] and max(renders) <= 1)
+    pipelined = (pipeline or speculate) and B > 1 and not grouped   # one exchange per camera ...
     # ... on the side stream -- not inside a hipGraph capture: the process group's watchdog thread polls the events of
     # collectives issued from a stream that has not joined the capture yet, which HIP forbids (measured: the capture
     # aborts with hipErrorCapturedEvent); a captured iteration keeps its exchanges on the capturing stream
@@ -606,6 +628,12 @@ def _batched_exchange_final(m2_views, rgb_views, co_views, radii_views, depths_v
         else:
             r, ev = _ExchangeGroup.apply(meta, bases, token, *views), None
         token = r[5]
+        if grouped:  # the whole message is the input of the one camera this rank renders (the rest: zero records)
+            for k in cams:
+                local = me in batched_strategies[k].gpu_ids
+                for c in range(5):
+                    out[c][k] = r[c] if local else r[c][:0]
+            continue
         start = 0
         for kk, k in enumerate(cams):
             n = per_cam[kk]

@@ -111,7 +111,11 @@ def _worker(rank, world, port, bsz, q):
                                                                                         strategies)
             else:
                 gr.set_exchange_overlap(mode == "pipelined")
-                spec = mode in ("speculative", "overflow")
+                gr.set_exchange_grouping(mode != "speculative_per_camera")
+                spec = mode in ("speculative", "overflow", "speculative_per_camera")
+                renders = [sum(1 for st in strategies if g in st.gpu_ids) for g in range(world)]
+                # (set_exchange_grouping: ONE slab exchange for the batch when no rank renders two of its cameras)
+                grouped = spec and mode != "speculative_per_camera" and bsz > 1 and max(renders) <= 1
                 planner = gr._planner(utils.DEFAULT_GROUP, world, bsz)
                 if mode == "overflow":  # every slab one row short of what is needed (where anything is sent)
                     import numpy as np
@@ -131,7 +135,7 @@ def _worker(rank, world, port, bsz, q):
                     pl, chunkcnt, counts, lazy, staged = pending
                     m, fitted = pl.resolve(staged)
                     assert m.tolist() == sizes_ref
-                    assert fitted == (mode == "speculative")
+                    assert fitted == (mode != "overflow")
                     if not fitted:
                         m2s, rgbs, cos, radiis, depthss, sizes, (events, token), pending = run(
                             known=(chunkcnt, counts, m.tolist()))
@@ -142,10 +146,15 @@ def _worker(rank, world, port, bsz, q):
                         for k in range(bsz):
                             keep = radiis[k] > 0
                             assert int(keep.sum()) == sum(sizes_ref[i][rank][k] for i in range(world))
-                            assert radiis[k].shape[0] == sum(pl.caps_list[i][rank][k] for i in range(world)) or \
-                                rank not in strategies[k].gpu_ids
+                            if grouped:  # the whole message (all cameras' slabs) is the local camera's input
+                                rows = sum(pl.caps_list[i][rank][kk] for i in range(world) for kk in range(bsz))
+                                assert radiis[k].shape[0] == (rows if rank in strategies[k].gpu_ids else 0)
+                            else:
+                                assert radiis[k].shape[0] == sum(pl.caps_list[i][rank][k] for i in range(world)) or \
+                                    rank not in strategies[k].gpu_ids
                 assert all(e is None for e in events)  # no side stream on the CPU
-                assert (token is not None) == ((mode == "pipelined" or (spec and pending is not None)) and bsz > 1)
+                assert (token is not None) == ((mode == "pipelined" or (spec and pending is not None)) and bsz > 1
+                                               and not (grouped and pending is not None))
             assert len(sizes) == world and len(sizes[0]) == world and len(sizes[0][0]) == bsz
             loss = torch.zeros((), dtype=torch.float64)
             images = []
@@ -171,7 +180,7 @@ def _worker(rank, world, port, bsz, q):
             return images, grads, cargs, m2_grads, received, sizes
 
         images, grads, cargs, m2g_ref, recv_ref, sizes_ref = one_pass("reference")
-        for mode in ("batched", "pipelined", "speculative", "overflow"):
+        for mode in ("batched", "pipelined", "speculative", "speculative_per_camera", "overflow"):
             im2, gr2, _, m2g, recv2, sizes2 = one_pass(mode)
             assert sizes2 == sizes_ref, mode
             for k in range(bsz):

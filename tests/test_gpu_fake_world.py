@@ -38,7 +38,7 @@ def _zero_lr_groups(model):
     return groups
 
 
-def _run_ranks(dev, world, bsz, fuse, overlap=True, live_balancer=False):
+def _run_ranks(dev, world, bsz, fuse, overlap=True, live_balancer=False, group=True):
     """-> per-rank results of STEPS product iterations on the fake world"""
     import gaussian_renderer as gr
     import gaussian_renderer.workload_division as wd
@@ -58,6 +58,7 @@ def _run_ranks(dev, world, bsz, fuse, overlap=True, live_balancer=False):
     gr._PLANNERS.clear()
     gr.set_exchange_overlap(overlap)
     gr.set_exchange_speculation(True)
+    gr.set_exchange_grouping(group)
 
     def rank_main(rank):
         utils.GLOBAL_RANK, utils.LOCAL_RANK, utils.WORLD_SIZE = rank, 0, world
@@ -165,10 +166,19 @@ def _rel(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
-@pytest.mark.parametrize("world,bsz,fuse,live", [(2, 1, True, False), (4, 1, True, True), (8, 1, True, False),
-                                                   (2, 2, True, False), (4, 2, False, False), (8, 4, True, False)])
-def test_async_fake_world_matches_single_rank(device, world, bsz, fuse, live):
-    res, fw = _run_ranks(device, world, bsz, fuse, live_balancer=live)
+@pytest.mark.parametrize("world,bsz,fuse,live,group", [
+    (2, 1, True, False, True), (4, 1, True, True, True), (8, 1, True, False, True),
+    # bsz > 1: every rank renders one camera of the batch -> ONE slab exchange per step (set_exchange_grouping) ...
+    (2, 2, True, False, True), (4, 2, False, False, True), (8, 4, True, False, True),
+    # ... or one per camera, pipelined on the side stream (what a rank that renders two cameras gets)
+    (4, 2, True, False, False), (8, 4, True, False, False)])
+def test_async_fake_world_matches_single_rank(device, world, bsz, fuse, live, group):
+    import gaussian_renderer as gr
+
+    try:
+        res, fw = _run_ranks(device, world, bsz, fuse, live_balancer=live, group=group)
+    finally:
+        gr.set_exchange_grouping(True)
     partitions = res[0]["partitions"]
     assert all(r["partitions"] == partitions for r in res), "the ranks disagree on the partition"
     ref = _run_single(device, world, bsz, fuse, partitions)
@@ -181,7 +191,9 @@ def test_async_fake_world_matches_single_rank(device, world, bsz, fuse, live):
         assert r["exchange"]["redone"] == 0, r["exchange"]
         assert r["fused_steps"] == (STEPS if fuse else 0)
     # every rank issued the same collectives in the same order (checked at every rendezvous); there were some
-    assert sum(1 for _, tag in fw.log if tag == "all_to_all_single") >= 2 * STEPS * (bsz if bsz > 1 else 1)
+    # (the first step is sized exactly, one exchange per camera; the speculative ones are ONE exchange when grouped)
+    a2a = sum(1 for _, tag in fw.log if tag == "all_to_all_single")  # (one log entry per collective, not per rank)
+    assert a2a == 2 * bsz + 2 * (STEPS - 1) * (1 if (group or bsz == 1) else bsz), (a2a, bsz, group)
 
     # loss: the ranks' band losses add up to the single-rank sum of band losses
     for step in range(STEPS):
@@ -207,7 +219,7 @@ def test_async_fake_world_matches_single_rank(device, world, bsz, fuse, live):
         e1, e2 = _rel(m1, ref["moments"][nm][0]), _rel(m2, ref["moments"][nm][1])
         worst = max(worst, e1, e2)
         assert e1 < 2e-5 and e2 < 4e-5, f"{nm}: moments differ from the single-rank run: {e1:.2e} / {e2:.2e}"
-    print(f"[fake world W={world} bsz={bsz} fuse={fuse} live={live}] worst moment rel err {worst:.2e}; "
+    print(f"[fake world W={world} bsz={bsz} fuse={fuse} live={live} group={group}] worst moment rel err {worst:.2e}; "
           f"{len(fw.log)} collectives", flush=True)
 
 
