@@ -258,11 +258,10 @@ def main():
             pr.disable()
             sio = io.StringIO()
             st = pstats.Stats(pr, stream=sio)
-            st.sort_stats("tottime").print_stats(30)
-            st.sort_stats("cumulative").print_stats("grendel-gs_amd|bench.py|fake_world", 60)
-            st.sort_stats("tottime").print_callers("contiguous|run_backward", 12)
+            st.sort_stats("tottime").print_stats(45)
+            st.sort_stats("cumulative").print_stats("grendel-gs_amd|bench.py|fake_world", 70)
             print(f"# host profile, W={W}: {a0.steps + a0.warmup + 8} steps (incl. priming / warmup)")
-            print(sio.getvalue()[:16000], flush=True)
+            print(sio.getvalue()[:24000], flush=True)
         kern = {k: v["avg_ms"] for k, v in res["kernels"].items()}
         results.append({"world": W, "rank": rank if W > 1 else 0, "ms_per_step": round(res["ms_per_step"], 4),
                         "gaussians_this_rank": res["gaussians_this_rank"], "kernel_ms": kern,
