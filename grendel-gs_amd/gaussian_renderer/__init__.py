@@ -348,6 +348,9 @@ class _ExchangeGroup(torch.autograd.Function):
     def forward(ctx, meta, bases, token, *views):
         (k0, nb, P, width, height, layout, send_splits, recv_splits, perm, inv_perm, group, chunkcnt, counts, cnt_B,
          bands, consumer_stream, holder) = meta
+        # (unused outputs -- radii, depths, the token -- arrive in backward as None, not as zero tensors the engine would
+        # fill first: two n_recv-sized fill launches per exchange otherwise)
+        ctx.set_materialize_grads(False)
         m2_all, rgb_all, co_all, radii_all, depths_all = bases
         dev = radii_all.device
         n_send, n_recv = sum(send_splits), sum(recv_splits)
@@ -374,6 +377,7 @@ class _ExchangeGroup(torch.autograd.Function):
             for t in bases:
                 t.record_stream(cur)
         ctx.meta = (k0, nb, P, cnt_B, send_splits, recv_splits, group, consumer_stream, holder)
+        ctx.fdt = msg.dtype  # the gradient message's type on EVERY rank, also one whose three gradients all are None
         ctx.save_for_backward(send_idx, inv_perm if inv_perm is not None else send_idx[:0])
         ctx.has_perm = inv_perm is not None
         r_radii = outs[3] if outs[3].dtype == torch.int32 else (
@@ -399,7 +403,7 @@ class _ExchangeGroup(torch.autograd.Function):
         n_recv, n_send = sum(recv_splits), sum(send_splits)
         dev = send_idx.device
         cur = torch.cuda.current_stream() if dev.type == "cuda" else None
-        fdt = next((g.dtype for g in (g_m2, g_rgb, g_co) if g is not None), torch.float32)  # fp32 (fp64 in CPU tests)
+        fdt = ctx.fdt  # fp32 (fp64 in the CPU tests)
         g_recv = None
         if not ctx.has_perm and all(g is not None and g.dtype == torch.float32 for g in (g_m2, g_rgb, g_co)):
             base = g_m2._base

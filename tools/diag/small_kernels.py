@@ -2,7 +2,7 @@
 a few eager iterations of the bench's step at the headline shape; prints every aten op that launched a device kernel,
 with device time per step and the innermost repo frames.
 
-    python tools/diag/small_kernels.py [n_gaussians] [steps]
+    python tools/diag/small_kernels.py [n_gaussians] [steps] [--exchange]
 """
 import os
 import sys
@@ -23,12 +23,23 @@ def main():
     from gaussian_renderer.workload_division import (DivisionStrategyHistoryFinal, finish_strategy_final,
                                                      start_strategy_final)
 
-    N = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
-    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+    argv = [x for x in sys.argv[1:] if not x.startswith("--")]
+    N = int(argv[0]) if len(argv) > 0 else 1_000_000
+    steps = int(argv[1]) if len(argv) > 1 else 4
+    forced = "--exchange" in sys.argv  # the exchange path too: every visible row "sent" to the rank itself over RCCL
     W, H = 1920, 1080
     dev = torch.device("cuda:0")
     utils.GLOBAL_RANK, utils.LOCAL_RANK, utils.WORLD_SIZE = 0, 0, 1
     utils.DEFAULT_GROUP = utils.IN_NODE_GROUP = utils.SingleGPUGroup()
+    if forced:
+        import torch.distributed as dist
+
+        import gaussian_renderer as gr
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        gr.set_exchange_forced(True)
     utils.set_args(utils.default_args(bsz=1))
     utils.set_img_size(H, W)
     utils.set_cur_iter(1)
@@ -72,7 +83,7 @@ def main():
         rows.append((dt / steps, e.count / steps, f"{e.key} {e.input_shapes}", frames))
     rows.sort(reverse=True)
     print(f"aten ops that launched device kernels, {N} Gaussians, per step over {steps} steps:")
-    for dt, cnt, key, frames in rows[:25]:
+    for dt, cnt, key, frames in rows[:40]:
         print(f"  {dt:8.1f} us  x{cnt:4.1f}  {key}")
         for f in frames:
             print(f"              {f.replace(ROOT + '/', '')}")
@@ -80,3 +91,5 @@ def main():
 
 if __name__ == "__main__":
     main()
+    sys.stdout.flush()
+    os._exit(0)  # (a process group that ran captured or forced collectives may hang in its destructor)
