@@ -8,11 +8,12 @@ const char *gsr_error_string(int code) {
     if (code == 0) return "success";
     if (code == GSR_EINVAL) return "gsraster: invalid argument";
     if (code == GSR_ENOSPACE) return "gsraster: workspace too small";
+    if (code == GSR_ERETRY) return "gsraster: pair count valid, bounded sort must be repeated";
     if (code > 0) return hipGetErrorString((hipError_t)code);
     return "gsraster: unknown error";
 }
 
-int gsr_abi_version(void) { return 10; }
+int gsr_abi_version(void) { return 11; }
 
 int gsr_get_block_xy(int *block_x, int *block_y, int *one_dim_block) {
     if (!block_x || !block_y || !one_dim_block) return GSR_EINVAL;

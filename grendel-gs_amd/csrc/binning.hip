@@ -34,6 +34,7 @@
 #include <mutex>
 
 #include "radix.h"
+#include "binning_persist.h"
 
 namespace {
 
@@ -518,6 +519,21 @@ PrepLayout prep_layout(int P, int W, int H) {
     L.total = o;
     return L;
 }
+// the persistent pipeline's control block shares the space of the look-back pipeline's (one of the two runs per call)
+int persist_grid_bound_p(int P) {
+    const long long nb = radix_blocks(P);
+    return (int)(nb < PERSIST_MAX_GRID_P ? (nb > 0 ? nb : 1) : PERSIST_MAX_GRID_P);
+}
+int persist_grid_bound_s(int64_t D) {
+    const long long nb = radix_blocks(D);
+    return (int)(nb < PERSIST_MAX_GRID_S ? (nb > 0 ? nb : 1) : PERSIST_MAX_GRID_S);
+}
+PrepLayout prep_layout_full(int P, int W, int H) {
+    PrepLayout L = prep_layout(P, W, H);
+    const size_t need = persist_layout_p(persist_grid_bound_p(P)).total;
+    if (need > L.C.total) L.total += need - L.C.total;
+    return L;
+}
 // Pinned, device-mapped result slots (64 per device, two words each): K4's last workgroup stores the pair count and
 // then the call's sequence tag; the host POLLS the tag (a few microseconds after the store lands) instead of paying a
 // stream synchronise (interrupt + wake-up, ~30-40 us measured) -- everything the host launches after this point is on
@@ -591,23 +607,36 @@ int tile_bits(int tiles) {  // bits of the largest key value, the sentinel `tile
 // ----------------------------------------------------------------------------------- K3..K7 API
 extern "C" size_t gsr_bin_prepare_bytes(int P, int width, int height) {
     if (P < 0 || width <= 0 || height <= 0) return 0;
-    return prep_layout(P, width, height).total;
+    return prep_layout_full(P, width, height).total;
 }
 
-extern "C" int gsr_bin_prepare_async(int P, int width, int height, const float *means2D, const float *depths,
-                                     const int32_t *radii, const float *conic_opacity, const uint8_t *compute_locally,
-                                     void *prep, size_t prep_bytes, uint32_t *ticket, gsr_stream_t stream_) {
-    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-    if (P < 0 || width <= 0 || height <= 0 || !ticket) return GSR_EINVAL;
-    *ticket = 0;  // 0: nothing was launched, the count is 0
-    if (P == 0) return 0;
-    if (!means2D || !depths || !radii || !conic_opacity || !compute_locally || !prep) return GSR_EINVAL;
-    if (P > RADIX_MAX_N) return GSR_EINVAL;
-    const PrepLayout L = prep_layout(P, width, height);
-    if (prep_bytes < L.total) return GSR_ENOSPACE;
-    const int gx = (width + GSR_BLOCK_X - 1) / GSR_BLOCK_X, gy = (height + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y;
-    if (gx > 0xFFFF || gy > 0xFFFF) return GSR_EINVAL;
-    char *base = reinterpret_cast<char *>(prep);
+namespace {
+// what a gsr_bin_prepare_async call was given: kept per count slot so that gsr_bin_count_wait can repeat the call on
+// the look-back pipeline when the persistent kernel gave up at its first barrier (binning_persist.h)
+struct PrepCall {
+    int P, width, height;
+    const float *means2D, *depths;
+    const int32_t *radii;
+    const float *conic_opacity;
+    const uint8_t *compute_locally;
+    void *prep;
+    hipStream_t stream;
+    bool persistent;
+};
+PrepCall g_prep_calls[64][TOTAL_SLOTS];
+
+int persist_effective_mode() {
+    const int o = g_persist_override.load(std::memory_order_relaxed);
+    return o >= 0 ? o : persist_mode();
+}
+
+// K3-K4 on the look-back pipeline: K3, four one-sweep passes, the offsets scan (six launches)
+int prepare_lookback(const PrepCall &c, uint32_t *ticket) {
+    const int P = c.P;
+    hipStream_t stream = c.stream;
+    const PrepLayout L = prep_layout(P, c.width, c.height);
+    const int gx = (c.width + GSR_BLOCK_X - 1) / GSR_BLOCK_X, gy = (c.height + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y;
+    char *base = reinterpret_cast<char *>(c.prep);
     uint32_t *tt = reinterpret_cast<uint32_t *>(base + L.tt);
     uint32_t *kA = reinterpret_cast<uint32_t *>(base + L.kA), *vA = reinterpret_cast<uint32_t *>(base + L.vA);
     uint32_t *kB = reinterpret_cast<uint32_t *>(base + L.kB), *vB = reinterpret_cast<uint32_t *>(base + L.vB);
@@ -621,8 +650,8 @@ extern "C" int gsr_bin_prepare_async(int P, int width, int height, const float *
     // persistent workgroups (mask hull + LDS tables are per-workgroup set-up)
     const int blocks = gsr_div_up(P, TC_THREADS) < TC_BLOCKS ? gsr_div_up(P, TC_THREADS) : TC_BLOCKS;
     hipLaunchKernelGGL(touch_count_kernel, dim3(blocks), dim3(TC_THREADS), 0, stream, P, gx, gy,
-                       reinterpret_cast<const float2 *>(means2D), depths, radii,
-                       reinterpret_cast<const float4 *>(conic_opacity), compute_locally, plan, tt, kA, vA, rects,
+                       reinterpret_cast<const float2 *>(c.means2D), c.depths, c.radii,
+                       reinterpret_cast<const float4 *>(c.conic_opacity), c.compute_locally, plan, tt, kA, vA, rects,
                        reinterpret_cast<uint32_t *>(ctrl + L.C.ghist), tile_hist,
                        reinterpret_cast<int32_t *>(base + L.hull));
     int in_first = 1;
@@ -637,7 +666,8 @@ extern "C" int gsr_bin_prepare_async(int P, int width, int height, const float *
     }
     if (g_tie_order.load(std::memory_order_relaxed) == 1)
         hipLaunchKernelGGL(depth_tie_fixup_kernel, dim3(gsr_div_up(P, GSR_ONE_DIM_BLOCK)), dim3(GSR_ONE_DIM_BLOCK), 0,
-                           stream, (long long)P, in_first ? kA : kB, sorted_ids, reinterpret_cast<const float2 *>(means2D));
+                           stream, (long long)P, in_first ? kA : kB, sorted_ids,
+                           reinterpret_cast<const float2 *>(c.means2D));
     const int nbs = gsr_div_up(P, SCAN_TILE);
     uint32_t *host_total = nullptr;
     uint32_t seq = 0;
@@ -648,6 +678,88 @@ extern "C" int gsr_bin_prepare_async(int P, int width, int height, const float *
                        reinterpret_cast<uint32_t *>(ctrl + L.C.tickets), nbs, host_total, seq);
     GSR_LAUNCH_CHECK();
     *ticket = seq;
+    return 0;
+}
+
+// K3-K4 as ONE persistent launch (binning_persist.h).  -> 0 launched, 1 not applicable here (use the look-back
+// pipeline), otherwise an error
+int prepare_persistent(const PrepCall &c, uint32_t *ticket) {
+    if (!(persist_effective_mode() & PERSIST_P) || g_tie_order.load(std::memory_order_relaxed) != 0) return 1;
+    int dev = 0;
+    GSR_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return 1;
+    PersistCaps caps;
+    persist_caps(dev, &caps);
+    const long long nb = radix_blocks(c.P);
+    const int G = (int)(nb < caps.grid_p ? nb : caps.grid_p);
+    if (G <= 0 || nb > (long long)G * PP_MAX_TPW) return 1;  // (long sorts are bandwidth-bound: look-back pipeline)
+    const long long admit = persist_admit(dev, c.stream);
+    if (admit < 0) return 1;
+    const int P = c.P;
+    const PrepLayout L = prep_layout(P, c.width, c.height);
+    const PersistLayoutP PL = persist_layout_p(G);
+    const int gx = (c.width + GSR_BLOCK_X - 1) / GSR_BLOCK_X, gy = (c.height + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y;
+    char *base = reinterpret_cast<char *>(c.prep);
+    char *ctrl = base + L.ctrl;
+    GSR_HIP(hipMemsetAsync(base + L.thist, 0, (L.ctrl - L.thist) + PL.zero_bytes, c.stream));
+    uint32_t *host_total = nullptr;
+    uint32_t seq = 0;
+    int rc = total_slot(&host_total, &seq);
+    if (rc) return rc;
+    PrepPersistArgs a{};
+    a.P = P; a.gx = gx; a.gy = gy;
+    a.means2D = reinterpret_cast<const float2 *>(c.means2D);
+    a.depths = c.depths;
+    a.radii = c.radii;
+    a.conic_opacity = reinterpret_cast<const float4 *>(c.conic_opacity);
+    a.mask = c.compute_locally;
+    a.tt = reinterpret_cast<uint32_t *>(base + L.tt);
+    a.kA = reinterpret_cast<uint32_t *>(base + L.kA); a.vA = reinterpret_cast<uint32_t *>(base + L.vA);
+    a.kB = reinterpret_cast<uint32_t *>(base + L.kB); a.vB = reinterpret_cast<uint32_t *>(base + L.vB);
+    a.offsets = reinterpret_cast<uint32_t *>(base + L.offsets);
+    a.rects = reinterpret_cast<uint2 *>(base + L.rects);
+    a.tile_hist = yx_path(gx, gy) ? reinterpret_cast<uint32_t *>(base + L.thist) : nullptr;
+    a.hull_out = reinterpret_cast<int32_t *>(base + L.hull);
+    const int ngroups = (G + GB_FAN - 1) / GB_FAN;
+    a.sync.leaf = reinterpret_cast<uint32_t *>(ctrl + PL.sync);
+    a.sync.root = a.sync.leaf + (size_t)ngroups * GB_LEAF_STRIDE;
+    a.grp = reinterpret_cast<uint32_t *>(ctrl + PL.grp);
+    a.cnt = reinterpret_cast<uint32_t *>(ctrl + PL.cnt);
+    a.wtot = reinterpret_cast<unsigned long long *>(ctrl + PL.wtot);
+    a.host_total = host_total;
+    a.seq = seq;
+    a.done_word = g_persist_done[dev];
+    a.done_seq = (uint32_t)admit;
+    a.timeout_ticks = 5000000ull;  // 50 ms of the 100 MHz clock at the first barrier
+    hipLaunchKernelGGL(bin_prepare_persist_kernel, dim3(G), dim3(PP_THREADS), 0, c.stream, a);
+    GSR_LAUNCH_CHECK();
+    *ticket = seq;
+    return 0;
+}
+}  // namespace
+
+extern "C" int gsr_bin_prepare_async(int P, int width, int height, const float *means2D, const float *depths,
+                                     const int32_t *radii, const float *conic_opacity, const uint8_t *compute_locally,
+                                     void *prep, size_t prep_bytes, uint32_t *ticket, gsr_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (P < 0 || width <= 0 || height <= 0 || !ticket) return GSR_EINVAL;
+    *ticket = 0;  // 0: nothing was launched, the count is 0
+    if (P == 0) return 0;
+    if (!means2D || !depths || !radii || !conic_opacity || !compute_locally || !prep) return GSR_EINVAL;
+    if (P > RADIX_MAX_N) return GSR_EINVAL;
+    if (prep_bytes < prep_layout_full(P, width, height).total) return GSR_ENOSPACE;
+    const int gx = (width + GSR_BLOCK_X - 1) / GSR_BLOCK_X, gy = (height + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y;
+    if (gx > 0xFFFF || gy > 0xFFFF) return GSR_EINVAL;
+    PrepCall c{P, width, height, means2D, depths, radii, conic_opacity, compute_locally, prep, stream, true};
+    int rc = prepare_persistent(c, ticket);
+    if (rc == 1) {
+        c.persistent = false;
+        rc = prepare_lookback(c, ticket);
+    }
+    if (rc) return rc;
+    int dev = 0;
+    GSR_HIP(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64) g_prep_calls[dev][*ticket % TOTAL_SLOTS] = c;
     return 0;
 }
 
@@ -667,7 +779,33 @@ extern "C" int gsr_bin_count_wait(uint32_t ticket, int64_t *num_rendered_host, g
     uint32_t total = 0;
     rc = wait_total(reinterpret_cast<hipStream_t>(stream_), host_total, ticket, &total);
     if (rc) return rc;
+    if (total == PAIRS_ABORTED) {
+        // the persistent kernel gave up at its first barrier (the device is shared with another barrier kernel): the
+        // same call again on the look-back pipeline.  A gsr_bin_sort_bounded launched meanwhile has written nothing
+        // (it saw a count above any capacity): GSR_ERETRY tells the caller to sort again
+        int dev = 0;
+        GSR_HIP(hipGetDevice(&dev));
+        if (dev < 0 || dev >= 64) return GSR_EINVAL;
+        PrepCall c = g_prep_calls[dev][ticket % TOTAL_SLOTS];
+        if (!c.persistent) return GSR_EINVAL;
+        c.persistent = false;
+        uint32_t again = 0;
+        rc = prepare_lookback(c, &again);
+        if (rc) return rc;
+        rc = slot_of_ticket(again, &host_total);
+        if (rc) return rc;
+        rc = wait_total(c.stream, host_total, again, &total);
+        if (rc) return rc;
+        *num_rendered_host = (int64_t)total;
+        return GSR_ERETRY;
+    }
     *num_rendered_host = (int64_t)total;
+    return 0;
+}
+
+extern "C" int gsr_set_bin_persistent(int mode) {
+    if (mode < -1 || mode > 3) return GSR_EINVAL;
+    g_persist_override.store(mode, std::memory_order_relaxed);
     return 0;
 }
 
@@ -680,7 +818,10 @@ extern "C" int gsr_bin_prepare(int P, int width, int height, const float *means2
     const int rc = gsr_bin_prepare_async(P, width, height, means2D, depths, radii, conic_opacity, compute_locally, prep,
                                          prep_bytes, &ticket, stream_);
     if (rc) return rc;
-    return gsr_bin_count_wait(ticket, num_rendered_host, stream_);
+    {
+        const int rw = gsr_bin_count_wait(ticket, num_rendered_host, stream_);
+        return rw == GSR_ERETRY ? 0 : rw;  // (no sort has been launched for this count yet)
+    }
 }
 
 namespace {
@@ -698,7 +839,8 @@ SortLayout sort_layout(int64_t D, int passes) {
     L.vB = o; o += nd;
     L.ctrl = o;
     L.C = ctrl_layout(D, passes, false);
-    o += L.C.total;
+    const size_t need = persist_layout_s(persist_grid_bound_s(D)).total;  // (either pipeline's control block)
+    o += L.C.total > need ? L.C.total : need;
     L.total = o;
     return L;
 }
@@ -737,8 +879,42 @@ int bin_sort_impl(int P, int width, int height, const uint8_t *compute_locally, 
     uint32_t *kB = reinterpret_cast<uint32_t *>(sbase + S.kB), *vB = reinterpret_cast<uint32_t *>(sbase + S.vB);
     char *ctrl = sbase + S.ctrl;
 
-    GSR_HIP(hipMemsetAsync(ctrl, 0, S.C.total, stream));
     if (bounded && !yx_path(gx, gy)) return GSR_EINVAL;
+    if (yx_path(gx, gy) && (persist_effective_mode() & PERSIST_S)) {
+        // K5-K7 as ONE persistent launch (binning_persist.h) when the device can hold the grid and no barrier kernel of
+        // another stream may still be waiting
+        int dev = 0;
+        GSR_HIP(hipGetDevice(&dev));
+        PersistCaps caps;
+        if (dev >= 0 && dev < 64) persist_caps(dev, &caps);
+        const long long nbD = radix_blocks(D);
+        const int G = (int)(nbD < caps.grid_s ? nbD : caps.grid_s);
+        const long long admit = G > 0 ? persist_admit(dev, stream) : -1;
+        if (admit >= 0) {
+            const PersistLayoutS PS = persist_layout_s(G);
+            GSR_HIP(hipMemsetAsync(ctrl, 0, PS.zero_bytes, stream));
+            SortPersistArgs a{};
+            a.P = P; a.gx = gx; a.xbits = bits_for(gx); a.ybits = bits_for(gy);
+            a.D = D; a.bounded = bounded ? 1 : 0;
+            a.rects = rects; a.sorted_ids = sorted_ids; a.offsets = offsets; a.mask = compute_locally;
+            a.kA = kA; a.kB = kB; a.vB = vB; a.point_list = point_list;
+            a.ranges = ranges; a.ranges_words = 2 * gx * gy;
+            a.hull = reinterpret_cast<const int32_t *>(pbase + L.hull);
+            const int ngroups = (G + GB_FAN - 1) / GB_FAN;
+            a.sync.leaf = reinterpret_cast<uint32_t *>(ctrl + PS.sync);
+            a.sync.root = a.sync.leaf + (size_t)ngroups * GB_LEAF_STRIDE;
+            a.grp = reinterpret_cast<uint32_t *>(ctrl + PS.grp);
+            a.cnt = reinterpret_cast<uint32_t *>(ctrl + PS.cnt);
+            a.done_word = g_persist_done[dev];
+            a.done_seq = (uint32_t)admit;
+            a.timeout_ticks = 200000000ull;  // two seconds at the first barrier, then a trap
+            a.owners_cap = env_cap("GSR_BIN_OWNERS", PS_OWNERS);
+            hipLaunchKernelGGL(bin_sort_persist_kernel, dim3(G), dim3(PS_THREADS), 0, stream, a);
+            GSR_LAUNCH_CHECK();
+            return 0;
+        }
+    }
+    GSR_HIP(hipMemsetAsync(ctrl, 0, S.C.total, stream));
     if (yx_path(gx, gy)) {
         const int xbits = bits_for(gx), ybits = bits_for(gy);
         const uint32_t *thist = reinterpret_cast<const uint32_t *>(pbase + L.thist);

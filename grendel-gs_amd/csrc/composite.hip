@@ -186,10 +186,12 @@ __device__ __forceinline__ RawEntry load_raw(bool have, uint32_t id, const float
 #endif
 constexpr int SEG_LEN = GSR_SEG_LEN;    // list entries per segment (a multiple of the 64-entry chunk)
 constexpr int SEG_MAXJ = GSR_SEG_MAXJ;  // boundaries per tile that can carry a checkpoint (<= 31; a list walked deeper keeps a long tail)
-static_assert(SEG_LEN % 64 == 0 && SEG_MAXJ <= 31, "segment geometry");
+static_assert(SEG_LEN % 64 == 0 && (SEG_LEN & (SEG_LEN - 1)) == 0 && SEG_MAXJ <= 31,
+              "segment geometry: K8 finds boundaries with c & (SEG_LEN - 1), so SEG_LEN is a power of two");
 constexpr int SEG_WORKERS = 1024;
 struct SegWs {
-    uint32_t *hdr;      // [0] segments queued by K8 (may exceed cap: only the first cap exist), [1] K10's ticket
+    uint32_t *hdr;      // [0] segments queued by K8 (may exceed cap: only the first cap exist), [1] K10's ticket,
+                        // [2] workers of the running K10 that have drawn their last ticket
     uint32_t *queue;    // [cap]: tile * 32 + segment index (>= 1)
     int32_t *seg_slot;  // [tiles][SEG_MAXJ]: checkpoint slot of the boundary at entry (j + 1) * SEG_LEN, -1: none
     float *ckpt;        // [cap][4][256]: T, C.r, C.g, C.b of the tile's 256 pixels (quadrant-major: wave * 64 + lane)
@@ -753,7 +755,16 @@ composite_backward_kernel(int W, int H, int gx, int tiles, const int2 *__restric
             if (threadIdx.x == 0) s_item = atomicAdd(&seg.hdr[1], 1u);
             __syncthreads();
             const uint32_t t = s_item;
-            if (t >= count) return;
+            if (t >= count) {
+                // every worker draws exactly one ticket past the end; the last of them rearms the ticket, so that a second
+                // backward over the same forward (retain_graph, gradcheck) walks the queued segments again
+                if (threadIdx.x == 0 && atomicAdd(&seg.hdr[2], 1u) == SEG_WORKERS - 1) {
+                    seg.hdr[2] = 0u;
+                    __threadfence();
+                    atomicExch(&seg.hdr[1], 0u);
+                }
+                return;
+            }
             const uint32_t item = seg.queue[t];
             tile = (int)(item >> 5);
             sidx = (int)(item & 31u);

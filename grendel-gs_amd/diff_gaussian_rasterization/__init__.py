@@ -672,6 +672,17 @@ def set_speculative_sort(on):
     _SPECULATIVE_SORT[0] = bool(on)
 
 
+GSR_ERETRY = -3
+
+
+def set_bin_persistent(mode):
+    """K3-K7 as two persistent launches with grid-wide barriers (default) or as the nine launches of the look-back
+    pipeline: "env" (GSR_BIN_PERSIST, default on), False / "off", "prepare", "sort", True / "both"
+    (include/gsraster.h: gsr_set_bin_persistent).  Lists are bit-identical either way."""
+    code = {"env": -1, False: 0, "off": 0, "prepare": 1, "sort": 2, True: 3, "both": 3}[mode]
+    check(lib.gsr_set_bin_persistent(code), "gsr_set_bin_persistent")
+
+
 def set_tie_order(order):
     """order of Gaussians with EXACTLY equal depth inside a tile list: "arrival" (default; the reference: index in the
     arrays the op is given, i.e. (source rank, index on the source) at world size > 1) or "position" (means2D.x, .y,
@@ -806,7 +817,14 @@ def bin_gaussians(means2D, depths, radii, conic_opacity, compute_locally, width,
                                                kept.numel(), _ptr(point_list), _ptr(ranges), stream),
                       "gsr_bin_sort_bounded")
     D = ctypes.c_int64(0)
-    check(lib.gsr_bin_count_wait(ticket, ctypes.byref(D), stream), "gsr_bin_count_wait")
+    rc = lib.gsr_bin_count_wait(ticket, ctypes.byref(D), stream)
+    if rc == GSR_ERETRY:
+        # the persistent prepare kernel shared the device with another barrier kernel and repeated itself on the
+        # look-back pipeline (include/gsraster.h: gsr_set_bin_persistent): the count is valid, the speculative sort
+        # launched above wrote nothing
+        cap = 0
+    else:
+        check(rc, "gsr_bin_count_wait")
     D = int(D.value)
     if D > _MAX_PAIRS.get(key, 0):
         _MAX_PAIRS[key] = D
@@ -883,7 +901,7 @@ class _RenderGaussians(torch.autograd.Function):
                                                  _ptr(conic_opacity), _ptr(rgb), _ptr(mask), _ptr(bg), _ptr(out),
                                                  _ptr(final_T), _ptr(n_contrib), _ptr(seg_ws), seg_bytes, row_lo, row_hi,
                                                  _stream()), "gsr_render_forward_seg")
-            ctx.seg = (seg_ws, seg_bytes, out if seg_ws is not None else None, row_lo, row_hi)
+            ctx.seg = (seg_ws, seg_bytes, row_lo, row_hi)
             if timing != "off":
                 ev1.record()
                 ctx.fwd_events = (ev0, ev1)
@@ -897,7 +915,11 @@ class _RenderGaussians(torch.autograd.Function):
         ctx.timing = timing
         ctx.num_rendered = D
         _RenderGaussians.last_num_rendered = D
-        ctx.save_for_backward(means2D, conic_opacity, rgb, mask, bg, point_list, ranges, final_T, n_contrib)
+        # the image itself is an input of the segmented backward (the colour behind a boundary is reconstructed from it):
+        # saved through autograd, so that an in-place edit of the output raises instead of corrupting gradients, and
+        # no ctx -> output -> grad_fn cycle keeps the buffers alive until the cyclic collector runs
+        ctx.save_for_backward(means2D, conic_opacity, rgb, mask, bg, point_list, ranges, final_T, n_contrib,
+                              out if seg_ws is not None else None)
         ctx.mark_non_differentiable(n_contrib)
         return out, n_contrib
 
@@ -905,7 +927,7 @@ class _RenderGaussians(torch.autograd.Function):
     def backward(ctx, g_out, _g_ncontrib):
         global _last_backward_ms
         rs = ctx.raster_settings
-        means2D, conic_opacity, rgb, mask, bg, point_list, ranges, final_T, n_contrib = ctx.saved_tensors
+        means2D, conic_opacity, rgb, mask, bg, point_list, ranges, final_T, n_contrib, out_img = ctx.saved_tensors
         H, W = int(rs.image_height), int(rs.image_width)
         P = means2D.shape[0]
         dev = means2D.device
@@ -924,7 +946,7 @@ class _RenderGaussians(torch.autograd.Function):
                 ev0.record()
             with kernel_timer.range("composite_backward", P=P, D=ctx.num_rendered, **ctx.px_meta), \
                     zhx_range(ctx.cuda_args, "b10 render time"):
-                seg_ws, seg_bytes, out_img, row_lo, row_hi = ctx.seg
+                seg_ws, seg_bytes, row_lo, row_hi = ctx.seg
                 check(lib.gsr_render_backward_seg(P, W, H, _ptr(ranges), _ptr(point_list), _ptr(means2D),
                                                   _ptr(conic_opacity), _ptr(rgb), _ptr(mask), _ptr(bg), _ptr(final_T),
                                                   _ptr(n_contrib), _ptr(g_out), _ptr(record), _ptr(out_img),

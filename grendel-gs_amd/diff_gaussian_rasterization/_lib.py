@@ -82,6 +82,7 @@ SIGNATURES = {
                                                      [c_void_p] * 5 + [c_int, c_int] + [c_void_p] * 6 + [c_int] +
                                                      [c_void_p] * 7 + [c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gsr_bin_total_offset": (c_size_t, [c_int, c_int, c_int]),
+    "gsr_set_bin_persistent": (c_int, [c_int]),
     "gsr_flag_if_greater": (c_int, [c_void_p, ctypes.c_uint32, c_void_p, ctypes.c_uint32, c_void_p, c_void_p]),
     "gsr_render_seg_bytes": (c_size_t, [c_int, c_int]),
     "gsr_render_forward_seg": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -97,7 +98,7 @@ SIGNATURES = {
     "gsr_render_backward": (c_int, [c_int, c_int, c_int] + [c_void_p] * 12),
 }
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 def _load():

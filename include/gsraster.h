@@ -35,6 +35,7 @@ extern "C" {
 
 #define GSR_EINVAL (-1)   /* bad argument (negative size, null pointer, sh_degree > 3, ...) */
 #define GSR_ENOSPACE (-2) /* caller-provided workspace too small */
+#define GSR_ERETRY (-3)   /* gsr_bin_count_wait: the count is valid, but a gsr_bin_sort_bounded launched for it wrote nothing */
 
 typedef void *gsr_stream_t;
 
@@ -137,6 +138,16 @@ int gsr_bin_prepare_async(int P, int width, int height, const float *means2D, co
                           uint32_t *ticket, gsr_stream_t stream);
 int gsr_bin_count_wait(uint32_t ticket, int64_t *num_rendered_host, gsr_stream_t stream);
 int64_t gsr_bin_sort_capacity(int P, size_t scratch_bytes, int width, int height);
+/* K3-K7 run as TWO persistent launches whose workgroups meet at grid-wide barriers (ABI 11; csrc/binning_persist.h)
+ * instead of the nine launches of the look-back pipeline, when the device can hold the grid at once, the frame has
+ * <= 256 x 256 tiles and P <= 8 x 4096 x CUs.  Lists, ranges and offsets are bit-identical.  A barrier kernel needs
+ * its whole grid resident: the library never has two of them in flight on different streams of one process (the second
+ * call takes the look-back pipeline); a device shared with ANOTHER PROCESS's barrier kernel is covered by a time-out at
+ * the first barrier -- the prepare step then repeats itself on the look-back pipeline inside gsr_bin_count_wait, which
+ * returns GSR_ERETRY (the count is valid; a gsr_bin_sort_bounded already launched for it wrote nothing: call
+ * gsr_bin_sort); the sort step traps after two seconds.  mode: -1 the environment's GSR_BIN_PERSIST (0 | 1 | p | s,
+ * default 1), 0 off, 1 prepare only, 2 sort only, 3 both. */
+int gsr_set_bin_persistent(int mode);
 /* Byte offset, inside the prep workspace of gsr_bin_prepare*, of the uint32 pair count D that K4 leaves on the DEVICE
  * (what gsr_bin_sort_bounded's kernels read).  For callers that capture the iteration in a hipGraph and therefore
  * cannot take D through gsr_bin_count_wait inside a replay: they copy the word out / test it with

@@ -154,6 +154,62 @@ def test_speculative_sort_equals_the_sized_sort(device):
         dgr.release_workspaces()
 
 
+@pytest.mark.parametrize("grid_p,grid_s,owners", [(None, None, None), (1, 3, None), (2, 5, 1), (3, 64, 2)])
+def test_persistent_binning_equals_the_lookback_pipeline(device, monkeypatch, grid_p, grid_s, owners):
+    """K3-K7 as two persistent launches with grid barriers (csrc/binning_persist.h) against the nine launches of the
+    look-back pipeline: bit-identical lists and ranges -- with one tile per workgroup and (grids capped through the
+    test hooks) many tiles per workgroup, with the chunk-owner table and with the per-chunk search, through the sized
+    and the speculative (bounded) sort, with an empty view; each half of the pipeline also combined with the other
+    pipeline's half"""
+    import diff_gaussian_rasterization as dgr
+    from oracle import cref as C
+
+    for name, v in (("GSR_BIN_GRID_P", grid_p), ("GSR_BIN_GRID_S", grid_s), ("GSR_BIN_OWNERS", owners)):
+        if v is not None:
+            monkeypatch.setenv(name, str(v))
+    W, H = 333, 211
+    cam = S.orbit_cameras(4, W, H)[1]
+
+    def inputs(N, sc, seed, band=None):
+        g = S.make_gaussians(N, W, H, seed=seed, scale_coef=sc)
+        m2, rgb, co, radii, depths, _, _ = C.preprocess_forward(*[g[k] for k in KEYS], **cam_kwargs(cam))
+        mask = _full_mask(cam)
+        if band is None:
+            mask[2, :] = False
+            mask[-1, ::2] = False
+        else:
+            mask[:band[0], :] = False
+            mask[band[1]:, :] = False
+        return [t.to(device) for t in (m2, depths, radii, co, mask.view(-1).to(torch.uint8))]
+
+    views = {"small": inputs(3000, 0.02, 5), "large": inputs(9000, 0.03, 6), "larger": inputs(20000, 0.06, 7),
+             "band": inputs(9000, 0.05, 8, band=(4, 9))}
+    views["empty"] = [t.clone() for t in views["small"]]
+    views["empty"][2].zero_()
+    order = ("large", "large", "small", "larger", "empty", "band", "large", "larger")
+    got = {}
+    try:
+        for mode in ("off", "both", "prepare", "sort"):
+            dgr.set_bin_persistent(mode)
+            for spec in (False, True):
+                dgr.release_workspaces()
+                dgr.set_speculative_sort(spec)
+                for i, name in enumerate(order):
+                    pl, rg, D = dgr.bin_gaussians(*views[name], W, H)
+                    got[(mode, spec, i)] = (pl.clone(), rg.clone(), D)
+    finally:
+        dgr.set_bin_persistent("env")
+        dgr.set_speculative_sort(True)
+        dgr.release_workspaces()
+    assert got[("off", False, 3)][2] > got[("off", False, 0)][2] > got[("off", False, 2)][2] > 0
+    for (mode, spec, i), (pl, rg, D) in got.items():
+        rpl, rrg, rD = got[("off", False, i)]
+        assert D == rD, (mode, spec, order[i])
+        assert torch.equal(rg, rrg), (mode, spec, order[i])
+        if D:
+            assert pl.numel() == D and torch.equal(pl, rpl), (mode, spec, order[i])
+
+
 @pytest.mark.parametrize("N,W,H,sc,seed,ci", SCENES)
 @pytest.mark.parametrize("bgv,sh_degree", [(0.0, 3), (0.7, 3), (0.0, 0), (0.7, 1), (0.0, 2)])
 def test_full_chain_matches_c_oracle(device, N, W, H, sc, seed, ci, bgv, sh_degree):

@@ -19,7 +19,9 @@ from diff_gaussian_rasterization import _lib  # noqa: E402
 
 def load(path):
     lib = ctypes.CDLL(path)
-    for name in ("gsr_bin_prepare_bytes", "gsr_bin_prepare", "gsr_bin_sort_bytes", "gsr_bin_sort"):
+    for name in ("gsr_bin_prepare_bytes", "gsr_bin_prepare", "gsr_bin_sort_bytes", "gsr_bin_sort", "gsr_set_bin_persistent"):
+        if name == "gsr_set_bin_persistent" and not hasattr(lib, name):
+            continue  # (a library built before ABI 11)
         res, args = _lib.SIGNATURES[name]
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
@@ -34,6 +36,10 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--view", type=int, default=0)
+    ap.add_argument("--band", type=int, nargs=2, default=None, metavar=("ROW_LO", "ROW_HI"),
+                    help="tile rows computed locally (default: the whole frame)")
+    ap.add_argument("--modes", nargs="*", default=["off", "prepare", "sort", "both"],
+                    help="gsr_set_bin_persistent modes to time on the production library (lists compared bitwise)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     W, H = a.width, a.height
@@ -48,11 +54,18 @@ def main():
     P = m2.shape[0]
     gx, gy = (W + 15) // 16, (H + 15) // 16
     mask = torch.ones(gy, gx, dtype=torch.bool, device=dev)
+    if a.band:
+        mask[:a.band[0]] = False
+        mask[a.band[1]:] = False
     ptr = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    libs = [("production", _lib.LIB_PATH)] + [(os.path.basename(p), p) for p in a.lib]
-    for name, path in libs:
+    codes = {"off": 0, "prepare": 1, "sort": 2, "both": 3}
+    libs = [(f"production[{m}]", _lib.LIB_PATH, codes[m]) for m in a.modes] + [(os.path.basename(p), p, None) for p in a.lib]
+    ref_lists = None
+    for name, path, mode in libs:
         lib = load(path)
+        if mode is not None:
+            assert lib.gsr_set_bin_persistent(mode) == 0
         ranges = torch.empty((gx * gy + 1, 2), dtype=torch.int32, device=dev)
         nb = lib.gsr_bin_prepare_bytes(P, W, H)
         prep = torch.zeros(nb, dtype=torch.uint8, device=dev)  # (zeros: timing probes with wrong lists must still read valid indices)
@@ -77,6 +90,13 @@ def main():
             if it >= 3:
                 t_prep += ev[0].elapsed_time(ev[1])
                 t_sort += ev[1].elapsed_time(ev[2])
+        if mode is not None:
+            cur = (plist[:D.value].clone(), ranges.clone())
+            if ref_lists is None:
+                ref_lists = cur
+            else:
+                same = torch.equal(cur[0], ref_lists[0]) and torch.equal(cur[1], ref_lists[1])
+                name += " lists==" + ("ok" if same else "DIFFER")
         print(f"{name:40s} D={D.value:9d} prepare {t_prep / a.iters * 1e3:7.1f} us   sort {t_sort / a.iters * 1e3:7.1f} us"
               f"   total {(t_prep + t_sort) / a.iters * 1e3:7.1f} us", flush=True)
 
