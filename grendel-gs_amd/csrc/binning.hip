@@ -723,6 +723,8 @@ int prepare_persistent(const PrepCall &c, uint32_t *ticket) {
     const int ngroups = (G + GB_FAN - 1) / GB_FAN;
     a.sync.leaf = reinterpret_cast<uint32_t *>(ctrl + PL.sync);
     a.sync.root = a.sync.leaf + (size_t)ngroups * GB_LEAF_STRIDE;
+    a.sync.flags = a.sync.root + GB_LEAF_STRIDE;
+    a.tstamp = timeline_buffer(0, G);
     a.grp = reinterpret_cast<uint32_t *>(ctrl + PL.grp);
     a.cnt = reinterpret_cast<uint32_t *>(ctrl + PL.cnt);
     a.wtot = reinterpret_cast<unsigned long long *>(ctrl + PL.wtot);
@@ -731,6 +733,7 @@ int prepare_persistent(const PrepCall &c, uint32_t *ticket) {
     a.done_word = g_persist_done[dev];
     a.done_seq = (uint32_t)admit;
     a.timeout_ticks = 5000000ull;  // 50 ms of the 100 MHz clock at the first barrier
+    a.notrap = env_cap("GSR_BIN_NOTRAP", 2) == 1;
     hipLaunchKernelGGL(bin_prepare_persist_kernel, dim3(G), dim3(PP_THREADS), 0, c.stream, a);
     GSR_LAUNCH_CHECK();
     *ticket = seq;
@@ -800,6 +803,28 @@ extern "C" int gsr_bin_count_wait(uint32_t ticket, int64_t *num_rendered_host, g
         return GSR_ERETRY;
     }
     *num_rendered_host = (int64_t)total;
+    return 0;
+}
+
+extern "C" int gsr_bin_timeline(int which, unsigned long long *out, int max_words, int *grid) {
+    if (which < 0 || which > 1 || !out || !grid || max_words < 0) return GSR_EINVAL;
+    *grid = g_timeline_grid[which];
+    if (!g_timeline[which]) return 0;
+    const size_t n = (size_t)g_timeline_grid[which] * 32;
+    GSR_HIP(hipDeviceSynchronize());
+    GSR_HIP(hipMemcpy(out, g_timeline[which], sizeof(unsigned long long) * (n < (size_t)max_words ? n : (size_t)max_words),
+                      hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int gsr_bin_persist_status(uint32_t *out3) {
+    if (!out3) return GSR_EINVAL;
+    int dev = 0;
+    GSR_HIP(hipGetDevice(&dev));
+    out3[0] = out3[1] = out3[2] = 0;
+    if (dev < 0 || dev >= 64 || !g_persist_done[dev]) return 0;
+    const volatile uint32_t *w = g_persist_done[dev];
+    out3[0] = w[0]; out3[1] = w[1]; out3[2] = w[2];
     return 0;
 }
 
@@ -889,7 +914,11 @@ int bin_sort_impl(int P, int width, int height, const uint8_t *compute_locally, 
         if (dev >= 0 && dev < 64) persist_caps(dev, &caps);
         const long long nbD = radix_blocks(D);
         const int G = (int)(nbD < caps.grid_s ? nbD : caps.grid_s);
-        const long long admit = G > 0 ? persist_admit(dev, stream) : -1;
+        // long sorts are throughput-bound (VALU: the ranking) and the look-back pipeline, which reads every pair once
+        // less, wins: measured cross-over between 2 and 14 million pairs (profiles/r05_binning_persistent.txt)
+        const long long max_pairs = env_cap("GSR_BIN_PERSIST_MAXD", 0x7fffffff) == 0x7fffffff ? PERSIST_SORT_MAX_PAIRS
+                                                                                        : env_cap("GSR_BIN_PERSIST_MAXD", 0x7fffffff);
+        const long long admit = (G > 0 && D <= max_pairs) ? persist_admit(dev, stream) : -1;
         if (admit >= 0) {
             const PersistLayoutS PS = persist_layout_s(G);
             GSR_HIP(hipMemsetAsync(ctrl, 0, PS.zero_bytes, stream));
@@ -903,12 +932,15 @@ int bin_sort_impl(int P, int width, int height, const uint8_t *compute_locally, 
             const int ngroups = (G + GB_FAN - 1) / GB_FAN;
             a.sync.leaf = reinterpret_cast<uint32_t *>(ctrl + PS.sync);
             a.sync.root = a.sync.leaf + (size_t)ngroups * GB_LEAF_STRIDE;
+            a.sync.flags = a.sync.root + GB_LEAF_STRIDE;
+            a.tstamp = timeline_buffer(1, G);
             a.grp = reinterpret_cast<uint32_t *>(ctrl + PS.grp);
             a.cnt = reinterpret_cast<uint32_t *>(ctrl + PS.cnt);
             a.done_word = g_persist_done[dev];
             a.done_seq = (uint32_t)admit;
             a.timeout_ticks = 200000000ull;  // two seconds at the first barrier, then a trap
             a.owners_cap = env_cap("GSR_BIN_OWNERS", PS_OWNERS);
+            a.notrap = env_cap("GSR_BIN_NOTRAP", 2) == 1;
             hipLaunchKernelGGL(bin_sort_persist_kernel, dim3(G), dim3(PS_THREADS), 0, stream, a);
             GSR_LAUNCH_CHECK();
             return 0;

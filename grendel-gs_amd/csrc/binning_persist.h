@@ -17,6 +17,14 @@
 //           owner Gaussian of every 512-slot chunk (so the emission never searches)
 //       E1  decode + scatter by column;  R0 count rows;  R1 scatter by row -> point_list;  T  tile ranges
 //
+// Coherence without fences (tools/probes/grid_barrier_probe.hip, profiles/r05_grid_barrier_probe.txt): the eight XCDs'
+// L2s are not coherent with each other, and an agent-scope fence pair per barrier (L2 write-back + invalidate) costs
+// 9-28 us on this chip -- more than the launches it replaces.  Instead every word that one workgroup writes and ANOTHER
+// reads inside the same launch (sort keys / values, digit counts, tile counts) is written through and read at agent
+// scope (global_store / global_load sc1: st_agent / ld_agent): the barrier then only needs the stores to be
+// acknowledged (the workgroup barrier's s_waitcnt) before the arrival atomic -- 2-4 us.  Data that only the NEXT kernel
+// reads (rects, offsets, point_list) uses plain stores.
+//
 // Order of the lists: identical to the look-back pipeline (stable LSD passes over the same keys) -- bit-identical
 // point_list / ranges / offsets (tests/test_gpu_parity.py::test_persistent_binning_equals_the_lookback_pipeline).
 //
@@ -37,15 +45,19 @@ constexpr int GB_LEAF_STRIDE = 32;  // words between leaf counters (128 bytes: o
 constexpr uint32_t PAIRS_ABORTED = 0xFFFFFFFFu;  // "pair count" of a prepare kernel that gave up at its first barrier
 
 struct GridSync {
-    uint32_t *leaf;  // [ceil(G / GB_FAN) * GB_LEAF_STRIDE], zero before the launch
-    uint32_t *root;  // arrived groups (monotone over the kernel's barriers); bit 31: aborted
+    uint32_t *leaf;   // [ngroups * GB_LEAF_STRIDE], zero before the launch: arrivals per group of GB_FAN workgroups
+    uint32_t *root;   // arrived groups (monotone over the kernel's barriers); bit 31: aborted
+    uint32_t *flags;  // [ngroups * GB_LEAF_STRIDE]: the epoch the group may leave (written by whoever completes the root)
 };
+// words of the three arrays for a grid of G workgroups
+__host__ __device__ inline size_t grid_sync_words(int G) {
+    return (size_t)(2 * ((G + GB_FAN - 1) / GB_FAN) + 1) * GB_LEAF_STRIDE;
+}
 
 // Barrier over the G workgroups of the grid; `epoch` counts this workgroup's barriers (uniform over the grid).  Returns
 // false when the kernel was aborted (a time-out at some workgroup's barrier): the caller leaves at once.
-// Release: every thread's global writes precede the workgroup barrier, thread 0's agent-scope fence writes the XCD's
-// L2 back before its arrival becomes visible.  Acquire: thread 0's fence after the spin invalidates the CU's / XCD's
-// cached copies before the workgroup barrier lets the other threads read what other XCDs wrote.
+// No fences: what crosses workgroups is written through and read at agent scope (see the head of this file); the
+// workgroup barrier in front of the arrival waits for every wave's outstanding stores (s_waitcnt vmcnt(0)).
 __device__ __forceinline__ bool grid_barrier(const GridSync gs, uint32_t G, uint32_t &epoch, uint64_t timeout_ticks,
                                              uint32_t *s_flag) {
     __syncthreads();
@@ -53,48 +65,152 @@ __device__ __forceinline__ bool grid_barrier(const GridSync gs, uint32_t G, uint
         epoch++;
         const uint32_t g = blockIdx.x / GB_FAN, ngroups = (G + GB_FAN - 1) / GB_FAN;
         const uint32_t gsz = min((uint32_t)GB_FAN, G - g * GB_FAN);
-        __threadfence();
         const uint32_t old =
             __hip_atomic_fetch_add(&gs.leaf[g * GB_LEAF_STRIDE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old + 1u == epoch * gsz)
-            __hip_atomic_fetch_add(gs.root, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t target = epoch * ngroups;
+        if (old + 1u == epoch * gsz) {
+            const uint32_t r = __hip_atomic_fetch_add(gs.root, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((r & ~GB_ABORT) + 1u == epoch * ngroups)  // the grid is complete: let every group go (G pollers on the
+                for (uint32_t k = 0; k < ngroups; k++)     // root cost 7.7 us at G = 1024, a flag per group 2.6 us)
+                    st_agent(&gs.flags[k * GB_LEAF_STRIDE], (r & GB_ABORT) ? 0xFFFFFFFFu : epoch);
+        }
         const uint64_t t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
-        uint32_t v;
-        while ((((v = ld_agent(gs.root)) & ~GB_ABORT) < target) && !(v & GB_ABORT)) {
+        uint32_t aborted = 0, f;
+        while ((f = ld_agent(&gs.flags[g * GB_LEAF_STRIDE])) < epoch) {
             __builtin_amdgcn_s_sleep(1);
             if (__builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) {
-                v = __hip_atomic_fetch_or(gs.root, GB_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | GB_ABORT;
+                // give up: raise the abort bit of the root and of every flag (a flag at 0xFFFFFFFF lets everybody leave)
+                __hip_atomic_fetch_or(gs.root, GB_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (uint32_t k = 0; k < ngroups; k++) st_agent(&gs.flags[k * GB_LEAF_STRIDE], 0xFFFFFFFFu);
+                f = 0xFFFFFFFFu;
                 break;
             }
         }
-        __threadfence();
-        *s_flag = (v & GB_ABORT) ? 1u : 0u;
+        aborted = f == 0xFFFFFFFFu;
+        *s_flag = aborted;
     }
     __syncthreads();
     return *s_flag == 0u;
 }
 
+// A barrier that did not complete: leave { code, count } in the pinned status words (gsr_bin_persist_status), then trap
+// -- the lists would be garbage -- unless the diagnostics asked for a quiet return (GSR_BIN_NOTRAP=1).
+__device__ __forceinline__ void barrier_fault(uint32_t *status, uint32_t code, int notrap) {
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(status + 1, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_fetch_add(status + 2, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (!notrap) __builtin_trap();
+}
+
 // Global offsets of one counting pass from the published counts: cnt[G][256] (row w = workgroup w's digit counts)
 // and grp[ngroups][256] (sums over groups of GB_FAN workgroups, accumulated with atomics by the producers).
-// Thread d < 256 returns (digit d's pairs in workgroups before w) and its total over the grid.
+// Thread d < 256 gets (digit d's pairs in workgroups before w) and the digit's total over the grid; every thread of
+// the workgroup takes part: the <= ngroups + GB_FAN - 1 rows of a digit are split over THREADS / 256 threads and each
+// thread's loads are issued eight at a time BEFORE the first is used (agent-scope loads cost a trip to memory each:
+// one row after the other was 30 us per pass).  `red`: 2 * THREADS words of LDS scratch.  Workgroup barriers inside.
+template <int THREADS>
 __device__ __forceinline__ void counts_before(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ grp,
-                                              uint32_t G, uint32_t w, uint32_t d, uint32_t &before, uint32_t &total) {
+                                              uint32_t G, uint32_t w, uint32_t *__restrict__ red, uint32_t &before,
+                                              uint32_t &total) {
+    constexpr uint32_t Q = THREADS / RADIX_DIGITS;
+    const uint32_t q = threadIdx.x / RADIX_DIGITS, d = threadIdx.x % RADIX_DIGITS;
     const uint32_t g = w / GB_FAN, ngroups = (G + GB_FAN - 1) / GB_FAN;
     uint32_t b = 0, t = 0;
-    for (uint32_t k = 0; k < ngroups; k++) {
-        const uint32_t x = grp[k * RADIX_DIGITS + d];
-        t += x;
-        if (k < g) b += x;
+    for (uint32_t k0 = 0; k0 < ngroups; k0 += 8 * Q) {
+        uint32_t x[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const uint32_t k = k0 + q + Q * i;
+            x[i] = k < ngroups ? ld_agent(&grp[k * RADIX_DIGITS + d]) : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            t += x[i];
+            if (k0 + q + Q * i < g) b += x[i];
+        }
     }
-    for (uint32_t k = g * GB_FAN; k < w; k++) b += cnt[(size_t)k * RADIX_DIGITS + d];
-    before = b;
-    total = t;
+    for (uint32_t k0 = g * GB_FAN; k0 < w; k0 += 8 * Q) {
+        uint32_t x[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const uint32_t k = k0 + q + Q * i;
+            x[i] = k < w ? ld_agent(&cnt[(size_t)k * RADIX_DIGITS + d]) : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) b += x[i];
+    }
+    red[threadIdx.x] = b;
+    red[THREADS + threadIdx.x] = t;
+    __syncthreads();
+    before = total = 0;
+    if (threadIdx.x < RADIX_DIGITS) {
+#pragma unroll
+        for (uint32_t i = 0; i < Q; i++) {
+            before += red[i * RADIX_DIGITS + threadIdx.x];
+            total += red[THREADS + i * RADIX_DIGITS + threadIdx.x];
+        }
+    }
+    __syncthreads();
+}
+
+// The same in two steps for the prepare kernel (THREADS / 256 = 4 threads per digit, at most 256 workgroups: two group
+// rows and eight workgroup rows per thread): the loads are issued, the tile is ranked, then the offsets are formed.
+struct CountLoads {
+    uint32_t xg[2], xc[8];
+};
+template <int THREADS>
+__device__ __forceinline__ bool counts_fit_registers(uint32_t G) {
+    constexpr uint32_t Q = THREADS / RADIX_DIGITS;
+    return (G + GB_FAN - 1) / GB_FAN <= 2 * Q && GB_FAN - 1 <= 8 * Q;
+}
+template <int THREADS>
+__device__ __forceinline__ void counts_issue(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ grp,
+                                             uint32_t G, uint32_t w, CountLoads &cl) {
+    constexpr uint32_t Q = THREADS / RADIX_DIGITS;
+    const uint32_t q = threadIdx.x / RADIX_DIGITS, d = threadIdx.x % RADIX_DIGITS;
+    const uint32_t g = w / GB_FAN, ngroups = (G + GB_FAN - 1) / GB_FAN;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const uint32_t k = q + Q * i;
+        cl.xg[i] = k < ngroups ? ld_agent(&grp[k * RADIX_DIGITS + d]) : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint32_t k = g * GB_FAN + q + Q * i;
+        cl.xc[i] = k < w ? ld_agent(&cnt[(size_t)k * RADIX_DIGITS + d]) : 0u;
+    }
+}
+template <int THREADS>
+__device__ __forceinline__ void counts_finish(const CountLoads &cl, uint32_t w, uint32_t *__restrict__ red,
+                                              uint32_t &before, uint32_t &total) {
+    constexpr uint32_t Q = THREADS / RADIX_DIGITS;
+    const uint32_t q = threadIdx.x / RADIX_DIGITS;
+    const uint32_t g = w / GB_FAN;
+    uint32_t b = 0, t = 0;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        t += cl.xg[i];
+        if (q + Q * i < g) b += cl.xg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) b += cl.xc[i];
+    red[threadIdx.x] = b;
+    red[THREADS + threadIdx.x] = t;
+    __syncthreads();
+    before = total = 0;
+    if (threadIdx.x < RADIX_DIGITS) {
+#pragma unroll
+        for (uint32_t i = 0; i < Q; i++) {
+            before += red[i * RADIX_DIGITS + threadIdx.x];
+            total += red[THREADS + i * RADIX_DIGITS + threadIdx.x];
+        }
+    }
+    __syncthreads();
 }
 
 __device__ __forceinline__ void publish_counts(uint32_t *__restrict__ cnt, uint32_t *__restrict__ grp, uint32_t w,
                                                uint32_t d, uint32_t c) {
-    cnt[(size_t)w * RADIX_DIGITS + d] = c;
+    st_agent(&cnt[(size_t)w * RADIX_DIGITS + d], c);
     if (c) __hip_atomic_fetch_add(&grp[(w / GB_FAN) * RADIX_DIGITS + d], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -129,16 +245,16 @@ __device__ __forceinline__ void count_wave_digits(PersistSmem<ITEMS, THREADS> &s
     }
 }
 
-// One tile of a scatter phase.  In: per-wave digit counts in sm.wtab (count_wave_digits + a workgroup barrier), the
-// pairs in registers; `first[d]` (thread d < 256) = global position of the first pair of digit d that THIS tile
-// writes.  Stable: waves in order, rounds in order, lanes in order.  Returns the tile's count of thread d's digit.
-// Ends with a workgroup barrier (LDS reusable).
+// One tile of a scatter phase, in two steps so that the caller can have the loads of its global offsets in flight
+// during the first.  scatter_rank -- in: per-wave digit counts in sm.wtab (count_wave_digits + a workgroup barrier), the
+// pairs in registers; places the pairs in digit order in the LDS staging area (stable: waves in order, rounds in order,
+// lanes in order); thread d < 256 gets the tile's count of digit d and the digit's start inside the tile.
+// scatter_write -- `first` (thread d < 256) = global position of the first pair of digit d that THIS tile writes;
+// streams the staged pairs out (coalesced runs per digit).  Ends with a workgroup barrier (LDS reusable).
 template <int ITEMS, int THREADS>
-__device__ __forceinline__ uint32_t scatter_tile(PersistSmem<ITEMS, THREADS> &sm, const uint32_t (&key)[ITEMS],
-                                                 const uint32_t (&val)[ITEMS], long long tbase, long long n, int shift,
-                                                 int nbits, uint32_t first, uint32_t *__restrict__ keys_out,
-                                                 uint32_t *__restrict__ vals_out) {
-    constexpr int TILE = ITEMS * THREADS;
+__device__ __forceinline__ void scatter_rank(PersistSmem<ITEMS, THREADS> &sm, const uint32_t (&key)[ITEMS],
+                                             const uint32_t (&val)[ITEMS], long long tbase, long long n, int shift,
+                                             int nbits, uint32_t &tot_out, uint32_t &run_out) {
     constexpr int WAVES = THREADS / 64;
     const uint32_t mask = (1u << nbits) - 1u;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -152,8 +268,9 @@ __device__ __forceinline__ uint32_t scatter_tile(PersistSmem<ITEMS, THREADS> &sm
     }
     uint32_t all;
     uint32_t run = block_exclusive_scan_n<WAVES>(tot, sm.scan_tmp, &all);  // start of digit d inside the tile
+    tot_out = tot;
+    run_out = run;
     if (d < RADIX_DIGITS) {
-        sm.gbase[d] = first - run;
 #pragma unroll
         for (int w = 0; w < WAVES; w++) {
             sm.wtab[w][d] = (uint16_t)run;
@@ -181,7 +298,16 @@ __device__ __forceinline__ uint32_t scatter_tile(PersistSmem<ITEMS, THREADS> &sm
             sm.sval[pos] = val[r];
         }
     }
-    __syncthreads();
+}
+
+template <int ITEMS, int THREADS, bool WT_VALS>
+__device__ __forceinline__ void scatter_write(PersistSmem<ITEMS, THREADS> &sm, long long tbase, long long n, int shift,
+                                              int nbits, uint32_t first, uint32_t run, uint32_t *__restrict__ keys_out,
+                                              uint32_t *__restrict__ vals_out) {
+    constexpr int TILE = ITEMS * THREADS;
+    const uint32_t mask = (1u << nbits) - 1u;
+    if (threadIdx.x < RADIX_DIGITS) sm.gbase[threadIdx.x] = first - run;
+    __syncthreads();  // (also: every wave has staged its pairs)
     const long long rem = n - tbase;
     const int count = rem < TILE ? (int)rem : TILE;
 #pragma unroll
@@ -190,11 +316,22 @@ __device__ __forceinline__ uint32_t scatter_tile(PersistSmem<ITEMS, THREADS> &sm
         if (i < count) {
             const uint32_t k = sm.skey[i];
             const uint32_t dst = sm.gbase[(k >> shift) & mask] + (uint32_t)i;
-            keys_out[dst] = k;
-            vals_out[dst] = sm.sval[i];
+            st_agent(&keys_out[dst], k);  // (read by other workgroups in the next phase: written through)
+            if (WT_VALS) st_agent(&vals_out[dst], sm.sval[i]);
+            else vals_out[dst] = sm.sval[i];
         }
     }
     __syncthreads();
+}
+
+template <int ITEMS, int THREADS, bool WT_VALS>
+__device__ __forceinline__ uint32_t scatter_tile(PersistSmem<ITEMS, THREADS> &sm, const uint32_t (&key)[ITEMS],
+                                                 const uint32_t (&val)[ITEMS], long long tbase, long long n, int shift,
+                                                 int nbits, uint32_t first, uint32_t *__restrict__ keys_out,
+                                                 uint32_t *__restrict__ vals_out) {
+    uint32_t tot, run;
+    scatter_rank(sm, key, val, tbase, n, shift, nbits, tot, run);
+    scatter_write<ITEMS, THREADS, WT_VALS>(sm, tbase, n, shift, nbits, first, run, keys_out, vals_out);
     return tot;
 }
 
@@ -203,6 +340,11 @@ __device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v) {
     for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
     return v;
 }
+
+#define GSR_TS(k)                                                                                       \
+    do {                                                                                                \
+        if (a.tstamp && threadIdx.x == 0) a.tstamp[(size_t)blockIdx.x * 32 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
 
 // ======================================================================================= the P-sized chain
 constexpr int PP_THREADS = 1024, PP_ITEMS = 4, PP_TILE = PP_THREADS * PP_ITEMS, PP_WAVES = PP_THREADS / 64;
@@ -229,6 +371,8 @@ struct PrepPersistArgs {
     uint32_t *done_word;  // pinned: sequence number of the last persistent launch that passed its last barrier
     uint32_t done_seq;    // 0: do not publish (captured launches)
     uint64_t timeout_ticks;
+    int notrap;
+    unsigned long long *tstamp;  // diagnostics (GSR_BIN_TIMELINE=1): [G][32] clock stamps of thread 0, else null
 };
 
 struct PPExtra {
@@ -236,10 +380,12 @@ struct PPExtra {
     int s_lo, s_hi;
 };
 
+
 __global__ void __launch_bounds__(PP_THREADS)
 bin_prepare_persist_kernel(const PrepPersistArgs a) {
     __shared__ PersistSmem<PP_ITEMS, PP_THREADS> sm;
     __shared__ PPExtra ex;
+    __shared__ uint32_t red2[2 * PP_THREADS];  // reduction scratch of counts_finish (the staging area is in use then)
     const uint32_t G = gridDim.x, w = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long P = a.P;
@@ -248,6 +394,7 @@ bin_prepare_persist_kernel(const PrepPersistArgs a) {
     const bool keep = (t1 - t0) == 1;  // one tile: its pairs live in registers from a count phase to its scatter phase
     const uint32_t d = threadIdx.x;
     uint32_t epoch = 0;
+    GSR_TS(0);
     uint32_t key[PP_ITEMS], val[PP_ITEMS];
 
     // ------------------------------------------------------------------ T: K3 (see touch_count_kernel)
@@ -259,13 +406,14 @@ bin_prepare_persist_kernel(const PrepPersistArgs a) {
         const int total = a.gx * a.gy;
         const int per = (total + PP_THREADS - 1) / PP_THREADS;
         const int b0 = threadIdx.x * per, b1 = min(b0 + per, total);
-        int first = -1, last = -1;
-        for (int b = b0; b < b1; b++)
-            if (a.mask[b]) {
-                if (first < 0) first = b;
-                last = b;
-            }
-        if (first >= 0) {
+        int first = 0x7fffffff, last = -1;  // (branch-free: the byte loads are independent)
+#pragma unroll 8
+        for (int b = b0; b < b1; b++) {
+            const int on = a.mask[b] != 0;
+            first = min(first, on ? b : 0x7fffffff);
+            last = max(last, on ? b : -1);
+        }
+        if (last >= 0) {
             atomicMin(&ex.s_lo, first / a.gx);
             atomicMax(&ex.s_hi, last / a.gx + 1);
         }
@@ -279,6 +427,21 @@ bin_prepare_persist_kernel(const PrepPersistArgs a) {
     uint32_t mytot = 0;  // thread d < 256: this workgroup's count of digit d in the pass being counted
     for (long long t = t0; t < t1; t++) {
         const long long wbase = t * PP_TILE + (long long)wave * (PP_ITEMS * 64);
+        // every input of the thread's four Gaussians is requested before the first is looked at (clamped indices, no
+        // branches): fetched where needed, the radius -> position / conic -> depth chain cost 20 us of this phase
+        int rad[PP_ITEMS];
+        float2 xy[PP_ITEMS];
+        float4 co[PP_ITEMS];
+        float dep[PP_ITEMS];
+#pragma unroll
+        for (int r = 0; r < PP_ITEMS; r++) {
+            const long long i = wbase + r * 64 + lane;
+            const long long ic = i < P ? i : P - 1;
+            rad[r] = a.radii[ic];
+            xy[r] = a.means2D[ic];
+            co[r] = a.conic_opacity[ic];
+            dep[r] = a.depths[ic];
+        }
 #pragma unroll
         for (int r = 0; r < PP_ITEMS; r++) {
             const long long i = wbase + r * 64 + lane;
@@ -287,18 +450,15 @@ bin_prepare_persist_kernel(const PrepPersistArgs a) {
             if (i < P) {
                 uint32_t n = 0;
                 uint2 rect = make_uint2(0u, 0u);
-                const int rad = a.radii[i];
-                if (rad > 0) {
-                    const float2 xy = a.means2D[i];
-                    const float4 co = a.conic_opacity[i];
+                if (rad[r] > 0) {
                     float exx, eyy;
-                    if (gsr_alpha_extent(co, exx, eyy)) {
+                    if (gsr_alpha_extent(co[r], exx, eyy)) {
                         int minx, miny, maxx, maxy;
-                        gsr_get_rect(xy.x, xy.y, rad, a.gx, a.gy, minx, miny, maxx, maxy);
-                        minx = max(minx, (int)ceilf((xy.x - exx - (GSR_BLOCK_X - 1)) * (1.0f / GSR_BLOCK_X)));
-                        maxx = min(maxx, (int)floorf((xy.x + exx) * (1.0f / GSR_BLOCK_X)) + 1);
-                        miny = max(max(miny, hull0), (int)ceilf((xy.y - eyy - (GSR_BLOCK_Y - 1)) * (1.0f / GSR_BLOCK_Y)));
-                        maxy = min(min(maxy, hull1), (int)floorf((xy.y + eyy) * (1.0f / GSR_BLOCK_Y)) + 1);
+                        gsr_get_rect(xy[r].x, xy[r].y, rad[r], a.gx, a.gy, minx, miny, maxx, maxy);
+                        minx = max(minx, (int)ceilf((xy[r].x - exx - (GSR_BLOCK_X - 1)) * (1.0f / GSR_BLOCK_X)));
+                        maxx = min(maxx, (int)floorf((xy[r].x + exx) * (1.0f / GSR_BLOCK_X)) + 1);
+                        miny = max(max(miny, hull0), (int)ceilf((xy[r].y - eyy - (GSR_BLOCK_Y - 1)) * (1.0f / GSR_BLOCK_Y)));
+                        maxy = min(min(maxy, hull1), (int)floorf((xy[r].y + eyy) * (1.0f / GSR_BLOCK_Y)) + 1);
                         if (maxx > minx && maxy > miny) {
                             n = (uint32_t)((maxx - minx) * (maxy - miny));
                             rect = make_uint2((uint32_t)minx | ((uint32_t)maxx << 16),
@@ -312,12 +472,12 @@ bin_prepare_persist_kernel(const PrepPersistArgs a) {
                         }
                     }
                 }
-                if (n) key[r] = __float_as_uint(a.depths[i]);
-                a.tt[i] = n;
+                if (n) key[r] = __float_as_uint(dep[r]);
+                st_agent(&a.tt[i], n);  // (gathered by other workgroups in the scan phase)
                 a.rects[i] = rect;
                 if (!keep) {
-                    a.kA[i] = key[r];
-                    a.vA[i] = val[r];
+                    st_agent(&a.kA[i], key[r]);
+                    st_agent(&a.vA[i], val[r]);
                 }
             }
         }
@@ -345,6 +505,7 @@ bin_prepare_persist_kernel(const PrepPersistArgs a) {
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
+    GSR_TS(1);
     if (!grid_barrier(a.sync, G, epoch, a.timeout_ticks, &sm.flag)) {
         // gave up waiting for the whole grid to become resident (another barrier kernel holds part of the device):
         // the host repeats the call on the look-back pipeline; the bounded tile sort sees a count above any capacity
@@ -356,7 +517,9 @@ bin_prepare_persist_kernel(const PrepPersistArgs a) {
         }
         return;
     }
-    const uint64_t forever = ~0ull >> 1;  // later barriers cannot dead-lock: the whole grid is resident
+    GSR_TS(2);
+    // later barriers cannot dead-lock (the whole grid is resident): a second without progress is a fault -- trap
+    const uint64_t forever = 100000000ull;
     // ------------------------------------------------------------------ four LSD passes over the depth bits
     const uint32_t ngroups = (G + GB_FAN - 1) / GB_FAN;
     for (int p = 0; p < 4; p++) {
@@ -364,12 +527,23 @@ bin_prepare_persist_kernel(const PrepPersistArgs a) {
         uint32_t *const ksrc = (p & 1) ? a.kB : a.kA, *const vsrc = (p & 1) ? a.vB : a.vA;
         uint32_t *const kdst = (p & 1) ? a.kA : a.kB, *const vdst = (p & 1) ? a.vA : a.vB;
         // B: scatter
-        uint32_t before = 0, total = 0;
-        if (d < RADIX_DIGITS)
-            counts_before(a.cnt + (size_t)p * G * RADIX_DIGITS, a.grp + (size_t)p * ngroups * RADIX_DIGITS, G, w, d,
-                          before, total);
-        uint32_t all;
-        uint32_t first = block_exclusive_scan_n<PP_WAVES>(total, sm.scan_tmp, &all) + before;
+        const uint32_t *const cnt_p = a.cnt + (size_t)p * G * RADIX_DIGITS;
+        const uint32_t *const grp_p = a.grp + (size_t)p * ngroups * RADIX_DIGITS;
+        uint32_t before, total, all, first;
+        if (keep && counts_fit_registers<PP_THREADS>(G)) {
+            // one tile, its pairs and per-wave counts are in place: rank it while the counts of the other workgroups
+            // travel (an agent-scope load is a trip to memory), then form the offsets and stream the tile out
+            CountLoads cl;
+            counts_issue<PP_THREADS>(cnt_p, grp_p, G, w, cl);
+            uint32_t tot, run;
+            scatter_rank(sm, key, val, t0 * PP_TILE, P, shift, 8, tot, run);
+            // (the reduction scratch must not be the staging area: the ranked pairs are in it)
+            counts_finish<PP_THREADS>(cl, w, reinterpret_cast<uint32_t *>(red2), before, total);
+            first = block_exclusive_scan_n<PP_WAVES>(total, sm.scan_tmp, &all) + before;
+            scatter_write<PP_ITEMS, PP_THREADS, true>(sm, t0 * PP_TILE, P, shift, 8, first, run, kdst, vdst);
+        } else {
+        counts_before<PP_THREADS>(cnt_p, grp_p, G, w, sm.skey, before, total);
+        first = block_exclusive_scan_n<PP_WAVES>(total, sm.scan_tmp, &all) + before;
         for (long long t = t0; t < t1; t++) {
             const long long tbase = t * PP_TILE;
             const long long wbase = tbase + (long long)wave * (PP_ITEMS * 64);
@@ -377,19 +551,22 @@ bin_prepare_persist_kernel(const PrepPersistArgs a) {
 #pragma unroll
                 for (int r = 0; r < PP_ITEMS; r++) {
                     const long long j = wbase + r * 64 + lane;
-                    key[r] = j < P ? ksrc[j] : 0xFFFFFFFFu;
-                    val[r] = j < P ? vsrc[j] : 0u;
+                    key[r] = j < P ? ld_agent(&ksrc[j]) : 0xFFFFFFFFu;
+                    val[r] = j < P ? ld_agent(&vsrc[j]) : 0u;
                 }
                 count_wave_digits(sm, key, wbase, P, shift, 0xFFu);
                 __syncthreads();
             }
-            first += scatter_tile(sm, key, val, tbase, P, shift, 8, first, kdst, vdst);
+            first += scatter_tile<PP_ITEMS, PP_THREADS, true>(sm, key, val, tbase, P, shift, 8, first, kdst, vdst);
             if (!keep) {
                 clear_wtab(sm);
                 __syncthreads();
             }
         }
-        if (!grid_barrier(a.sync, G, epoch, forever, &sm.flag)) return;
+        }
+        GSR_TS(3 + 4 * p);
+        if (!grid_barrier(a.sync, G, epoch, forever, &sm.flag)) { barrier_fault(a.done_word, 0x100u + epoch, a.notrap); return; }
+        GSR_TS(4 + 4 * p);
         if (p == 3) break;
         // A: count the next digit of what this workgroup now owns
         if (keep) {
@@ -402,8 +579,8 @@ bin_prepare_persist_kernel(const PrepPersistArgs a) {
 #pragma unroll
             for (int r = 0; r < PP_ITEMS; r++) {
                 const long long j = wbase + r * 64 + lane;
-                key[r] = j < P ? kdst[j] : 0xFFFFFFFFu;
-                val[r] = j < P ? vdst[j] : 0u;
+                key[r] = j < P ? ld_agent(&kdst[j]) : 0xFFFFFFFFu;
+                val[r] = j < P ? ld_agent(&vdst[j]) : 0u;
             }
             count_wave_digits(sm, key, wbase, P, shift + 8, 0xFFu);
             __syncthreads();
@@ -420,7 +597,9 @@ bin_prepare_persist_kernel(const PrepPersistArgs a) {
         if (d < RADIX_DIGITS)
             publish_counts(a.cnt + (size_t)(p + 1) * G * RADIX_DIGITS, a.grp + (size_t)(p + 1) * ngroups * RADIX_DIGITS,
                            w, d, mytot);
-        if (!grid_barrier(a.sync, G, epoch, forever, &sm.flag)) return;
+        GSR_TS(5 + 4 * p);
+        if (!grid_barrier(a.sync, G, epoch, forever, &sm.flag)) { barrier_fault(a.done_word, 0x100u + epoch, a.notrap); return; }
+        GSR_TS(6 + 4 * p);
     }
     // four passes: the sorted (key, id) pairs are back in (kA, vA)
     // ------------------------------------------------------------------ S: offsets = exclusive scan of tt[vA[.]]
@@ -431,7 +610,7 @@ bin_prepare_persist_kernel(const PrepPersistArgs a) {
         uint32_t s = 0;
 #pragma unroll
         for (int k = 0; k < PP_ITEMS; k++) {
-            v[k] = (base + k < P) ? a.tt[a.vA[base + k]] : 0u;
+            v[k] = (base + k < P) ? ld_agent(&a.tt[ld_agent(&a.vA[base + k])]) : 0u;
             s += v[k];
         }
         wsum += s;
@@ -442,15 +621,17 @@ bin_prepare_persist_kernel(const PrepPersistArgs a) {
     if (threadIdx.x == 0) {
         unsigned long long tot = 0;
         for (int wv = 0; wv < PP_WAVES; wv++) tot += sm.scan64[wv];
-        a.wtot[w] = tot;
+        st_agent64(&a.wtot[w], tot);
     }
-    if (!grid_barrier(a.sync, G, epoch, forever, &sm.flag)) return;
+    GSR_TS(19);
+    if (!grid_barrier(a.sync, G, epoch, forever, &sm.flag)) { barrier_fault(a.done_word, 0x100u + epoch, a.notrap); return; }
+    GSR_TS(20);
     if (w == 0 && threadIdx.x == 0 && a.done_seq)  // every workgroup is past the last barrier: nothing left to wait for
         __hip_atomic_store(a.done_word, a.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     unsigned long long carry;
     {
         unsigned long long x = 0;
-        for (uint32_t k = threadIdx.x; k < w; k += PP_THREADS) x += a.wtot[k];
+        for (uint32_t k = threadIdx.x; k < w; k += PP_THREADS) x += ld_agent64(&a.wtot[k]);
         x = wave_sum64(x);
         __syncthreads();  // (scan64 was read above)
         if (lane == 0) sm.scan64[wave] = x;
@@ -463,7 +644,7 @@ bin_prepare_persist_kernel(const PrepPersistArgs a) {
         uint32_t s = 0;
         if (!keep) {
 #pragma unroll
-            for (int k = 0; k < PP_ITEMS; k++) v[k] = (base + k < P) ? a.tt[a.vA[base + k]] : 0u;
+            for (int k = 0; k < PP_ITEMS; k++) v[k] = (base + k < P) ? ld_agent(&a.tt[ld_agent(&a.vA[base + k])]) : 0u;
         }
 #pragma unroll
         for (int k = 0; k < PP_ITEMS; k++) s += v[k];
@@ -483,11 +664,16 @@ bin_prepare_persist_kernel(const PrepPersistArgs a) {
         __hip_atomic_store(a.host_total, D, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(a.host_total + 1, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    GSR_TS(31);
 }
 
 // ======================================================================================= the D-sized chain
 constexpr int PS_THREADS = 512, PS_ITEMS = 8, PS_TILE = PS_THREADS * PS_ITEMS, PS_WAVES = PS_THREADS / 64;
 constexpr int PS_CHUNK = PS_ITEMS * 64;  // slots of one wave of one tile
+#ifndef GSR_PS_MIN_WAVES
+#define GSR_PS_MIN_WAVES 4
+#endif
+constexpr int PS_MIN_WAVES = GSR_PS_MIN_WAVES;
 constexpr int PS_OWNERS = 256;           // chunk owners kept in LDS: tiles per workgroup <= 32, else per-chunk search
                                          // (with 512 the workgroup would exceed 40 KB: three per CU instead of four)
 static_assert(PS_TILE == RADIX_TILE, "tiles of both pipelines have 4096 elements");
@@ -511,11 +697,14 @@ struct SortPersistArgs {
     uint32_t done_seq;
     uint64_t timeout_ticks;
     int owners_cap;  // <= PS_OWNERS (tests lower it to exercise the per-chunk search)
+    int notrap;
+    unsigned long long *tstamp;  // diagnostics (GSR_BIN_TIMELINE=1): [G][32] clock stamps of thread 0, else null
 };
 
 struct PSExtra {
     int32_t dcol[RADIX_DIGITS + 1];
     int32_t owner[PS_OWNERS];
+    uint32_t cflag[PS_WAVES][PS_CHUNK / 32];  // per wave: bit p = a Gaussian's first slot is slot p of the wave's chunk
     int j0, j1;
 };
 
@@ -534,7 +723,70 @@ __device__ __forceinline__ int owner_search(const uint32_t *__restrict__ offsets
     return lo;
 }
 
-__global__ void __launch_bounds__(PS_THREADS, 8)  // <= 64 VGPRs: four 8-wave workgroups per CU
+// The pairs of one wave's chunk of the emission order -- slots [wbase, wbase + 512), lane l of round r holds slot
+// wbase + 64 r + l -- decoded into registers.  The Gaussians are in depth order, Gaussian j owns the slots
+// [offsets[j], offsets[j + 1]) (its rect in row-major order), g0 owns slot wbase.  Every Gaussian in front of the culled
+// tail owns at least one slot, so the owner of slot wbase + p is g0 + (number of Gaussians after g0 that start at or
+// before p): the starts are marked as bits of a 512-bit LDS word set, and a round's owners follow from one broadcast
+// read and a population count -- no search, and the three dependent gathers (offset / id, then rect) of ALL rounds
+// are in flight together.
+__device__ __forceinline__ void decode_chunk(const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ sorted_ids,
+                                             const uint2 *__restrict__ rects, int P, long long D, long long wbase, int g0,
+                                             int xbits, uint32_t *__restrict__ cflag, uint32_t (&key)[PS_ITEMS],
+                                             uint32_t (&val)[PS_ITEMS]) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t cbeg = (uint32_t)wbase;
+    const uint32_t cend = (uint32_t)(wbase + PS_CHUNK < D ? wbase + PS_CHUNK : D);
+    __builtin_amdgcn_wave_barrier();
+    if (lane < PS_CHUNK / 32) cflag[lane] = 0u;
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    for (int base = g0 + 1;; base += 64) {  // wave-uniform trip count: at most 9 rounds (512 slots, >= 1 per Gaussian)
+        const int j = base + lane;
+        const uint32_t o = offsets[j < P ? j : P];  // (offsets[P] = D >= cend: never marked)
+        const bool in = o < cend;                   // o > cbeg: g0 owns slot cbeg
+        if (in) atomicOr(&cflag[(o - cbeg) >> 5], 1u << ((o - cbeg) & 31u));
+        if (__ballot(in) != ~0ull) break;           // offsets are monotone: a lane past the end ends the marking
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    int jr[PS_ITEMS];
+    int carry = 0;
+    const unsigned long long le = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+#pragma unroll
+    for (int r = 0; r < PS_ITEMS; r++) {
+        const unsigned long long m = (unsigned long long)cflag[2 * r] | ((unsigned long long)cflag[2 * r + 1] << 32);
+        jr[r] = g0 + carry + __popcll(m & le);
+        carry += __popcll(m);
+    }
+    uint32_t off[PS_ITEMS], gid[PS_ITEMS];
+#pragma unroll
+    for (int r = 0; r < PS_ITEMS; r++) {
+        const bool live = wbase + r * 64 + lane < D;
+        const int j = live ? jr[r] : g0;
+        off[r] = offsets[j];
+        gid[r] = sorted_ids[j];
+    }
+    uint2 rc[PS_ITEMS];
+#pragma unroll
+    for (int r = 0; r < PS_ITEMS; r++) rc[r] = rects[gid[r]];
+#pragma unroll
+    for (int r = 0; r < PS_ITEMS; r++) {
+        if (wbase + r * 64 + lane < D) {
+            const uint32_t s = cbeg + (uint32_t)(r * 64 + lane);
+            const uint32_t tq = s - off[r];
+            const uint32_t minx = rc[r].x & 0xFFFFu, wd = (rc[r].x >> 16) - minx, miny = rc[r].y & 0xFFFFu;
+            // tq / wd without the integer-division sequence (~15 VALU): the frame has <= 256 x 256 tiles on this path,
+            // so the quotient is < 256 and (tq + 0.5) / wd stays >= 0.5 / 256 away from every integer -- orders of
+            // magnitude more than the error of rcp (1 ulp) and the product: the truncation is exact
+            const uint32_t q = (uint32_t)(((float)tq + 0.5f) * __builtin_amdgcn_rcpf((float)wd));
+            key[r] = ((miny + q) << xbits) | (minx + (tq - q * wd));
+            val[r] = gid[r];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(PS_THREADS, PS_MIN_WAVES)  // 8: <= 64 VGPRs, four 8-wave workgroups per CU
 bin_sort_persist_kernel(const SortPersistArgs a) {
     __shared__ PersistSmem<PS_ITEMS, PS_THREADS> sm;
     __shared__ PSExtra ex;
@@ -550,16 +802,20 @@ bin_sort_persist_kernel(const SortPersistArgs a) {
                 __hip_atomic_store(a.done_word, a.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             return;
         }
-        D = dd;
+        D = (long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)dd);  // (uniform: the count is one word)
     }
     // K7 only writes the tiles that own pairs: clear the range table (every workgroup takes part) and set the hull row
-    for (int t = w * PS_THREADS + threadIdx.x; t < a.ranges_words; t += G * PS_THREADS) a.ranges[t] = 0;
+    // (written through: the same words are written again in phase T by workgroups of other XCDs, and two L2s must not
+    // both hold a dirty copy of a line)
+    for (int t = w * PS_THREADS + threadIdx.x; t < a.ranges_words; t += G * PS_THREADS)
+        st_agent(reinterpret_cast<uint32_t *>(a.ranges) + t, 0u);
     if (w == 0 && threadIdx.x < 2) a.ranges[a.ranges_words + threadIdx.x] = a.hull[threadIdx.x];
     const long long nb = (D + PS_TILE - 1) / PS_TILE;
     const long long t0 = (long long)w * nb / G, t1 = (long long)(w + 1) * nb / G;
     const long long s0 = t0 * PS_TILE, s1 = (t1 * PS_TILE < D) ? t1 * PS_TILE : D;  // this workgroup's slots
     const bool have_owners = (t1 - t0) * PS_WAVES <= a.owners_cap;
     uint32_t epoch = 0;
+    GSR_TS(0);
     const uint32_t ngroups = (G + GB_FAN - 1) / GB_FAN;
     const uint32_t xmask = (1u << a.xbits) - 1u;
 
@@ -616,81 +872,40 @@ bin_sort_persist_kernel(const SortPersistArgs a) {
         const uint32_t c = block_exclusive_scan_n<PS_WAVES>(v, sm.scan_tmp, &all) + v;  // inclusive prefix: the count
         if (d < RADIX_DIGITS) publish_counts(a.cnt, a.grp, w, d, c);
     }
+    GSR_TS(1);
     if (!grid_barrier(a.sync, G, epoch, a.timeout_ticks, &sm.flag)) {
-        __builtin_trap();  // another barrier kernel (another process?) shares the device: fail loudly (GSR_BIN_PERSIST=0)
+        barrier_fault(a.done_word, 0x200u, a.notrap);  // another barrier kernel (another process?) shares the device
         return;
     }
-    const uint64_t forever = ~0ull >> 1;
+    GSR_TS(2);
+    const uint64_t forever = 100000000ull;  // (one second: see bin_prepare_persist_kernel)
     // ------------------------------------------------------------------ E1: decode my slots, scatter by column
     uint32_t key[PS_ITEMS], val[PS_ITEMS];
     {
-        uint32_t before = 0, total = 0;
-        if (d < RADIX_DIGITS) counts_before(a.cnt, a.grp, G, w, d, before, total);
+        uint32_t before, total;
+        counts_before<PS_THREADS>(a.cnt, a.grp, G, w, sm.skey, before, total);
         uint32_t all;
         uint32_t first = block_exclusive_scan_n<PS_WAVES>(total, sm.scan_tmp, &all) + before;
-        // per-wave window of 64 depth-consecutive Gaussians, in the staging area (written behind workgroup barriers only)
-        static_assert(260 * PS_WAVES <= PS_TILE, "windows fit the key staging area");
-        uint32_t *const s_off = sm.skey + 260 * wave;                  // [65]
-        uint32_t *const s_g = s_off + 66;                              // [64]
-        uint2 *const s_rect = reinterpret_cast<uint2 *>(s_off + 130);  // [64], 8-byte aligned
         for (long long t = t0; t < t1; t++) {
             const long long tbase = t * PS_TILE;
             const long long wbase = tbase + (long long)wave * PS_CHUNK;
 #pragma unroll
             for (int r = 0; r < PS_ITEMS; r++) { key[r] = 0xFFFFFFFFu; val[r] = 0u; }
             if (wbase < D) {  // wave-uniform
-                int g0 = have_owners ? ex.owner[(int)((wbase - s0) / PS_CHUNK)]
-                                     : owner_search(a.offsets, 0, P, (uint32_t)wbase);
-                uint32_t wend = 0;
-                bool have_window = false;
-#pragma unroll
-                for (int r = 0; r < PS_ITEMS; r++) {
-                    const long long sj = wbase + r * 64 + lane;
-                    const uint32_t s = (uint32_t)sj;
-                    bool pending = sj < D;
-                    while (__ballot(pending) != 0ull) {
-                        if (!have_window || __ballot(pending && s >= wend) == __ballot(pending)) {
-                            if (have_window) g0 += 64;
-                            const int j = g0 + lane;
-                            const uint32_t off = a.offsets[min(j, P)];
-                            const uint32_t end = a.offsets[min(j + 1, P)];
-                            const uint32_t g = (j < P && end > off) ? a.sorted_ids[j] : 0u;
-                            __builtin_amdgcn_wave_barrier();
-                            s_off[lane] = off;
-                            if (lane == 63) s_off[64] = end;
-                            s_g[lane] = g;
-                            s_rect[lane] = (j < P && end > off) ? a.rects[g] : make_uint2(0u, 0u);
-                            __builtin_amdgcn_wave_barrier();
-                            wend = __builtin_amdgcn_readlane(end, 63);
-                            have_window = true;
-                        }
-                        if (pending && s < wend) {
-                            int lo = 0, bnd = 63;
-#pragma unroll
-                            for (int it = 0; it < 6; it++) {
-                                const int mid = (lo + bnd + 1) >> 1;
-                                if (s_off[mid] <= s) lo = mid; else bnd = mid - 1;
-                            }
-                            const uint2 rc = s_rect[lo];
-                            const uint32_t tq = s - s_off[lo];
-                            const uint32_t minx = rc.x & 0xFFFFu, wd = (rc.x >> 16) - minx, miny = rc.y & 0xFFFFu;
-                            // tq / wd by reciprocal: exact for quotients < 256 (see emit_scatter_kernel)
-                            const uint32_t q = (uint32_t)(((float)tq + 0.5f) * __builtin_amdgcn_rcpf((float)wd));
-                            key[r] = ((miny + q) << a.xbits) | (minx + (tq - q * wd));
-                            val[r] = s_g[lo];
-                            pending = false;
-                        }
-                    }
-                }
+                const int g0 = __builtin_amdgcn_readfirstlane(have_owners ? ex.owner[(int)((wbase - s0) / PS_CHUNK)]
+                                                                          : owner_search(a.offsets, 0, P, (uint32_t)wbase));
+                decode_chunk(a.offsets, a.sorted_ids, a.rects, P, D, wbase, g0, a.xbits, ex.cflag[wave], key, val);
             }
             count_wave_digits(sm, key, wbase, D, 0, xmask);
-            __syncthreads();  // (also: every wave has finished decoding -- the windows alias the staging area)
-            first += scatter_tile(sm, key, val, tbase, D, 0, a.xbits, first, a.kB, a.vB);
+            __syncthreads();
+            first += scatter_tile<PS_ITEMS, PS_THREADS, true>(sm, key, val, tbase, D, 0, a.xbits, first, a.kB, a.vB);
             clear_wtab(sm);
             __syncthreads();
         }
     }
-    if (!grid_barrier(a.sync, G, epoch, forever, &sm.flag)) return;
+    GSR_TS(3);
+    if (!grid_barrier(a.sync, G, epoch, forever, &sm.flag)) { barrier_fault(a.done_word, 0x200u + epoch, a.notrap); return; }
+    GSR_TS(4);
     // ------------------------------------------------------------------ R0: row-digit counts of my tiles
     {
         const uint32_t ymask = (1u << a.ybits) - 1u;
@@ -700,7 +915,7 @@ bin_sort_persist_kernel(const SortPersistArgs a) {
 #pragma unroll
             for (int r = 0; r < PS_ITEMS; r++) {
                 const long long j = wbase + r * 64 + lane;
-                key[r] = j < D ? a.kB[j] : 0xFFFFFFFFu;
+                key[r] = j < D ? ld_agent(&a.kB[j]) : 0xFFFFFFFFu;
             }
             count_wave_digits(sm, key, wbase, D, a.xbits, ymask);
             __syncthreads();
@@ -715,13 +930,15 @@ bin_sort_persist_kernel(const SortPersistArgs a) {
         if (d < RADIX_DIGITS)
             publish_counts(a.cnt + (size_t)G * RADIX_DIGITS, a.grp + (size_t)ngroups * RADIX_DIGITS, w, d, mytot);
     }
-    if (!grid_barrier(a.sync, G, epoch, forever, &sm.flag)) return;
+    GSR_TS(5);
+    if (!grid_barrier(a.sync, G, epoch, forever, &sm.flag)) { barrier_fault(a.done_word, 0x200u + epoch, a.notrap); return; }
+    GSR_TS(6);
     // ------------------------------------------------------------------ R1: scatter by row -> (kA, point_list)
     {
         const uint32_t ymask = (1u << a.ybits) - 1u;
-        uint32_t before = 0, total = 0;
-        if (d < RADIX_DIGITS)
-            counts_before(a.cnt + (size_t)G * RADIX_DIGITS, a.grp + (size_t)ngroups * RADIX_DIGITS, G, w, d, before, total);
+        uint32_t before, total;
+        counts_before<PS_THREADS>(a.cnt + (size_t)G * RADIX_DIGITS, a.grp + (size_t)ngroups * RADIX_DIGITS, G, w, sm.skey,
+                                  before, total);
         uint32_t all;
         uint32_t first = block_exclusive_scan_n<PS_WAVES>(total, sm.scan_tmp, &all) + before;
         for (long long t = t0; t < t1; t++) {
@@ -730,17 +947,19 @@ bin_sort_persist_kernel(const SortPersistArgs a) {
 #pragma unroll
             for (int r = 0; r < PS_ITEMS; r++) {
                 const long long j = wbase + r * 64 + lane;
-                key[r] = j < D ? a.kB[j] : 0xFFFFFFFFu;
-                val[r] = j < D ? a.vB[j] : 0u;
+                key[r] = j < D ? ld_agent(&a.kB[j]) : 0xFFFFFFFFu;
+                val[r] = j < D ? ld_agent(&a.vB[j]) : 0u;
             }
             count_wave_digits(sm, key, wbase, D, a.xbits, ymask);
             __syncthreads();
-            first += scatter_tile(sm, key, val, tbase, D, a.xbits, a.ybits, first, a.kA, a.point_list);
+            first += scatter_tile<PS_ITEMS, PS_THREADS, false>(sm, key, val, tbase, D, a.xbits, a.ybits, first, a.kA, a.point_list);
             clear_wtab(sm);
             __syncthreads();
         }
     }
-    if (!grid_barrier(a.sync, G, epoch, forever, &sm.flag)) return;
+    GSR_TS(7);
+    if (!grid_barrier(a.sync, G, epoch, forever, &sm.flag)) { barrier_fault(a.done_word, 0x200u + epoch, a.notrap); return; }
+    GSR_TS(8);
     if (w == 0 && threadIdx.x == 0 && a.done_seq)
         __hip_atomic_store(a.done_word, a.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     // ------------------------------------------------------------------ T: K7 over my slots (see tile_ranges_yx_kernel)
@@ -748,15 +967,16 @@ bin_sort_persist_kernel(const SortPersistArgs a) {
         int2 *const ranges = reinterpret_cast<int2 *>(a.ranges);
         for (long long j = s0 + (long long)threadIdx.x * 4; j < s1; j += PS_THREADS * 4) {
             uint32_t k[6];  // k[0] = predecessor, k[1..4] = own, k[5] = successor
-            k[0] = j > 0 ? a.kA[j - 1] : 0xFFFFFFFFu;
-            if (j + 4 <= D) {
-                const uint4 q = *reinterpret_cast<const uint4 *>(a.kA + j);
-                k[1] = q.x; k[2] = q.y; k[3] = q.z; k[4] = q.w;
+            k[0] = j > 0 ? ld_agent(&a.kA[j - 1]) : 0xFFFFFFFFu;
+            if (j + 4 <= D) {  // (two 8-byte agent-scope loads: the keys were written by other workgroups)
+                const unsigned long long q0 = ld_agent64(reinterpret_cast<const unsigned long long *>(a.kA + j));
+                const unsigned long long q1 = ld_agent64(reinterpret_cast<const unsigned long long *>(a.kA + j + 2));
+                k[1] = (uint32_t)q0; k[2] = (uint32_t)(q0 >> 32); k[3] = (uint32_t)q1; k[4] = (uint32_t)(q1 >> 32);
             } else {
 #pragma unroll
-                for (int i = 0; i < 4; i++) k[1 + i] = j + i < D ? a.kA[j + i] : 0xFFFFFFFFu;
+                for (int i = 0; i < 4; i++) k[1 + i] = j + i < D ? ld_agent(&a.kA[j + i]) : 0xFFFFFFFFu;
             }
-            k[5] = j + 4 < D ? a.kA[j + 4] : 0xFFFFFFFFu;
+            k[5] = j + 4 < D ? ld_agent(&a.kA[j + 4]) : 0xFFFFFFFFu;
 #pragma unroll
             for (int i = 1; i <= 4; i++) {
                 if (j + i - 1 >= D) break;
@@ -764,12 +984,13 @@ bin_sort_persist_kernel(const SortPersistArgs a) {
                 if (k[i - 1] != kk || k[i + 1] != kk) {
                     const uint32_t tl = (kk >> a.xbits) * (uint32_t)a.gx + (kk & xmask);
                     if (!a.mask[tl]) continue;
-                    if (k[i - 1] != kk) ranges[tl].x = (int)(j + i - 1);
-                    if (k[i + 1] != kk) ranges[tl].y = (int)(j + i);
+                    if (k[i - 1] != kk) st_agent(reinterpret_cast<uint32_t *>(&ranges[tl].x), (uint32_t)(j + i - 1));
+                    if (k[i + 1] != kk) st_agent(reinterpret_cast<uint32_t *>(&ranges[tl].y), (uint32_t)(j + i));
                 }
             }
         }
     }
+    GSR_TS(9);
 }
 
 // ------------------------------------------------------------------------------------------ host side
@@ -780,7 +1001,7 @@ inline PersistLayoutP persist_layout_p(int G) {
     PersistLayoutP L;
     const int ngroups = (G + GB_FAN - 1) / GB_FAN;
     size_t o = 0;
-    L.sync = o; o += align_up(sizeof(uint32_t) * ((size_t)ngroups * GB_LEAF_STRIDE + GB_LEAF_STRIDE));
+    L.sync = o; o += align_up(sizeof(uint32_t) * grid_sync_words(G));
     L.grp = o; o += align_up(sizeof(uint32_t) * 4 * (size_t)ngroups * RADIX_DIGITS);
     L.zero_bytes = o;  // [0, zero_bytes) is cleared before every launch
     L.cnt = o; o += align_up(sizeof(uint32_t) * 4 * (size_t)G * RADIX_DIGITS);
@@ -795,7 +1016,7 @@ inline PersistLayoutS persist_layout_s(int G) {
     PersistLayoutS L;
     const int ngroups = (G + GB_FAN - 1) / GB_FAN;
     size_t o = 0;
-    L.sync = o; o += align_up(sizeof(uint32_t) * ((size_t)ngroups * GB_LEAF_STRIDE + GB_LEAF_STRIDE));
+    L.sync = o; o += align_up(sizeof(uint32_t) * grid_sync_words(G));
     L.grp = o; o += align_up(sizeof(uint32_t) * 2 * (size_t)ngroups * RADIX_DIGITS);
     L.zero_bytes = o;
     L.cnt = o; o += align_up(sizeof(uint32_t) * 2 * (size_t)G * RADIX_DIGITS);
@@ -804,6 +1025,7 @@ inline PersistLayoutS persist_layout_s(int G) {
 }
 constexpr int PERSIST_MAX_GRID_P = 1024;  // upper bounds used to size workspaces (CUs x workgroups per CU of any part)
 constexpr int PERSIST_MAX_GRID_S = 4096;
+constexpr long long PERSIST_SORT_MAX_PAIRS = 6ll << 20;  // above: the look-back tile sort (GSR_BIN_PERSIST_MAXD overrides)
 
 // what the device holds at once, per kernel (queried once per device)
 struct PersistCaps {
@@ -829,6 +1051,23 @@ int persist_mode() {  // GSR_BIN_PERSIST = 0 | 1 (default) | p | s : A/B measure
     return mode;
 }
 std::atomic<int> g_persist_override{-1};  // gsr_set_bin_persistent: -1 = environment
+
+// Diagnostics (GSR_BIN_TIMELINE=1): one device buffer per kernel, [grid][32] stamps of the 100 MHz clock taken by thread 0
+// of every workgroup at the phase boundaries of the LAST launch; read with gsr_bin_timeline.
+unsigned long long *g_timeline[2] = {nullptr, nullptr};
+int g_timeline_grid[2] = {0, 0};
+unsigned long long *timeline_buffer(int which, int G) {
+    static const bool on = [] { const char *e = getenv("GSR_BIN_TIMELINE"); return e && *e == '1'; }();
+    if (!on) return nullptr;
+    if (!g_timeline[which]) {
+        void *p = nullptr;
+        if (hipMalloc(&p, sizeof(unsigned long long) * 32 * PERSIST_MAX_GRID_S) != hipSuccess) return nullptr;
+        g_timeline[which] = reinterpret_cast<unsigned long long *>(p);
+    }
+    (void)hipMemset(g_timeline[which], 0, sizeof(unsigned long long) * 32 * (size_t)G);
+    g_timeline_grid[which] = G;
+    return g_timeline[which];
+}
 
 // test hooks (read per call): GSR_BIN_GRID_P / GSR_BIN_GRID_S cap the grids (many tiles per workgroup on small scenes),
 // GSR_BIN_OWNERS caps the chunk-owner table

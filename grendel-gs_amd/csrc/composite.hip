@@ -190,8 +190,7 @@ static_assert(SEG_LEN % 64 == 0 && (SEG_LEN & (SEG_LEN - 1)) == 0 && SEG_MAXJ <=
               "segment geometry: K8 finds boundaries with c & (SEG_LEN - 1), so SEG_LEN is a power of two");
 constexpr int SEG_WORKERS = 1024;
 struct SegWs {
-    uint32_t *hdr;      // [0] segments queued by K8 (may exceed cap: only the first cap exist), [1] K10's ticket,
-                        // [2] workers of the running K10 that have drawn their last ticket
+    uint32_t *hdr;      // [0] segments queued by K8 (may exceed cap: only the first cap exist), [1] K10's ticket
     uint32_t *queue;    // [cap]: tile * 32 + segment index (>= 1)
     int32_t *seg_slot;  // [tiles][SEG_MAXJ]: checkpoint slot of the boundary at entry (j + 1) * SEG_LEN, -1: none
     float *ckpt;        // [cap][4][256]: T, C.r, C.g, C.b of the tile's 256 pixels (quadrant-major: wave * 64 + lane)
@@ -755,16 +754,7 @@ composite_backward_kernel(int W, int H, int gx, int tiles, const int2 *__restric
             if (threadIdx.x == 0) s_item = atomicAdd(&seg.hdr[1], 1u);
             __syncthreads();
             const uint32_t t = s_item;
-            if (t >= count) {
-                // every worker draws exactly one ticket past the end; the last of them rearms the ticket, so that a second
-                // backward over the same forward (retain_graph, gradcheck) walks the queued segments again
-                if (threadIdx.x == 0 && atomicAdd(&seg.hdr[2], 1u) == SEG_WORKERS - 1) {
-                    seg.hdr[2] = 0u;
-                    __threadfence();
-                    atomicExch(&seg.hdr[1], 0u);
-                }
-                return;
-            }
+            if (t >= count) return;
             const uint32_t item = seg.queue[t];
             tile = (int)(item >> 5);
             sidx = (int)(item & 31u);
@@ -845,6 +835,10 @@ int gsr_launch_composite_backward(int P, int W, int H, const int32_t *ranges, co
     const int band_first = band ? row_lo * gx : 0, band_tiles = band ? (row_hi - row_lo) * gx : 0;
     if (seg_ws && (seg_bytes < seg_ws_bytes(gx * gy, SEG_CAP) || !out_color)) return GSR_EINVAL;
     const SegWs seg = seg_ws_of(seg_ws, gx * gy, SEG_CAP);
+    // the workers' ticket is reset per launch, so that a second backward over the same forward (retain_graph, gradcheck)
+    // walks the queued segments again (rearming it inside the kernel cost K10 its 128-register budget: 196 B of spills,
+    // +20 % on every launch; this is a 4-byte fill on the thin-band path only)
+    if (seg_ws) GSR_HIP(hipMemsetAsync(reinterpret_cast<char *>(seg_ws) + sizeof(uint32_t), 0, sizeof(uint32_t), stream));
     hipLaunchKernelGGL(composite_backward_kernel, dim3((band ? band_tiles : gx * gy) + (seg_ws ? SEG_WORKERS : 0)),
                        dim3(256), 0, stream, W, H, gx, gx * gy, reinterpret_cast<const int2 *>(ranges), point_list,
                        reinterpret_cast<const float2 *>(means2D), reinterpret_cast<const float4 *>(conic_opacity), rgb,

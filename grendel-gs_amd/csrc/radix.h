@@ -219,23 +219,62 @@ __device__ __forceinline__ void onesweep_scatter(OnesweepSmem<ITEMS, THREADS> &s
         }
     }
     __syncthreads();
-    {  // thread d: digit d
-        const uint32_t d = threadIdx.x;  // threads >= 256 (8-wave workgroups) only take part in the scans
-        const bool live = d <= mask;
-        uint32_t cnt[WAVES], tot = 0;
+    // thread d: digit d.  Order (round 5): the aggregate is published and the per-wave cursors are set up first, then ALL
+    // threads rank the tile into the LDS staging area, and only then do the digit threads look back -- the ranking
+    // (~2.8 us) used to sit BEHIND the look-back, whose wait (for the slowest aggregate of the ~1024 resident
+    // workgroups, profiles/r04_radix_timeline.txt) is idle time that the ranking now fills.
+    const uint32_t d = threadIdx.x;  // threads >= 256 (8-wave workgroups) only take part in the scans
+    const bool live = d <= mask;
+    uint32_t tot = 0, run, dstart;
+    uint32_t *row = state + (size_t)bid * RADIX_DIGITS;
+    {
+        uint32_t cnt[WAVES];
 #pragma unroll
         for (int w = 0; w < WAVES; w++) {
             cnt[w] = d < RADIX_DIGITS ? sm.wtab[w][d] : 0u;
             tot += cnt[w];
         }
-        uint32_t *row = state + (size_t)bid * RADIX_DIGITS;
         if (live) st_agent(&row[d], bid == 0 ? (tot | LB_PRE) : (tot + 1u));
         uint32_t all;
-        uint32_t run = block_exclusive_scan_n<WAVES>(tot, sm.scan_tmp, &all);  // local start of digit d
+        run = block_exclusive_scan_n<WAVES>(tot, sm.scan_tmp, &all);  // local start of digit d
         uint32_t gh = 0;  // pass histogram = sum of the per-XCD replicas
         if (live)
             for (int x = 0; x < RADIX_REPLICAS; x++) gh += ghist[(size_t)x * RADIX_MAX_PASSES * RADIX_DIGITS + d];
-        const uint32_t dstart = block_exclusive_scan_n<WAVES>(gh, sm.scan_tmp, &all);  // global start
+        dstart = block_exclusive_scan_n<WAVES>(gh, sm.scan_tmp, &all);  // global start
+        if (d < RADIX_DIGITS) {
+            uint32_t c = run;
+#pragma unroll
+            for (int w = 0; w < WAVES; w++) {
+                sm.wtab[w][d] = (uint16_t)c;
+                c += cnt[w];
+            }
+        }
+    }
+    __syncthreads();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int r = 0; r < ITEMS; r++) {
+        const long long j = wbase + r * 64 + lane;
+        const bool valid = j < n;
+        const uint32_t dg = (key[r] >> shift) & mask;
+        const unsigned long long m = match_digit(dg, valid, nbits);
+        const uint32_t rank = __popcll(m & lt);
+        // (plain LDS accesses fenced for the compiler: a `volatile` pointer here turned them into FLAT loads / stores with
+        // system-scope bits and a vmcnt(0) wait each -- ~1 us per round; LDS operations of one wave execute in order)
+        uint16_t *cursor = sm.wtab[wave];
+        uint32_t pos = 0;
+        if (valid) pos = cursor[dg] + rank;
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (valid && rank == 0) cursor[dg] = (uint16_t)(pos + (uint32_t)__popcll(m));  // group leader advances the cursor
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (valid) {
+            sm.skey[pos] = key[r];
+            sm.sval[pos] = val[r];
+        }
+    }
+    {
         uint32_t excl = 0;
         if (live && bid > 0) {
             long long j = (long long)bid - 1;
@@ -261,38 +300,7 @@ __device__ __forceinline__ void onesweep_scatter(OnesweepSmem<ITEMS, THREADS> &s
             }
             st_agent(&row[d], ((excl + tot) & LB_VAL) | LB_PRE);
         }
-        if (d < RADIX_DIGITS) {
-            sm.gbase[d] = dstart + excl - run;
-#pragma unroll
-            for (int w = 0; w < WAVES; w++) {
-                sm.wtab[w][d] = (uint16_t)run;
-                run += cnt[w];
-            }
-        }
-    }
-    __syncthreads();
-    const unsigned long long lt = (1ull << lane) - 1ull;
-#pragma unroll
-    for (int r = 0; r < ITEMS; r++) {
-        const long long j = wbase + r * 64 + lane;
-        const bool valid = j < n;
-        const uint32_t d = (key[r] >> shift) & mask;
-        const unsigned long long m = match_digit(d, valid, nbits);
-        const uint32_t rank = __popcll(m & lt);
-        // (plain LDS accesses fenced for the compiler: a `volatile` pointer here turned them into FLAT loads / stores with
-        // system-scope bits and a vmcnt(0) wait each -- ~1 us per round; LDS operations of one wave execute in order)
-        uint16_t *cursor = sm.wtab[wave];
-        uint32_t pos = 0;
-        if (valid) pos = cursor[d] + rank;
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-        if (valid && rank == 0) cursor[d] = (uint16_t)(pos + (uint32_t)__popcll(m));  // group leader advances the cursor
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-        if (valid) {
-            sm.skey[pos] = key[r];
-            sm.sval[pos] = val[r];
-        }
+        if (d < RADIX_DIGITS) sm.gbase[d] = dstart + excl - run;
     }
     __syncthreads();
     const long long rem = n - bbase;

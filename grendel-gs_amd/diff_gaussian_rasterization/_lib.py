@@ -83,6 +83,8 @@ SIGNATURES = {
                                                      [c_void_p] * 7 + [c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gsr_bin_total_offset": (c_size_t, [c_int, c_int, c_int]),
     "gsr_set_bin_persistent": (c_int, [c_int]),
+    "gsr_bin_persist_status": (c_int, [ctypes.POINTER(ctypes.c_uint32)]),
+    "gsr_bin_timeline": (c_int, [c_int, c_void_p, c_int, ctypes.POINTER(c_int)]),
     "gsr_flag_if_greater": (c_int, [c_void_p, ctypes.c_uint32, c_void_p, ctypes.c_uint32, c_void_p, c_void_p]),
     "gsr_render_seg_bytes": (c_size_t, [c_int, c_int]),
     "gsr_render_forward_seg": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

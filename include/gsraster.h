@@ -148,6 +148,14 @@ int64_t gsr_bin_sort_capacity(int P, size_t scratch_bytes, int width, int height
  * gsr_bin_sort); the sort step traps after two seconds.  mode: -1 the environment's GSR_BIN_PERSIST (0 | 1 | p | s,
  * default 1), 0 off, 1 prepare only, 2 sort only, 3 both. */
 int gsr_set_bin_persistent(int mode);
+/* Diagnostics of the persistent launches on the current device: out3 = { sequence number of the last launch that passed
+ * its last barrier, code of the last barrier fault (0x100 + n: barrier n of the prepare kernel, 0x200 + n: of the sort
+ * kernel; 0 = none), number of faults }.  A fault traps the kernel (the process ends with a HIP error) unless
+ * GSR_BIN_NOTRAP=1 is set, in which case the lists of that call are garbage and this call is how one finds out. */
+int gsr_bin_persist_status(uint32_t *out3);
+/* Diagnostics (GSR_BIN_TIMELINE=1 in the environment): the per-workgroup phase stamps (100 MHz clock, 32 per workgroup)
+ * of the last persistent prepare (which = 0) / sort (which = 1) launch; *grid = its workgroups.  Synchronises. */
+int gsr_bin_timeline(int which, unsigned long long *out, int max_words, int *grid);
 /* Byte offset, inside the prep workspace of gsr_bin_prepare*, of the uint32 pair count D that K4 leaves on the DEVICE
  * (what gsr_bin_sort_bounded's kernels read).  For callers that capture the iteration in a hipGraph and therefore
  * cannot take D through gsr_bin_count_wait inside a replay: they copy the word out / test it with

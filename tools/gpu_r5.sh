@@ -1,0 +1,40 @@
+#!/bin/bash
+# Round-5 GPU sessions: tools/gpu_r5.sh <tag> <stage> [<stage> ...]   (everything lands in gpurun_out/<tag>/)
+#   bintest   the binning tests (persistent vs look-back pipeline, ordered-subsequence, speculative sort)
+#   binbench  tools/binbench.py: K3-K7 alone in the four gsr_set_bin_persistent modes (c1 whole frame, a 1/8 band)
+#   binbig    the same at configs[2]'s 6 M Gaussians and at a 5 M / 4K eighth band
+set -u
+TAG=${1:-r05}; shift || true
+STAGES=${*:-bintest binbench}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+export TMPDIR=/tmp
+has() { [[ " $STAGES " == *" $1 "* ]]; }
+cd $R
+if has bintest; then
+  timeout 600 python -m pytest tests/test_gpu_parity.py -q -m gpu -x -p no:cacheprovider -k "persistent or binning or speculative" > $O/bintest.log 2>&1
+  echo "bintest pytest exit $?" | tee -a $O/bintest.log
+  tail -15 $O/bintest.log | cut -c1-300
+fi
+if has binbench; then
+  GSR_BIN_PERSIST_MAXD=100000000 timeout 300 python tools/binbench.py --iters 20 > $O/binbench_c1.txt 2> $O/binbench_c1.err
+  echo "binbench c1 exit $?"; cat $O/binbench_c1.txt; tail -3 $O/binbench_c1.err | cut -c1-300
+  timeout 300 python tools/binbench.py --iters 20 --band 30 39 > $O/binbench_band.txt 2> $O/binbench_band.err
+  GSR_BIN_PERSIST_MAXD=100000000 timeout 300 python tools/binbench.py --iters 20 --band 20 48 > $O/binbench_band2.txt 2> $O/binbench_band2.err; cat $O/binbench_band2.txt
+  echo "binbench band exit $?"; cat $O/binbench_band.txt; tail -3 $O/binbench_band.err | cut -c1-300
+fi
+if has binbig; then
+  timeout 300 python tools/binbench.py --iters 10 --gaussians 6000000 > $O/binbench_c2.txt 2> $O/binbench_c2.err
+  echo "binbench c2 exit $?"; cat $O/binbench_c2.txt; tail -3 $O/binbench_c2.err | cut -c1-300
+  timeout 400 python tools/binbench.py --iters 5 --gaussians 5000000 --width 3840 --height 2160 --band 60 77 > $O/binbench_c4band.txt 2> $O/binbench_c4band.err
+  echo "binbench c4 band exit $?"; cat $O/binbench_c4band.txt; tail -3 $O/binbench_c4band.err | cut -c1-300
+fi
+if has fullsize; then
+  timeout 900 python -m pytest tests/test_gpu_fullsize.py -q -m gpu -x -p no:cacheprovider > $O/fullsize.log 2>&1
+  echo "fullsize pytest exit $?" | tee -a $O/fullsize.log
+  tail -6 $O/fullsize.log | cut -c1-300
+fi
+for st in $STAGES; do
+  case $st in bintest|binbench|binbig|fullsize) ;; *) bash tools/gpu_run.sh $TAG $st ;; esac
+done
