@@ -197,6 +197,58 @@ def self_launch_command(n, argv):
             "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
 
 
+_LAUNCHER_ENV = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK",
+                 "ROLE_WORLD_SIZE", "ROLE_NAME", "MASTER_ADDR", "MASTER_PORT", "NCCL_ASYNC_ERROR_HANDLING",
+                 "TORCH_NCCL_ASYNC_ERROR_HANDLING")
+
+
+def run_guarded_leg(n, argv, timeout_s):
+    """One more measurement leg as a CHILD launch of this file (python -m torch.distributed.run, one rank per GPU) with
+    a wall-clock limit: -> the child's JSON line as a dict, or {"error": ...}.  A leg that hangs (an RCCL collective
+    captured in a hipGraph has never run with two ranks) or dies costs one field of the line, not the line: the child
+    runs in its own session and exactly that process group is killed on time-out."""
+    import signal
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in _LAUNCHER_ENV and not k.startswith("TORCHELASTIC")}
+    cmd = self_launch_command(n, argv)
+    t0 = time.time()
+    try:
+        p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, start_new_session=True, text=True)
+    except OSError as e:
+        return {"error": f"could not launch the leg: {e}"}
+    try:
+        so, se = p.communicate(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)  # the session this function started, nothing else
+        except ProcessLookupError:
+            pass
+        so, se = p.communicate()
+        return {"error": f"timed out after {timeout_s} s", "stderr_tail": (se or "")[-600:]}
+    for line in reversed((so or "").strip().splitlines()):
+        if line.startswith("{"):
+            try:
+                d = json.loads(line)
+                d["leg_wall_s"] = round(time.time() - t0, 1)
+                return d
+            except json.JSONDecodeError:
+                break
+    why = [ln.strip() for ln in (se or "").splitlines() if "Error" in ln or "error:" in ln or "fault" in ln]
+    return {"error": f"exit code {p.returncode}, no JSON line" + (f"; {why[-1][:300]}" if why else ""),
+            "stderr_tail": (se or "")[-600:]}
+
+
+def brief_leg(d):
+    """the fields of a leg's line that the parent line carries"""
+    if d is None or "error" in d:
+        return d
+    keep = ("value", "unit", "ms_per_step", "steps", "warmup", "timing", "graph", "speedup_vs_1gpu", "leg_wall_s")
+    out = {k: d[k] for k in keep if k in d}
+    out["balance_timing"] = d.get("config", {}).get("balance_timing")
+    return out
+
+
 def percentile(xs, q):
     xs = sorted(xs)
     k = (len(xs) - 1) * q
@@ -477,13 +529,27 @@ def run_workload(a, name, world, rank, dev, steps, warmup, repeats, render_steps
     if world > 1 and state["sizes"] is not None:
         sizes = state["sizes"]  # sizes[i][j][k]: rows rank i sends to rank j for camera k (last step)
         rows = [[sum(sizes[i][j]) for j in range(world)] for i in range(world)]
+        import gaussian_renderer as gr_
+
+        pl = gr_._planner(utils.DEFAULT_GROUP, world, len(sizes[0][0]))
+        caps = pl.caps_list  # caps[i][j][k]: slab rows reserved for what rank i sends rank j of camera k (None: exact layout)
+        slab_rows = ([sum(sum(caps[i][j]) for j in range(world) if j != i) for i in range(world)] if caps else None)
+        useful = [sum(r) - r[i] for i, r in enumerate(rows)]
         out["exchange"] = {
+            "slab_rows_sent_per_rank": slab_rows,
+            "bytes_padded_fwd_per_rank": ([44 * (slab_rows[i] - useful[i]) for i in range(world)] if slab_rows else None),
+            "bytes_padded_bwd_per_rank": ([36 * (slab_rows[i] - useful[i]) for i in range(world)] if slab_rows else None),
+            "planner": {"capacity": "1.25 x the largest count of the last 64 iterations + 256 rows, rounded up to 256, per "
+                                    "(source, destination, camera)", "slabs_per_rank": (world - 1) * len(sizes[0][0]),
+                        "layouts": dict(gr_.exchange_stats)},
             "rows_sent_per_rank": [sum(r) - r[i] for i, r in enumerate(rows)],
             "bytes_fwd_per_rank": [44 * (sum(r) - r[i]) for i, r in enumerate(rows)],  # 11 floats per row
             "bytes_bwd_per_rank": [36 * (sum(r) - r[i]) for i, r in enumerate(rows)],  # 9 gradient floats back
             "rows_kept_local_per_rank": [rows[i][i] for i in range(world)],
             "bands_last_step": [[list(g), list(d)] for g, d in state.get("bands", [])],
-            "note": "last step; all-to-all-v over xGMI, rank i -> rank j peer copies; local rows do not leave the GPU"}
+            "note": "last step; all-to-all-v over xGMI, rank i -> rank j peer copies; local rows do not leave the GPU; "
+                    "bytes_fwd / bytes_bwd are the USEFUL rows, bytes_padded_* the zero rows that fill the capacity slabs "
+                    "on top of them (the wire carries both)"}
     opt.set_fuse_backward(False)
     del model, opt, cameras, history
     torch.cuda.empty_cache()
@@ -509,9 +575,16 @@ def main():
     ap.add_argument("--no-priming", action="store_true", help="skip the untimed set-up pass over the distinct cameras")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra workloads (N = 1: 4K, low opacity, 6 M "
                                                                 "Gaussians; N > 1: c4)")
-    ap.add_argument("--balance-timing", default="pipelined", choices=["exact", "pipelined"],
-                    help="N > 1 with live heuristics: how finish_strategy_final gets its timings (the library default "
-                         "is the reference's `exact`, which waits for the iteration's own events every step)")
+    ap.add_argument("--balance-timing", default="exact", choices=["exact", "pipelined"],
+                    help="N > 1 with live heuristics: how finish_strategy_final gets its timings.  `exact` (default, the "
+                         "headline) is the reference's schedule: wait for the iteration's own events every step "
+                         "(workload_division.py:944-998); `pipelined` uses the previous iteration's and is reported as a leg")
+    ap.add_argument("--no-legs", action="store_true",
+                    help="N > 1: skip the extra legs of the line (the same workload with pipelined balance timings, and "
+                         "the iteration replayed as one hipGraph -- the latter as a guarded child launch)")
+    ap.add_argument("--leg-child", action="store_true", help=argparse.SUPPRESS)  # this process IS a leg: no legs of its own
+    ap.add_argument("--leg-timeout", type=int, default=300, help="wall-clock limit of a guarded leg (seconds)")
+    ap.add_argument("--with-pipelined-leg", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-fuse-backward", action="store_true",
                     help="run K11 and Adam as two kernels (the parameter gradients go through HBM) instead of the fused "
                          "K11 + Adam launch")
@@ -534,8 +607,22 @@ def main():
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` on its own: become the launcher the reference's README uses (torchrun --standalone
         # --nproc-per-node N, README.md:199-202) -- one process per GPU over RCCL; rank 0 prints the JSON line
-        sys.stdout.flush()
-        os.execv(sys.executable, self_launch_command(a.gpus, sys.argv[1:]))
+        # -- as a SUPERVISOR: the eager leg and the graph leg are guarded child launches, so that whatever happens inside
+        # them (RCCL refusing two ranks on one device, a captured collective that never returns) this process still
+        # prints ONE JSON line, with the error of each leg in its place
+        argv = [x for x in sys.argv[1:]]
+        main_leg = run_guarded_leg(a.gpus, argv + ["--leg-child"] + ([] if a.no_legs else ["--with-pipelined-leg"]),
+                                   a.leg_timeout * 2)
+        out = main_leg if "error" not in main_leg else {
+            "metric": "training iters/sec (fwd+bwd)", "value": None, "unit": "images/s", "n_gpus": a.gpus,
+            "steps": a.steps, "warmup": a.warmup, "higher_is_better": True, "data": "synthetic", "dtype": "f32",
+            "error": main_leg["error"], "stderr_tail": main_leg.get("stderr_tail")}
+        if not a.no_legs and a.graph == "off":
+            g = run_guarded_leg(a.gpus, argv + ["--leg-child", "--graph", "on", "--no-extra", "--no-1gpu-leg",
+                                                "--repeats", "1", "--render-steps", "0"], a.leg_timeout)
+            out["graph_leg"] = brief_leg(g)
+        print(json.dumps(out), flush=True)
+        sys.exit(0 if "error" not in main_leg else 1)
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
@@ -552,6 +639,23 @@ def main():
         set_balance_timing(a.balance_timing)
     name = a.workload if a.workload != "auto" else ("c1" if world == 1 else "c2")
     main_res = run_workload(a, name, world, rank, dev, a.steps, a.warmup, a.repeats, a.render_steps)
+    legs = {}
+    legs_wanted = world > 1 and not a.no_legs and a.graph == "off" and (not a.leg_child or a.with_pipelined_leg)
+    if legs_wanted and a.balance_timing == "exact":
+        # the same workload with the previous iteration's timings feeding the load balancer (no wait for the iteration's
+        # own events): not the reference's schedule, hence a leg and not the headline
+        from gaussian_renderer.workload_division import set_balance_timing
+
+        set_balance_timing("pipelined")
+        try:
+            r = run_workload(a, name, world, rank, dev, min(a.steps, 20), min(a.warmup, 3), 1, 0, collect_kernels=False)
+            legs["pipelined"] = {"value": round(r["images_per_s"], 3), "unit": "images/s",
+                                 "ms_per_step": round(r["ms_per_step"], 4), "steps": r["steps"], "timing": r["timing"],
+                                 "balance_timing": "pipelined"}
+        except Exception as e:  # noqa: BLE001  (every rank fails alike)
+            legs["pipelined"] = {"error": f"{type(e).__name__}: {e}"}
+            torch.cuda.empty_cache()
+        set_balance_timing(a.balance_timing)
 
     def same_workload_1gpu(wname):
         """the same scene + camera on ONE GPU (rank 0's device); the other ranks wait at the barrier"""
@@ -609,6 +713,8 @@ def main():
             torch.mul(x, 2.0, out=y)  # vectorised elementwise kernel: 256 MiB read (16 B/lane) + 256 MiB written
         torch.cuda.synchronize()
 
+    if world > 1:
+        dist.barrier()  # every rank is done measuring (rank 0 may launch a guarded leg on the same GPUs afterwards)
     if rank != 0:
         return
 
@@ -764,6 +870,21 @@ def main():
         out["exchange_layouts"] = dict(gr.exchange_stats)
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(W, H, n_total)
+    if legs:
+        out["legs"] = legs
+    if world > 1 and not a.leg_child and not a.no_legs and a.graph == "off":
+        # launched by the driver (torch.distributed.run ... bench.py --gpus N): the graph leg is a guarded CHILD launch on
+        # the same GPUs once this job's ranks have left their process group -- an RCCL collective captured in a hipGraph
+        # has never run with two ranks, and whatever it does must not cost this line
+        try:
+            dist.destroy_process_group()
+        except Exception:  # noqa: BLE001
+            pass
+        torch.cuda.empty_cache()
+        argv = [x for x in sys.argv[1:] if x not in ("--with-pipelined-leg",)]
+        g = run_guarded_leg(world, argv + ["--leg-child", "--graph", "on", "--no-extra", "--no-1gpu-leg", "--repeats", "1",
+                                           "--render-steps", "0"], a.leg_timeout)
+        out["graph_leg"] = brief_leg(g)
     print(json.dumps(out), flush=True)
 
 

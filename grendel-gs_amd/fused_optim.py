@@ -189,6 +189,20 @@ class FusedAdam(torch.optim.Optimizer):
                 st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
             sts.append(st)
+        cap = _dgr.capturing()
+        if cap is not None:
+            # a captured iteration at world size > 1: the capacity flag is raised per rank (a band of THIS rank received too
+            # few rows, THIS rank's pair count outgrew its sort capacity), but skipping the update must be ONE decision --
+            # a rank that skips repeats the iteration eagerly and its collectives would pair with its peers' next replays.
+            # One 4-byte all-reduce (MAX) in front of the update makes every rank see every rank's flag
+            import torch.distributed as dist
+
+            import utils.general_utils as utils
+
+            group = utils.DEFAULT_GROUP
+            if group is not None and group.size() > 1 and dist.is_initialized():
+                dist.all_reduce(cap.flag, op=dist.ReduceOp.MAX,
+                                group=group if isinstance(group, dist.ProcessGroup) else None)
         # (the launch first, the host-side step counters after it: at world size > 1 the host is the bottleneck and
         # everything in front of this launch is time the GPU idles)
         pend.fused_step([st["exp_avg"] for st in sts], [st["exp_avg_sq"] for st in sts],

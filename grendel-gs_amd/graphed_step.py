@@ -217,6 +217,21 @@ class GraphedIteration:
         _dbg("captured; pair capacities", [c for _, c in e.ctx.pairs])
         return e
 
+    @staticmethod
+    def _group_says_no(failed):
+        """-> True when the capture failed on ANY rank of the default group (one eager 4-byte all-reduce)"""
+        import torch.distributed as dist
+
+        import utils.general_utils as utils
+
+        group = utils.DEFAULT_GROUP
+        if group is None or group.size() == 1 or not dist.is_initialized() or not isinstance(group, dist.ProcessGroup):
+            return failed
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        t = torch.tensor([1 if failed else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        return bool(int(t.item()))
+
     def _stage(self, entry, cameras):
         """-> sequence number of the replay these inputs are staged for"""
         self._seq = seq = (self._seq + 1) & 0x3FFFFFFF or 1
@@ -269,10 +284,29 @@ class GraphedIteration:
         self.entries.clear()
         self._seen.clear()
         out = None
-        for (cameras, strategies, tasks) in queue:
+        now = self._hyper_snapshot()
+        for (cameras, strategies, tasks, hyper) in queue:
+            self._hyper_restore(hyper)  # the learning rates / iteration counter of THAT iteration, not of the latest
             out = self.body(cameras, strategies, tasks)
             self.stats["redone"] += 1
+        self._hyper_restore(now)
         return out
+
+    def _hyper_snapshot(self):
+        """what the host-side schedule has set for the iteration being launched: per-group learning rates and the
+        process-wide iteration counter (a flagged replay is repeated eagerly LATER, when both have moved on)"""
+        import utils.general_utils as utils
+
+        return ([g["lr"] for g in self.opt.param_groups], utils.get_cur_iter())
+
+    def _hyper_restore(self, hyper):
+        import utils.general_utils as utils
+
+        lrs, it = hyper
+        for g, lr in zip(self.opt.param_groups, lrs):
+            g["lr"] = lr
+        if it is not None:
+            utils.set_cur_iter(it)
 
     def validate(self):
         """wait for the iteration in flight and make sure it counted (repeating it eagerly if a capacity overflowed);
@@ -292,14 +326,19 @@ class GraphedIteration:
             out = self.body(cameras, strategies, tasks)
             n = self._seen[key] = self._seen.get(key, 0) + 1
             if n >= self.warmup:
+                err = None
                 try:
                     self._capture(self._key(cameras, strategies), cameras, strategies, tasks)
                 except Exception as exc:  # noqa: BLE001
-                    # no graph for this process from here on: every rank fails the same way (the capture is
-                    # deterministic), so the ranks stay in step
                     _dgr._CAPTURE[0] = None
+                    err = f"{type(exc).__name__}: {exc}"
+                # replaying is ONE decision of the whole group: a rank whose capture failed would run eagerly while its
+                # peers replay, and their collectives would no longer pair up.  (Every rank reaches this point in the
+                # same iteration: the key's sightings are functions of the partition, which all ranks share.)
+                if self._group_says_no(err is not None):
+                    self.entries.clear()
                     self.enabled = False
-                    self.stats["disabled"] = f"{type(exc).__name__}: {exc}"
+                    self.stats["disabled"] = err or "the capture failed on another rank"
             return out
         # replay: inputs + hyper-parameters (one host-to-device copy, one band copy per camera), then ONE launch
         seq = self._stage(entry, cameras)
@@ -316,13 +355,13 @@ class GraphedIteration:
         self.stats["replayed"] += 1
         prev = self._inflight
         if prev is None:
-            self._inflight = (entry, seq, ev, [(cameras, strategies, tasks)])
+            self._inflight = (entry, seq, ev, [(cameras, strategies, tasks, self._hyper_snapshot())])
             return entry.out
         # look at the PREVIOUS replay now that this one keeps the device busy
         p_entry, p_seq, p_ev, p_queue = prev
-        self._inflight = (p_entry, p_seq, p_ev, p_queue + [(cameras, strategies, tasks)])
+        self._inflight = (p_entry, p_seq, p_ev, p_queue + [(cameras, strategies, tasks, self._hyper_snapshot())])
         redo = self._check_inflight()
         if redo is not None:
             return redo
-        self._inflight = (entry, seq, ev, [(cameras, strategies, tasks)])
+        self._inflight = (entry, seq, ev, [(cameras, strategies, tasks, self._hyper_snapshot())])
         return entry.out
