@@ -34,6 +34,9 @@
 #include <mutex>
 
 #include "radix.h"
+#ifndef GSR_EMIT_DECODE_BATCH
+#define GSR_EMIT_DECODE_BATCH 4
+#endif
 #include "binning_persist.h"
 
 namespace {
@@ -319,12 +322,7 @@ emit_scatter_kernel(int P, long long D, int xbits, const uint2 *__restrict__ rec
         if (d > D) return;
         D = d;
     }
-    // the decode's per-wave windows live in the pass's staging area (it is only written behind the workgroup barriers
-    // of onesweep_scatter, when every wave has finished decoding): no LDS of their own, four workgroups per CU
-    static_assert(260 * WAVES <= ITEMS * THREADS, "windows fit the key staging area");
-    uint32_t *const s_off = sm.skey + 260 * (threadIdx.x >> 6);    // [65]
-    uint32_t *const s_g = s_off + 66;                              // [64]
-    uint2 *const s_rect = reinterpret_cast<uint2 *>(s_off + 130);  // [64], 8-byte aligned
+    __shared__ uint32_t cflag[WAVES][ITEMS * 64 / 32];  // decode_chunk's 512 start bits per wave
     const uint32_t bid = onesweep_begin(sm, ticket);
     if ((long long)bid * (ITEMS * THREADS) >= D) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -333,63 +331,12 @@ emit_scatter_kernel(int P, long long D, int xbits, const uint2 *__restrict__ rec
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) { key[r] = 0xFFFFFFFFu; val[r] = 0u; }
     if (wbase < D) {  // wave-uniform
-        const uint32_t s_begin = (uint32_t)wbase;
-        // largest j in [0, P] with offsets[j] <= s_begin  (offsets is non-decreasing, offsets[P] = D > s_begin)
-        int lo = 0, hi = P;
-        while (hi - lo > 1) {
-            const int step = (hi - lo + 63) / 64;
-            const int idx = min(lo + lane * step, hi);
-            const bool le = offsets[idx] <= s_begin;
-            const int c = __popcll(__ballot(le));
-            const int nlo = lo + (c - 1) * step;
-            hi = min(hi, nlo + step);
-            lo = nlo;
-        }
-        int g0 = lo;
-        uint32_t wend = 0;  // first slot NOT covered by the window staged in LDS (0: nothing staged yet)
-        bool have_window = false;
-#pragma unroll
-        for (int r = 0; r < ITEMS; r++) {
-            const long long sj = wbase + r * 64 + lane;
-            const uint32_t s = (uint32_t)sj;
-            bool pending = sj < D;
-            while (__ballot(pending) != 0ull) {  // at most a few windows per round of 64 slots
-                if (!have_window || __ballot(pending && s >= wend) == __ballot(pending)) {
-                    // every pending slot lies beyond the staged window: stage the next 64 Gaussians
-                    if (have_window) g0 += 64;
-                    const int j = g0 + lane;
-                    const uint32_t off = offsets[min(j, P)];
-                    const uint32_t end = offsets[min(j + 1, P)];
-                    const uint32_t g = (j < P && end > off) ? sorted_ids[j] : 0u;
-                    __builtin_amdgcn_wave_barrier();
-                    s_off[lane] = off;
-                    if (lane == 63) s_off[64] = end;
-                    s_g[lane] = g;
-                    s_rect[lane] = (j < P && end > off) ? rects[g] : make_uint2(0u, 0u);
-                    __builtin_amdgcn_wave_barrier();
-                    wend = __builtin_amdgcn_readlane(end, 63);
-                    have_window = true;
-                }
-                if (pending && s < wend) {
-                    int a = 0, bnd = 63;
-#pragma unroll
-                    for (int it = 0; it < 6; it++) {
-                        const int mid = (a + bnd + 1) >> 1;
-                        if (s_off[mid] <= s) a = mid; else bnd = mid - 1;
-                    }
-                    const uint2 rc = s_rect[a];
-                    const uint32_t t = s - s_off[a];
-                    const uint32_t minx = rc.x & 0xFFFFu, w = (rc.x >> 16) - minx, miny = rc.y & 0xFFFFu;
-                    // t / w without the integer-division sequence (~15 VALU): the frame has <= 256 x 256 tiles on this
-                    // path, so the quotient is < 256 and (t + 0.5) / w stays >= 0.5 / 256 away from every integer --
-                    // orders of magnitude more than the error of rcp (1 ulp) and the product: the truncation is exact
-                    const uint32_t q = (uint32_t)(((float)t + 0.5f) * __builtin_amdgcn_rcpf((float)w));
-                    key[r] = ((miny + q) << xbits) | (minx + (t - q * w));
-                    val[r] = s_g[a];
-                    pending = false;
-                }
-            }
-        }
+        // the Gaussian that owns the chunk's first slot (64-ary search over the offsets), then the flag-word decode of
+        // binning_persist.h (round 5: replaces the per-slot binary search in LDS windows of 64 Gaussians -- ~30 VALU
+        // instructions per pair in a kernel that is 60-76 % VALU-busy -- by one broadcast read and a population count)
+        const int g0 = owner_search(offsets, 0, P, (uint32_t)wbase);
+        static_assert(ITEMS == PS_ITEMS, "decode_chunk decodes 8 rounds of 64 slots");
+        decode_chunk<GSR_EMIT_DECODE_BATCH>(offsets, sorted_ids, rects, P, D, wbase, g0, xbits, cflag[wave], key, val);
     }
     onesweep_scatter(sm, key, val, bid, D, 0, xbits, ghist, state, keys_out, vals_out);
 }
@@ -998,6 +945,36 @@ extern "C" int gsr_bin_sort_bounded(int P, int width, int height, const uint8_t 
     if (capacity <= 0) return GSR_EINVAL;
     return bin_sort_impl(P, width, height, compute_locally, prep, capacity, scratch, scratch_bytes, point_list, ranges,
                          reinterpret_cast<hipStream_t>(stream_), true);
+}
+
+// K3-K7 of one view in ONE call for callers that keep a grow-only scratch (the operator's path): gsr_bin_prepare_async,
+// then -- when `capacity` > 0 -- gsr_bin_sort_bounded into (scratch, point_list), then gsr_bin_count_wait.
+// *status = 0: the lists are complete (the count fitted the capacity); 1: the caller must run gsr_bin_sort with buffers for
+// *num_rendered_host pairs (no capacity yet, the count outgrew it, or the persistent prepare kernel repeated itself).
+extern "C" int gsr_bin_speculative(int P, int width, int height, const float *means2D, const float *depths,
+                                   const int32_t *radii, const float *conic_opacity, const uint8_t *compute_locally,
+                                   void *prep, size_t prep_bytes, int64_t capacity, void *scratch, size_t scratch_bytes,
+                                   uint32_t *point_list, int32_t *ranges, int64_t *num_rendered_host, int *status,
+                                   gsr_stream_t stream_) {
+    if (!num_rendered_host || !status) return GSR_EINVAL;
+    *num_rendered_host = 0;
+    *status = 1;
+    uint32_t ticket = 0;
+    int rc = gsr_bin_prepare_async(P, width, height, means2D, depths, radii, conic_opacity, compute_locally, prep,
+                                   prep_bytes, &ticket, stream_);
+    if (rc) return rc;
+    bool sorted = false;
+    if (capacity > 0 && ticket != 0 && scratch && point_list) {
+        rc = gsr_bin_sort_bounded(P, width, height, compute_locally, prep, capacity, scratch, scratch_bytes, point_list,
+                                  ranges, stream_);
+        if (rc) return rc;
+        sorted = true;
+    }
+    rc = gsr_bin_count_wait(ticket, num_rendered_host, stream_);
+    if (rc == GSR_ERETRY) return 0;  // (count valid, the bounded sort wrote nothing: status 1)
+    if (rc) return rc;
+    if (sorted && *num_rendered_host <= capacity) *status = 0;
+    return 0;
 }
 
 extern "C" size_t gsr_bin_total_offset(int P, int width, int height) {

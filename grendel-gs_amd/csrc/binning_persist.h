@@ -730,6 +730,7 @@ __device__ __forceinline__ int owner_search(const uint32_t *__restrict__ offsets
 // before p): the starts are marked as bits of a 512-bit LDS word set, and a round's owners follow from one broadcast
 // read and a population count -- no search, and the three dependent gathers (offset / id, then rect) of ALL rounds
 // are in flight together.
+template <int BATCH>  // rounds whose gathers are in flight together (8: all of them; 4 halves the registers held)
 __device__ __forceinline__ void decode_chunk(const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ sorted_ids,
                                              const uint2 *__restrict__ rects, int P, long long D, long long wbase, int g0,
                                              int xbits, uint32_t *__restrict__ cflag, uint32_t (&key)[PS_ITEMS],
@@ -759,29 +760,33 @@ __device__ __forceinline__ void decode_chunk(const uint32_t *__restrict__ offset
         jr[r] = g0 + carry + __popcll(m & le);
         carry += __popcll(m);
     }
-    uint32_t off[PS_ITEMS], gid[PS_ITEMS];
 #pragma unroll
-    for (int r = 0; r < PS_ITEMS; r++) {
-        const bool live = wbase + r * 64 + lane < D;
-        const int j = live ? jr[r] : g0;
-        off[r] = offsets[j];
-        gid[r] = sorted_ids[j];
-    }
-    uint2 rc[PS_ITEMS];
+    for (int r0 = 0; r0 < PS_ITEMS; r0 += BATCH) {
+        uint32_t off[BATCH], gid[BATCH];
 #pragma unroll
-    for (int r = 0; r < PS_ITEMS; r++) rc[r] = rects[gid[r]];
+        for (int i = 0; i < BATCH; i++) {
+            const bool live = wbase + (r0 + i) * 64 + lane < D;
+            const int j = live ? jr[r0 + i] : g0;
+            off[i] = offsets[j];
+            gid[i] = sorted_ids[j];
+        }
+        uint2 rc[BATCH];
 #pragma unroll
-    for (int r = 0; r < PS_ITEMS; r++) {
-        if (wbase + r * 64 + lane < D) {
-            const uint32_t s = cbeg + (uint32_t)(r * 64 + lane);
-            const uint32_t tq = s - off[r];
-            const uint32_t minx = rc[r].x & 0xFFFFu, wd = (rc[r].x >> 16) - minx, miny = rc[r].y & 0xFFFFu;
-            // tq / wd without the integer-division sequence (~15 VALU): the frame has <= 256 x 256 tiles on this path,
-            // so the quotient is < 256 and (tq + 0.5) / wd stays >= 0.5 / 256 away from every integer -- orders of
-            // magnitude more than the error of rcp (1 ulp) and the product: the truncation is exact
-            const uint32_t q = (uint32_t)(((float)tq + 0.5f) * __builtin_amdgcn_rcpf((float)wd));
-            key[r] = ((miny + q) << xbits) | (minx + (tq - q * wd));
-            val[r] = gid[r];
+        for (int i = 0; i < BATCH; i++) rc[i] = rects[gid[i]];
+#pragma unroll
+        for (int i = 0; i < BATCH; i++) {
+            const int r = r0 + i;
+            if (wbase + r * 64 + lane < D) {
+                const uint32_t s = cbeg + (uint32_t)(r * 64 + lane);
+                const uint32_t tq = s - off[i];
+                const uint32_t minx = rc[i].x & 0xFFFFu, wd = (rc[i].x >> 16) - minx, miny = rc[i].y & 0xFFFFu;
+                // tq / wd without the integer-division sequence (~15 VALU): the frame has <= 256 x 256 tiles on this
+                // path, so the quotient is < 256 and (tq + 0.5) / wd stays >= 0.5 / 256 away from every integer -- orders
+                // of magnitude more than the error of rcp (1 ulp) and the product: the truncation is exact
+                const uint32_t q = (uint32_t)(((float)tq + 0.5f) * __builtin_amdgcn_rcpf((float)wd));
+                key[r] = ((miny + q) << xbits) | (minx + (tq - q * wd));
+                val[r] = gid[i];
+            }
         }
     }
 }
@@ -894,7 +899,7 @@ bin_sort_persist_kernel(const SortPersistArgs a) {
             if (wbase < D) {  // wave-uniform
                 const int g0 = __builtin_amdgcn_readfirstlane(have_owners ? ex.owner[(int)((wbase - s0) / PS_CHUNK)]
                                                                           : owner_search(a.offsets, 0, P, (uint32_t)wbase));
-                decode_chunk(a.offsets, a.sorted_ids, a.rects, P, D, wbase, g0, a.xbits, ex.cflag[wave], key, val);
+                decode_chunk<PS_ITEMS>(a.offsets, a.sorted_ids, a.rects, P, D, wbase, g0, a.xbits, ex.cflag[wave], key, val);
             }
             count_wave_digits(sm, key, wbase, D, 0, xmask);
             __syncthreads();

@@ -798,37 +798,28 @@ def bin_gaussians(means2D, depths, radii, conic_opacity, compute_locally, width,
         _debug_overlap("prep", prep)
         _debug_overlap("means2D", means2D)
     stream = _stream()
-    ticket = ctypes.c_uint32(0)
-    with zhx_range(cuda_args, "24 updateDistributedStatLocally.updateTileTouched time"):
-        check(lib.gsr_bin_prepare_async(P, width, height, _ptr(means2D), _ptr(depths), _ptr(radii), _ptr(conic_opacity),
-                                        _ptr(compute_locally), _ptr(prep), prep_bytes, ctypes.byref(ticket), stream),
-              "gsr_bin_prepare_async")
     key = (dev.index if dev.index is not None else torch.cuda.current_device(), int(stream.value or 0))
     cap, point_list = 0, None
     kept = _SORT_SCRATCH.get(key)
-    if _SPECULATIVE_SORT[0] and kept is not None and ticket.value != 0:
+    if _SPECULATIVE_SORT[0] and kept is not None:
         # pairs the kept scratch can sort, but no more than the largest count seen here plus some slack (point_list
         # is allocated at the capacity)
         cap = min(int(lib.gsr_bin_sort_capacity(P, kept.numel(), width, height)), _bucket(4 * _MAX_PAIRS.get(key, 0)) // 4)
         if cap > 0:
             point_list = torch.empty((cap,), dtype=torch.int32, device=dev)
-            with zhx_range(cuda_args, "50 SortPairs time"):
-                check(lib.gsr_bin_sort_bounded(P, width, height, _ptr(compute_locally), _ptr(prep), cap, _ptr(kept),
-                                               kept.numel(), _ptr(point_list), _ptr(ranges), stream),
-                      "gsr_bin_sort_bounded")
-    D = ctypes.c_int64(0)
-    rc = lib.gsr_bin_count_wait(ticket, ctypes.byref(D), stream)
-    if rc == GSR_ERETRY:
-        # the persistent prepare kernel shared the device with another barrier kernel and repeated itself on the
-        # look-back pipeline (include/gsraster.h: gsr_set_bin_persistent): the count is valid, the speculative sort
-        # launched above wrote nothing
-        cap = 0
-    else:
-        check(rc, "gsr_bin_count_wait")
+    D, status = ctypes.c_int64(0), ctypes.c_int(1)
+    # ONE host-side call: K3-K4, the tile sort at the scratch's capacity, the pair count (include/gsraster.h)
+    with zhx_range(cuda_args, "24 updateDistributedStatLocally.updateTileTouched time"), \
+            zhx_range(cuda_args, "50 SortPairs time"):
+        check(lib.gsr_bin_speculative(P, width, height, _ptr(means2D), _ptr(depths), _ptr(radii), _ptr(conic_opacity),
+                                      _ptr(compute_locally), _ptr(prep), prep_bytes, cap if cap > 0 else 0,
+                                      _ptr(kept) if cap > 0 else None, kept.numel() if cap > 0 else 0,
+                                      _ptr(point_list) if cap > 0 else None, _ptr(ranges), ctypes.byref(D),
+                                      ctypes.byref(status), stream), "gsr_bin_speculative")
     D = int(D.value)
     if D > _MAX_PAIRS.get(key, 0):
         _MAX_PAIRS[key] = D
-    if cap > 0 and D <= cap:
+    if status.value == 0:
         return point_list[:max(D, 1)], ranges, D
     sort_bytes = lib.gsr_bin_sort_bytes(P, D, width, height)
     scratch = _sort_scratch(max(sort_bytes, 4), dev)

@@ -82,6 +82,9 @@ SIGNATURES = {
                                                      [c_void_p] * 5 + [c_int, c_int] + [c_void_p] * 6 + [c_int] +
                                                      [c_void_p] * 7 + [c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gsr_bin_total_offset": (c_size_t, [c_int, c_int, c_int]),
+    "gsr_bin_speculative": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_size_t, c_int64, c_void_p, c_size_t, c_void_p, c_void_p, ctypes.POINTER(c_int64),
+                                    ctypes.POINTER(c_int), c_void_p]),
     "gsr_set_bin_persistent": (c_int, [c_int]),
     "gsr_bin_persist_status": (c_int, [ctypes.POINTER(ctypes.c_uint32)]),
     "gsr_bin_timeline": (c_int, [c_int, c_void_p, c_int, ctypes.POINTER(c_int)]),

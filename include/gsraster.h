@@ -138,6 +138,14 @@ int gsr_bin_prepare_async(int P, int width, int height, const float *means2D, co
                           uint32_t *ticket, gsr_stream_t stream);
 int gsr_bin_count_wait(uint32_t ticket, int64_t *num_rendered_host, gsr_stream_t stream);
 int64_t gsr_bin_sort_capacity(int P, size_t scratch_bytes, int width, int height);
+/* The three calls above as ONE (ABI 11; one host-side call per view instead of three): prepare, then -- `capacity` > 0 --
+ * the bounded sort into (scratch, point_list [capacity]), then the count.  *status = 0: lists and ranges are complete;
+ * 1: run gsr_bin_sort with buffers for *num_rendered_host pairs (no capacity given, the count outgrew it, or the
+ * persistent prepare kernel had to repeat itself: see gsr_set_bin_persistent). */
+int gsr_bin_speculative(int P, int width, int height, const float *means2D, const float *depths, const int32_t *radii,
+                        const float *conic_opacity, const uint8_t *compute_locally, void *prep, size_t prep_bytes,
+                        int64_t capacity, void *scratch, size_t scratch_bytes, uint32_t *point_list, int32_t *ranges,
+                        int64_t *num_rendered_host, int *status, gsr_stream_t stream);
 /* K3-K7 run as TWO persistent launches whose workgroups meet at grid-wide barriers (ABI 11; csrc/binning_persist.h)
  * instead of the nine launches of the look-back pipeline, when the device can hold the grid at once, the frame has
  * <= 256 x 256 tiles and P <= 8 x 4096 x CUs.  Lists, ranges and offsets are bit-identical.  A barrier kernel needs
