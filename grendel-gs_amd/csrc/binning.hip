@@ -637,9 +637,16 @@ int prepare_persistent(const PrepCall &c, uint32_t *ticket) {
     if (dev < 0 || dev >= 64) return 1;
     PersistCaps caps;
     persist_caps(dev, &caps);
-    const long long nb = radix_blocks(c.P);
+    // tiles of 4096 Gaussians, or of 8192 when that brings the launch down to one tile per workgroup
+    const int max_tpw = env_cap("GSR_BIN_MAX_TPW", PP_MAX_TPW + 1) <= PP_MAX_TPW ? env_cap("GSR_BIN_MAX_TPW", PP_MAX_TPW + 1) : 1;
+    long long nb = radix_blocks(c.P);
+    int items = 4;
+    if (nb > caps.grid_p && (nb + 1) / 2 <= caps.grid_p) {
+        items = 8;
+        nb = (nb + 1) / 2;
+    }
     const int G = (int)(nb < caps.grid_p ? nb : caps.grid_p);
-    if (G <= 0 || nb > (long long)G * PP_MAX_TPW) return 1;  // (long sorts are bandwidth-bound: look-back pipeline)
+    if (G <= 0 || nb > (long long)G * max_tpw) return 1;  // (long sorts are bandwidth-bound: look-back pipeline)
     const long long admit = persist_admit(dev, c.stream);
     if (admit < 0) return 1;
     const int P = c.P;
@@ -681,7 +688,8 @@ int prepare_persistent(const PrepCall &c, uint32_t *ticket) {
     a.done_seq = (uint32_t)admit;
     a.timeout_ticks = 5000000ull;  // 50 ms of the 100 MHz clock at the first barrier
     a.notrap = env_cap("GSR_BIN_NOTRAP", 2) == 1;
-    hipLaunchKernelGGL(bin_prepare_persist_kernel, dim3(G), dim3(PP_THREADS), 0, c.stream, a);
+    if (items == 4) hipLaunchKernelGGL(bin_prepare_persist_kernel<4>, dim3(G), dim3(PP_THREADS), 0, c.stream, a);
+    else hipLaunchKernelGGL(bin_prepare_persist_kernel<8>, dim3(G), dim3(PP_THREADS), 0, c.stream, a);
     GSR_LAUNCH_CHECK();
     *ticket = seq;
     return 0;

@@ -347,9 +347,13 @@ __device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v) {
     } while (0)
 
 // ======================================================================================= the P-sized chain
-constexpr int PP_THREADS = 1024, PP_ITEMS = 4, PP_TILE = PP_THREADS * PP_ITEMS, PP_WAVES = PP_THREADS / 64;
-constexpr int PP_MAX_TPW = 8;  // tiles per workgroup above which the look-back pipeline (bandwidth-bound there) is used
-static_assert(PP_TILE == RADIX_TILE, "tiles of both pipelines have 4096 elements");
+constexpr int PP_THREADS = 1024, PP_WAVES = PP_THREADS / 64;
+// Elements per thread: 4 (tiles of 4096: up to CUs x 4096 Gaussians with ONE tile per workgroup -- its pairs never leave
+// the registers between a count phase and its scatter phase) or 8 (tiles of 8192: twice as many).  Several tiles per
+// workgroup work (tests run them through GSR_BIN_GRID_P) but lose to the look-back pipeline: every phase then lasts as
+// long as the workgroups with one tile more (measured on configs[2]'s 6 M Gaussians, 5.7 tiles per workgroup: +0.11 ms),
+// so production launches need one tile per workgroup (GSR_BIN_MAX_TPW raises it for experiments).
+constexpr int PP_MAX_TPW = 8;
 
 struct PrepPersistArgs {
     int P, gx, gy;
@@ -381,8 +385,10 @@ struct PPExtra {
 };
 
 
+template <int PP_ITEMS>
 __global__ void __launch_bounds__(PP_THREADS)
 bin_prepare_persist_kernel(const PrepPersistArgs a) {
+    constexpr int PP_TILE = PP_THREADS * PP_ITEMS;
     __shared__ PersistSmem<PP_ITEMS, PP_THREADS> sm;
     __shared__ PPExtra ex;
     __shared__ uint32_t red2[2 * PP_THREADS];  // reduction scratch of counts_finish (the staging area is in use then)
@@ -427,38 +433,42 @@ bin_prepare_persist_kernel(const PrepPersistArgs a) {
     uint32_t mytot = 0;  // thread d < 256: this workgroup's count of digit d in the pass being counted
     for (long long t = t0; t < t1; t++) {
         const long long wbase = t * PP_TILE + (long long)wave * (PP_ITEMS * 64);
-        // every input of the thread's four Gaussians is requested before the first is looked at (clamped indices, no
+        // every input of four of the thread's Gaussians is requested before the first is looked at (clamped indices, no
         // branches): fetched where needed, the radius -> position / conic -> depth chain cost 20 us of this phase
-        int rad[PP_ITEMS];
-        float2 xy[PP_ITEMS];
-        float4 co[PP_ITEMS];
-        float dep[PP_ITEMS];
 #pragma unroll
-        for (int r = 0; r < PP_ITEMS; r++) {
+        for (int r0 = 0; r0 < PP_ITEMS; r0 += 4) {
+        int rad[4];
+        float2 xy[4];
+        float4 co[4];
+        float dep[4];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; q4++) {
+            const int r = r0 + q4;
             const long long i = wbase + r * 64 + lane;
             const long long ic = i < P ? i : P - 1;
-            rad[r] = a.radii[ic];
-            xy[r] = a.means2D[ic];
-            co[r] = a.conic_opacity[ic];
-            dep[r] = a.depths[ic];
+            rad[q4] = a.radii[ic];
+            xy[q4] = a.means2D[ic];
+            co[q4] = a.conic_opacity[ic];
+            dep[q4] = a.depths[ic];
         }
 #pragma unroll
-        for (int r = 0; r < PP_ITEMS; r++) {
+        for (int q4 = 0; q4 < 4; q4++) {
+            const int r = r0 + q4;
             const long long i = wbase + r * 64 + lane;
             key[r] = 0xFFFFFFFFu;
             val[r] = (uint32_t)i;
             if (i < P) {
                 uint32_t n = 0;
                 uint2 rect = make_uint2(0u, 0u);
-                if (rad[r] > 0) {
+                if (rad[q4] > 0) {
                     float exx, eyy;
-                    if (gsr_alpha_extent(co[r], exx, eyy)) {
+                    if (gsr_alpha_extent(co[q4], exx, eyy)) {
                         int minx, miny, maxx, maxy;
-                        gsr_get_rect(xy[r].x, xy[r].y, rad[r], a.gx, a.gy, minx, miny, maxx, maxy);
-                        minx = max(minx, (int)ceilf((xy[r].x - exx - (GSR_BLOCK_X - 1)) * (1.0f / GSR_BLOCK_X)));
-                        maxx = min(maxx, (int)floorf((xy[r].x + exx) * (1.0f / GSR_BLOCK_X)) + 1);
-                        miny = max(max(miny, hull0), (int)ceilf((xy[r].y - eyy - (GSR_BLOCK_Y - 1)) * (1.0f / GSR_BLOCK_Y)));
-                        maxy = min(min(maxy, hull1), (int)floorf((xy[r].y + eyy) * (1.0f / GSR_BLOCK_Y)) + 1);
+                        gsr_get_rect(xy[q4].x, xy[q4].y, rad[q4], a.gx, a.gy, minx, miny, maxx, maxy);
+                        minx = max(minx, (int)ceilf((xy[q4].x - exx - (GSR_BLOCK_X - 1)) * (1.0f / GSR_BLOCK_X)));
+                        maxx = min(maxx, (int)floorf((xy[q4].x + exx) * (1.0f / GSR_BLOCK_X)) + 1);
+                        miny = max(max(miny, hull0), (int)ceilf((xy[q4].y - eyy - (GSR_BLOCK_Y - 1)) * (1.0f / GSR_BLOCK_Y)));
+                        maxy = min(min(maxy, hull1), (int)floorf((xy[q4].y + eyy) * (1.0f / GSR_BLOCK_Y)) + 1);
                         if (maxx > minx && maxy > miny) {
                             n = (uint32_t)((maxx - minx) * (maxy - miny));
                             rect = make_uint2((uint32_t)minx | ((uint32_t)maxx << 16),
@@ -472,7 +482,7 @@ bin_prepare_persist_kernel(const PrepPersistArgs a) {
                         }
                     }
                 }
-                if (n) key[r] = __float_as_uint(dep[r]);
+                if (n) key[r] = __float_as_uint(dep[q4]);
                 st_agent(&a.tt[i], n);  // (gathered by other workgroups in the scan phase)
                 a.rects[i] = rect;
                 if (!keep) {
@@ -480,6 +490,7 @@ bin_prepare_persist_kernel(const PrepPersistArgs a) {
                     st_agent(&a.vA[i], val[r]);
                 }
             }
+        }
         }
         count_wave_digits(sm, key, wbase, P, 0, 0xFFu);
         __syncthreads();
@@ -670,6 +681,9 @@ bin_prepare_persist_kernel(const PrepPersistArgs a) {
 // ======================================================================================= the D-sized chain
 constexpr int PS_THREADS = 512, PS_ITEMS = 8, PS_TILE = PS_THREADS * PS_ITEMS, PS_WAVES = PS_THREADS / 64;
 constexpr int PS_CHUNK = PS_ITEMS * 64;  // slots of one wave of one tile
+#ifndef GSR_PS_DECODE_BATCH
+#define GSR_PS_DECODE_BATCH 8
+#endif
 #ifndef GSR_PS_MIN_WAVES
 #define GSR_PS_MIN_WAVES 4
 #endif
@@ -899,7 +913,7 @@ bin_sort_persist_kernel(const SortPersistArgs a) {
             if (wbase < D) {  // wave-uniform
                 const int g0 = __builtin_amdgcn_readfirstlane(have_owners ? ex.owner[(int)((wbase - s0) / PS_CHUNK)]
                                                                           : owner_search(a.offsets, 0, P, (uint32_t)wbase));
-                decode_chunk<PS_ITEMS>(a.offsets, a.sorted_ids, a.rects, P, D, wbase, g0, a.xbits, ex.cflag[wave], key, val);
+                decode_chunk<GSR_PS_DECODE_BATCH>(a.offsets, a.sorted_ids, a.rects, P, D, wbase, g0, a.xbits, ex.cflag[wave], key, val);
             }
             count_wave_digits(sm, key, wbase, D, 0, xmask);
             __syncthreads();
@@ -1088,13 +1102,14 @@ int persist_caps(int dev, PersistCaps *out) {
     PersistCaps &c = g_persist_caps[dev];
     if (!c.init) {
         c.init = true;
-        int cus = 0, per_p = 0, per_s = 0;
+        int cus = 0, per_p = 0, per_p8 = 0, per_s = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0 &&
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_p, bin_prepare_persist_kernel, PP_THREADS, 0) == hipSuccess &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_p, bin_prepare_persist_kernel<4>, PP_THREADS, 0) == hipSuccess &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_p8, bin_prepare_persist_kernel<8>, PP_THREADS, 0) == hipSuccess &&
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_s, bin_sort_persist_kernel, PS_THREADS, 0) == hipSuccess) {
             // one prepare workgroup per CU (16 waves: the latency chain of a tile wants the CU to itself); the sort
             // fills the device (four per CU when the registers allow)
-            c.grid_p = per_p >= 1 ? (cus < PERSIST_MAX_GRID_P ? cus : PERSIST_MAX_GRID_P) : 0;
+            c.grid_p = (per_p >= 1 && per_p8 >= 1) ? (cus < PERSIST_MAX_GRID_P ? cus : PERSIST_MAX_GRID_P) : 0;
             const long long gs = (long long)cus * (per_s < 4 ? per_s : 4);
             c.grid_s = per_s >= 1 ? (int)(gs < PERSIST_MAX_GRID_S ? gs : PERSIST_MAX_GRID_S) : 0;
         }

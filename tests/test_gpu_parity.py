@@ -154,17 +154,22 @@ def test_speculative_sort_equals_the_sized_sort(device):
         dgr.release_workspaces()
 
 
-@pytest.mark.parametrize("grid_p,grid_s,owners", [(None, None, None), (1, 3, None), (2, 5, 1), (3, 64, 2)])
-def test_persistent_binning_equals_the_lookback_pipeline(device, monkeypatch, grid_p, grid_s, owners):
+@pytest.mark.parametrize("grid_p,grid_s,owners,max_tpw", [(None, None, None, None), (1, 3, None, 8), (2, 5, 1, 8),
+                                                          (3, 64, 2, 8), (2, None, None, None)])
+def test_persistent_binning_equals_the_lookback_pipeline(device, monkeypatch, grid_p, grid_s, owners, max_tpw):
     """K3-K7 as two persistent launches with grid barriers (csrc/binning_persist.h) against the nine launches of the
-    look-back pipeline: bit-identical lists and ranges -- with one tile per workgroup and (grids capped through the
-    test hooks) many tiles per workgroup, with the chunk-owner table and with the per-chunk search, through the sized
+    look-back pipeline: bit-identical lists and ranges -- with one tile per workgroup (4096 or 8192 elements) and (grids
+    capped through the test hooks) many tiles per workgroup, with the chunk-owner table and with the per-chunk search, through the sized
     and the speculative (bounded) sort, with an empty view; each half of the pipeline also combined with the other
     pipeline's half"""
     import diff_gaussian_rasterization as dgr
     from oracle import cref as C
 
-    for name, v in (("GSR_BIN_GRID_P", grid_p), ("GSR_BIN_GRID_S", grid_s), ("GSR_BIN_OWNERS", owners)):
+    # (grid_p = 2 without max_tpw: 9000 Gaussians take the 8192-element tiles, 20000 fall back to the look-back pipeline;
+    # GSR_BIN_PERSIST_MAXD: the sort kernel whatever the pair count)
+    monkeypatch.setenv("GSR_BIN_PERSIST_MAXD", "1000000000")
+    for name, v in (("GSR_BIN_GRID_P", grid_p), ("GSR_BIN_GRID_S", grid_s), ("GSR_BIN_OWNERS", owners),
+                    ("GSR_BIN_MAX_TPW", max_tpw)):
         if v is not None:
             monkeypatch.setenv(name, str(v))
     W, H = 333, 211

@@ -12,6 +12,18 @@ mkdir -p $O
 export TMPDIR=/tmp
 has() { [[ " $STAGES " == *" $1 "* ]]; }
 cd $R
+summ() {  # json file -> one line
+  python - "$1" "$2" <<'PY'
+import json, sys
+try:
+    d = json.load(open(sys.argv[1]))
+    k = d["kernels"]
+    print("%-14s %7.1f img/s  %.3f ms  views %7.1f | " % (sys.argv[2], d["value"], d["ms_per_step"], d["rendered_views_per_sec"]) +
+          "  ".join("%s %.4f" % (n[:16], v["avg_ms"]) for n, v in k.items()))
+except Exception as e:
+    print(sys.argv[2], "FAILED", e)
+PY
+}
 if has bintest; then
   timeout 600 python -m pytest tests/test_gpu_parity.py -q -m gpu -x -p no:cacheprovider -k "persistent or binning or speculative" > $O/bintest.log 2>&1
   echo "bintest pytest exit $?" | tee -a $O/bintest.log
@@ -36,5 +48,19 @@ if has fullsize; then
   tail -6 $O/fullsize.log | cut -c1-300
 fi
 for st in $STAGES; do
-  case $st in bintest|binbench|binbig|fullsize) ;; *) bash tools/gpu_run.sh $TAG $st ;; esac
+  case $st in bintest|binbench|binbig|fullsize|shapes|fakeab) ;; *) bash tools/gpu_run.sh $TAG $st ;; esac
 done
+if has shapes; then
+  for wl in c2 c4; do
+    timeout 600 python bench.py --workload $wl --no-cpu-baseline --no-extra --steps 10 --warmup 4 --repeats 1 --render-steps 4 > $O/bench_${wl}_shape.json 2> $O/bench_${wl}_shape.err
+    echo "bench $wl shape exit $?"; summ $O/bench_${wl}_shape.json $wl
+    GSR_BIN_PERSIST=0 timeout 600 python bench.py --workload $wl --no-cpu-baseline --no-extra --steps 10 --warmup 4 --repeats 1 --render-steps 4 > $O/bench_${wl}_shape_off.json 2> $O/bench_${wl}_shape_off.err
+    summ $O/bench_${wl}_shape_off.json "$wl persist=0"
+  done
+fi
+if has fakeab; then
+  for v in 1 0; do
+    GSR_BIN_PERSIST=$v timeout 400 python tools/fake_world_bench.py --workload c2 --worlds 1 8 --steps 20 > $O/fake_c2_persist$v.txt 2> $O/fake_c2_persist$v.err
+    echo "persist=$v"; cut -c1-600 $O/fake_c2_persist$v.txt
+  done
+fi
