@@ -300,13 +300,8 @@ def run_workload(a, name, world, rank, dev, steps, warmup, repeats, render_steps
     # scene/gaussian_model.py:292 settings; grad /= bsz (train_internal.py:319-324) folded into the update.  With
     # fuse_backward the projection backward K11 runs inside the optimizer kernel (fused_optim.py): same arithmetic, the
     # six parameter gradients never reach HBM; --no-fuse-backward measures the two-kernel form
-    # step_in_backward (multi-rank runs, where the step is host-bound): the fused launch is issued at the end of
-    # loss.backward() instead of from opt.step() -- same arithmetic, nothing reads the parameters in between here
-    # (measured on one rank of a fake 8-rank world: 1.382 ms with, 1.381 ms without -- the host is the bottleneck of the
-    # whole step, an earlier launch only moves the gap -- hence off unless asked for)
-    sib = getattr(a, "step_in_backward", "off") == "on" and not a.no_fuse_backward
     opt = FusedAdam(model.param_groups(), lr=0.0, eps=1e-15, fuse_backward=not a.no_fuse_backward,
-                    grad_scale=1.0 / bsz, step_in_backward=sib)
+                    grad_scale=1.0 / bsz)
     state = {"it": 0, "sizes": None}
 
     def batch():
@@ -457,7 +452,6 @@ def run_workload(a, name, world, rank, dev, steps, warmup, repeats, render_steps
            "ms_per_step": 1e3 * dt / steps, "images_per_s": bsz * steps / dt, "priming_steps": priming,
            "kernels_region_ms_per_step": (1e3 * dt_instr / steps) if dt_instr else None,
            "optimizer": {"fuse_backward": bool(opt.fuse_backward), "fused_steps": fused_steps,
-                         "step_in_backward": bool(opt.step_in_backward), "stepped_in_backward": opt.stepped_in_backward,
                          "materialized_steps": opt.materialized_steps,
                          "ms_per_step_two_kernels": round(1e3 * dt_unfused / steps, 4) if dt_unfused else None,
                          "images_per_s_two_kernels": round(bsz * steps / dt_unfused, 3) if dt_unfused else None,
@@ -619,8 +613,6 @@ def main():
     ap.add_argument("--balance-every", type=int, default=0,
                     help="with --graph on and live heuristics: every R-th iteration is an eager, timed one that feeds "
                          "the load balancer; the partition is frozen in between (0: never freeze -> no graph)")
-    ap.add_argument("--step-in-backward", default="off", choices=["on", "off"],
-                    help="issue the fused K11 + Adam launch at the end of loss.backward() instead of from opt.step()")
     ap.add_argument("--no-1gpu-leg", action="store_true", help="N > 1: skip the same-workload single-GPU leg")
     ap.add_argument("--render-steps", type=int, default=20, help="forward-only views/sec leg (untimed by driver)")
     ap.add_argument("--pmc-calib", action="store_true", help="also run a 256 MiB streaming multiply (PMC calibration)")

@@ -27,20 +27,9 @@ from diff_gaussian_rasterization import _lib, _on, _stream, kernel_timer
 
 
 class FusedAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, fuse_backward=False, grad_scale=1.0,
-                 step_in_backward=False):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, fuse_backward=False, grad_scale=1.0):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self.grad_scale = float(grad_scale)
-        # step_in_backward (opt-in, needs fuse_backward): the fused K11 + Adam launch is issued where the projection
-        # backward would have run K11 -- at the END of loss.backward() -- instead of when step() is called.  On a
-        # host-bound step (world size > 1) the launch otherwise waits for the host to finish the backward, the load
-        # balancer's bookkeeping and the optimizer's own (measured: a 180-240 us gap in front of the kernel on one rank of
-        # eight, profiles/r03s2_fake_world_w8_gaps.txt).  step() then only completes the bookkeeping.  Same arithmetic;
-        # what changes is WHEN the parameters move: code between backward() and step() sees the updated values, and a
-        # second backward before step() cannot be accumulated -- not for densification iterations of the reference's loop
-        # (they replace parameters between the two calls): switch it off around them (set_step_in_backward(False)).
-        self.step_in_backward = bool(step_in_backward)
-        self.stepped_in_backward = 0
         self._pending = None
         self._owners_cache = None
         self._launch_cache = {}
@@ -57,8 +46,6 @@ class FusedAdam(torch.optim.Optimizer):
         self.__dict__.setdefault("grad_scale", 1.0)
         self._pending, self._owners_cache, self._launch_cache, self.fuse_backward = None, None, {}, False
         self._warned_replicated = False
-        self.__dict__.setdefault("step_in_backward", False)
-        self.__dict__.setdefault("stepped_in_backward", 0)
         self.__dict__.setdefault("fused_steps", 0)
         self.__dict__.setdefault("materialized_steps", 0)
 
@@ -124,9 +111,6 @@ class FusedAdam(torch.optim.Optimizer):
             self._warned_replicated = True
         return True
 
-    def set_step_in_backward(self, on):
-        self.step_in_backward = bool(on)
-
     def offer(self, pending):
         if self._pending is not None:  # a second backward before the step: both become ordinary gradients
             self._flush_pending()
@@ -134,12 +118,6 @@ class FusedAdam(torch.optim.Optimizer):
             self._flush_pending()
             return
         self._pending = pending
-        if self.step_in_backward and _dgr.capturing() is None:
-            # launch now (we are inside loss.backward(), on the stream the backward runs on); step() finds nothing pending
-            with torch.no_grad():
-                done = self._fused_backward_step(self.grad_scale)
-            if done:
-                self.stepped_in_backward += 1
 
     def _flush_pending(self):
         """materialize the pending projection backward into `.grad` of the parameters that are still the tensors it

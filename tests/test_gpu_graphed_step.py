@@ -35,7 +35,7 @@ def _setup(device, bsz, forced):
     return N, W, H, cams
 
 
-def _train(device, steps, bsz, graph, forced=False, shrink_pairs=None, eager_at=(), burst_at=(), sib=False):
+def _train(device, steps, bsz, graph, forced=False, shrink_pairs=None, eager_at=(), burst_at=()):
     """-> (losses per step, final parameters, moments, GraphedIteration stats)"""
     import diff_gaussian_rasterization as dgr
     import synthetic_scene as S
@@ -52,8 +52,7 @@ def _train(device, steps, bsz, graph, forced=False, shrink_pairs=None, eager_at=
     hist = DivisionStrategyHistoryFinal(S.SyntheticDataset(cams), 1, 0)
     bg = torch.tensor([0.1, 0.2, 0.3], device=device)
     pipe = type("P", (), {"debug": False})()
-    opt = FusedAdam(model.param_groups(), lr=0.0, eps=1e-15, fuse_backward=True, grad_scale=1.0 / bsz,
-                    step_in_backward=sib)
+    opt = FusedAdam(model.param_groups(), lr=0.0, eps=1e-15, fuse_backward=True, grad_scale=1.0 / bsz)
 
     def body(batch, strategies, tasks):
         load_camera_from_cpu_to_all_gpu(batch, strategies, tasks)
@@ -100,7 +99,6 @@ def _train(device, steps, bsz, graph, forced=False, shrink_pairs=None, eager_at=
     delta = {n: params[n] - getattr(init, n).detach() for n in NAMES}
     opt.set_fuse_backward(False)
     st = dict(step.stats)
-    st["stepped_in_backward"] = opt.stepped_in_backward
     return losses, delta, moments, st
 
 
@@ -182,16 +180,4 @@ def test_replays_resume_after_eager_iterations(device):
     run = _train(device, steps, 1, graph=True, eager_at=eager_at, burst_at=(4, 9, 52, 55))
     st = run[3]
     assert st["disabled"] is None and st["captured"] == 1 and st["replayed"] == steps - 2 - len(eager_at), st
-    _compare(run, ref, steps)
-
-
-@pytest.mark.parametrize("graph", [False, True])
-def test_step_in_backward_equals_step_at_step(device, graph):
-    """FusedAdam(step_in_backward=True): the fused K11 + Adam launch is issued at the end of loss.backward() (where the
-    host of a multi-rank step would otherwise leave the GPU waiting for opt.step()); same arithmetic, same results --
-    eagerly and with the iteration captured (the captured launch stays where step() is called)"""
-    steps = 6
-    ref = _train(device, steps, 2, graph=False)
-    run = _train(device, steps, 2, graph=graph, sib=True)
-    assert run[3]["stepped_in_backward"] == (2 if graph else steps), run[3]
     _compare(run, ref, steps)

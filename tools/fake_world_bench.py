@@ -151,7 +151,6 @@ def main():
     ap.add_argument("--bsz", type=int, default=0)
     ap.add_argument("--no-fuse-backward", action="store_true", help="K11 and Adam as two kernels")
     ap.add_argument("--graph", default="off", choices=["off", "on"], help="replay the iteration as one hipGraph")
-    ap.add_argument("--step-in-backward", default="off", choices=["on", "off"])
     ap.add_argument("--balanced", type=int, default=0, metavar="ROUNDS",
                     help="balance the row partition with Grendel's own rule over ROUNDS rounds (every rank position "
                          "measured in turn), then measure EVERY rank position on the converged partition")
@@ -177,8 +176,7 @@ def main():
     def one_run(W, rank, graph, steps, warmup, frozen, timed_probe=False, collect=True):
         a = argparse.Namespace(gaussians=0, width=0, height=0, bsz=a0.bsz, views=8, opacity_logit_mean=0.0,
                                opacity_logit_std=2.0, device_scene=False, no_priming=False,
-                               no_fuse_backward=a0.no_fuse_backward, graph=graph, balance_every=0,
-                               step_in_backward=a0.step_in_backward)
+                               no_fuse_backward=a0.no_fuse_backward, graph=graph, balance_every=0)
         os.environ["WORLD_SIZE"] = str(W)
         utils.GLOBAL_RANK, utils.LOCAL_RANK, utils.WORLD_SIZE = (rank if W > 1 else 0), 0, W
         utils.DEFAULT_GROUP = utils.IN_NODE_GROUP = FakeGroup(W, rank) if W > 1 else utils.SingleGPUGroup()
@@ -229,8 +227,7 @@ def main():
         # the fields run_workload reads
         a = argparse.Namespace(gaussians=0, width=0, height=0, bsz=a0.bsz, views=8, opacity_logit_mean=0.0,
                                opacity_logit_std=2.0, device_scene=False, no_priming=False,
-                               no_fuse_backward=a0.no_fuse_backward, graph=a0.graph, balance_every=0,
-                               step_in_backward=a0.step_in_backward)
+                               no_fuse_backward=a0.no_fuse_backward, graph=a0.graph, balance_every=0)
         os.environ["WORLD_SIZE"] = str(W)
         utils.GLOBAL_RANK, utils.LOCAL_RANK, utils.WORLD_SIZE = (rank if W > 1 else 0), 0, W
         utils.DEFAULT_GROUP = utils.IN_NODE_GROUP = FakeGroup(W, rank) if W > 1 else utils.SingleGPUGroup()

@@ -31,8 +31,10 @@ GROUPS = [  # (group, substrings of the kernel symbol, substring that marks ONE 
     ("preprocess_forward", ["preprocess_forward"], "preprocess_forward"),
     ("preprocess_backward_adam", ["preprocess_backward_adam"], "preprocess_backward_adam"),  # fused K11 + Adam (first)
     ("preprocess_backward", ["preprocess_backward"], "preprocess_backward"),
+    # (one call = one K3: the look-back pipeline's touch_count_kernel or the persistent prepare kernel of round 5)
     ("binning", ["touch_count_kernel", "radix_onesweep_kernel", "scan_gather_lookback_kernel", "emit_scatter_kernel",
-                 "emit_pairs_kernel", "tile_ranges"], "touch_count_kernel"),
+                 "emit_pairs_kernel", "tile_ranges", "bin_prepare_persist_kernel", "bin_sort_persist_kernel"],
+     ("touch_count_kernel", "bin_prepare_persist_kernel")),
     ("l1_ssim_forward", ["l1_ssim_forward_kernel", "l1_ssim_finalize_kernel"], "l1_ssim_forward_kernel"),
     ("l1_ssim_backward", ["l1_ssim_backward_kernel"], "l1_ssim_backward_kernel"),
     ("adam", ["adam_kernel", "adam_multi_kernel"], None),
@@ -97,7 +99,8 @@ def main():
         marker = [m for gg, _, m in GROUPS if gg == g][0]
         if marker is None:
             return sum(n for sym, (n, *_) in table.items() if group_of(sym) == g)
-        return sum(n for sym, (n, *_) in table.items() if marker in sym)
+        markers = (marker,) if isinstance(marker, str) else marker
+        return sum(n for sym, (n, *_) in table.items() if any(m in sym for m in markers))
 
     tdb = find_db(a.trace)
     if tdb:
