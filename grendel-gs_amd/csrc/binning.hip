@@ -35,7 +35,7 @@
 
 #include "radix.h"
 #ifndef GSR_EMIT_DECODE_BATCH
-#define GSR_EMIT_DECODE_BATCH 4
+#define GSR_EMIT_DECODE_BATCH 2
 #endif
 #include "binning_persist.h"
 
@@ -129,8 +129,9 @@ __global__ void __launch_bounds__(TC_THREADS)
 touch_count_kernel(int P, int gx, int gy, const float2 *__restrict__ means2D, const float *__restrict__ depths,
                    const int32_t *__restrict__ radii, const float4 *__restrict__ conic_opacity,
                    const uint8_t *__restrict__ mask, RadixPlan plan, uint32_t *__restrict__ tt,
-                   uint32_t *__restrict__ keys, uint32_t *__restrict__ vals, uint2 *__restrict__ rects,
-                   uint32_t *__restrict__ ghist, uint32_t *__restrict__ tile_hist, int32_t *__restrict__ hull_out) {
+                   uint32_t *__restrict__ keys, uint32_t *__restrict__ vals, TileRect *__restrict__ rects,
+                   uint32_t *__restrict__ ghist, uint32_t *__restrict__ tile_hist, int32_t *__restrict__ hull_out,
+                   int cull) {
     __shared__ int s_lo, s_hi;
     __shared__ uint32_t mh[RADIX_MAX_PASSES][RADIX_DIGITS];
     // digit histograms of the TILE sort (keys (y, x): pass 0 = column, pass 1 = row), known here without looking at
@@ -170,7 +171,7 @@ touch_count_kernel(int P, int gx, int gy, const float2 *__restrict__ means2D, co
         uint32_t key = 0xFFFFFFFFu;
         if (valid) {
             uint32_t n = 0;
-            uint2 rect = make_uint2(0u, 0u);
+            TileRect rect{0u, 0u, 0ull};
             const int rad = radii[i];
             if (rad > 0) {
                 const float2 xy = means2D[i];
@@ -184,17 +185,9 @@ touch_count_kernel(int P, int gx, int gy, const float2 *__restrict__ means2D, co
                     maxx = min(maxx, (int)floorf((xy.x + ex) * (1.0f / GSR_BLOCK_X)) + 1);
                     miny = max(max(miny, hull0), (int)ceilf((xy.y - ey - (GSR_BLOCK_Y - 1)) * (1.0f / GSR_BLOCK_Y)));
                     maxy = min(min(maxy, hull1), (int)floorf((xy.y + ey) * (1.0f / GSR_BLOCK_Y)) + 1);
-                    if (maxx > minx && maxy > miny) {
-                        n = (uint32_t)((maxx - minx) * (maxy - miny));
-                        rect = make_uint2((uint32_t)minx | ((uint32_t)maxx << 16),
-                                          (uint32_t)miny | ((uint32_t)maxy << 16));
-                        if (tile_hist) {
-                            atomicAdd(&dxy[0][minx], maxy - miny);
-                            atomicAdd(&dxy[0][maxx], miny - maxy);
-                            atomicAdd(&dxy[1][miny], maxx - minx);
-                            atomicAdd(&dxy[1][maxy], minx - maxx);
-                        }
-                    }
+                    // (the tile count, the exact tile mask when culling is on, the tile sort's digit histograms)
+                    if (maxx > minx && maxy > miny)
+                        n = gsr_rect_tiles(xy, co, minx, miny, maxx, maxy, cull != 0, tile_hist ? dxy : nullptr, rect);
                 }
             }
             if (n) key = __float_as_uint(depths[i]);
@@ -228,7 +221,7 @@ touch_count_kernel(int P, int gx, int gy, const float2 *__restrict__ means2D, co
 // The digit histograms of the tile-sort passes are accumulated on the way.
 constexpr int EMIT_CHUNK = 1024;  // slots per wave (measured: 512-1024 best, 4096 8 % slower)
 __global__ void __launch_bounds__(256)
-emit_pairs_kernel(int P, long long D, int gx, int tiles, const uint2 *__restrict__ rects,
+emit_pairs_kernel(int P, long long D, int gx, int tiles, const TileRect *__restrict__ rects,
                   const uint8_t *__restrict__ mask, const uint32_t *__restrict__ sorted_ids,
                   const uint32_t *__restrict__ offsets, RadixPlan plan, uint32_t *__restrict__ keys,
                   uint32_t *__restrict__ vals, uint32_t *__restrict__ ghist) {
@@ -265,7 +258,8 @@ emit_pairs_kernel(int P, long long D, int gx, int tiles, const uint2 *__restrict
             s_off[wave][lane] = off;
             if (lane == 63) s_off[wave][64] = end;
             s_g[wave][lane] = g;
-            s_rect[wave][lane] = (j < P && end > off) ? rects[g] : make_uint2(0u, 0u);
+            // (frames above 256 x 256 tiles: K3 keeps every tile of the rect, the mask is not looked at)
+            s_rect[wave][lane] = (j < P && end > off) ? make_uint2(rects[g].xs, rects[g].ys) : make_uint2(0u, 0u);
             __builtin_amdgcn_wave_barrier();
             const uint32_t wend = min(__builtin_amdgcn_readlane(end, 63), s_end);
             while (__ballot(s < wend) != 0ull) {  // wave-uniform trip count (the histogram uses ballots)
@@ -306,7 +300,7 @@ emit_pairs_kernel(int P, long long D, int gx, int tiles, const uint2 *__restrict
 // or not: K7 leaves the ranges of tiles that are not computed locally empty, and K8 / K10 never look at them.
 template <int ITEMS, int THREADS>
 __global__ void __launch_bounds__(THREADS, 8)  // <= 64 VGPRs: four 8-wave workgroups per CU
-emit_scatter_kernel(int P, long long D, int xbits, const uint2 *__restrict__ rects,
+emit_scatter_kernel(int P, long long D, int xbits, const TileRect *__restrict__ rects,
                     const uint32_t *__restrict__ sorted_ids, const uint32_t *__restrict__ offsets,
                     const uint32_t *__restrict__ ghist, uint32_t *__restrict__ state, uint32_t *__restrict__ ticket,
                     uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, bool bounded,
@@ -325,7 +319,7 @@ emit_scatter_kernel(int P, long long D, int xbits, const uint2 *__restrict__ rec
     __shared__ uint32_t cflag[WAVES][ITEMS * 64 / 32];  // decode_chunk's 512 start bits per wave
     const uint32_t bid = onesweep_begin(sm, ticket);
     if ((long long)bid * (ITEMS * THREADS) >= D) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wave = threadIdx.x >> 6;
     const long long wbase = (long long)bid * (ITEMS * THREADS) + (long long)wave * (ITEMS * 64);
     uint32_t key[ITEMS], val[ITEMS];
 #pragma unroll
@@ -457,7 +451,7 @@ PrepLayout prep_layout(int P, int W, int H) {
     L.kB = o; o += np;
     L.vB = o; o += np;
     L.offsets = o; o += np;
-    L.rects = o; o += align_up((size_t)(P + 1) * 8);
+    L.rects = o; o += align_up((size_t)(P + 1) * sizeof(TileRect));
     L.hull = o; o += 256;  // int32 [2]: the row hull of the mask (written by K3, copied into the range table by the sort)
     L.thist = o; o += align_up(sizeof(uint32_t) * RADIX_REPLICAS * RADIX_MAX_PASSES * RADIX_DIGITS);  // zeroed with ctrl
     L.ctrl = o;
@@ -558,6 +552,32 @@ extern "C" size_t gsr_bin_prepare_bytes(int P, int width, int height) {
 }
 
 namespace {
+// Exact tile culling (binning_persist.h: gsr_tile_mask).  Its cost is K3's -- per Gaussian, ~50 instructions per tile
+// row of the rect, +42 us per 10^6 Gaussians at 4K -- its return the D-sized passes' and the composite kernels'.
+// Measured (profiles/r05_tile_cull.txt): D -9..17 %; K3-K7 702 -> 687 us at 4K (42 pairs per Gaussian), the 4K training step
+// 2.750 -> 2.760 ms, the 1080p step 1.166 -> 1.167 ms (K8 / K10 -2 %, binning +3 %): the composite kernels skip such pairs
+// with one box test per quadrant anyway.  Hence OFF by default; "auto" (frames above GSR_TILE_CULL_TILES tiles, default
+// 16384) is a static rule for scenes whose splats cover many tiles -- not a function of earlier views.
+std::atomic<int> g_tile_cull{-1};  // gsr_set_tile_cull: -1 = environment (GSR_TILE_CULL = 0 | 1 | auto, default 0)
+int tile_cull_on(int tiles) {
+    int mode = g_tile_cull.load(std::memory_order_relaxed);
+    if (mode < 0) {
+        static const int env_mode = [] {
+            const char *e = getenv("GSR_TILE_CULL");
+            if (!e || !*e || strcmp(e, "0") == 0) return 0;
+            return strcmp(e, "auto") == 0 ? 2 : 1;
+        }();
+        mode = env_mode;
+    }
+    if (mode != 2) return mode;
+    static const int min_tiles = [] {
+        const char *e = getenv("GSR_TILE_CULL_TILES");
+        const int v = e ? atoi(e) : 0;
+        return v > 0 ? v : 16384;
+    }();
+    return tiles > min_tiles ? 1 : 0;
+}
+
 // what a gsr_bin_prepare_async call was given: kept per count slot so that gsr_bin_count_wait can repeat the call on
 // the look-back pipeline when the persistent kernel gave up at its first barrier (binning_persist.h)
 struct PrepCall {
@@ -588,7 +608,7 @@ int prepare_lookback(const PrepCall &c, uint32_t *ticket) {
     uint32_t *kA = reinterpret_cast<uint32_t *>(base + L.kA), *vA = reinterpret_cast<uint32_t *>(base + L.vA);
     uint32_t *kB = reinterpret_cast<uint32_t *>(base + L.kB), *vB = reinterpret_cast<uint32_t *>(base + L.vB);
     uint32_t *offsets = reinterpret_cast<uint32_t *>(base + L.offsets);
-    uint2 *rects = reinterpret_cast<uint2 *>(base + L.rects);
+    TileRect *rects = reinterpret_cast<TileRect *>(base + L.rects);
     char *ctrl = base + L.ctrl;
 
     GSR_HIP(hipMemsetAsync(base + L.thist, 0, (L.ctrl - L.thist) + L.C.total, stream));
@@ -600,7 +620,7 @@ int prepare_lookback(const PrepCall &c, uint32_t *ticket) {
                        reinterpret_cast<const float2 *>(c.means2D), c.depths, c.radii,
                        reinterpret_cast<const float4 *>(c.conic_opacity), c.compute_locally, plan, tt, kA, vA, rects,
                        reinterpret_cast<uint32_t *>(ctrl + L.C.ghist), tile_hist,
-                       reinterpret_cast<int32_t *>(base + L.hull));
+                       reinterpret_cast<int32_t *>(base + L.hull), tile_hist ? tile_cull_on(gx * gy) : 0);
     int in_first = 1;
     int rc = radix_sort_pairs(kA, vA, kB, vB, P, plan, ctrl, L.C, &in_first, stream, nullptr);
     if (rc) return rc;
@@ -671,8 +691,9 @@ int prepare_persistent(const PrepCall &c, uint32_t *ticket) {
     a.kA = reinterpret_cast<uint32_t *>(base + L.kA); a.vA = reinterpret_cast<uint32_t *>(base + L.vA);
     a.kB = reinterpret_cast<uint32_t *>(base + L.kB); a.vB = reinterpret_cast<uint32_t *>(base + L.vB);
     a.offsets = reinterpret_cast<uint32_t *>(base + L.offsets);
-    a.rects = reinterpret_cast<uint2 *>(base + L.rects);
+    a.rects = reinterpret_cast<TileRect *>(base + L.rects);
     a.tile_hist = yx_path(gx, gy) ? reinterpret_cast<uint32_t *>(base + L.thist) : nullptr;
+    a.cull = a.tile_hist ? tile_cull_on(gx * gy) : 0;
     a.hull_out = reinterpret_cast<int32_t *>(base + L.hull);
     const int ngroups = (G + GB_FAN - 1) / GB_FAN;
     a.sync.leaf = reinterpret_cast<uint32_t *>(ctrl + PL.sync);
@@ -758,6 +779,12 @@ extern "C" int gsr_bin_count_wait(uint32_t ticket, int64_t *num_rendered_host, g
         return GSR_ERETRY;
     }
     *num_rendered_host = (int64_t)total;
+    return 0;
+}
+
+extern "C" int gsr_set_tile_cull(int mode) {
+    if (mode < -1 || mode > 2) return GSR_EINVAL;
+    g_tile_cull.store(mode, std::memory_order_relaxed);
     return 0;
 }
 
@@ -853,7 +880,7 @@ int bin_sort_impl(int P, int width, int height, const uint8_t *compute_locally, 
     const char *pbase = reinterpret_cast<const char *>(prep);
     const uint32_t *sorted_ids = reinterpret_cast<const uint32_t *>(pbase + L.vA);
     const uint32_t *offsets = reinterpret_cast<const uint32_t *>(pbase + L.offsets);
-    const uint2 *rects = reinterpret_cast<const uint2 *>(pbase + L.rects);
+    const TileRect *rects = reinterpret_cast<const TileRect *>(pbase + L.rects);
     char *sbase = reinterpret_cast<char *>(scratch);
     uint32_t *kA = reinterpret_cast<uint32_t *>(sbase + S.kA), *vA = reinterpret_cast<uint32_t *>(sbase + S.vA);
     uint32_t *kB = reinterpret_cast<uint32_t *>(sbase + S.kB), *vB = reinterpret_cast<uint32_t *>(sbase + S.vB);

@@ -214,6 +214,128 @@ __device__ __forceinline__ void publish_counts(uint32_t *__restrict__ cnt, uint3
     if (c) __hip_atomic_fetch_add(&grp[(w / GB_FAN) * RADIX_DIGITS + d], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ---- exact tile culling (round 5; verdict r04 item 1c) ------------------------------------------------------------
+// K3's rect is a bounding box: the 3-sigma rect intersected with the box of the alpha >= 1/255 ellipse.  A tile in a
+// corner of that box that the ellipse itself does not reach receives nothing under the reference's alpha < 1/255 rule
+// (K8 / K10 skip it with their per-quadrant test, same quadratic form, same tolerance), yet it is a pair that is emitted,
+// sorted twice and walked.  With culling on, K3 works out per tile ROW of the rect the exact span of tiles the ellipse
+// reaches -- closed form: the ellipse's rightmost / leftmost point inside the row's strip of pixel centres -- and keeps
+// it as a 64-bit mask (rects of up to 64 tiles; larger ones keep every tile): bit (r * w + c) = tile (minx + c, miny + r).
+// tiles_touched = popcount; the emission enumerates the set bits in row-major order, i.e. the lists stay
+// order-preserving subsequences of the uncut ones (D -14..20 %).
+// "Tile (x, y) is kept" == gsr_can_touch_box(xy, co, 16x, 16y, 16x + 15, 16y + 15): min of the form over the box <= lim.
+struct alignas(16) TileRect {  // what K3 leaves per Gaussian (16 bytes, one gather in the emission)
+    uint32_t xs, ys;         // minx | maxx << 16, miny | maxy << 16
+    unsigned long long mask; // ~0: every tile of the rect; else the kept tiles of a rect of <= 64 tiles
+};
+static_assert(sizeof(TileRect) == 16, "one 16-byte gather");
+
+__device__ __forceinline__ unsigned long long gsr_full_mask(int n) { return n >= 64 ? ~0ull : ((1ull << n) - 1ull); }
+
+__device__ __forceinline__ unsigned long long gsr_tile_mask(const float2 xy, const float4 co, int minx, int miny, int maxx,
+                                                            int maxy) {
+    const int w = maxx - minx, h = maxy - miny;
+    if (w * h > 64) return ~0ull;
+    const unsigned long long all = gsr_full_mask(w * h);
+    const float A = co.x, B = co.y, C = co.z;
+    const float det = A * C - B * B;
+    // an improper or ill-conditioned conic is not culled (gsr_can_touch_box keeps those too)
+    if (!(A > 0.f && C > 0.f && det > 1e-6f * A * C) || !(co.w >= 1.0f / 255.0f)) return all;
+    const float lim = (2.0f * 0.6931471805599453f) * __builtin_amdgcn_logf(255.0f * co.w) * 1.002f + 0.01f;
+    const float rA = 1.0f / A, rC = 1.0f / C;
+    const float dxs = sqrtf(lim * C / det);  // half extent in x of the whole ellipse, reached at dy = -/+ B dxs / C
+    const float dys = B * dxs * rC;
+    unsigned long long mask = 0ull;
+    for (int r = 0; r < h; r++) {
+        const float t0 = (float)((miny + r) * GSR_BLOCK_Y) - xy.y, t1 = t0 + (float)(GSR_BLOCK_Y - 1);  // the row's strip
+        float dxR, dxL;
+        bool emptyR = false, emptyL = false;
+        if (-dys >= t0 && -dys <= t1) {
+            dxR = dxs;
+        } else {  // the rightmost point of the ellipse lies outside the strip: the extreme is on the nearer edge
+            const float t = -dys < t0 ? t0 : t1;
+            const float disc = lim * A - det * t * t;
+            emptyR = disc < 0.f;
+            dxR = (-B * t + sqrtf(fmaxf(disc, 0.f))) * rA;
+        }
+        if (dys >= t0 && dys <= t1) {
+            dxL = -dxs;
+        } else {
+            const float t = dys < t0 ? t0 : t1;
+            const float disc = lim * A - det * t * t;
+            emptyL = disc < 0.f;
+            dxL = (-B * t - sqrtf(fmaxf(disc, 0.f))) * rA;
+        }
+        int xa = 0, xb = w;  // columns kept in this row, relative to minx
+        if (emptyR && emptyL) continue;  // the strip misses the ellipse
+        if (!emptyR && !emptyL) {        // (they disagree only at a tangency: keep the row)
+            dxR += 0.02f + 1e-4f * fabsf(dxR);
+            dxL -= 0.02f + 1e-4f * fabsf(dxL);
+            // tile x covers pixel centres [16 x, 16 x + 15]: kept when that interval meets [cx + dxL, cx + dxR]
+            xa = max(0, (int)ceilf((xy.x + dxL - (float)(GSR_BLOCK_X - 1)) * (1.0f / GSR_BLOCK_X)) - minx);
+            xb = min(w, (int)floorf((xy.x + dxR) * (1.0f / GSR_BLOCK_X)) + 1 - minx);
+            if (xb <= xa) continue;
+        }
+        mask |= gsr_full_mask(xb - xa) << (r * w + xa);
+    }
+    return mask & all;
+}
+
+// position of the t-th (0-based) set bit of m; t < popcount(m)
+__device__ __forceinline__ uint32_t gsr_select_bit(unsigned long long m, uint32_t t) {
+    uint32_t v = (uint32_t)m, base = 0;
+    const uint32_t c = __popc(v);
+    if (t >= c) { t -= c; v = (uint32_t)(m >> 32); base = 32; }
+    const uint32_t c16 = __popc(v & 0xFFFFu);
+    if (t >= c16) { t -= c16; v >>= 16; base += 16; }
+    const uint32_t c8 = __popc(v & 0xFFu);
+    if (t >= c8) { t -= c8; v >>= 8; base += 8; }
+    const uint32_t c4 = __popc(v & 0xFu);
+    if (t >= c4) { t -= c4; v >>= 4; base += 4; }
+    const uint32_t c2 = __popc(v & 3u);
+    if (t >= c2) { t -= c2; v >>= 2; base += 2; }
+    if (t >= (v & 1u)) base += 1;
+    return base;
+}
+
+// K3's tail for one Gaussian with a non-empty rect: the tile mask, the tile count and the tile sort's digit histograms
+// (dxy[0]: column digits, dxy[1]: row digits, both as difference arrays) -- shared by the two pipelines' K3.
+__device__ __forceinline__ uint32_t gsr_rect_tiles(const float2 xy, const float4 co, int minx, int miny, int maxx, int maxy,
+                                                   bool cull, int32_t (*dxy)[RADIX_DIGITS + 1], TileRect &out) {
+    const int w = maxx - minx, h = maxy - miny;
+    out.xs = (uint32_t)minx | ((uint32_t)maxx << 16);
+    out.ys = (uint32_t)miny | ((uint32_t)maxy << 16);
+    out.mask = ~0ull;
+    if (!cull || w * h > 64) {  // every tile of the rect (mask ~0: "not culled"): h more in its columns, w in its rows
+        if (dxy) {
+            atomicAdd(&dxy[0][minx], h);
+            atomicAdd(&dxy[0][maxx], -h);
+            atomicAdd(&dxy[1][miny], w);
+            atomicAdd(&dxy[1][maxy], -w);
+        }
+        return (uint32_t)(w * h);
+    }
+    const unsigned long long mask = gsr_tile_mask(xy, co, minx, miny, maxx, maxy);
+    out.mask = mask;
+    if (dxy) {
+        const unsigned long long rowm = gsr_full_mask(w);
+        for (int r = 0; r < h; r++) {
+            unsigned long long bits = (mask >> (r * w)) & rowm;
+            while (bits) {  // one run per row (the kept tiles of a row are contiguous), written for any pattern
+                const int a0 = __ffsll((long long)bits) - 1;
+                const unsigned long long rest = ~(bits >> a0);
+                const int len = rest ? __ffsll((long long)rest) - 1 : 64 - a0;
+                atomicAdd(&dxy[0][minx + a0], 1);
+                atomicAdd(&dxy[0][minx + a0 + len], -1);
+                atomicAdd(&dxy[1][miny + r], len);
+                atomicAdd(&dxy[1][miny + r + 1], -len);
+                bits &= ~(gsr_full_mask(len) << a0);
+            }
+        }
+    }
+    return (uint32_t)__popcll(mask);
+}
+
 // LDS of a persistent sort workgroup (the staging area doubles as scratch of the phases that do not scatter)
 template <int ITEMS, int THREADS>
 struct PersistSmem {
@@ -363,8 +485,9 @@ struct PrepPersistArgs {
     const float4 *conic_opacity;
     const uint8_t *mask;
     uint32_t *tt, *kA, *vA, *kB, *vB, *offsets;
-    uint2 *rects;
+    TileRect *rects;
     uint32_t *tile_hist;  // [8 replicas][4][256] or null (frames above 256 x 256 tiles)
+    int cull;             // exact tile culling (gsr_tile_mask); only with tile_hist (the (row, column) path)
     int32_t *hull_out;
     GridSync sync;
     uint32_t *cnt;  // [4][G][256]
@@ -459,7 +582,7 @@ bin_prepare_persist_kernel(const PrepPersistArgs a) {
             val[r] = (uint32_t)i;
             if (i < P) {
                 uint32_t n = 0;
-                uint2 rect = make_uint2(0u, 0u);
+                TileRect rect{0u, 0u, 0ull};
                 if (rad[q4] > 0) {
                     float exx, eyy;
                     if (gsr_alpha_extent(co[q4], exx, eyy)) {
@@ -469,17 +592,9 @@ bin_prepare_persist_kernel(const PrepPersistArgs a) {
                         maxx = min(maxx, (int)floorf((xy[q4].x + exx) * (1.0f / GSR_BLOCK_X)) + 1);
                         miny = max(max(miny, hull0), (int)ceilf((xy[q4].y - eyy - (GSR_BLOCK_Y - 1)) * (1.0f / GSR_BLOCK_Y)));
                         maxy = min(min(maxy, hull1), (int)floorf((xy[q4].y + eyy) * (1.0f / GSR_BLOCK_Y)) + 1);
-                        if (maxx > minx && maxy > miny) {
-                            n = (uint32_t)((maxx - minx) * (maxy - miny));
-                            rect = make_uint2((uint32_t)minx | ((uint32_t)maxx << 16),
-                                              (uint32_t)miny | ((uint32_t)maxy << 16));
-                            if (a.tile_hist) {
-                                atomicAdd(&ex.dxy[0][minx], maxy - miny);
-                                atomicAdd(&ex.dxy[0][maxx], miny - maxy);
-                                atomicAdd(&ex.dxy[1][miny], maxx - minx);
-                                atomicAdd(&ex.dxy[1][maxy], minx - maxx);
-                            }
-                        }
+                        if (maxx > minx && maxy > miny)
+                            n = gsr_rect_tiles(xy[q4], co[q4], minx, miny, maxx, maxy, a.cull != 0,
+                                               a.tile_hist ? ex.dxy : nullptr, rect);
                     }
                 }
                 if (n) key[r] = __float_as_uint(dep[q4]);
@@ -682,7 +797,7 @@ bin_prepare_persist_kernel(const PrepPersistArgs a) {
 constexpr int PS_THREADS = 512, PS_ITEMS = 8, PS_TILE = PS_THREADS * PS_ITEMS, PS_WAVES = PS_THREADS / 64;
 constexpr int PS_CHUNK = PS_ITEMS * 64;  // slots of one wave of one tile
 #ifndef GSR_PS_DECODE_BATCH
-#define GSR_PS_DECODE_BATCH 8
+#define GSR_PS_DECODE_BATCH 4
 #endif
 #ifndef GSR_PS_MIN_WAVES
 #define GSR_PS_MIN_WAVES 4
@@ -696,7 +811,7 @@ struct SortPersistArgs {
     int P, gx, xbits, ybits;
     long long D;    // the pair count, or (bounded) the capacity of the buffers
     int bounded;    // the pair count is offsets[P] on the device; nothing is written when it exceeds D
-    const uint2 *rects;
+    const TileRect *rects;
     const uint32_t *sorted_ids;
     const uint32_t *offsets;
     const uint8_t *mask;
@@ -746,7 +861,7 @@ __device__ __forceinline__ int owner_search(const uint32_t *__restrict__ offsets
 // are in flight together.
 template <int BATCH>  // rounds whose gathers are in flight together (8: all of them; 4 halves the registers held)
 __device__ __forceinline__ void decode_chunk(const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ sorted_ids,
-                                             const uint2 *__restrict__ rects, int P, long long D, long long wbase, int g0,
+                                             const TileRect *__restrict__ rects, int P, long long D, long long wbase, int g0,
                                              int xbits, uint32_t *__restrict__ cflag, uint32_t (&key)[PS_ITEMS],
                                              uint32_t (&val)[PS_ITEMS]) {
     const int lane = threadIdx.x & 63;
@@ -784,7 +899,7 @@ __device__ __forceinline__ void decode_chunk(const uint32_t *__restrict__ offset
             off[i] = offsets[j];
             gid[i] = sorted_ids[j];
         }
-        uint2 rc[BATCH];
+        TileRect rc[BATCH];
 #pragma unroll
         for (int i = 0; i < BATCH; i++) rc[i] = rects[gid[i]];
 #pragma unroll
@@ -792,8 +907,9 @@ __device__ __forceinline__ void decode_chunk(const uint32_t *__restrict__ offset
             const int r = r0 + i;
             if (wbase + r * 64 + lane < D) {
                 const uint32_t s = cbeg + (uint32_t)(r * 64 + lane);
-                const uint32_t tq = s - off[i];
-                const uint32_t minx = rc[i].x & 0xFFFFu, wd = (rc[i].x >> 16) - minx, miny = rc[i].y & 0xFFFFu;
+                const uint32_t minx = rc[i].xs & 0xFFFFu, wd = (rc[i].xs >> 16) - minx, miny = rc[i].ys & 0xFFFFu;
+                uint32_t tq = s - off[i];  // the Gaussian's tq-th kept tile: row-major position inside the rect
+                if (rc[i].mask != ~0ull) tq = gsr_select_bit(rc[i].mask, tq);
                 // tq / wd without the integer-division sequence (~15 VALU): the frame has <= 256 x 256 tiles on this
                 // path, so the quotient is < 256 and (tq + 0.5) / wd stays >= 0.5 / 256 away from every integer -- orders
                 // of magnitude more than the error of rcp (1 ulp) and the product: the truncation is exact
@@ -856,27 +972,46 @@ bin_sort_persist_kernel(const SortPersistArgs a) {
         for (int j = j0 + (int)threadIdx.x; j <= j1; j += PS_THREADS) {
             const uint32_t off = a.offsets[j], end = a.offsets[j + 1];
             if (end <= off) continue;
-            const uint2 rc = a.rects[a.sorted_ids[j]];
-            const int minx = (int)(rc.x & 0xFFFFu), maxx = (int)(rc.x >> 16);
-            const int wd = maxx - minx;
-            // the Gaussian's slots [off, end) are its rect in row-major order; mine are [lo, hi) of them
+            const TileRect rc = a.rects[a.sorted_ids[j]];
+            const int minx = (int)(rc.xs & 0xFFFFu), maxx = (int)(rc.xs >> 16);
+            const int wd = maxx - minx, ht = (int)(rc.ys >> 16) - (int)(rc.ys & 0xFFFFu);
+            // the Gaussian's slots [off, end) are its kept tiles in row-major order; mine are [lo, hi) of them
             const long long glo = off > s0 ? (long long)off : s0, ghi = (long long)end < s1 ? (long long)end : s1;
             const int lo = (int)(glo - off), hi = (int)(ghi - off);
-            if (lo == 0 && hi == (int)(end - off)) {  // the whole rect (all but the first and the last Gaussian)
-                const int h = (int)(rc.y >> 16) - (int)(rc.y & 0xFFFFu);
-                atomicAdd(&ex.dcol[minx], h);
-                atomicAdd(&ex.dcol[maxx], -h);
+            if (rc.mask != ~0ull) {
+                // a tile mask: the bits of rank [lo, hi), row by row -- a run of kept tiles adds 1 to its columns
+                unsigned long long m = rc.mask;
+                if (lo > 0) m &= ~0ull << gsr_select_bit(rc.mask, (uint32_t)lo);
+                if (hi < (int)(end - off)) {
+                    const uint32_t ph = gsr_select_bit(rc.mask, (uint32_t)(hi - 1));
+                    m &= ph >= 63u ? ~0ull : ((2ull << ph) - 1ull);
+                }
+                const unsigned long long rowm = gsr_full_mask(wd);
+                for (int r = 0; r < ht; r++) {
+                    unsigned long long bits = (m >> (r * wd)) & rowm;
+                    while (bits) {
+                        const int a0 = __ffsll((long long)bits) - 1;
+                        const unsigned long long rest = ~(bits >> a0);
+                        const int len = rest ? __ffsll((long long)rest) - 1 : 64 - a0;
+                        atomicAdd(&ex.dcol[minx + a0], 1);
+                        atomicAdd(&ex.dcol[minx + a0 + len], -1);
+                        bits &= ~(gsr_full_mask(len) << a0);
+                    }
+                }
+            } else if (lo == 0 && hi == (int)(end - off)) {  // the whole rect (all but the first and the last Gaussian)
+                atomicAdd(&ex.dcol[minx], ht);
+                atomicAdd(&ex.dcol[maxx], -ht);
             } else {
-            const int ra = lo / wd, xa = lo - ra * wd, rb = (hi - 1) / wd, xb = (hi - 1) - rb * wd + 1;
-            if (ra == rb) {
-                atomicAdd(&ex.dcol[minx + xa], 1);
-                atomicAdd(&ex.dcol[minx + xb], -1);
-            } else {
-                atomicAdd(&ex.dcol[minx + xa], 1);  // the first row from xa on, the last row up to xb, full rows between
-                atomicAdd(&ex.dcol[minx], rb - ra);
-                atomicAdd(&ex.dcol[minx + xb], -1);
-                atomicAdd(&ex.dcol[maxx], ra - rb);
-            }
+                const int ra = lo / wd, xa = lo - ra * wd, rb = (hi - 1) / wd, xb = (hi - 1) - rb * wd + 1;
+                if (ra == rb) {
+                    atomicAdd(&ex.dcol[minx + xa], 1);
+                    atomicAdd(&ex.dcol[minx + xb], -1);
+                } else {
+                    atomicAdd(&ex.dcol[minx + xa], 1);  // the first row from xa on, the last row up to xb, full rows between
+                    atomicAdd(&ex.dcol[minx], rb - ra);
+                    atomicAdd(&ex.dcol[minx + xb], -1);
+                    atomicAdd(&ex.dcol[maxx], ra - rb);
+                }
             }
             if (have_owners) {  // the chunk starts (multiples of 512 slots) that fall into this Gaussian's slots
                 long long c = (glo + PS_CHUNK - 1) / PS_CHUNK * PS_CHUNK;

@@ -683,6 +683,14 @@ def set_bin_persistent(mode):
     check(lib.gsr_set_bin_persistent(code), "gsr_set_bin_persistent")
 
 
+def set_tile_cull(mode):
+    """exact tile culling in K3 (include/gsraster.h: gsr_set_tile_cull): "env" (GSR_TILE_CULL, default off), False / "off",
+    True / "on", "auto" (on for frames of more than 16384 tiles, i.e. above ~2048 x 2048).  Lists stay order-preserving
+    subsequences of the uncut ones; image and gradients unchanged up to the blend's summation order."""
+    code = {"env": -1, False: 0, "off": 0, True: 1, "on": 1, "auto": 2}[mode]
+    check(lib.gsr_set_tile_cull(code), "gsr_set_tile_cull")
+
+
 def set_tie_order(order):
     """order of Gaussians with EXACTLY equal depth inside a tile list: "arrival" (default; the reference: index in the
     arrays the op is given, i.e. (source rank, index on the source) at world size > 1) or "position" (means2D.x, .y,

@@ -156,6 +156,15 @@ int gsr_bin_speculative(int P, int width, int height, const float *means2D, cons
  * gsr_bin_sort); the sort step traps after two seconds.  mode: -1 the environment's GSR_BIN_PERSIST (0 | 1 | p | s,
  * default 1), 0 off, 1 prepare only, 2 sort only, 3 both. */
 int gsr_set_bin_persistent(int mode);
+/* Exact tile culling in K3 (ABI 11; csrc/binning_persist.h: gsr_tile_mask): per tile row of a Gaussian's rect the exact span
+ * of tiles its alpha >= 1/255 ellipse reaches (the quadratic form and tolerance of the composite kernels' own skip test),
+ * kept as a 64-bit mask (rects of <= 64 tiles on frames of <= 256 x 256 tiles).  The lists stay order-preserving
+ * subsequences of the uncut ones -- a dropped (tile, Gaussian) has alpha < 1/255 on every pixel of the tile -- so the image
+ * and the gradients are unchanged up to the summation order of the blend; D shrinks by 9-17 %.  OFF by default: measured
+ * neutral (K3 pays per Gaussian what the D-sized passes and the composite kernels save per pair).  mode: -1 the
+ * environment's GSR_TILE_CULL (0 | 1 | auto, default 0), 0 off, 1 on, 2 auto = on for frames of more than
+ * GSR_TILE_CULL_TILES (default 16384) tiles -- a static rule: the lists do not depend on earlier views. */
+int gsr_set_tile_cull(int mode);
 /* Diagnostics of the persistent launches on the current device: out3 = { sequence number of the last launch that passed
  * its last barrier, code of the last barrier fault (0x100 + n: barrier n of the prepare kernel, 0x200 + n: of the sort
  * kernel; 0 = none), number of faults }.  A fault traps the kernel (the process ends with a HIP error) unless

@@ -64,13 +64,25 @@ def test_preprocess_forward_matches_c_oracle(device, N, W, H, sc, seed, ci, sh_d
     assert m2[culled].abs().sum().item() == 0 and co[culled].abs().sum().item() == 0
 
 
+@pytest.mark.parametrize("cull", [False, True])
 @pytest.mark.parametrize("N,W,H,sc,seed,ci", SCENES)
-def test_binning_is_ordered_subsequence_of_reference_lists(device, N, W, H, sc, seed, ci):
+def test_binning_is_ordered_subsequence_of_reference_lists(device, N, W, H, sc, seed, ci, cull):
     """per tile: the HIP list is a SUBSEQUENCE of the reference-order list (depth, then index), and
     every Gaussian dropped from a tile has alpha < 1/255 on all of the tile's pixels (float64 check),
-    i.e. the reference algorithm would have skipped it on every pixel"""
+    i.e. the reference algorithm would have skipped it on every pixel -- with the bounding rect of the
+    alpha >= 1/255 ellipse and with the exact per-row tile spans (gsr_set_tile_cull)"""
+    import diff_gaussian_rasterization as dgr
     from diff_gaussian_rasterization import bin_gaussians
     from oracle import cref as C
+
+    dgr.set_tile_cull(cull)
+    try:
+        _binning_subsequence_case(device, N, W, H, sc, seed, ci, cull, bin_gaussians, C)
+    finally:
+        dgr.set_tile_cull("env")
+
+
+def _binning_subsequence_case(device, N, W, H, sc, seed, ci, cull, bin_gaussians, C):
 
     g = S.make_gaussians(N, W, H, seed=seed, scale_coef=sc)
     cam = S.orbit_cameras(4, W, H)[ci]
@@ -108,7 +120,7 @@ def test_binning_is_ordered_subsequence_of_reference_lists(device, N, W, H, sc, 
             alpha = torch.where(power > 0, torch.zeros_like(alpha), alpha)
             assert alpha.max().item() < 1.0 / 255.0, f"tile {t}: a dropped Gaussian would have contributed"
     assert kept_total > 0
-    print(f"pairs kept {kept_total}, dropped {dropped_total} of {pl_ref.numel()}")
+    print(f"cull={cull}: pairs kept {kept_total}, dropped {dropped_total} of {pl_ref.numel()}")
 
 
 def test_speculative_sort_equals_the_sized_sort(device):
@@ -154,9 +166,10 @@ def test_speculative_sort_equals_the_sized_sort(device):
         dgr.release_workspaces()
 
 
-@pytest.mark.parametrize("grid_p,grid_s,owners,max_tpw", [(None, None, None, None), (1, 3, None, 8), (2, 5, 1, 8),
-                                                          (3, 64, 2, 8), (2, None, None, None)])
-def test_persistent_binning_equals_the_lookback_pipeline(device, monkeypatch, grid_p, grid_s, owners, max_tpw):
+@pytest.mark.parametrize("grid_p,grid_s,owners,max_tpw,cull", [
+    (None, None, None, None, False), (1, 3, None, 8, False), (2, 5, 1, 8, True), (3, 64, 2, 8, False),
+    (2, None, None, None, False), (None, None, None, None, True)])
+def test_persistent_binning_equals_the_lookback_pipeline(device, monkeypatch, grid_p, grid_s, owners, max_tpw, cull):
     """K3-K7 as two persistent launches with grid barriers (csrc/binning_persist.h) against the nine launches of the
     look-back pipeline: bit-identical lists and ranges -- with one tile per workgroup (4096 or 8192 elements) and (grids
     capped through the test hooks) many tiles per workgroup, with the chunk-owner table and with the per-chunk search, through the sized
@@ -193,6 +206,7 @@ def test_persistent_binning_equals_the_lookback_pipeline(device, monkeypatch, gr
     views["empty"][2].zero_()
     order = ("large", "large", "small", "larger", "empty", "band", "large", "larger")
     got = {}
+    dgr.set_tile_cull(cull)  # (exact tile spans: both pipelines' K3 and emissions, the sort kernel's rect-derived counts)
     try:
         for mode in ("off", "both", "prepare", "sort"):
             dgr.set_bin_persistent(mode)
@@ -204,6 +218,7 @@ def test_persistent_binning_equals_the_lookback_pipeline(device, monkeypatch, gr
                     got[(mode, spec, i)] = (pl.clone(), rg.clone(), D)
     finally:
         dgr.set_bin_persistent("env")
+        dgr.set_tile_cull("env")
         dgr.set_speculative_sort(True)
         dgr.release_workspaces()
     assert got[("off", False, 3)][2] > got[("off", False, 0)][2] > got[("off", False, 2)][2] > 0
@@ -213,6 +228,42 @@ def test_persistent_binning_equals_the_lookback_pipeline(device, monkeypatch, gr
         assert torch.equal(rg, rrg), (mode, spec, order[i])
         if D:
             assert pl.numel() == D and torch.equal(pl, rpl), (mode, spec, order[i])
+
+
+@pytest.mark.parametrize("N,W,H,sc,seed,ci", SCENES[1:4])
+def test_exact_tile_culling_changes_nothing_but_the_pair_count(device, N, W, H, sc, seed, ci):
+    """gsr_set_tile_cull(1): fewer (tile, Gaussian) pairs, the same image and gradients -- against the run without culling
+    (<= 2e-6 / 2e-5: the dropped pairs contribute nothing, only the blend's chunk boundaries move) and against the C oracle
+    (the usual 1e-4), which knows no culling at all"""
+    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization import GaussianRasterizer
+
+    g = S.make_gaussians(N, W, H, seed=seed, scale_coef=sc)
+    cam = S.orbit_cameras(4, W, H)[ci]
+    bg = torch.tensor([0.2, 0.1, 0.4])
+    mask = _full_mask(cam)
+    wgt = torch.rand(3, H, W, generator=torch.Generator().manual_seed(5))
+    ref = oracle_c_chain(g, cam, bg, mask, wgt)
+    res = {}
+    try:
+        for cull in (False, True):
+            dgr.set_tile_cull(cull)
+            rast = GaussianRasterizer(settings_from(cam, bg))
+            gg = {k: v.to(device).requires_grad_(True) for k, v in g.items()}
+            a, b, c, d, e = rast.preprocess_gaussians(*[gg[k] for k in KEYS], {})
+            img, _, _, _ = rast.render_gaussians(a, c, b, e, d, mask.to(device), None, {"stats_collector": {}})
+            (img * wgt.to(device)).sum().backward()
+            res[cull] = (img.detach().cpu(), {k: gg[k].grad.detach().cpu() for k in KEYS},
+                         dgr._RenderGaussians.last_num_rendered)
+    finally:
+        dgr.set_tile_cull("env")
+    assert res[True][2] < res[False][2], (res[True][2], res[False][2])
+    print(f"pairs {res[False][2]} -> {res[True][2]} ({res[True][2] / res[False][2]:.3f})")
+    assert rel_err(res[True][0], res[False][0]) < 2e-6
+    assert rel_err(res[True][0], ref["image"]) < 1e-4
+    for k in KEYS:
+        assert rel_err(res[True][1][k], res[False][1][k]) < 2e-5, k
+        assert rel_err(res[True][1][k], ref["d_" + k]) < 1e-4, k
 
 
 @pytest.mark.parametrize("N,W,H,sc,seed,ci", SCENES)

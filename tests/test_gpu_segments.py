@@ -99,3 +99,34 @@ def test_checkpoint_queue_overflow_leaves_tails_unsplit(device):
     for name, a, b in (("means2D", d2_s, d2_1), ("conic_opacity", dco_s, dco_1), ("rgb", drgb_s, drgb_1)):
         e = _rel(a, b)
         assert e < 2e-5, f"d{name}: {e:.2e}"
+
+
+def test_second_backward_over_one_forward_walks_the_segments_again(device):
+    """retain_graph / gradcheck run K10 twice over one forward: the workers' ticket is reset per launch (it
+    used to be zeroed by the forward only, and a second backward silently dropped every queued segment); and the image
+    the segmented backward reads is saved through autograd, so an in-place edit raises instead of corrupting gradients"""
+    import diff_gaussian_rasterization as dgr
+    from helpers import KEYS, settings_from
+
+    W, H = 320, 208
+    g, cam, wgt = _scene(60_000, W, H, seed=13, scale_coef=0.02, op_mean=-3.5)
+    gy, gx = (H + 15) // 16, (W + 15) // 16
+    mask = torch.ones(gy, gx, dtype=torch.bool)
+    dgr.set_list_segments("always")
+    try:
+        rast = dgr.GaussianRasterizer(settings_from(cam, torch.tensor([0.1, 0.2, 0.3]), device=device))
+        with torch.no_grad():
+            m2, rgb, co, radii, depths = rast.preprocess_gaussians(*[g[k].to(device) for k in KEYS], {})
+        m2, rgb, co = [t.detach().clone().requires_grad_(True) for t in (m2, rgb, co)]
+        img, _, _, _ = rast.render_gaussians(m2, co, rgb, depths, radii, mask.to(device), None, {"stats_collector": {}})
+        loss = (img * wgt.to(device)).sum()
+        first = torch.autograd.grad(loss, (m2, co, rgb), retain_graph=True)
+        second = torch.autograd.grad(loss, (m2, co, rgb), retain_graph=True)
+        for a, b in zip(first, second):
+            assert _rel(a, b) < 2e-6  # (the order of K10's atomics differs between launches)
+        with torch.no_grad():
+            img.mul_(0.5)
+        with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+            torch.autograd.grad(loss, (m2, co, rgb))
+    finally:
+        dgr.set_list_segments(True)

@@ -19,8 +19,9 @@ from diff_gaussian_rasterization import _lib  # noqa: E402
 
 def load(path):
     lib = ctypes.CDLL(path)
-    for name in ("gsr_bin_prepare_bytes", "gsr_bin_prepare", "gsr_bin_sort_bytes", "gsr_bin_sort", "gsr_set_bin_persistent"):
-        if name == "gsr_set_bin_persistent" and not hasattr(lib, name):
+    for name in ("gsr_bin_prepare_bytes", "gsr_bin_prepare", "gsr_bin_sort_bytes", "gsr_bin_sort", "gsr_set_bin_persistent",
+                 "gsr_set_tile_cull"):
+        if name in ("gsr_set_bin_persistent", "gsr_set_tile_cull") and not hasattr(lib, name):
             continue  # (a library built before ABI 11)
         res, args = _lib.SIGNATURES[name]
         fn = getattr(lib, name)
@@ -40,6 +41,7 @@ def main():
                     help="tile rows computed locally (default: the whole frame)")
     ap.add_argument("--modes", nargs="*", default=["off", "prepare", "sort", "both"],
                     help="gsr_set_bin_persistent modes to time on the production library (lists compared bitwise)")
+    ap.add_argument("--cull", nargs="*", type=int, default=[0], help="gsr_set_tile_cull modes to time (0 off, 1 on)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     W, H = a.width, a.height
@@ -60,12 +62,16 @@ def main():
     ptr = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     codes = {"off": 0, "prepare": 1, "sort": 2, "both": 3}
-    libs = [(f"production[{m}]", _lib.LIB_PATH, codes[m]) for m in a.modes] + [(os.path.basename(p), p, None) for p in a.lib]
-    ref_lists = None
+    libs = [(f"production[{m}, cull {c}]", _lib.LIB_PATH, (codes[m], c)) for c in a.cull for m in a.modes] + \
+           [(os.path.basename(p), p, None) for p in a.lib]
+    ref_lists, ref_cull = None, None
     for name, path, mode in libs:
         lib = load(path)
         if mode is not None:
-            assert lib.gsr_set_bin_persistent(mode) == 0
+            assert lib.gsr_set_bin_persistent(mode[0]) == 0
+            assert lib.gsr_set_tile_cull(mode[1]) == 0
+            if mode[1] != ref_cull:
+                ref_lists, ref_cull = None, mode[1]  # (lists are compared between modes of ONE culling setting)
         ranges = torch.empty((gx * gy + 1, 2), dtype=torch.int32, device=dev)
         nb = lib.gsr_bin_prepare_bytes(P, W, H)
         prep = torch.zeros(nb, dtype=torch.uint8, device=dev)  # (zeros: timing probes with wrong lists must still read valid indices)

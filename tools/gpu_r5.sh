@@ -30,7 +30,7 @@ if has bintest; then
   tail -15 $O/bintest.log | cut -c1-300
 fi
 if has binbench; then
-  GSR_BIN_PERSIST_MAXD=100000000 timeout 300 python tools/binbench.py --iters 20 $BINBENCH_LIBS > $O/binbench_c1.txt 2> $O/binbench_c1.err
+  GSR_BIN_PERSIST_MAXD=100000000 timeout 300 python tools/binbench.py --iters 20 --cull 0 1 $BINBENCH_LIBS > $O/binbench_c1.txt 2> $O/binbench_c1.err
   echo "binbench c1 exit $?"; cat $O/binbench_c1.txt; tail -3 $O/binbench_c1.err | cut -c1-300
   timeout 300 python tools/binbench.py --iters 20 --band 30 39 > $O/binbench_band.txt 2> $O/binbench_band.err
   GSR_BIN_PERSIST_MAXD=100000000 timeout 300 python tools/binbench.py --iters 20 --band 20 48 > $O/binbench_band2.txt 2> $O/binbench_band2.err; cat $O/binbench_band2.txt
@@ -48,7 +48,7 @@ if has fullsize; then
   tail -6 $O/fullsize.log | cut -c1-300
 fi
 for st in $STAGES; do
-  case $st in bintest|binbench|binbig|fullsize|shapes|fakeab) ;; *) bash tools/gpu_run.sh $TAG $st ;; esac
+  case $st in bintest|binbench|binbig|fullsize|shapes|fakeab|cull) ;; *) bash tools/gpu_run.sh $TAG $st ;; esac
 done
 if has shapes; then
   for wl in c2 c4; do
@@ -62,5 +62,17 @@ if has fakeab; then
   for v in 1 0; do
     GSR_BIN_PERSIST=$v timeout 400 python tools/fake_world_bench.py --workload c2 --worlds 1 8 --steps 20 > $O/fake_c2_persist$v.txt 2> $O/fake_c2_persist$v.err
     echo "persist=$v"; cut -c1-600 $O/fake_c2_persist$v.txt
+  done
+fi
+if has cull; then
+  timeout 600 python -m pytest tests/test_gpu_parity.py -q -m gpu -x -s -p no:cacheprovider -k "exact_tile_culling" > $O/culltest.log 2>&1
+  echo "culltest exit $?"; grep -E "pairs|passed|failed|rror" $O/culltest.log | tail -8
+  timeout 300 python tools/binbench.py --iters 10 --width 3840 --height 2160 --modes off both --cull 0 1 > $O/binbench_4k.txt 2> $O/binbench_4k.err
+  echo "binbench 4k exit $?"; cat $O/binbench_4k.txt; tail -2 $O/binbench_4k.err | grep -v amdgpu
+  for v in 0 1; do
+    GSR_TILE_CULL=$v timeout 600 python bench.py --workload c1_4k --no-cpu-baseline --no-extra --steps 10 --warmup 4 --repeats 1 --render-steps 4 > $O/bench_4k_cull$v.json 2> $O/bench_4k_cull$v.err
+    summ $O/bench_4k_cull$v.json "c1_4k cull=$v"
+    GSR_TILE_CULL=$v timeout 600 python bench.py --no-cpu-baseline --no-extra --steps 20 --warmup 6 --repeats 2 --render-steps 10 > $O/bench_c1_cull$v.json 2> $O/bench_c1_cull$v.err
+    summ $O/bench_c1_cull$v.json "c1 cull=$v"
   done
 fi
