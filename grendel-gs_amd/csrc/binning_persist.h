@@ -945,10 +945,14 @@ bin_sort_persist_kernel(const SortPersistArgs a) {
     for (int t = w * PS_THREADS + threadIdx.x; t < a.ranges_words; t += G * PS_THREADS)
         st_agent(reinterpret_cast<uint32_t *>(a.ranges) + t, 0u);
     if (w == 0 && threadIdx.x < 2) a.ranges[a.ranges_words + threadIdx.x] = a.hull[threadIdx.x];
-    const long long nb = (D + PS_TILE - 1) / PS_TILE;
-    const long long t0 = (long long)w * nb / G, t1 = (long long)(w + 1) * nb / G;
-    const long long s0 = t0 * PS_TILE, s1 = (t1 * PS_TILE < D) ? t1 * PS_TILE : D;  // this workgroup's slots
-    const bool have_owners = (t1 - t0) * PS_WAVES <= a.owners_cap;
+    // This workgroup's slots [s0, s1): an equal share of the 512-slot wave chunks, walked in tiles of eight chunks, the
+    // last one partial.  (Sharing out whole 4096-slot tiles left half the grid with one tile more at 6.5 tiles per
+    // workgroup; this evens the waiting at the barriers out but not the phase: a partial tile costs a tile's latency
+    // chain, so a phase lasts ceil(tiles per workgroup) rounds either way -- measured 203.6 against 201.8 us at c1.)
+    const long long nc = (D + PS_CHUNK - 1) / PS_CHUNK;
+    const long long c0 = (long long)w * nc / G, c1 = (long long)(w + 1) * nc / G;
+    const long long s0 = c0 * PS_CHUNK, s1 = (c1 * PS_CHUNK < D) ? c1 * PS_CHUNK : D;
+    const bool have_owners = (c1 - c0) <= a.owners_cap;
     uint32_t epoch = 0;
     GSR_TS(0);
     const uint32_t ngroups = (G + GB_FAN - 1) / GB_FAN;
@@ -969,10 +973,20 @@ bin_sort_persist_kernel(const SortPersistArgs a) {
     __syncthreads();
     if (s1 > s0) {
         const int j0 = ex.j0, j1 = ex.j1;
-        for (int j = j0 + (int)threadIdx.x; j <= j1; j += PS_THREADS) {
-            const uint32_t off = a.offsets[j], end = a.offsets[j + 1];
+        // (two dependent gathers per Gaussian -- offset / id, then the rect: the next trip's first gather is issued
+        // before this trip's rect is used)
+        int j = j0 + (int)threadIdx.x;
+        uint32_t off_n = 0, end_n = 0, id_n = 0;
+        if (j <= j1) { off_n = a.offsets[j]; end_n = a.offsets[j + 1]; id_n = a.sorted_ids[j]; }
+        for (; j <= j1; j += PS_THREADS) {
+            const uint32_t off = off_n, end = end_n;
+            const TileRect rc = a.rects[id_n];
+            if (j + PS_THREADS <= j1) {
+                off_n = a.offsets[j + PS_THREADS];
+                end_n = a.offsets[j + PS_THREADS + 1];
+                id_n = a.sorted_ids[j + PS_THREADS];
+            }
             if (end <= off) continue;
-            const TileRect rc = a.rects[a.sorted_ids[j]];
             const int minx = (int)(rc.xs & 0xFFFFu), maxx = (int)(rc.xs >> 16);
             const int wd = maxx - minx, ht = (int)(rc.ys >> 16) - (int)(rc.ys & 0xFFFFu);
             // the Gaussian's slots [off, end) are its kept tiles in row-major order; mine are [lo, hi) of them
@@ -1040,19 +1054,18 @@ bin_sort_persist_kernel(const SortPersistArgs a) {
         counts_before<PS_THREADS>(a.cnt, a.grp, G, w, sm.skey, before, total);
         uint32_t all;
         uint32_t first = block_exclusive_scan_n<PS_WAVES>(total, sm.scan_tmp, &all) + before;
-        for (long long t = t0; t < t1; t++) {
-            const long long tbase = t * PS_TILE;
+        for (long long tbase = s0; tbase < s1; tbase += PS_TILE) {
             const long long wbase = tbase + (long long)wave * PS_CHUNK;
 #pragma unroll
             for (int r = 0; r < PS_ITEMS; r++) { key[r] = 0xFFFFFFFFu; val[r] = 0u; }
-            if (wbase < D) {  // wave-uniform
+            if (wbase < s1) {  // wave-uniform
                 const int g0 = __builtin_amdgcn_readfirstlane(have_owners ? ex.owner[(int)((wbase - s0) / PS_CHUNK)]
                                                                           : owner_search(a.offsets, 0, P, (uint32_t)wbase));
-                decode_chunk<GSR_PS_DECODE_BATCH>(a.offsets, a.sorted_ids, a.rects, P, D, wbase, g0, a.xbits, ex.cflag[wave], key, val);
+                decode_chunk<GSR_PS_DECODE_BATCH>(a.offsets, a.sorted_ids, a.rects, P, s1, wbase, g0, a.xbits, ex.cflag[wave], key, val);
             }
-            count_wave_digits(sm, key, wbase, D, 0, xmask);
+            count_wave_digits(sm, key, wbase, s1, 0, xmask);
             __syncthreads();
-            first += scatter_tile<PS_ITEMS, PS_THREADS, true>(sm, key, val, tbase, D, 0, a.xbits, first, a.kB, a.vB);
+            first += scatter_tile<PS_ITEMS, PS_THREADS, true>(sm, key, val, tbase, s1, 0, a.xbits, first, a.kB, a.vB);
             clear_wtab(sm);
             __syncthreads();
         }
@@ -1064,14 +1077,14 @@ bin_sort_persist_kernel(const SortPersistArgs a) {
     {
         const uint32_t ymask = (1u << a.ybits) - 1u;
         uint32_t mytot = 0;
-        for (long long t = t0; t < t1; t++) {
-            const long long wbase = t * PS_TILE + (long long)wave * PS_CHUNK;
+        for (long long tbase = s0; tbase < s1; tbase += PS_TILE) {
+            const long long wbase = tbase + (long long)wave * PS_CHUNK;
 #pragma unroll
             for (int r = 0; r < PS_ITEMS; r++) {
                 const long long j = wbase + r * 64 + lane;
-                key[r] = j < D ? ld_agent(&a.kB[j]) : 0xFFFFFFFFu;
+                key[r] = j < s1 ? ld_agent(&a.kB[j]) : 0xFFFFFFFFu;
             }
-            count_wave_digits(sm, key, wbase, D, a.xbits, ymask);
+            count_wave_digits(sm, key, wbase, s1, a.xbits, ymask);
             __syncthreads();
             if (d < RADIX_DIGITS) {
 #pragma unroll
@@ -1095,18 +1108,17 @@ bin_sort_persist_kernel(const SortPersistArgs a) {
                                   before, total);
         uint32_t all;
         uint32_t first = block_exclusive_scan_n<PS_WAVES>(total, sm.scan_tmp, &all) + before;
-        for (long long t = t0; t < t1; t++) {
-            const long long tbase = t * PS_TILE;
+        for (long long tbase = s0; tbase < s1; tbase += PS_TILE) {
             const long long wbase = tbase + (long long)wave * PS_CHUNK;
 #pragma unroll
             for (int r = 0; r < PS_ITEMS; r++) {
                 const long long j = wbase + r * 64 + lane;
-                key[r] = j < D ? ld_agent(&a.kB[j]) : 0xFFFFFFFFu;
-                val[r] = j < D ? ld_agent(&a.vB[j]) : 0u;
+                key[r] = j < s1 ? ld_agent(&a.kB[j]) : 0xFFFFFFFFu;
+                val[r] = j < s1 ? ld_agent(&a.vB[j]) : 0u;
             }
-            count_wave_digits(sm, key, wbase, D, a.xbits, ymask);
+            count_wave_digits(sm, key, wbase, s1, a.xbits, ymask);
             __syncthreads();
-            first += scatter_tile<PS_ITEMS, PS_THREADS, false>(sm, key, val, tbase, D, a.xbits, a.ybits, first, a.kA, a.point_list);
+            first += scatter_tile<PS_ITEMS, PS_THREADS, false>(sm, key, val, tbase, s1, a.xbits, a.ybits, first, a.kA, a.point_list);
             clear_wtab(sm);
             __syncthreads();
         }
@@ -1119,8 +1131,9 @@ bin_sort_persist_kernel(const SortPersistArgs a) {
     // ------------------------------------------------------------------ T: K7 over my slots (see tile_ranges_yx_kernel)
     {
         int2 *const ranges = reinterpret_cast<int2 *>(a.ranges);
-        for (long long j = s0 + (long long)threadIdx.x * 4; j < s1; j += PS_THREADS * 4) {
-            uint32_t k[6];  // k[0] = predecessor, k[1..4] = own, k[5] = successor
+        // four keys per thread and trip, with their neighbours; the loads of the NEXT trip are issued before this one's
+        // keys are looked at (every agent-scope load is a trip to memory: one after the other they were 15 us)
+        auto load6 = [&](long long j, uint32_t (&k)[6]) {  // k[0] = predecessor, k[1..4] = own, k[5] = successor
             k[0] = j > 0 ? ld_agent(&a.kA[j - 1]) : 0xFFFFFFFFu;
             if (j + 4 <= D) {  // (two 8-byte agent-scope loads: the keys were written by other workgroups)
                 const unsigned long long q0 = ld_agent64(reinterpret_cast<const unsigned long long *>(a.kA + j));
@@ -1131,6 +1144,13 @@ bin_sort_persist_kernel(const SortPersistArgs a) {
                 for (int i = 0; i < 4; i++) k[1 + i] = j + i < D ? ld_agent(&a.kA[j + i]) : 0xFFFFFFFFu;
             }
             k[5] = j + 4 < D ? ld_agent(&a.kA[j + 4]) : 0xFFFFFFFFu;
+        };
+        long long j = s0 + (long long)threadIdx.x * 4;
+        uint32_t k[6], kn[6];
+        if (j < s1) load6(j, k);
+        while (j < s1) {
+            const long long jn = j + PS_THREADS * 4;
+            if (jn < s1) load6(jn, kn);
 #pragma unroll
             for (int i = 1; i <= 4; i++) {
                 if (j + i - 1 >= D) break;
@@ -1142,6 +1162,9 @@ bin_sort_persist_kernel(const SortPersistArgs a) {
                     if (k[i + 1] != kk) st_agent(reinterpret_cast<uint32_t *>(&ranges[tl].y), (uint32_t)(j + i));
                 }
             }
+#pragma unroll
+            for (int i = 0; i < 6; i++) k[i] = kn[i];
+            j = jn;
         }
     }
     GSR_TS(9);

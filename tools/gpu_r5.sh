@@ -30,7 +30,7 @@ if has bintest; then
   tail -15 $O/bintest.log | cut -c1-300
 fi
 if has binbench; then
-  GSR_BIN_PERSIST_MAXD=100000000 timeout 300 python tools/binbench.py --iters 20 --cull 0 1 $BINBENCH_LIBS > $O/binbench_c1.txt 2> $O/binbench_c1.err
+  GSR_BIN_PERSIST_MAXD=100000000 timeout 300 python tools/binbench.py --iters 20 --cull 0 1 ${BINBENCH_LIBS:-} > $O/binbench_c1.txt 2> $O/binbench_c1.err
   echo "binbench c1 exit $?"; cat $O/binbench_c1.txt; tail -3 $O/binbench_c1.err | cut -c1-300
   timeout 300 python tools/binbench.py --iters 20 --band 30 39 > $O/binbench_band.txt 2> $O/binbench_band.err
   GSR_BIN_PERSIST_MAXD=100000000 timeout 300 python tools/binbench.py --iters 20 --band 20 48 > $O/binbench_band2.txt 2> $O/binbench_band2.err; cat $O/binbench_band2.txt
