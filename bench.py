@@ -374,11 +374,14 @@ def run_workload(a, name, world, rank, dev, steps, warmup, repeats, render_steps
             dist.barrier()
         torch.cuda.synchronize()
 
+    host_enqueue = {}  # id(fn) -> seconds the host needed to ENQUEUE the n calls (before it waited for the device)
+
     def timed(fn, n):
         fence()
         t0 = time.perf_counter()
         for _ in range(n):
             fn()
+        host_enqueue[fn.__name__] = time.perf_counter() - t0
         fence()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -468,6 +471,7 @@ def run_workload(a, name, world, rank, dev, steps, warmup, repeats, render_steps
             render_step()
         dt_r = timed(render_step, render_steps)
         out["rendered_views_per_sec_one_stream"] = bsz * render_steps / dt_r
+        out["render_host_ms_per_view"] = 1e3 * host_enqueue.get("render_step", 0.0) / (bsz * render_steps)
         out["rendered_views_per_sec"] = out["rendered_views_per_sec_one_stream"]
         if world == 1 and dev.type == "cuda" and os.environ.get("GSR_RENDER_STREAMS", "2") != "1":
             # Forward-only views are independent (the reference's render driver walks the cameras one after the other,
@@ -489,6 +493,8 @@ def run_workload(a, name, world, rank, dev, steps, warmup, repeats, render_steps
                 render_step_two_streams()
             dt_2 = timed(render_step_two_streams, render_steps)
             out["rendered_views_per_sec_two_streams"] = bsz * render_steps / dt_2
+            out["render_host_ms_per_view_two_streams"] = 1e3 * host_enqueue.get("render_step_two_streams", 0.0) / (
+                bsz * render_steps)
             out["rendered_views_per_sec"] = max(out["rendered_views_per_sec_one_stream"],
                                                 out["rendered_views_per_sec_two_streams"])
             torch.cuda.current_stream(dev).wait_stream(side[0])
@@ -846,7 +852,13 @@ def main():
         "rendered_views": {"one_stream": round(main_res.get("rendered_views_per_sec_one_stream", 0.0), 3),
                            "two_streams": (round(main_res["rendered_views_per_sec_two_streams"], 3)
                                            if "rendered_views_per_sec_two_streams" in main_res else None),
-                           "note": "forward-only views at the workload's resolution; two_streams = consecutive views "
+                           "host_ms_per_view": (round(main_res["render_host_ms_per_view"], 4)
+                                                if "render_host_ms_per_view" in main_res else None),
+                           "host_ms_per_view_two_streams": (round(main_res["render_host_ms_per_view_two_streams"], 4)
+                                                            if "render_host_ms_per_view_two_streams" in main_res else None),
+                           "note": "host_ms_per_view = time the host needs to enqueue a view (the loop is device-bound "
+                                   "while this is below 1 / views_per_sec); "
+                                   "forward-only views at the workload's resolution; two_streams = consecutive views "
                                    "alternate between two HIP streams (binning of view k+1 beside the composite of view k); "
                                    "rendered_views_per_sec is the better of the two"},
         "kernels": kern,
