@@ -608,7 +608,7 @@ def main():
                     help="N > 1: skip the extra legs of the line (the same workload with pipelined balance timings, and "
                          "the iteration replayed as one hipGraph -- the latter as a guarded child launch)")
     ap.add_argument("--leg-child", action="store_true", help=argparse.SUPPRESS)  # this process IS a leg: no legs of its own
-    ap.add_argument("--leg-timeout", type=int, default=300, help="wall-clock limit of a guarded leg (seconds)")
+    ap.add_argument("--leg-timeout", type=int, default=180, help="wall-clock limit of a guarded leg (seconds)")
     ap.add_argument("--with-pipelined-leg", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-fuse-backward", action="store_true",
                     help="run K11 and Adam as two kernels (the parameter gradients go through HBM) instead of the fused "
