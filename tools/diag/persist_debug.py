@@ -1,4 +1,4 @@
-"""Round-5 debugging aid: bin_gaussians (the operator's path: async prepare, speculative bounded sort) in every
+"""Round-5 aid: bin_gaussians (the operator's path: one C-ABI call per view, speculative bounded sort) in every
 gsr_set_bin_persistent mode on the bench scene, lists compared with the look-back pipeline's.  GPU box only."""
 import math
 import os
