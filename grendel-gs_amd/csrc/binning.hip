@@ -552,12 +552,12 @@ extern "C" size_t gsr_bin_prepare_bytes(int P, int width, int height) {
 }
 
 namespace {
-// Exact tile culling (binning_persist.h: gsr_tile_mask).  Its cost is K3's -- per Gaussian, ~50 instructions per tile
-// row of the rect, +42 us per 10^6 Gaussians at 4K -- its return the D-sized passes' and the composite kernels'.
-// Measured (profiles/r05_tile_cull.txt): D -9..17 %; K3-K7 702 -> 687 us at 4K (42 pairs per Gaussian), the 4K training step
-// 2.750 -> 2.760 ms, the 1080p step 1.166 -> 1.167 ms (K8 / K10 -2 %, binning +3 %): the composite kernels skip such pairs
-// with one box test per quadrant anyway.  Hence OFF by default; "auto" (frames above GSR_TILE_CULL_TILES tiles, default
-// 16384) is a static rule for scenes whose splats cover many tiles -- not a function of earlier views.
+// Exact tile culling (binning_persist.h: gsr_tile_mask).  Its cost is K3's -- per Gaussian and tile row of the rect,
+// +27 us per 10^6 Gaussians at 1080p, +37 us at 4K -- its return the D-sized passes' and the composite kernels'.
+// Measured (profiles/r05_tile_cull.txt): D -9..19 %; K3-K7 327 -> 330 us at c1, 713 -> 694 us at 4K; the training steps
+// 1.206 -> 1.204 ms and 2.811 -> 2.799 ms: the composite kernels skip such pairs with one box test per quadrant anyway.
+// Hence OFF by default; "auto" (frames above GSR_TILE_CULL_TILES tiles, default 16384) is a static rule for scenes whose
+// splats cover many tiles -- not a function of earlier views.
 std::atomic<int> g_tile_cull{-1};  // gsr_set_tile_cull: -1 = environment (GSR_TILE_CULL = 0 | 1 | auto, default 0)
 int tile_cull_on(int tiles) {
     int mode = g_tile_cull.load(std::memory_order_relaxed);

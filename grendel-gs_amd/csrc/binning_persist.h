@@ -242,9 +242,11 @@ __device__ __forceinline__ unsigned long long gsr_tile_mask(const float2 xy, con
     // an improper or ill-conditioned conic is not culled (gsr_can_touch_box keeps those too)
     if (!(A > 0.f && C > 0.f && det > 1e-6f * A * C) || !(co.w >= 1.0f / 255.0f)) return all;
     const float lim = (2.0f * 0.6931471805599453f) * __builtin_amdgcn_logf(255.0f * co.w) * 1.002f + 0.01f;
-    const float rA = 1.0f / A, rC = 1.0f / C;
-    const float dxs = sqrtf(lim * C / det);  // half extent in x of the whole ellipse, reached at dy = -/+ B dxs / C
-    const float dys = B * dxs * rC;
+    // (hardware reciprocal / square root, 1 ulp: the IEEE sequences of `/` and sqrtf() were most of this function's ~50
+    // instructions per row; the 0.2 % + 0.01 inflation of lim and the 0.02 px slack below dwarf their error)
+    const float rA = __builtin_amdgcn_rcpf(A), rC = __builtin_amdgcn_rcpf(C);
+    const float dxs = __builtin_amdgcn_sqrtf(lim * C * __builtin_amdgcn_rcpf(det));  // half extent in x of the whole
+    const float dys = B * dxs * rC;                                                  // ellipse, reached at dy = -/+ dys
     unsigned long long mask = 0ull;
     for (int r = 0; r < h; r++) {
         const float t0 = (float)((miny + r) * GSR_BLOCK_Y) - xy.y, t1 = t0 + (float)(GSR_BLOCK_Y - 1);  // the row's strip
@@ -256,7 +258,7 @@ __device__ __forceinline__ unsigned long long gsr_tile_mask(const float2 xy, con
             const float t = -dys < t0 ? t0 : t1;
             const float disc = lim * A - det * t * t;
             emptyR = disc < 0.f;
-            dxR = (-B * t + sqrtf(fmaxf(disc, 0.f))) * rA;
+            dxR = (-B * t + __builtin_amdgcn_sqrtf(fmaxf(disc, 0.f))) * rA;
         }
         if (dys >= t0 && dys <= t1) {
             dxL = -dxs;
@@ -264,7 +266,7 @@ __device__ __forceinline__ unsigned long long gsr_tile_mask(const float2 xy, con
             const float t = dys < t0 ? t0 : t1;
             const float disc = lim * A - det * t * t;
             emptyL = disc < 0.f;
-            dxL = (-B * t - sqrtf(fmaxf(disc, 0.f))) * rA;
+            dxL = (-B * t - __builtin_amdgcn_sqrtf(fmaxf(disc, 0.f))) * rA;
         }
         int xa = 0, xb = w;  // columns kept in this row, relative to minx
         if (emptyR && emptyL) continue;  // the strip misses the ellipse
@@ -318,20 +320,37 @@ __device__ __forceinline__ uint32_t gsr_rect_tiles(const float2 xy, const float4
     const unsigned long long mask = gsr_tile_mask(xy, co, minx, miny, maxx, maxy);
     out.mask = mask;
     if (dxy) {
+        // the tile sort's digit histograms as difference arrays.  Rows of an ellipse mostly keep the same span, so equal
+        // consecutive runs are merged into one +m / -m pair (columns) and a row only touches the row-digit array where
+        // its tile count differs from the row above (LDS atomics on a handful of hot addresses are what K3 pays here)
         const unsigned long long rowm = gsr_full_mask(w);
+        int prev_cnt = 0, run_a0 = 0, run_len = 0, run_mult = 0;
         for (int r = 0; r < h; r++) {
             unsigned long long bits = (mask >> (r * w)) & rowm;
+            const int cnt = __popcll(bits);
+            if (cnt != prev_cnt) atomicAdd(&dxy[1][miny + r], cnt - prev_cnt);
+            prev_cnt = cnt;
             while (bits) {  // one run per row (the kept tiles of a row are contiguous), written for any pattern
                 const int a0 = __ffsll((long long)bits) - 1;
                 const unsigned long long rest = ~(bits >> a0);
                 const int len = rest ? __ffsll((long long)rest) - 1 : 64 - a0;
-                atomicAdd(&dxy[0][minx + a0], 1);
-                atomicAdd(&dxy[0][minx + a0 + len], -1);
-                atomicAdd(&dxy[1][miny + r], len);
-                atomicAdd(&dxy[1][miny + r + 1], -len);
+                if (run_mult && a0 == run_a0 && len == run_len) {
+                    run_mult++;
+                } else {
+                    if (run_mult) {
+                        atomicAdd(&dxy[0][minx + run_a0], run_mult);
+                        atomicAdd(&dxy[0][minx + run_a0 + run_len], -run_mult);
+                    }
+                    run_a0 = a0; run_len = len; run_mult = 1;
+                }
                 bits &= ~(gsr_full_mask(len) << a0);
             }
         }
+        if (run_mult) {
+            atomicAdd(&dxy[0][minx + run_a0], run_mult);
+            atomicAdd(&dxy[0][minx + run_a0 + run_len], -run_mult);
+        }
+        if (prev_cnt) atomicAdd(&dxy[1][maxy], -prev_cnt);
     }
     return (uint32_t)__popcll(mask);
 }
