@@ -160,7 +160,7 @@ int gsr_set_bin_persistent(int mode);
  * of tiles its alpha >= 1/255 ellipse reaches (the quadratic form and tolerance of the composite kernels' own skip test),
  * kept as a 64-bit mask (rects of <= 64 tiles on frames of <= 256 x 256 tiles).  The lists stay order-preserving
  * subsequences of the uncut ones -- a dropped (tile, Gaussian) has alpha < 1/255 on every pixel of the tile -- so the image
- * and the gradients are unchanged up to the summation order of the blend; D shrinks by 9-17 %.  OFF by default: measured
+ * and the gradients are unchanged up to the summation order of the blend; D shrinks by 9-19 %.  OFF by default: measured
  * neutral (K3 pays per Gaussian what the D-sized passes and the composite kernels save per pair).  mode: -1 the
  * environment's GSR_TILE_CULL (0 | 1 | auto, default 0), 0 off, 1 on, 2 auto = on for frames of more than
  * GSR_TILE_CULL_TILES (default 16384) tiles -- a static rule: the lists do not depend on earlier views. */
