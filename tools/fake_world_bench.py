@@ -260,8 +260,12 @@ def main():
             print(f"# host profile, W={W}: {a0.steps + a0.warmup + 8} steps (incl. priming / warmup)")
             print(sio.getvalue()[:24000], flush=True)
         kern = {k: v["avg_ms"] for k, v in res["kernels"].items()}
+        import diff_gaussian_rasterization as _dgr_
+
         results.append({"world": W, "rank": rank if W > 1 else 0, "ms_per_step": round(res["ms_per_step"], 4),
-                        "gaussians_this_rank": res["gaussians_this_rank"], "kernel_ms": kern,
+                        "gaussians_this_rank": res["gaussians_this_rank"],
+                        "pairs_last_view": int(getattr(_dgr_._RenderGaussians, "last_num_rendered", 0) or 0),
+                        "kernel_ms": kern,
                         "kernel_sum_ms": round(sum(kern.values()), 4), "exchange_layouts": dict(gr.exchange_stats),
                         "graph": res.get("graph")})
         if a0.graph == "on":
