@@ -1,8 +1,14 @@
 #!/bin/bash
 # Round-5 GPU sessions: tools/gpu_r5.sh <tag> <stage> [<stage> ...]   (everything lands in gpurun_out/<tag>/)
-#   bintest   the binning tests (persistent vs look-back pipeline, ordered-subsequence, speculative sort)
-#   binbench  tools/binbench.py: K3-K7 alone in the four gsr_set_bin_persistent modes (c1 whole frame, a 1/8 band)
+#   bintest   the binning tests (persistent vs look-back pipeline, ordered-subsequence with culling on / off, speculative sort)
+#   binbench  tools/binbench.py: K3-K7 alone in the four gsr_set_bin_persistent modes (c1 whole frame with culling off / on,
+#             tile rows 20-47, a 1/8 band); BINBENCH_LIBS="--lib variants/libgsraster_X.so ..." adds experiment builds
 #   binbig    the same at configs[2]'s 6 M Gaussians and at a 5 M / 4K eighth band
+#   cull      the exact-tile-culling tests, K3-K7 at 4K and the c1 / 4K training steps with GSR_TILE_CULL = 0 / 1
+#   shapes    bench.py --workload c2 / c4 on one GPU, persistent binning on / off
+#   fakeab    tools/fake_world_bench.py --workload c2 --worlds 1 8 with GSR_BIN_PERSIST = 1 / 0
+#   fullsize  tests/test_gpu_fullsize.py
+#   any other stage name is handed to tools/gpu_run.sh (test, quick, bench, benchq, pmc, fake, fakeg, ...)
 set -u
 TAG=${1:-r05}; shift || true
 STAGES=${*:-bintest binbench}
