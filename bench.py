@@ -234,8 +234,13 @@ def run_guarded_leg(n, argv, timeout_s):
                 return d
             except json.JSONDecodeError:
                 break
-    why = [ln.strip() for ln in (se or "").splitlines() if "Error" in ln or "error:" in ln or "fault" in ln]
-    return {"error": f"exit code {p.returncode}, no JSON line" + (f"; {why[-1][:300]}" if why else ""),
+    lines = [ln.strip() for ln in (se or "").splitlines()]
+    # the rank's own complaint (an RCCL / HIP / Python error) says more than the launcher's summary of it
+    why = [ln for ln in lines if any(k in ln for k in ("Duplicate GPU", "ncclInvalidUsage", "NCCL error", "HIP error",
+                                                       "RuntimeError", "Memory access fault", "ValueError", "SystemExit"))]
+    if not why:
+        why = [ln for ln in lines if "Error" in ln or "error:" in ln or "fault" in ln]
+    return {"error": f"exit code {p.returncode}, no JSON line" + (f"; {why[0][:300]}" if why else ""),
             "stderr_tail": (se or "")[-600:]}
 
 
