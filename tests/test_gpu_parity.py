@@ -230,6 +230,66 @@ def test_persistent_binning_equals_the_lookback_pipeline(device, monkeypatch, gr
             assert pl.numel() == D and torch.equal(pl, rpl), (mode, spec, order[i])
 
 
+def test_two_host_threads_on_two_streams_bin_the_same_lists(device):
+    """K3-K7 called from TWO host threads, each on its own stream (bench.py's two-thread views leg; a render server with a
+    thread per stream): the per-(device, stream) scratch, the count slots and the admission of the barrier kernels (the
+    second stream's launch takes the look-back pipeline while the first one's persistent kernel is in flight) must give
+    the lists of the sequential calls, bit for bit"""
+    import threading
+
+    import diff_gaussian_rasterization as dgr
+    from oracle import cref as C
+
+    W, H = 333, 211
+    cam = S.orbit_cameras(4, W, H)[1]
+
+    def inputs(N, sc, seed):
+        g = S.make_gaussians(N, W, H, seed=seed, scale_coef=sc)
+        m2, rgb, co, radii, depths, _, _ = C.preprocess_forward(*[g[k] for k in KEYS], **cam_kwargs(cam))
+        mask = _full_mask(cam)
+        mask[1, :] = False
+        return [t.to(device) for t in (m2, depths, radii, co, mask.view(-1).to(torch.uint8))]
+
+    views = [inputs(3000, 0.02, 5), inputs(9000, 0.03, 6), inputs(20000, 0.06, 7), inputs(9000, 0.05, 8)]
+    dgr.release_workspaces()
+    ref = []
+    for x in views:
+        pl, rg, D = dgr.bin_gaussians(*x, W, H)
+        ref.append((pl.clone(), rg.clone(), D))
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device), torch.cuda.Stream(device)]
+    got, errs = [[], []], []
+
+    def worker(k):
+        try:
+            torch.cuda.set_device(device)
+            with torch.cuda.stream(streams[k]):
+                for i in range(24):
+                    v = (2 * i + k + i // 5) % len(views)
+                    pl, rg, D = dgr.bin_gaussians(*views[v], W, H)
+                    got[k].append((v, pl.clone(), rg.clone(), D))
+        except BaseException as e:  # noqa: BLE001
+            errs.append(e)
+
+    try:
+        ths = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        torch.cuda.synchronize()
+    finally:
+        dgr.release_workspaces()
+    assert not errs, errs
+    for k in range(2):
+        assert len(got[k]) == 24
+        for v, pl, rg, D in got[k]:
+            rpl, rrg, rD = ref[v]
+            assert D == rD, (k, v)
+            assert torch.equal(rg, rrg), (k, v)
+            assert pl.numel() == D and torch.equal(pl, rpl), (k, v)
+
+
 @pytest.mark.parametrize("N,W,H,sc,seed,ci", SCENES[1:4])
 def test_exact_tile_culling_changes_nothing_but_the_pair_count(device, N, W, H, sc, seed, ci):
     """gsr_set_tile_cull(1): fewer (tile, Gaussian) pairs, the same image and gradients -- against the run without culling
