@@ -9,11 +9,14 @@ const char *gsr_error_string(int code) {
     if (code == GSR_EINVAL) return "gsraster: invalid argument";
     if (code == GSR_ENOSPACE) return "gsraster: workspace too small";
     if (code == GSR_ERETRY) return "gsraster: pair count valid, bounded sort must be repeated";
+    if (code == GSR_EFAULT)
+        return "gsraster: a persistent binning kernel of an earlier call timed out at a grid barrier (hung or preempted "
+               "device); that view's lists are incomplete; the look-back pipeline is used from now on";
     if (code > 0) return hipGetErrorString((hipError_t)code);
     return "gsraster: unknown error";
 }
 
-int gsr_abi_version(void) { return 11; }
+int gsr_abi_version(void) { return 12; }
 
 int gsr_get_block_xy(int *block_x, int *block_y, int *one_dim_block) {
     if (!block_x || !block_y || !one_dim_block) return GSR_EINVAL;

@@ -708,7 +708,7 @@ int prepare_persistent(const PrepCall &c, uint32_t *ticket) {
     a.done_word = g_persist_done[dev];
     a.done_seq = (uint32_t)admit;
     a.timeout_ticks = 5000000ull;  // 50 ms of the 100 MHz clock at the first barrier
-    a.notrap = env_cap("GSR_BIN_NOTRAP", 2) == 1;
+    a.force_abort = force_abort_env('p') ? 1 : 0;
     if (items == 4) hipLaunchKernelGGL(bin_prepare_persist_kernel<4>, dim3(G), dim3(PP_THREADS), 0, c.stream, a);
     else hipLaunchKernelGGL(bin_prepare_persist_kernel<8>, dim3(G), dim3(PP_THREADS), 0, c.stream, a);
     GSR_LAUNCH_CHECK();
@@ -730,6 +730,12 @@ extern "C" int gsr_bin_prepare_async(int P, int width, int height, const float *
     const int gx = (width + GSR_BLOCK_X - 1) / GSR_BLOCK_X, gy = (height + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y;
     if (gx > 0xFFFF || gy > 0xFFFF) return GSR_EINVAL;
     PrepCall c{P, width, height, means2D, depths, radii, conic_opacity, compute_locally, prep, stream, true};
+    {
+        int dev0 = 0;
+        GSR_HIP(hipGetDevice(&dev0));
+        const int fault = persist_fault_check(dev0);  // (a barrier fault of an earlier call: reported once)
+        if (fault) return fault;
+    }
     int rc = prepare_persistent(c, ticket);
     if (rc == 1) {
         c.persistent = false;
@@ -799,20 +805,28 @@ extern "C" int gsr_bin_timeline(int which, unsigned long long *out, int max_word
     return 0;
 }
 
-extern "C" int gsr_bin_persist_status(uint32_t *out3) {
-    if (!out3) return GSR_EINVAL;
+extern "C" int gsr_bin_persist_status(uint32_t *out4) {
+    if (!out4) return GSR_EINVAL;
     int dev = 0;
     GSR_HIP(hipGetDevice(&dev));
-    out3[0] = out3[1] = out3[2] = 0;
+    out4[0] = out4[1] = out4[2] = out4[3] = 0;
     if (dev < 0 || dev >= 64 || !g_persist_done[dev]) return 0;
     const volatile uint32_t *w = g_persist_done[dev];
-    out3[0] = w[0]; out3[1] = w[1]; out3[2] = w[2];
+    out4[0] = w[0]; out4[1] = w[1]; out4[2] = w[2]; out4[3] = w[3];
     return 0;
 }
 
 extern "C" int gsr_set_bin_persistent(int mode) {
     if (mode < -1 || mode > 3) return GSR_EINVAL;
     g_persist_override.store(mode, std::memory_order_relaxed);
+    {  // an explicit choice also ends the back-off that follows a one-workgroup recovery of the sort kernel
+        std::lock_guard<std::mutex> guard(g_persist_mutex);
+        for (int dev = 0; dev < 64; dev++) {
+            if (!g_persist_done[dev]) continue;
+            g_persist_solo_seen[dev] = reinterpret_cast<volatile uint32_t *>(g_persist_done[dev])[3];
+            g_persist_backoff[dev] = 0;
+        }
+    }
     return 0;
 }
 
@@ -887,20 +901,28 @@ int bin_sort_impl(int P, int width, int height, const uint8_t *compute_locally, 
     char *ctrl = sbase + S.ctrl;
 
     if (bounded && !yx_path(gx, gy)) return GSR_EINVAL;
+    {
+        int dev0 = 0;
+        GSR_HIP(hipGetDevice(&dev0));
+        const int fault = persist_fault_check(dev0);
+        if (fault) return fault;
+    }
     if (yx_path(gx, gy) && (persist_effective_mode() & PERSIST_S)) {
         // K5-K7 as ONE persistent launch (binning_persist.h) when the device can hold the grid and no barrier kernel of
         // another stream may still be waiting
         int dev = 0;
         GSR_HIP(hipGetDevice(&dev));
         PersistCaps caps;
-        if (dev >= 0 && dev < 64) persist_caps(dev, &caps);
+        const bool dev_ok = dev >= 0 && dev < 64;
+        if (dev_ok) persist_caps(dev, &caps);
         const long long nbD = radix_blocks(D);
         const int G = (int)(nbD < caps.grid_s ? nbD : caps.grid_s);
         // long sorts are throughput-bound (VALU: the ranking) and the look-back pipeline, which reads every pair once
         // less, wins: measured cross-over between 2 and 14 million pairs (profiles/r05_binning_persistent.txt)
         const long long max_pairs = env_cap("GSR_BIN_PERSIST_MAXD", 0x7fffffff) == 0x7fffffff ? PERSIST_SORT_MAX_PAIRS
                                                                                         : env_cap("GSR_BIN_PERSIST_MAXD", 0x7fffffff);
-        const long long admit = (G > 0 && D <= max_pairs) ? persist_admit(dev, stream) : -1;
+        const bool want = dev_ok && G > 0 && g_persist_done[dev] && D <= max_pairs && !persist_sort_backoff(dev);
+        const long long admit = want ? persist_admit(dev, stream) : -1;
         if (admit >= 0) {
             const PersistLayoutS PS = persist_layout_s(G);
             GSR_HIP(hipMemsetAsync(ctrl, 0, PS.zero_bytes, stream));
@@ -918,11 +940,15 @@ int bin_sort_impl(int P, int width, int height, const uint8_t *compute_locally, 
             a.tstamp = timeline_buffer(1, G);
             a.grp = reinterpret_cast<uint32_t *>(ctrl + PS.grp);
             a.cnt = reinterpret_cast<uint32_t *>(ctrl + PS.cnt);
+            a.grp_solo = reinterpret_cast<uint32_t *>(ctrl + PS.grp_solo);
+            a.cnt_solo = reinterpret_cast<uint32_t *>(ctrl + PS.cnt_solo);
             a.done_word = g_persist_done[dev];
             a.done_seq = (uint32_t)admit;
-            a.timeout_ticks = 200000000ull;  // two seconds at the first barrier, then a trap
+            // a quarter of a second at the first barrier, then workgroup 0 sorts the view alone (no trap, no host round
+            // trip: binning_persist.h); GSR_BIN_SORT_TIMEOUT_MS overrides (tests)
+            a.timeout_ticks = 100000ull * (unsigned long long)env_cap("GSR_BIN_SORT_TIMEOUT_MS", 250);
             a.owners_cap = env_cap("GSR_BIN_OWNERS", PS_OWNERS);
-            a.notrap = env_cap("GSR_BIN_NOTRAP", 2) == 1;
+            a.force_abort = force_abort_env('s') ? 1 : 0;
             hipLaunchKernelGGL(bin_sort_persist_kernel, dim3(G), dim3(PS_THREADS), 0, stream, a);
             GSR_LAUNCH_CHECK();
             return 0;

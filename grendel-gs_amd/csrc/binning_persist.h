@@ -32,9 +32,10 @@
 // CUs, checked on the host), so all workgroups arrive at the first barrier as soon as earlier kernels drain.  Two
 // barrier kernels on DIFFERENT streams could each hold part of the machine and wait for the rest forever: the host
 // admits a persistent launch only when the previous one was on the same stream or has passed its last barrier (a
-// pinned word); another process sharing the device is covered by a time-out at the FIRST barrier -- the prepare kernel
-// then reports the pair count 0xFFFFFFFF and the host repeats the call on the look-back pipeline; the sort kernel
-// traps (fails loudly) after two seconds.
+// pinned word); another process sharing the device (or a graph replay, or a collective waiting for a late peer on
+// another stream) is covered by a time-out at the FIRST barrier, decided for the whole grid at once -- the prepare kernel
+// then reports the pair count 0xFFFFFFFF and the host repeats the call on the look-back pipeline; in the sort kernel
+// workgroup 0 finishes the view alone (round 6: no trap anywhere, see bin_sort_persist_kernel and barrier_fault).
 #pragma once
 
 namespace {
@@ -56,50 +57,76 @@ __host__ __device__ inline size_t grid_sync_words(int G) {
 
 // Barrier over the G workgroups of the grid; `epoch` counts this workgroup's barriers (uniform over the grid).  Returns
 // false when the kernel was aborted (a time-out at some workgroup's barrier): the caller leaves at once.
-// No fences: what crosses workgroups is written through and read at agent scope (see the head of this file); the
-// workgroup barrier in front of the arrival waits for every wave's outstanding stores (s_waitcnt vmcnt(0)).
+// No fences: what crosses workgroups is written through and read at agent scope (see the head of this file); every wave
+// waits for its own outstanding stores (s_waitcnt vmcnt(0): on gfx9 stores count in vmcnt) in front of the workgroup
+// barrier that precedes the arrival atomic -- __syncthreads() alone compiles to `s_waitcnt lgkmcnt(0); s_barrier` here, and
+// an arrival that overtakes a store of another wave would let a remote reader see the flag before the data.
+// The abort decision is SINGLE-SOURCED in the root word (round 6; advisor r05): a workgroup that times out sets the abort
+// bit with a compare-and-swap that fails once the root holds the complete count, and whoever completes the count looks at
+// the bit in the value its own arrival returned.  So either every workgroup passes the barrier or none does: a completer
+// can no longer release the flags over an abort it did not see (some groups went on, the rest had left).
+// `force_abort` (test hook): this workgroup raises the abort bit BEFORE it arrives -- its group, hence the root, cannot be
+// complete yet, so the abort always wins.
+__device__ __forceinline__ bool grid_barrier_try_abort(const GridSync gs, uint32_t complete) {
+    uint32_t r = __hip_atomic_load(gs.root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (true) {
+        if (r & GB_ABORT) return true;
+        if (r == complete) return false;  // the grid arrived after all: the flags are on their way
+        if (__hip_atomic_compare_exchange_strong(gs.root, &r, r | GB_ABORT, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT))
+            return true;
+    }
+}
 __device__ __forceinline__ bool grid_barrier(const GridSync gs, uint32_t G, uint32_t &epoch, uint64_t timeout_ticks,
-                                             uint32_t *s_flag) {
+                                             uint32_t *s_flag, bool force_abort = false) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
         epoch++;
         const uint32_t g = blockIdx.x / GB_FAN, ngroups = (G + GB_FAN - 1) / GB_FAN;
         const uint32_t gsz = min((uint32_t)GB_FAN, G - g * GB_FAN);
+        const uint32_t complete = epoch * ngroups;
+        if (force_abort && grid_barrier_try_abort(gs, complete))
+            for (uint32_t k = 0; k < ngroups; k++) st_agent(&gs.flags[k * GB_LEAF_STRIDE], 0xFFFFFFFFu);
         const uint32_t old =
             __hip_atomic_fetch_add(&gs.leaf[g * GB_LEAF_STRIDE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (old + 1u == epoch * gsz) {
             const uint32_t r = __hip_atomic_fetch_add(gs.root, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((r & ~GB_ABORT) + 1u == epoch * ngroups)  // the grid is complete: let every group go (G pollers on the
-                for (uint32_t k = 0; k < ngroups; k++)     // root cost 7.7 us at G = 1024, a flag per group 2.6 us)
+            if ((r & ~GB_ABORT) + 1u == complete)       // the grid is complete: let every group go (G pollers on the
+                for (uint32_t k = 0; k < ngroups; k++)  // root cost 7.7 us at G = 1024, a flag per group 2.6 us)
                     st_agent(&gs.flags[k * GB_LEAF_STRIDE], (r & GB_ABORT) ? 0xFFFFFFFFu : epoch);
         }
-        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
-        uint32_t aborted = 0, f;
+        uint64_t t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
+        uint32_t f;
         while ((f = ld_agent(&gs.flags[g * GB_LEAF_STRIDE])) < epoch) {
             __builtin_amdgcn_s_sleep(1);
             if (__builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) {
-                // give up: raise the abort bit of the root and of every flag (a flag at 0xFFFFFFFF lets everybody leave)
-                __hip_atomic_fetch_or(gs.root, GB_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                for (uint32_t k = 0; k < ngroups; k++) st_agent(&gs.flags[k * GB_LEAF_STRIDE], 0xFFFFFFFFu);
-                f = 0xFFFFFFFFu;
-                break;
+                // give up -- unless the count completed meanwhile: raise the abort bit of the root, then every flag (a flag
+                // at 0xFFFFFFFF lets everybody leave, now and at every later barrier)
+                if (grid_barrier_try_abort(gs, complete)) {
+                    for (uint32_t k = 0; k < ngroups; k++) st_agent(&gs.flags[k * GB_LEAF_STRIDE], 0xFFFFFFFFu);
+                    f = 0xFFFFFFFFu;
+                    break;
+                }
+                t0 = __builtin_amdgcn_s_memrealtime();
             }
         }
-        aborted = f == 0xFFFFFFFFu;
-        *s_flag = aborted;
+        *s_flag = f == 0xFFFFFFFFu;
     }
     __syncthreads();
     return *s_flag == 0u;
 }
 
-// A barrier that did not complete: leave { code, count } in the pinned status words (gsr_bin_persist_status), then trap
-// -- the lists would be garbage -- unless the diagnostics asked for a quiet return (GSR_BIN_NOTRAP=1).
-__device__ __forceinline__ void barrier_fault(uint32_t *status, uint32_t code, int notrap) {
+// A barrier AFTER the first one did not complete although the whole grid is resident (a hung or heavily preempted
+// device): leave { code, count } in the pinned status words and return -- no trap (round 6: a trap kills the rank's HIP
+// context and its RCCL peers hang, SURVEY 8(b) "Errors").  The lists of this call are incomplete but in bounds (the range
+// table only ever receives slot indices below the pair count); the host sees the count move at its next binning call on
+// the device, returns GSR_EFAULT (a Python exception in the operator) and keeps to the look-back pipeline from then on.
+__device__ __forceinline__ void barrier_fault(uint32_t *status, uint32_t code) {
     if (threadIdx.x == 0) {
         __hip_atomic_store(status + 1, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_fetch_add(status + 2, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    if (!notrap) __builtin_trap();
 }
 
 // Global offsets of one counting pass from the published counts: cnt[G][256] (row w = workgroup w's digit counts)
@@ -517,7 +544,7 @@ struct PrepPersistArgs {
     uint32_t *done_word;  // pinned: sequence number of the last persistent launch that passed its last barrier
     uint32_t done_seq;    // 0: do not publish (captured launches)
     uint64_t timeout_ticks;
-    int notrap;
+    int force_abort;  // test hook (GSR_BIN_FORCE_ABORT=p): the first barrier aborts as if it had timed out
     unsigned long long *tstamp;  // diagnostics (GSR_BIN_TIMELINE=1): [G][32] clock stamps of thread 0, else null
 };
 
@@ -651,7 +678,7 @@ bin_prepare_persist_kernel(const PrepPersistArgs a) {
         }
     }
     GSR_TS(1);
-    if (!grid_barrier(a.sync, G, epoch, a.timeout_ticks, &sm.flag)) {
+    if (!grid_barrier(a.sync, G, epoch, a.timeout_ticks, &sm.flag, a.force_abort != 0)) {
         // gave up waiting for the whole grid to become resident (another barrier kernel holds part of the device):
         // the host repeats the call on the look-back pipeline; the bounded tile sort sees a count above any capacity
         if (threadIdx.x == 0) {
@@ -663,7 +690,7 @@ bin_prepare_persist_kernel(const PrepPersistArgs a) {
         return;
     }
     GSR_TS(2);
-    // later barriers cannot dead-lock (the whole grid is resident): a second without progress is a fault -- trap
+    // later barriers cannot dead-lock (the whole grid is resident): a second without progress is a fault (barrier_fault)
     const uint64_t forever = 100000000ull;
     // ------------------------------------------------------------------ four LSD passes over the depth bits
     const uint32_t ngroups = (G + GB_FAN - 1) / GB_FAN;
@@ -710,7 +737,7 @@ bin_prepare_persist_kernel(const PrepPersistArgs a) {
         }
         }
         GSR_TS(3 + 4 * p);
-        if (!grid_barrier(a.sync, G, epoch, forever, &sm.flag)) { barrier_fault(a.done_word, 0x100u + epoch, a.notrap); return; }
+        if (!grid_barrier(a.sync, G, epoch, forever, &sm.flag)) { barrier_fault(a.done_word, 0x100u + epoch); return; }
         GSR_TS(4 + 4 * p);
         if (p == 3) break;
         // A: count the next digit of what this workgroup now owns
@@ -743,7 +770,7 @@ bin_prepare_persist_kernel(const PrepPersistArgs a) {
             publish_counts(a.cnt + (size_t)(p + 1) * G * RADIX_DIGITS, a.grp + (size_t)(p + 1) * ngroups * RADIX_DIGITS,
                            w, d, mytot);
         GSR_TS(5 + 4 * p);
-        if (!grid_barrier(a.sync, G, epoch, forever, &sm.flag)) { barrier_fault(a.done_word, 0x100u + epoch, a.notrap); return; }
+        if (!grid_barrier(a.sync, G, epoch, forever, &sm.flag)) { barrier_fault(a.done_word, 0x100u + epoch); return; }
         GSR_TS(6 + 4 * p);
     }
     // four passes: the sorted (key, id) pairs are back in (kA, vA)
@@ -769,7 +796,7 @@ bin_prepare_persist_kernel(const PrepPersistArgs a) {
         st_agent64(&a.wtot[w], tot);
     }
     GSR_TS(19);
-    if (!grid_barrier(a.sync, G, epoch, forever, &sm.flag)) { barrier_fault(a.done_word, 0x100u + epoch, a.notrap); return; }
+    if (!grid_barrier(a.sync, G, epoch, forever, &sm.flag)) { barrier_fault(a.done_word, 0x100u + epoch); return; }
     GSR_TS(20);
     if (w == 0 && threadIdx.x == 0 && a.done_seq)  // every workgroup is past the last barrier: nothing left to wait for
         __hip_atomic_store(a.done_word, a.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -841,11 +868,12 @@ struct SortPersistArgs {
     GridSync sync;
     uint32_t *cnt;  // [2][G][256]
     uint32_t *grp;  // [2][ngroups][256], zero before the launch
+    uint32_t *cnt_solo, *grp_solo;  // [2][256] each (grp_solo zero before the launch): workgroup 0 alone after an abort
     uint32_t *done_word;
     uint32_t done_seq;
     uint64_t timeout_ticks;
     int owners_cap;  // <= PS_OWNERS (tests lower it to exercise the per-chunk search)
-    int notrap;
+    int force_abort;  // test hook (GSR_BIN_FORCE_ABORT=s): the first barrier aborts as if it had timed out
     unsigned long long *tstamp;  // diagnostics (GSR_BIN_TIMELINE=1): [G][32] clock stamps of thread 0, else null
 };
 
@@ -940,11 +968,18 @@ __device__ __forceinline__ void decode_chunk(const uint32_t *__restrict__ offset
     }
 }
 
+// between the phases of a workgroup that runs ALONE (below): its own write-through stores acknowledged, then the barrier
+__device__ __forceinline__ void solo_sync() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __threadfence();
+    __syncthreads();
+}
+
 __global__ void __launch_bounds__(PS_THREADS, PS_MIN_WAVES)  // 8: <= 64 VGPRs, four 8-wave workgroups per CU
 bin_sort_persist_kernel(const SortPersistArgs a) {
     __shared__ PersistSmem<PS_ITEMS, PS_THREADS> sm;
     __shared__ PSExtra ex;
-    const uint32_t G = gridDim.x, w = blockIdx.x;
+    uint32_t G = gridDim.x, w = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t d = threadIdx.x;
     const int P = a.P;
@@ -958,25 +993,33 @@ bin_sort_persist_kernel(const SortPersistArgs a) {
         }
         D = (long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)dd);  // (uniform: the count is one word)
     }
-    // K7 only writes the tiles that own pairs: clear the range table (every workgroup takes part) and set the hull row
-    // (written through: the same words are written again in phase T by workgroups of other XCDs, and two L2s must not
-    // both hold a dirty copy of a line)
-    for (int t = w * PS_THREADS + threadIdx.x; t < a.ranges_words; t += G * PS_THREADS)
-        st_agent(reinterpret_cast<uint32_t *>(a.ranges) + t, 0u);
-    if (w == 0 && threadIdx.x < 2) a.ranges[a.ranges_words + threadIdx.x] = a.hull[threadIdx.x];
+    // Round 6 -- no trap, no host round trip when the grid cannot become resident (another process's barrier kernel, a
+    // graph replay or a collective that waits for a late peer holds part of the device): the first barrier's time-out is
+    // decided for the WHOLE grid (grid_barrier), nothing but control words has been written by then, every workgroup but
+    // number 0 leaves, and workgroup 0 -- which is running, so nothing can keep it from finishing -- sorts the view ALONE
+    // through the same phases with G = 1 (workgroup barriers instead of grid barriers, its own count rows).  Slow (tens of
+    // milliseconds for millions of pairs) but correct lists, inside the same launch, captured or not; the host sees the
+    // recovery counter move (gsr_bin_persist_status) and keeps to the look-back tile sort for a while.
+    bool solo = false;
+    uint32_t *cnt = a.cnt, *grp = a.grp;
     // This workgroup's slots [s0, s1): an equal share of the 512-slot wave chunks, walked in tiles of eight chunks, the
     // last one partial.  (Sharing out whole 4096-slot tiles left half the grid with one tile more at 6.5 tiles per
     // workgroup; this evens the waiting at the barriers out but not the phase: a partial tile costs a tile's latency
     // chain, so a phase lasts ceil(tiles per workgroup) rounds either way -- measured 203.6 against 201.8 us at c1.)
     const long long nc = (D + PS_CHUNK - 1) / PS_CHUNK;
-    const long long c0 = (long long)w * nc / G, c1 = (long long)(w + 1) * nc / G;
-    const long long s0 = c0 * PS_CHUNK, s1 = (c1 * PS_CHUNK < D) ? c1 * PS_CHUNK : D;
-    const bool have_owners = (c1 - c0) <= a.owners_cap;
+    long long s0, s1;
+    bool have_owners;
     uint32_t epoch = 0;
     GSR_TS(0);
-    const uint32_t ngroups = (G + GB_FAN - 1) / GB_FAN;
+    uint32_t ngroups;
     const uint32_t xmask = (1u << a.xbits) - 1u;
 
+    for (;;) {  // at most two trips: the grid; after an aborted first barrier, workgroup 0 alone
+    const long long c0 = (long long)w * nc / G, c1 = (long long)(w + 1) * nc / G;
+    s0 = c0 * PS_CHUNK;
+    s1 = (c1 * PS_CHUNK < D) ? c1 * PS_CHUNK : D;
+    have_owners = (c1 - c0) <= a.owners_cap;
+    ngroups = (G + GB_FAN - 1) / GB_FAN;
     // ------------------------------------------------------------------ E0: column counts of my slots, from the rects
     if (threadIdx.x <= RADIX_DIGITS) ex.dcol[threadIdx.x] = 0;
     clear_wtab(sm);
@@ -1057,20 +1100,38 @@ bin_sort_persist_kernel(const SortPersistArgs a) {
         const uint32_t v = d < RADIX_DIGITS ? (uint32_t)ex.dcol[d] : 0u;
         uint32_t all;
         const uint32_t c = block_exclusive_scan_n<PS_WAVES>(v, sm.scan_tmp, &all) + v;  // inclusive prefix: the count
-        if (d < RADIX_DIGITS) publish_counts(a.cnt, a.grp, w, d, c);
+        if (d < RADIX_DIGITS) publish_counts(cnt, grp, w, d, c);
     }
     GSR_TS(1);
-    if (!grid_barrier(a.sync, G, epoch, a.timeout_ticks, &sm.flag)) {
-        barrier_fault(a.done_word, 0x200u, a.notrap);  // another barrier kernel (another process?) shares the device
-        return;
+    if (solo) {
+        solo_sync();
+        break;
+    }
+    if (grid_barrier(a.sync, G, epoch, a.timeout_ticks, &sm.flag, a.force_abort != 0)) break;
+    // nobody passed and nobody will: the other workgroups (running now, or when they become resident) leave
+    if (blockIdx.x != 0) return;
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(a.done_word + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    solo = true;
+    G = 1;
+    w = 0;
+    cnt = a.cnt_solo;
+    grp = a.grp_solo;
+    __syncthreads();
     }
     GSR_TS(2);
     const uint64_t forever = 100000000ull;  // (one second: see bin_prepare_persist_kernel)
+    // K7 only writes the tiles that own pairs: clear the range table (every workgroup takes part, AFTER the first barrier:
+    // a workgroup that becomes resident after an abort must not touch what workgroup 0 is producing alone; the next
+    // barriers order the clears in front of phase T) and set the hull row.  Written through: the same words are written
+    // again in phase T by workgroups of other XCDs, and two L2s must not both hold a dirty copy of a line.
+    for (int t = w * PS_THREADS + threadIdx.x; t < a.ranges_words; t += G * PS_THREADS)
+        st_agent(reinterpret_cast<uint32_t *>(a.ranges) + t, 0u);
+    if (w == 0 && threadIdx.x < 2) a.ranges[a.ranges_words + threadIdx.x] = a.hull[threadIdx.x];
     // ------------------------------------------------------------------ E1: decode my slots, scatter by column
     uint32_t key[PS_ITEMS], val[PS_ITEMS];
     {
         uint32_t before, total;
-        counts_before<PS_THREADS>(a.cnt, a.grp, G, w, sm.skey, before, total);
+        counts_before<PS_THREADS>(cnt, grp, G, w, sm.skey, before, total);
         uint32_t all;
         uint32_t first = block_exclusive_scan_n<PS_WAVES>(total, sm.scan_tmp, &all) + before;
         for (long long tbase = s0; tbase < s1; tbase += PS_TILE) {
@@ -1090,7 +1151,8 @@ bin_sort_persist_kernel(const SortPersistArgs a) {
         }
     }
     GSR_TS(3);
-    if (!grid_barrier(a.sync, G, epoch, forever, &sm.flag)) { barrier_fault(a.done_word, 0x200u + epoch, a.notrap); return; }
+    if (solo) solo_sync();
+    else if (!grid_barrier(a.sync, G, epoch, forever, &sm.flag)) { barrier_fault(a.done_word, 0x200u + epoch); return; }
     GSR_TS(4);
     // ------------------------------------------------------------------ R0: row-digit counts of my tiles
     {
@@ -1114,16 +1176,17 @@ bin_sort_persist_kernel(const SortPersistArgs a) {
             __syncthreads();
         }
         if (d < RADIX_DIGITS)
-            publish_counts(a.cnt + (size_t)G * RADIX_DIGITS, a.grp + (size_t)ngroups * RADIX_DIGITS, w, d, mytot);
+            publish_counts(cnt + (size_t)G * RADIX_DIGITS, grp + (size_t)ngroups * RADIX_DIGITS, w, d, mytot);
     }
     GSR_TS(5);
-    if (!grid_barrier(a.sync, G, epoch, forever, &sm.flag)) { barrier_fault(a.done_word, 0x200u + epoch, a.notrap); return; }
+    if (solo) solo_sync();
+    else if (!grid_barrier(a.sync, G, epoch, forever, &sm.flag)) { barrier_fault(a.done_word, 0x200u + epoch); return; }
     GSR_TS(6);
     // ------------------------------------------------------------------ R1: scatter by row -> (kA, point_list)
     {
         const uint32_t ymask = (1u << a.ybits) - 1u;
         uint32_t before, total;
-        counts_before<PS_THREADS>(a.cnt + (size_t)G * RADIX_DIGITS, a.grp + (size_t)ngroups * RADIX_DIGITS, G, w, sm.skey,
+        counts_before<PS_THREADS>(cnt + (size_t)G * RADIX_DIGITS, grp + (size_t)ngroups * RADIX_DIGITS, G, w, sm.skey,
                                   before, total);
         uint32_t all;
         uint32_t first = block_exclusive_scan_n<PS_WAVES>(total, sm.scan_tmp, &all) + before;
@@ -1143,7 +1206,8 @@ bin_sort_persist_kernel(const SortPersistArgs a) {
         }
     }
     GSR_TS(7);
-    if (!grid_barrier(a.sync, G, epoch, forever, &sm.flag)) { barrier_fault(a.done_word, 0x200u + epoch, a.notrap); return; }
+    if (solo) solo_sync();
+    else if (!grid_barrier(a.sync, G, epoch, forever, &sm.flag)) { barrier_fault(a.done_word, 0x200u + epoch); return; }
     GSR_TS(8);
     if (w == 0 && threadIdx.x == 0 && a.done_seq)
         __hip_atomic_store(a.done_word, a.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1206,7 +1270,7 @@ inline PersistLayoutP persist_layout_p(int G) {
     return L;
 }
 struct PersistLayoutS {
-    size_t sync, grp, cnt, zero_bytes, total;
+    size_t sync, grp, grp_solo, cnt, cnt_solo, zero_bytes, total;
 };
 inline PersistLayoutS persist_layout_s(int G) {
     PersistLayoutS L;
@@ -1214,8 +1278,10 @@ inline PersistLayoutS persist_layout_s(int G) {
     size_t o = 0;
     L.sync = o; o += align_up(sizeof(uint32_t) * grid_sync_words(G));
     L.grp = o; o += align_up(sizeof(uint32_t) * 2 * (size_t)ngroups * RADIX_DIGITS);
+    L.grp_solo = o; o += align_up(sizeof(uint32_t) * 2 * RADIX_DIGITS);  // (workgroup 0 alone after an aborted first barrier)
     L.zero_bytes = o;
     L.cnt = o; o += align_up(sizeof(uint32_t) * 2 * (size_t)G * RADIX_DIGITS);
+    L.cnt_solo = o; o += align_up(sizeof(uint32_t) * 2 * RADIX_DIGITS);
     L.total = o;
     return L;
 }
@@ -1230,7 +1296,12 @@ struct PersistCaps {
 };
 std::mutex g_persist_mutex;
 PersistCaps g_persist_caps[64];
-uint32_t *g_persist_done[64] = {};       // pinned: sequence number of the last launch past its last barrier
+uint32_t *g_persist_done[64] = {};       // pinned: { sequence number of the last launch past its last barrier, fault code,
+                                         // faults (barrier_fault), solo recoveries of the sort kernel }
+uint32_t g_persist_faults_seen[64] = {}; // faults already reported to a caller
+uint32_t g_persist_solo_seen[64] = {};   // recoveries already answered with a back-off
+int g_persist_backoff[64] = {};          // sort calls that still take the look-back tile sort after a recovery
+bool g_persist_faulted[64] = {};         // a barrier after the first timed out once: look-back pipeline from then on
 uint32_t g_persist_seq[64] = {};         // last sequence number handed out
 hipStream_t g_persist_stream[64] = {};   // stream of that launch
 bool g_persist_any[64] = {};
@@ -1313,6 +1384,7 @@ long long persist_admit(int dev, hipStream_t stream) {
     if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return 0;
     (void)hipGetLastError();
     std::lock_guard<std::mutex> guard(g_persist_mutex);
+    if (g_persist_faulted[dev]) return -1;
     if (g_persist_any[dev] && g_persist_stream[dev] != stream) {
         const uint32_t done = *reinterpret_cast<volatile uint32_t *>(g_persist_done[dev]);
         if (done != g_persist_seq[dev]) return -1;
@@ -1323,5 +1395,40 @@ long long persist_admit(int dev, hipStream_t stream) {
     g_persist_any[dev] = true;
     return (long long)s;
 }
+
+// Has a persistent kernel of this device reported a barrier fault (barrier_fault) that no caller has been told about?
+// -> GSR_EFAULT once per fault; the device keeps to the look-back pipeline afterwards.
+int persist_fault_check(int dev) {
+    if (dev < 0 || dev >= 64 || !g_persist_done[dev]) return 0;
+    std::lock_guard<std::mutex> guard(g_persist_mutex);
+    const uint32_t faults = reinterpret_cast<volatile uint32_t *>(g_persist_done[dev])[2];
+    if (faults == g_persist_faults_seen[dev]) return 0;
+    g_persist_faults_seen[dev] = faults;
+    g_persist_faulted[dev] = true;
+    return GSR_EFAULT;
+}
+
+// test hook: GSR_BIN_FORCE_ABORT = p | s | ps (read per call): the named kernels' first barrier aborts
+bool force_abort_env(char which) {
+    const char *e = getenv("GSR_BIN_FORCE_ABORT");
+    return e && strchr(e, which) != nullptr;
+}
+
+// The sort kernel finished a view with workgroup 0 alone (the grid could not become resident within the time-out): the
+// next calls take the look-back tile sort instead of waiting out the time-out again.
+bool persist_sort_backoff(int dev) {
+    std::lock_guard<std::mutex> guard(g_persist_mutex);
+    const uint32_t solo = reinterpret_cast<volatile uint32_t *>(g_persist_done[dev])[3];
+    if (solo != g_persist_solo_seen[dev]) {
+        g_persist_solo_seen[dev] = solo;
+        g_persist_backoff[dev] = force_abort_env('s') ? 0 : 64;  // (a forced abort is a test: keep the kernel in use)
+    }
+    if (g_persist_backoff[dev] > 0) {
+        g_persist_backoff[dev]--;
+        return true;
+    }
+    return false;
+}
+
 
 }  // namespace

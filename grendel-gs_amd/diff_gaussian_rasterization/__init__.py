@@ -683,6 +683,16 @@ def set_bin_persistent(mode):
     check(lib.gsr_set_bin_persistent(code), "gsr_set_bin_persistent")
 
 
+def bin_persist_status():
+    """-> dict(done, fault_code, faults, solo_recoveries) of the persistent binning launches on the current device
+    (include/gsraster.h: gsr_bin_persist_status).  `solo_recoveries` counts the views whose tile sort was finished by one
+    workgroup because the grid did not become resident within the time-out (a shared device); `faults` the barrier
+    time-outs that the next binning call reports as an exception (GSR_EFAULT)."""
+    w = (ctypes.c_uint32 * 4)()
+    check(lib.gsr_bin_persist_status(w), "gsr_bin_persist_status")
+    return dict(done=int(w[0]), fault_code=int(w[1]), faults=int(w[2]), solo_recoveries=int(w[3]))
+
+
 def set_tile_cull(mode):
     """exact tile culling in K3 (include/gsraster.h: gsr_set_tile_cull): "env" (GSR_TILE_CULL, default off), False / "off",
     True / "on", "auto" (on for frames of more than 16384 tiles, i.e. above ~2048 x 2048).  Lists stay order-preserving

@@ -104,7 +104,7 @@ SIGNATURES = {
     "gsr_render_backward": (c_int, [c_int, c_int, c_int] + [c_void_p] * 12),
 }
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 def _load():

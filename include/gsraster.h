@@ -36,6 +36,9 @@ extern "C" {
 #define GSR_EINVAL (-1)   /* bad argument (negative size, null pointer, sh_degree > 3, ...) */
 #define GSR_ENOSPACE (-2) /* caller-provided workspace too small */
 #define GSR_ERETRY (-3)   /* gsr_bin_count_wait: the count is valid, but a gsr_bin_sort_bounded launched for it wrote nothing */
+#define GSR_EFAULT (-4)   /* a persistent binning kernel of an EARLIER call gave up at a barrier behind its first one (a hung or
+                             heavily preempted device): that call's lists are incomplete (in bounds); reported once, the
+                             device keeps to the look-back pipeline afterwards (gsr_bin_persist_status has the code) */
 
 typedef void *gsr_stream_t;
 
@@ -153,7 +156,11 @@ int gsr_bin_speculative(int P, int width, int height, const float *means2D, cons
  * call takes the look-back pipeline); a device shared with ANOTHER PROCESS's barrier kernel is covered by a time-out at
  * the first barrier -- the prepare step then repeats itself on the look-back pipeline inside gsr_bin_count_wait, which
  * returns GSR_ERETRY (the count is valid; a gsr_bin_sort_bounded already launched for it wrote nothing: call
- * gsr_bin_sort); the sort step traps after two seconds.  mode: -1 the environment's GSR_BIN_PERSIST (0 | 1 | p | s,
+ * gsr_bin_sort); in the sort step the time-out (250 ms) is decided for the whole grid, every workgroup but one leaves and
+ * that one sorts the view alone inside the same launch -- correct lists, no host round trip, works in a captured graph --
+ * after which the next 64 sorts of the device take the look-back pipeline (ABI 12; ABI 11 trapped here).  No kernel of
+ * this library traps: a time-out at a LATER barrier (whole grid resident: a hung or preempted device) leaves a code in the
+ * status words and the next binning call on the device returns GSR_EFAULT.  mode: -1 the environment's GSR_BIN_PERSIST (0 | 1 | p | s,
  * default 1), 0 off, 1 prepare only, 2 sort only, 3 both. */
 int gsr_set_bin_persistent(int mode);
 /* Exact tile culling in K3 (ABI 11; csrc/binning_persist.h: gsr_tile_mask): per tile row of a Gaussian's rect the exact span
@@ -165,11 +172,11 @@ int gsr_set_bin_persistent(int mode);
  * environment's GSR_TILE_CULL (0 | 1 | auto, default 0), 0 off, 1 on, 2 auto = on for frames of more than
  * GSR_TILE_CULL_TILES (default 16384) tiles -- a static rule: the lists do not depend on earlier views. */
 int gsr_set_tile_cull(int mode);
-/* Diagnostics of the persistent launches on the current device: out3 = { sequence number of the last launch that passed
+/* Diagnostics of the persistent launches on the current device: out4 = { sequence number of the last launch that passed
  * its last barrier, code of the last barrier fault (0x100 + n: barrier n of the prepare kernel, 0x200 + n: of the sort
- * kernel; 0 = none), number of faults }.  A fault traps the kernel (the process ends with a HIP error) unless
- * GSR_BIN_NOTRAP=1 is set, in which case the lists of that call are garbage and this call is how one finds out. */
-int gsr_bin_persist_status(uint32_t *out3);
+ * kernel; 0 = none), number of faults (each is reported once as GSR_EFAULT by the next binning call), number of views
+ * the sort kernel finished with one workgroup after its first barrier timed out }.  ABI 12: four words (ABI 11: three). */
+int gsr_bin_persist_status(uint32_t *out4);
 /* Diagnostics (GSR_BIN_TIMELINE=1 in the environment): the per-workgroup phase stamps (100 MHz clock, 32 per workgroup)
  * of the last persistent prepare (which = 0) / sort (which = 1) launch; *grid = its workgroups.  Synchronises. */
 int gsr_bin_timeline(int which, unsigned long long *out, int max_words, int *grid);

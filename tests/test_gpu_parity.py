@@ -230,6 +230,137 @@ def test_persistent_binning_equals_the_lookback_pipeline(device, monkeypatch, gr
             assert pl.numel() == D and torch.equal(pl, rpl), (mode, spec, order[i])
 
 
+def _binning_views(device, W=333, H=211):
+    from oracle import cref as C
+
+    cam = S.orbit_cameras(4, W, H)[1]
+
+    def inputs(N, sc, seed):
+        g = S.make_gaussians(N, W, H, seed=seed, scale_coef=sc)
+        m2, rgb, co, radii, depths, _, _ = C.preprocess_forward(*[g[k] for k in KEYS], **cam_kwargs(cam))
+        mask = _full_mask(cam)
+        mask[1, :] = False
+        return [t.to(device) for t in (m2, depths, radii, co, mask.view(-1).to(torch.uint8))]
+
+    return [inputs(3000, 0.02, 5), inputs(9000, 0.03, 6), inputs(20000, 0.06, 7), inputs(9000, 0.05, 8)]
+
+
+@pytest.mark.parametrize("which,grid_s", [("s", None), ("s", 5), ("p", None), ("ps", 3)])
+def test_persistent_binning_survives_an_aborted_first_barrier(device, monkeypatch, which, grid_s):
+    """Round 6 (verdict r05 item 4: no trap in the product path).  GSR_BIN_FORCE_ABORT makes the first grid barrier of the
+    prepare ("p") and / or the sort ("s") kernel abort exactly as its time-out would: the prepare step repeats itself on
+    the look-back pipeline (GSR_ERETRY inside the operator), in the sort step every workgroup but number 0 leaves and
+    that one sorts the view alone inside the same launch.  Lists, ranges and counts must be those of the look-back
+    pipeline, bit for bit, through the sized and the speculative (bounded) sort; the recovery counter moves; no fault"""
+    import diff_gaussian_rasterization as dgr
+
+    W, H = 333, 211
+    views = _binning_views(device, W, H)
+    dgr.release_workspaces()
+    dgr.set_bin_persistent("off")
+    try:
+        ref = []
+        for x in views:
+            pl, rg, D = dgr.bin_gaussians(*x, W, H)
+            ref.append((pl.clone(), rg.clone(), D))
+        monkeypatch.setenv("GSR_BIN_PERSIST_MAXD", "1000000000")
+        monkeypatch.setenv("GSR_BIN_FORCE_ABORT", which)
+        if grid_s is not None:
+            monkeypatch.setenv("GSR_BIN_GRID_S", str(grid_s))
+        torch.cuda.synchronize()
+        dgr.set_bin_persistent("both")  # (also ends the back-off an earlier recovery may have started)
+        before = dgr.bin_persist_status()
+        for spec in (False, True):
+            dgr.release_workspaces()
+            dgr.set_speculative_sort(spec)
+            for v in (1, 1, 0, 2, 3, 1, 2):
+                pl, rg, D = dgr.bin_gaussians(*views[v], W, H)
+                rpl, rrg, rD = ref[v]
+                assert D == rD, (spec, v)
+                assert torch.equal(rg, rrg), (spec, v)
+                assert pl.numel() == D and torch.equal(pl, rpl), (spec, v)
+        torch.cuda.synchronize()
+        after = dgr.bin_persist_status()
+        assert after["faults"] == before["faults"]
+        if "s" in which:
+            assert after["solo_recoveries"] >= before["solo_recoveries"] + 14, (before, after)
+        else:
+            assert after["solo_recoveries"] == before["solo_recoveries"]
+    finally:
+        dgr.set_bin_persistent("env")
+        dgr.set_speculative_sort(True)
+        dgr.release_workspaces()
+
+
+def _shared_device_worker(rank, q, iters):
+    try:
+        import os
+        import sys
+
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        for p in (os.path.join(root, "grendel-gs_amd"), root, os.path.join(root, "tests")):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        os.environ["GSR_BIN_PERSIST_MAXD"] = "1000000000"
+        os.environ["GSR_BIN_SORT_TIMEOUT_MS"] = "20"
+        import diff_gaussian_rasterization as dgr
+
+        device = torch.device("cuda:0")
+        torch.cuda.set_device(device)
+        W, H = 1920, 1080
+        g = S.make_gaussians(200_000, W, H, seed=11 + rank, scale_coef=0.004)
+        cams = S.orbit_cameras(3, W, H)
+        views = []
+        for cam in cams:
+            rast = dgr.GaussianRasterizer(settings_from(cam, torch.zeros(3)))
+            gg = {k: v.to(device) for k, v in g.items()}
+            m2, rgb, co, radii, depths = rast.preprocess_gaussians(*[gg[k] for k in KEYS], {})
+            mask = torch.ones(((H + 15) // 16) * ((W + 15) // 16), dtype=torch.uint8, device=device)
+            views.append([m2.detach(), depths.detach(), radii, co.detach(), mask])
+        dgr.set_bin_persistent("off")
+        ref = []
+        for x in views:
+            pl, rg, D = dgr.bin_gaussians(*x, W, H)
+            ref.append((pl.clone(), rg.clone(), D))
+        dgr.set_bin_persistent("both")
+        bad = 0
+        for i in range(iters):
+            v = i % len(views)
+            pl, rg, D = dgr.bin_gaussians(*views[v], W, H)
+            rpl, rrg, rD = ref[v]
+            if D != rD or not torch.equal(rg, rrg) or not torch.equal(pl, rpl):
+                bad += 1
+        torch.cuda.synchronize()
+        q.put((rank, bad, dgr.bin_persist_status(), None))
+    except BaseException as e:  # noqa: BLE001
+        import traceback
+
+        q.put((rank, -1, None, traceback.format_exc() + repr(e)))
+
+
+def test_two_processes_share_a_device_with_persistent_binning():
+    """Two PROCESSES on one device, both running the persistent prepare AND sort kernels whatever the pair count (each
+    asks for the whole device; their grids cannot both be resident): every view must finish with the look-back
+    pipeline's lists -- through the prepare kernel's repeat on the look-back pipeline, the sort kernel's one-workgroup
+    recovery and the back-off that follows -- and no process may die (ABI 11 trapped here after two seconds)"""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_shared_device_worker, args=(r, q, 150)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, bad, status, err in results:
+        assert err is None, err
+        assert bad == 0, (rank, bad, status)
+        assert status["faults"] == 0, status
+    print("persist status per process:", [r[2] for r in results])
+    assert all(p.exitcode == 0 for p in procs)
+
+
 def test_two_host_threads_on_two_streams_bin_the_same_lists(device):
     """K3-K7 called from TWO host threads, each on its own stream (bench.py's two-thread views leg; a render server with a
     thread per stream): the per-(device, stream) scratch, the count slots and the admission of the barrier kernels (the
