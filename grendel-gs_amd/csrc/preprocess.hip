@@ -1131,6 +1131,52 @@ preprocess_forward_batched_kernel(int P, int B, int M, const float *__restrict__
     }
 }
 
+// What one lane reads per CAMERA in the batched K11: radius, the nine floats of the camera's [P,9] gradient record row and the
+// three clamp flags.  Round 6: the loop used to fetch them where they were first needed -- radius, branch, conic gradient,
+// ..., position gradient, colour gradient: three dependent trips to memory per camera in a kernel that holds two waves per
+// SIMD -- and ran at 0.47 of the HBM peak at four cameras against 0.78 for the one-camera kernel.  Now a queue of
+// K11_CAMQ cameras is always in flight: the first ones are requested at the top of the kernel together with the
+// Gaussian's own 59 floats and the _features_rest block, camera c + K11_CAMQ while camera c is being differentiated.
+#ifndef GSR_K11_CAMQ
+#define GSR_K11_CAMQ 2
+#endif
+constexpr int K11_CAMQ = GSR_K11_CAMQ;
+#ifndef GSR_K11B_WAVES
+#define GSR_K11B_WAVES 2
+#endif
+constexpr int K11B_WAVES_PER_EU = GSR_K11B_WAVES;  // waves per SIMD the camera-batched K11 kernels are compiled for
+struct K11CamSH {  // the colour part's share
+    int32_t rad;
+    float grgb[3];
+    uint8_t cl[3];
+};
+struct K11CamGeo {  // the geometry part's share
+    int32_t rad;
+    float4 gco;
+    float2 g2;
+};
+__device__ __forceinline__ K11CamSH k11_cam_load_sh(size_t o, const int32_t *__restrict__ radii,
+                                                    const uint8_t *__restrict__ clamped,
+                                                    const float *__restrict__ dL_drgb, int gstride) {
+    K11CamSH c;
+    c.rad = radii[o];
+#pragma unroll
+    for (int e = 0; e < 3; e++) {
+        c.grgb[e] = dL_drgb[(gstride ? gstride : 3) * o + e];
+        c.cl[e] = clamped[3 * o + e];
+    }
+    return c;
+}
+__device__ __forceinline__ K11CamGeo k11_cam_load_geo(size_t o, const int32_t *__restrict__ radii,
+                                                      const float *__restrict__ dL_dmeans2D,
+                                                      const float *__restrict__ dL_dconic_opacity, int gstride) {
+    K11CamGeo c;
+    c.rad = radii[o];
+    c.gco = grad_ld4(dL_dconic_opacity, o, gstride);
+    c.g2 = grad_ld2(dL_dmeans2D, o, gstride);
+    return c;
+}
+
 template <int DEG, bool ADAM>
 __device__ __forceinline__ void
 preprocess_backward_batched_body(int P, int B, int M, const float *__restrict__ xyz,
@@ -1148,22 +1194,45 @@ preprocess_backward_batched_body(int P, int B, int M, const float *__restrict__ 
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     __shared__ float s_rest[K11_BLOCK * REST_W];
     const bool staged = M == 16;  // _features_rest in, its gradient out: coalesced through LDS (ADAM: always)
+    constexpr int NC = (DEG + 1) * (DEG + 1);
+    // ---- every load of the lane that does not depend on another is issued here, before the first result is used
+    // (clamped index: lanes past the end load the last Gaussian's inputs and compute nothing)
+    const size_t ic = (size_t)min(i, P - 1);
+    RestStage st;
+    if (staged) st = rest_stage_issue(f_rest, P);
+    const float p[3] = {xyz[3 * ic], xyz[3 * ic + 1], xyz[3 * ic + 2]};
+    float cvr[6];
+#pragma unroll
+    for (int e = 0; e < 6; e++) cvr[e] = cov3D[6 * ic + e];
+    const float dc[3] = {f_dc[3 * ic], f_dc[3 * ic + 1], f_dc[3 * ic + 2]};
+    const float oraw = opacity[ic];
+    const float4 qraw = *reinterpret_cast<const float4 *>(rotation + 4 * ic);
+    const float scraw[3] = {scaling[3 * ic], scaling[3 * ic + 1], scaling[3 * ic + 2]};
+    K11CamSH shq[K11_CAMQ];
+    K11CamGeo geoq[K11_CAMQ];
+#pragma unroll
+    for (int u = 0; u < K11_CAMQ; u++) {
+        const size_t o = (size_t)min(u, B - 1) * P + ic;
+        shq[u] = k11_cam_load_sh(o, radii, clamped, dL_drgb, gstride);
+        geoq[u] = k11_cam_load_geo(o, radii, dL_dmeans2D, dL_dconic_opacity, gstride);
+    }
+    __builtin_amdgcn_sched_barrier(0);
     if (staged) {
-        rest_stage_in(s_rest, f_rest, P);
+        rest_stage_commit(s_rest, st, f_rest, P);
         __syncthreads();
     }
     float sp[14], sg[14];  // ADAM: the per-lane parameters / gradients, updated after the stage-out (below)
     if (i < P) {
-    constexpr int NC = (DEG + 1) * (DEG + 1);
-    const float p[3] = {xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2]};
-    const float *cv = cov3D + 6 * (size_t)i;
-    const float S[3][3] = {{cv[0], cv[1], cv[2]}, {cv[1], cv[3], cv[4]}, {cv[2], cv[4], cv[5]}};
+    const float S[3][3] = {{cvr[0], cvr[1], cvr[2]}, {cvr[1], cvr[3], cvr[4]}, {cvr[2], cvr[4], cvr[5]}};
+    // the SH coefficients above the DC term: read from the LDS stage where they are needed (staged), not held in 45
+    // registers across the camera loop next to the 48 accumulators (the kernel needed 270 registers and spilled)
+    const float *const shl = s_rest + threadIdx.x * REST_W;  // (an LDS address: ds_read, not a flat load)
     float sh[NC * 3];
-    sh[0] = f_dc[3 * (size_t)i];
-    sh[1] = f_dc[3 * (size_t)i + 1];
-    sh[2] = f_dc[3 * (size_t)i + 2];
-    {
-        const float *rp = staged ? s_rest + threadIdx.x * REST_W : f_rest + (size_t)i * (M - 1) * 3;
+    sh[0] = dc[0];
+    sh[1] = dc[1];
+    sh[2] = dc[2];
+    if (!staged) {
+        const float *rp = f_rest + (size_t)i * (M - 1) * 3;
 #pragma unroll
         for (int k = 3; k < NC * 3; k++) sh[k] = rp[k - 3];
     }
@@ -1174,14 +1243,115 @@ preprocess_backward_batched_body(int P, int B, int M, const float *__restrict__ 
     for (int k = 0; k < NC * 3; k++) dsh[k] = 0.f;
     float dop = 0.f;
 
+#define SHV(k) (staged ? shl[(k) * 3 + ch - 3] : sh[(k) * 3 + ch])
+    // Two loops over the cameras (round 6): the colour part first -- its 48 accumulators and the coefficients it reads
+    // from the LDS stage are dead before the geometry part starts, whose covariance chain then has the registers to
+    // itself (one loop needed 270 registers and spilled; the sums per camera are unchanged, dmean's order of summation
+    // is colour part of all cameras, then geometry part of all cameras).
     for (int bc = 0; bc < B; bc++) {
-        const size_t o = (size_t)bc * P + i;
-        if (radii[o] <= 0) continue;
+        const K11CamSH cin = shq[0];
+#pragma unroll
+        for (int u = 0; u + 1 < K11_CAMQ; u++) shq[u] = shq[u + 1];
+        if (bc + K11_CAMQ < B)  // (uniform) the camera K11_CAMQ ahead: in flight while this one is differentiated
+            shq[K11_CAMQ - 1] = k11_cam_load_sh((size_t)(bc + K11_CAMQ) * P + i, radii, clamped, dL_drgb, gstride);
+        if (cin.rad <= 0) continue;
+        if (staged) asm volatile("" ::: "memory");  // (keeps the LDS reads of the coefficients inside the loop)
+        const float *cp = cams + (size_t)bc * CAM_STRIDE;
+        const float camc[3] = {cp[32], cp[33], cp[34]};
+        {
+            const float dox = p[0] - camc[0], doy = p[1] - camc[1], doz = p[2] - camc[2];
+            const float len = sqrtf(dox * dox + doy * doy + doz * doz);
+            const float x = dox / len, y = doy / len, z = doz / len;
+            float ddir[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                const float g = cin.cl[ch] ? 0.f : cin.grgb[ch];
+                float dx = 0.f, dy = 0.f, dz = 0.f;
+                dsh[0 * 3 + ch] += SH_C0 * g;
+                if (DEG > 0) {
+                    dsh[1 * 3 + ch] += -SH_C1 * y * g;
+                    dsh[2 * 3 + ch] += SH_C1 * z * g;
+                    dsh[3 * 3 + ch] += -SH_C1 * x * g;
+                    dx = -SH_C1 * SHV(3);
+                    dy = -SH_C1 * SHV(1);
+                    dz = SH_C1 * SHV(2);
+                    if (DEG > 1) {
+                        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                        dsh[4 * 3 + ch] += SH_C2[0] * xy * g;
+                        dsh[5 * 3 + ch] += SH_C2[1] * yz * g;
+                        dsh[6 * 3 + ch] += SH_C2[2] * (2.f * zz - xx - yy) * g;
+                        dsh[7 * 3 + ch] += SH_C2[3] * xz * g;
+                        dsh[8 * 3 + ch] += SH_C2[4] * (xx - yy) * g;
+                        dx += SH_C2[0] * y * SHV(4) + SH_C2[2] * 2.f * -x * SHV(6) +
+                              SH_C2[3] * z * SHV(7) + SH_C2[4] * 2.f * x * SHV(8);
+                        dy += SH_C2[0] * x * SHV(4) + SH_C2[1] * z * SHV(5) +
+                              SH_C2[2] * 2.f * -y * SHV(6) + SH_C2[4] * 2.f * -y * SHV(8);
+                        dz += SH_C2[1] * y * SHV(5) + SH_C2[2] * 2.f * 2.f * z * SHV(6) +
+                              SH_C2[3] * x * SHV(7);
+                        if (DEG > 2) {
+                            dsh[9 * 3 + ch] += SH_C3[0] * y * (3.f * xx - yy) * g;
+                            dsh[10 * 3 + ch] += SH_C3[1] * xy * z * g;
+                            dsh[11 * 3 + ch] += SH_C3[2] * y * (4.f * zz - xx - yy) * g;
+                            dsh[12 * 3 + ch] += SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy) * g;
+                            dsh[13 * 3 + ch] += SH_C3[4] * x * (4.f * zz - xx - yy) * g;
+                            dsh[14 * 3 + ch] += SH_C3[5] * z * (xx - yy) * g;
+                            dsh[15 * 3 + ch] += SH_C3[6] * x * (xx - 3.f * yy) * g;
+                            dx += SH_C3[0] * SHV(9) * 3.f * 2.f * xy + SH_C3[1] * SHV(10) * yz +
+                                  SH_C3[2] * SHV(11) * -2.f * xy + SH_C3[3] * SHV(12) * -3.f * 2.f * xz +
+                                  SH_C3[4] * SHV(13) * (-3.f * xx + 4.f * zz - yy) +
+                                  SH_C3[5] * SHV(14) * 2.f * xz + SH_C3[6] * SHV(15) * 3.f * (xx - yy);
+                            dy += SH_C3[0] * SHV(9) * 3.f * (xx - yy) + SH_C3[1] * SHV(10) * xz +
+                                  SH_C3[2] * SHV(11) * (-3.f * yy + 4.f * zz - xx) +
+                                  SH_C3[3] * SHV(12) * -3.f * 2.f * yz + SH_C3[4] * SHV(13) * -2.f * xy +
+                                  SH_C3[5] * SHV(14) * -2.f * yz + SH_C3[6] * SHV(15) * -3.f * 2.f * xy;
+                            dz += SH_C3[1] * SHV(10) * xy + SH_C3[2] * SHV(11) * 4.f * 2.f * yz +
+                                  SH_C3[3] * SHV(12) * 3.f * (2.f * zz - xx - yy) +
+                                  SH_C3[4] * SHV(13) * 4.f * 2.f * xz + SH_C3[5] * SHV(14) * (xx - yy);
+                        }
+                    }
+                }
+                ddir[0] += dx * g;
+                ddir[1] += dy * g;
+                ddir[2] += dz * g;
+            }
+            const float dot = x * ddir[0] + y * ddir[1] + z * ddir[2];
+            dmean[0] += (ddir[0] - x * dot) / len;
+            dmean[1] += (ddir[1] - y * dot) / len;
+            dmean[2] += (ddir[2] - z * dot) / len;
+        }
+    }
+#undef SHV
+    // the colour gradient is complete: DC to the per-lane slots / HBM, the rest over the coefficients in the stage
+    if constexpr (ADAM) {
+#pragma unroll
+        for (int e = 0; e < 3; e++) {
+            sp[10 + e] = sh[e];
+            sg[10 + e] = dsh[e];
+        }
+    } else {
+        dL_ddc[3 * (size_t)i] = dsh[0];
+        dL_ddc[3 * (size_t)i + 1] = dsh[1];
+        dL_ddc[3 * (size_t)i + 2] = dsh[2];
+    }
+    {
+        float *rp = staged ? s_rest + threadIdx.x * REST_W : dL_drest + (size_t)i * (M - 1) * 3;
+#pragma unroll
+        for (int k = 3; k < NC * 3; k++) rp[k - 3] = dsh[k];
+        for (int k = NC * 3; k < M * 3; k++) rp[k - 3] = 0.f;
+    }
+    for (int bc = 0; bc < B; bc++) {
+        const K11CamGeo cin = geoq[0];
+#pragma unroll
+        for (int u = 0; u + 1 < K11_CAMQ; u++) geoq[u] = geoq[u + 1];
+        if (bc + K11_CAMQ < B)
+            geoq[K11_CAMQ - 1] = k11_cam_load_geo((size_t)(bc + K11_CAMQ) * P + i, radii, dL_dmeans2D, dL_dconic_opacity,
+                                                  gstride);
+        if (cin.rad <= 0) continue;
         const float *cp = cams + (size_t)bc * CAM_STRIDE;
         const Cam cam = load_cam_packed(cp);
         const float tanfovx = cp[35], tanfovy = cp[36];
         const float fx = W / (2.0f * tanfovx), fy = H / (2.0f * tanfovy);
-        const float4 gco = grad_ld4(dL_dconic_opacity, o, gstride);
+        const float4 gco = cin.gco;
         const float gA = gco.x, gB = gco.y, gC = gco.z;
         dop += gco.w;
         float t[3];
@@ -1241,72 +1411,11 @@ preprocess_backward_batched_body(int P, int B, int M, const float *__restrict__ 
             const float phw = cam.p[3] * p[0] + cam.p[7] * p[1] + cam.p[11] * p[2] + cam.p[15];
             const float mw = 1.0f / (phw + 0.0000001f);
             const float mul1 = phx * mw * mw, mul2 = phy * mw * mw;
-            const float2 g2 = grad_ld2(dL_dmeans2D, o, gstride);
+            const float2 g2 = cin.g2;
 #pragma unroll
             for (int k = 0; k < 3; k++)
                 dmean[k] += (cam.p[k * 4 + 0] * mw - cam.p[k * 4 + 3] * mul1) * g2.x +
                             (cam.p[k * 4 + 1] * mw - cam.p[k * 4 + 3] * mul2) * g2.y;
-        }
-        {
-            const float dox = p[0] - cam.c[0], doy = p[1] - cam.c[1], doz = p[2] - cam.c[2];
-            const float len = sqrtf(dox * dox + doy * doy + doz * doz);
-            const float x = dox / len, y = doy / len, z = doz / len;
-            float ddir[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++) {
-                const float g = clamped[3 * o + ch] ? 0.f : dL_drgb[(gstride ? gstride : 3) * o + ch];
-                float dx = 0.f, dy = 0.f, dz = 0.f;
-                dsh[0 * 3 + ch] += SH_C0 * g;
-                if (DEG > 0) {
-                    dsh[1 * 3 + ch] += -SH_C1 * y * g;
-                    dsh[2 * 3 + ch] += SH_C1 * z * g;
-                    dsh[3 * 3 + ch] += -SH_C1 * x * g;
-                    dx = -SH_C1 * sh[3 * 3 + ch];
-                    dy = -SH_C1 * sh[1 * 3 + ch];
-                    dz = SH_C1 * sh[2 * 3 + ch];
-                    if (DEG > 1) {
-                        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-                        dsh[4 * 3 + ch] += SH_C2[0] * xy * g;
-                        dsh[5 * 3 + ch] += SH_C2[1] * yz * g;
-                        dsh[6 * 3 + ch] += SH_C2[2] * (2.f * zz - xx - yy) * g;
-                        dsh[7 * 3 + ch] += SH_C2[3] * xz * g;
-                        dsh[8 * 3 + ch] += SH_C2[4] * (xx - yy) * g;
-                        dx += SH_C2[0] * y * sh[4 * 3 + ch] + SH_C2[2] * 2.f * -x * sh[6 * 3 + ch] +
-                              SH_C2[3] * z * sh[7 * 3 + ch] + SH_C2[4] * 2.f * x * sh[8 * 3 + ch];
-                        dy += SH_C2[0] * x * sh[4 * 3 + ch] + SH_C2[1] * z * sh[5 * 3 + ch] +
-                              SH_C2[2] * 2.f * -y * sh[6 * 3 + ch] + SH_C2[4] * 2.f * -y * sh[8 * 3 + ch];
-                        dz += SH_C2[1] * y * sh[5 * 3 + ch] + SH_C2[2] * 2.f * 2.f * z * sh[6 * 3 + ch] +
-                              SH_C2[3] * x * sh[7 * 3 + ch];
-                        if (DEG > 2) {
-                            dsh[9 * 3 + ch] += SH_C3[0] * y * (3.f * xx - yy) * g;
-                            dsh[10 * 3 + ch] += SH_C3[1] * xy * z * g;
-                            dsh[11 * 3 + ch] += SH_C3[2] * y * (4.f * zz - xx - yy) * g;
-                            dsh[12 * 3 + ch] += SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy) * g;
-                            dsh[13 * 3 + ch] += SH_C3[4] * x * (4.f * zz - xx - yy) * g;
-                            dsh[14 * 3 + ch] += SH_C3[5] * z * (xx - yy) * g;
-                            dsh[15 * 3 + ch] += SH_C3[6] * x * (xx - 3.f * yy) * g;
-                            dx += SH_C3[0] * sh[9 * 3 + ch] * 3.f * 2.f * xy + SH_C3[1] * sh[10 * 3 + ch] * yz +
-                                  SH_C3[2] * sh[11 * 3 + ch] * -2.f * xy + SH_C3[3] * sh[12 * 3 + ch] * -3.f * 2.f * xz +
-                                  SH_C3[4] * sh[13 * 3 + ch] * (-3.f * xx + 4.f * zz - yy) +
-                                  SH_C3[5] * sh[14 * 3 + ch] * 2.f * xz + SH_C3[6] * sh[15 * 3 + ch] * 3.f * (xx - yy);
-                            dy += SH_C3[0] * sh[9 * 3 + ch] * 3.f * (xx - yy) + SH_C3[1] * sh[10 * 3 + ch] * xz +
-                                  SH_C3[2] * sh[11 * 3 + ch] * (-3.f * yy + 4.f * zz - xx) +
-                                  SH_C3[3] * sh[12 * 3 + ch] * -3.f * 2.f * yz + SH_C3[4] * sh[13 * 3 + ch] * -2.f * xy +
-                                  SH_C3[5] * sh[14 * 3 + ch] * -2.f * yz + SH_C3[6] * sh[15 * 3 + ch] * -3.f * 2.f * xy;
-                            dz += SH_C3[1] * sh[10 * 3 + ch] * xy + SH_C3[2] * sh[11 * 3 + ch] * 4.f * 2.f * yz +
-                                  SH_C3[3] * sh[12 * 3 + ch] * 3.f * (2.f * zz - xx - yy) +
-                                  SH_C3[4] * sh[13 * 3 + ch] * 4.f * 2.f * xz + SH_C3[5] * sh[14 * 3 + ch] * (xx - yy);
-                        }
-                    }
-                }
-                ddir[0] += dx * g;
-                ddir[1] += dy * g;
-                ddir[2] += dz * g;
-            }
-            const float dot = x * ddir[0] + y * ddir[1] + z * ddir[2];
-            dmean[0] += (ddir[0] - x * dot) / len;
-            dmean[1] += (ddir[1] - y * dot) / len;
-            dmean[2] += (ddir[2] - z * dot) / len;
         }
     }
     // ---- stores + the camera-independent tail (cov3D -> scale / quaternion, activations), once
@@ -1315,25 +1424,13 @@ preprocess_backward_batched_body(int P, int B, int M, const float *__restrict__ 
         for (int e = 0; e < 3; e++) {
             sp[e] = p[e];
             sg[e] = dmean[e];
-            sp[10 + e] = sh[e];
-            sg[10 + e] = dsh[e];
         }
     } else {
         dL_dxyz[3 * (size_t)i] = dmean[0];
         dL_dxyz[3 * (size_t)i + 1] = dmean[1];
         dL_dxyz[3 * (size_t)i + 2] = dmean[2];
-        dL_ddc[3 * (size_t)i] = dsh[0];
-        dL_ddc[3 * (size_t)i + 1] = dsh[1];
-        dL_ddc[3 * (size_t)i + 2] = dsh[2];
     }
     {
-        float *rp = staged ? s_rest + threadIdx.x * REST_W : dL_drest + (size_t)i * (M - 1) * 3;
-#pragma unroll
-        for (int k = 3; k < NC * 3; k++) rp[k - 3] = dsh[k];
-        for (int k = NC * 3; k < M * 3; k++) rp[k - 3] = 0.f;
-    }
-    {
-        const float oraw = opacity[i];
         const float so = 1.0f / (1.0f + expf(-oraw));
         if constexpr (ADAM) {
             sp[13] = oraw;
@@ -1343,11 +1440,9 @@ preprocess_backward_batched_body(int P, int B, int M, const float *__restrict__ 
         }
     }
     {
-        const float4 qraw = *reinterpret_cast<const float4 *>(rotation + 4 * (size_t)i);
         const float qnr = sqrtf(qraw.x * qraw.x + qraw.y * qraw.y + qraw.z * qraw.z + qraw.w * qraw.w);
         const float qn = fmaxf(qnr, 1e-12f);
         const float4 q = make_float4(qraw.x / qn, qraw.y / qn, qraw.z / qn, qraw.w / qn);
-        const float scraw[3] = {scaling[3 * (size_t)i], scaling[3 * (size_t)i + 1], scaling[3 * (size_t)i + 2]};
         const float sc[3] = {expf(scraw[0]), expf(scraw[1]), expf(scraw[2])};
         float gsc[3];
         float R[3][3];
@@ -1417,7 +1512,7 @@ preprocess_backward_batched_body(int P, int B, int M, const float *__restrict__ 
 }
 
 template <int DEG>
-__global__ void __launch_bounds__(K11_BLOCK, 2)  // two waves per SIMD (<= 256 registers), not one
+__global__ void __launch_bounds__(K11_BLOCK, K11B_WAVES_PER_EU)
 preprocess_backward_batched_kernel(int P, int B, int M, const float *__restrict__ xyz,
                                    const float *__restrict__ scaling, float scale_modifier,
                                    const float *__restrict__ rotation, const float *__restrict__ f_dc,
@@ -1436,7 +1531,7 @@ preprocess_backward_batched_kernel(int P, int B, int M, const float *__restrict_
 }
 
 template <int DEG>
-__global__ void __launch_bounds__(K11_BLOCK, 2)  // two waves per SIMD (<= 256 registers), not one
+__global__ void __launch_bounds__(K11_BLOCK, K11B_WAVES_PER_EU)
 preprocess_backward_adam_batched_kernel(int P, int B, float *__restrict__ xyz, float *__restrict__ scaling,
                                         float scale_modifier, float *__restrict__ rotation,
                                         float *__restrict__ f_dc, float *__restrict__ f_rest,
