@@ -97,9 +97,12 @@ scan_gather_lookback_kernel(const uint32_t *__restrict__ src, const uint32_t *__
             s_excl = excl;
             if ((int)bid == nb - 1) {
                 out[n] = (uint32_t)(excl + tot);
-                // pinned host words: value, then (system-scope release) the call's sequence tag the host polls
-                __hip_atomic_store(host_total, (uint32_t)(excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                __hip_atomic_store(host_total + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                // (round 6: the host gets the count from K3 -- publish_pair_count -- ~100 us earlier; a caller that still
+                // hands the pinned words to this kernel gets the value then the call's sequence tag, as before)
+                if (host_total) {
+                    __hip_atomic_store(host_total, (uint32_t)(excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(host_total + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
             }
         }
     }
@@ -131,8 +134,10 @@ touch_count_kernel(int P, int gx, int gy, const float2 *__restrict__ means2D, co
                    const uint8_t *__restrict__ mask, RadixPlan plan, uint32_t *__restrict__ tt,
                    uint32_t *__restrict__ keys, uint32_t *__restrict__ vals, TileRect *__restrict__ rects,
                    uint32_t *__restrict__ ghist, uint32_t *__restrict__ tile_hist, int32_t *__restrict__ hull_out,
-                   int cull) {
+                   int cull, unsigned long long *__restrict__ early, uint32_t *__restrict__ host_total, uint32_t seq) {
     __shared__ int s_lo, s_hi;
+    __shared__ unsigned long long s_nsum[TC_THREADS / 64];
+    unsigned long long nsum = 0;  // this thread's share of the pair count D = sum of tiles_touched
     __shared__ uint32_t mh[RADIX_MAX_PASSES][RADIX_DIGITS];
     // digit histograms of the TILE sort (keys (y, x): pass 0 = column, pass 1 = row), known here without looking at
     // a single pair: a rect of w x h tiles adds h to every column digit in [minx, maxx) and w to every row digit in
@@ -191,6 +196,7 @@ touch_count_kernel(int P, int gx, int gy, const float2 *__restrict__ means2D, co
                 }
             }
             if (n) key = __float_as_uint(depths[i]);
+            nsum += n;
             tt[i] = n;
             rects[i] = rect;
             keys[i] = key;
@@ -198,7 +204,14 @@ touch_count_kernel(int P, int gx, int gy, const float2 *__restrict__ means2D, co
         }
         multihist_add(mh, plan, key, valid);
     }
+    nsum = wave_sum64(nsum);
+    if ((threadIdx.x & 63) == 0) s_nsum[threadIdx.x >> 6] = nsum;
     __syncthreads();
+    if (threadIdx.x == 0) {  // the pair count reaches the host HERE, not four sort passes and a scan later
+        unsigned long long tot = 0;
+        for (int wv = 0; wv < TC_THREADS / 64; wv++) tot += s_nsum[wv];
+        publish_pair_count(early, tot, gridDim.x, host_total, seq);
+    }
     multihist_flush(mh, plan, ghist);
     if (tile_hist) {  // kernel-uniform
         const uint32_t xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u;  // HW_REG_XCC_ID[3:0]
@@ -437,7 +450,7 @@ copy_u32_kernel(long long n, const uint32_t *__restrict__ src, uint32_t *__restr
 }
 
 struct PrepLayout {
-    size_t tt, kA, vA, kB, vB, offsets, rects, hull, thist, ctrl, total;
+    size_t tt, kA, vA, kB, vB, offsets, rects, hull, early, thist, ctrl, total;
     CtrlLayout C;
 };
 PrepLayout prep_layout(int P, int W, int H) {
@@ -453,6 +466,7 @@ PrepLayout prep_layout(int P, int W, int H) {
     L.offsets = o; o += np;
     L.rects = o; o += align_up((size_t)(P + 1) * sizeof(TileRect));
     L.hull = o; o += 256;  // int32 [2]: the row hull of the mask (written by K3, copied into the range table by the sort)
+    L.early = o; o += 256;  // { u64 sum of tiles_touched (K3's atomics), u32 workgroups that added theirs }: zeroed with ctrl
     L.thist = o; o += align_up(sizeof(uint32_t) * RADIX_REPLICAS * RADIX_MAX_PASSES * RADIX_DIGITS);  // zeroed with ctrl
     L.ctrl = o;
     L.C = ctrl_layout(P, 4, true);
@@ -611,8 +625,12 @@ int prepare_lookback(const PrepCall &c, uint32_t *ticket) {
     TileRect *rects = reinterpret_cast<TileRect *>(base + L.rects);
     char *ctrl = base + L.ctrl;
 
-    GSR_HIP(hipMemsetAsync(base + L.thist, 0, (L.ctrl - L.thist) + L.C.total, stream));
+    GSR_HIP(hipMemsetAsync(base + L.early, 0, (L.ctrl - L.early) + L.C.total, stream));
     const RadixPlan plan = radix_plan(0, 32);
+    uint32_t *host_total = nullptr;
+    uint32_t seq = 0;
+    int rc = total_slot(&host_total, &seq);
+    if (rc) return rc;
     uint32_t *tile_hist = yx_path(gx, gy) ? reinterpret_cast<uint32_t *>(base + L.thist) : nullptr;
     // persistent workgroups (mask hull + LDS tables are per-workgroup set-up)
     const int blocks = gsr_div_up(P, TC_THREADS) < TC_BLOCKS ? gsr_div_up(P, TC_THREADS) : TC_BLOCKS;
@@ -620,9 +638,10 @@ int prepare_lookback(const PrepCall &c, uint32_t *ticket) {
                        reinterpret_cast<const float2 *>(c.means2D), c.depths, c.radii,
                        reinterpret_cast<const float4 *>(c.conic_opacity), c.compute_locally, plan, tt, kA, vA, rects,
                        reinterpret_cast<uint32_t *>(ctrl + L.C.ghist), tile_hist,
-                       reinterpret_cast<int32_t *>(base + L.hull), tile_hist ? tile_cull_on(gx * gy) : 0);
+                       reinterpret_cast<int32_t *>(base + L.hull), tile_hist ? tile_cull_on(gx * gy) : 0,
+                       reinterpret_cast<unsigned long long *>(base + L.early), host_total, seq);
     int in_first = 1;
-    int rc = radix_sort_pairs(kA, vA, kB, vB, P, plan, ctrl, L.C, &in_first, stream, nullptr);
+    rc = radix_sort_pairs(kA, vA, kB, vB, P, plan, ctrl, L.C, &in_first, stream, nullptr);
     if (rc) return rc;
     // 4 passes -> back in (kA, vA); the sorted ids stay in vA for K5
     uint32_t *sorted_ids = in_first ? vA : vB;
@@ -636,13 +655,9 @@ int prepare_lookback(const PrepCall &c, uint32_t *ticket) {
                            stream, (long long)P, in_first ? kA : kB, sorted_ids,
                            reinterpret_cast<const float2 *>(c.means2D));
     const int nbs = gsr_div_up(P, SCAN_TILE);
-    uint32_t *host_total = nullptr;
-    uint32_t seq = 0;
-    rc = total_slot(&host_total, &seq);
-    if (rc) return rc;
     hipLaunchKernelGGL(scan_gather_lookback_kernel, dim3(nbs), dim3(SCAN_THREADS), 0, stream, tt, sorted_ids, offsets,
                        (long long)P, reinterpret_cast<unsigned long long *>(ctrl + L.C.scan_state),
-                       reinterpret_cast<uint32_t *>(ctrl + L.C.tickets), nbs, host_total, seq);
+                       reinterpret_cast<uint32_t *>(ctrl + L.C.tickets), nbs, (uint32_t *)nullptr, seq);
     GSR_LAUNCH_CHECK();
     *ticket = seq;
     return 0;
@@ -675,7 +690,7 @@ int prepare_persistent(const PrepCall &c, uint32_t *ticket) {
     const int gx = (c.width + GSR_BLOCK_X - 1) / GSR_BLOCK_X, gy = (c.height + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y;
     char *base = reinterpret_cast<char *>(c.prep);
     char *ctrl = base + L.ctrl;
-    GSR_HIP(hipMemsetAsync(base + L.thist, 0, (L.ctrl - L.thist) + PL.zero_bytes, c.stream));
+    GSR_HIP(hipMemsetAsync(base + L.early, 0, (L.ctrl - L.early) + PL.zero_bytes, c.stream));
     uint32_t *host_total = nullptr;
     uint32_t seq = 0;
     int rc = total_slot(&host_total, &seq);
@@ -695,6 +710,7 @@ int prepare_persistent(const PrepCall &c, uint32_t *ticket) {
     a.tile_hist = yx_path(gx, gy) ? reinterpret_cast<uint32_t *>(base + L.thist) : nullptr;
     a.cull = a.tile_hist ? tile_cull_on(gx * gy) : 0;
     a.hull_out = reinterpret_cast<int32_t *>(base + L.hull);
+    a.early = reinterpret_cast<unsigned long long *>(base + L.early);
     const int ngroups = (G + GB_FAN - 1) / GB_FAN;
     a.sync.leaf = reinterpret_cast<uint32_t *>(ctrl + PL.sync);
     a.sync.root = a.sync.leaf + (size_t)ngroups * GB_LEAF_STRIDE;
@@ -1009,7 +1025,30 @@ extern "C" int gsr_bin_sort_bounded(int P, int width, int height, const uint8_t 
 }
 
 // K3-K7 of one view in ONE call for callers that keep a grow-only scratch (the operator's path): gsr_bin_prepare_async,
-// then -- when `capacity` > 0 -- gsr_bin_sort_bounded into (scratch, point_list), then gsr_bin_count_wait.
+// then -- when `capacity` > 0 -- gsr_bin_sort_bounded into (scratch, point_list).  Nothing waits: *ticket names the
+// pair count for gsr_bin_count_wait, which the caller may call after it has launched the kernels that consume the
+// lists (they read the ranges, never the count) -- round 6: the host no longer stands between K3-K7 and K8.
+// *sorted = 1 when the bounded sort was launched.
+extern "C" int gsr_bin_speculative_async(int P, int width, int height, const float *means2D, const float *depths,
+                                         const int32_t *radii, const float *conic_opacity,
+                                         const uint8_t *compute_locally, void *prep, size_t prep_bytes,
+                                         int64_t capacity, void *scratch, size_t scratch_bytes, uint32_t *point_list,
+                                         int32_t *ranges, uint32_t *ticket, int *sorted, gsr_stream_t stream_) {
+    if (!ticket || !sorted) return GSR_EINVAL;
+    *sorted = 0;
+    int rc = gsr_bin_prepare_async(P, width, height, means2D, depths, radii, conic_opacity, compute_locally, prep,
+                                   prep_bytes, ticket, stream_);
+    if (rc) return rc;
+    if (capacity > 0 && *ticket != 0 && scratch && point_list) {
+        rc = gsr_bin_sort_bounded(P, width, height, compute_locally, prep, capacity, scratch, scratch_bytes, point_list,
+                                  ranges, stream_);
+        if (rc) return rc;
+        *sorted = 1;
+    }
+    return 0;
+}
+
+// The same followed by gsr_bin_count_wait.
 // *status = 0: the lists are complete (the count fitted the capacity); 1: the caller must run gsr_bin_sort with buffers for
 // *num_rendered_host pairs (no capacity yet, the count outgrew it, or the persistent prepare kernel repeated itself).
 extern "C" int gsr_bin_speculative(int P, int width, int height, const float *means2D, const float *depths,
@@ -1021,16 +1060,11 @@ extern "C" int gsr_bin_speculative(int P, int width, int height, const float *me
     *num_rendered_host = 0;
     *status = 1;
     uint32_t ticket = 0;
-    int rc = gsr_bin_prepare_async(P, width, height, means2D, depths, radii, conic_opacity, compute_locally, prep,
-                                   prep_bytes, &ticket, stream_);
+    int sorted = 0;
+    int rc = gsr_bin_speculative_async(P, width, height, means2D, depths, radii, conic_opacity, compute_locally, prep,
+                                       prep_bytes, capacity, scratch, scratch_bytes, point_list, ranges, &ticket, &sorted,
+                                       stream_);
     if (rc) return rc;
-    bool sorted = false;
-    if (capacity > 0 && ticket != 0 && scratch && point_list) {
-        rc = gsr_bin_sort_bounded(P, width, height, compute_locally, prep, capacity, scratch, scratch_bytes, point_list,
-                                  ranges, stream_);
-        if (rc) return rc;
-        sorted = true;
-    }
     rc = gsr_bin_count_wait(ticket, num_rendered_host, stream_);
     if (rc == GSR_ERETRY) return 0;  // (count valid, the bounded sort wrote nothing: status 1)
     if (rc) return rc;

@@ -509,6 +509,27 @@ __device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v) {
     return v;
 }
 
+// Round 6: the pair count D = sum of tiles_touched is known when K3 has looked at every Gaussian -- not four sort passes
+// and a scan later (~100 us at 10^6 Gaussians), which is what the host's poll used to wait for.  Every workgroup adds
+// its share to a 64-bit counter (zero before the launch); the one whose arrival completes the grid hands the sum to the
+// pinned host words: the value, then (system-scope release) the call's sequence tag.
+__device__ __forceinline__ uint32_t clamp_pair_count(unsigned long long d) {
+    return d >= 0xFFFFFFFEull ? 0xFFFFFFFEu : (uint32_t)d;  // (0xFFFFFFFF is PAIRS_ABORTED)
+}
+__device__ __forceinline__ void publish_pair_count(unsigned long long *early, unsigned long long mine, uint32_t nwg,
+                                                   uint32_t *host_total, uint32_t seq) {
+    // (agent scope: the workgroups sit on eight XCDs whose L2s do not see each other's lines)
+    __hip_atomic_fetch_add(early, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t *ticket = reinterpret_cast<uint32_t *>(early + 1);
+    // release / acquire on the ticket orders every workgroup's add in front of the last arriver's read
+    const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (t + 1u == nwg && host_total) {
+        const unsigned long long d = __hip_atomic_load(early, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(host_total, clamp_pair_count(d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(host_total + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 #define GSR_TS(k)                                                                                       \
     do {                                                                                                \
         if (a.tstamp && threadIdx.x == 0) a.tstamp[(size_t)blockIdx.x * 32 + (k)] = __builtin_amdgcn_s_memrealtime(); \
@@ -535,6 +556,7 @@ struct PrepPersistArgs {
     uint32_t *tile_hist;  // [8 replicas][4][256] or null (frames above 256 x 256 tiles)
     int cull;             // exact tile culling (gsr_tile_mask); only with tile_hist (the (row, column) path)
     int32_t *hull_out;
+    unsigned long long *early;  // { sum of tiles_touched, arrivals }: zero before the launch
     GridSync sync;
     uint32_t *cnt;  // [4][G][256]
     uint32_t *grp;  // [4][ngroups][256], zero before the launch
@@ -600,6 +622,7 @@ bin_prepare_persist_kernel(const PrepPersistArgs a) {
         a.hull_out[1] = hull1 > hull0 ? hull1 : 0;
     }
     uint32_t mytot = 0;  // thread d < 256: this workgroup's count of digit d in the pass being counted
+    unsigned long long nsum = 0;  // this thread's share of the pair count
     for (long long t = t0; t < t1; t++) {
         const long long wbase = t * PP_TILE + (long long)wave * (PP_ITEMS * 64);
         // every input of four of the thread's Gaussians is requested before the first is looked at (clamped indices, no
@@ -644,6 +667,7 @@ bin_prepare_persist_kernel(const PrepPersistArgs a) {
                     }
                 }
                 if (n) key[r] = __float_as_uint(dep[q4]);
+                nsum += n;
                 st_agent(&a.tt[i], n);  // (gathered by other workgroups in the scan phase)
                 a.rects[i] = rect;
                 if (!keep) {
@@ -666,6 +690,17 @@ bin_prepare_persist_kernel(const PrepPersistArgs a) {
         }
     }
     if (d < RADIX_DIGITS) publish_counts(a.cnt, a.grp, w, d, mytot);
+    {  // this workgroup's share of the pair count (read by workgroup 0 behind the first barrier): ONE atomic per workgroup
+        nsum = wave_sum64(nsum);
+        __syncthreads();  // (scan64 is free: nothing has used it yet, but keep the phases apart)
+        if (lane == 0) sm.scan64[wave] = nsum;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long tot = 0;
+            for (int wv = 0; wv < PP_WAVES; wv++) tot += sm.scan64[wv];
+            if (tot) __hip_atomic_fetch_add(a.early, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     if (a.tile_hist) {  // the tile sort's digit histograms, for the look-back tile sort (large D, contended device)
         const uint32_t xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u;  // HW_REG_XCC_ID[3:0]
         for (int p = 0; p < 2; p++) {
@@ -690,6 +725,13 @@ bin_prepare_persist_kernel(const PrepPersistArgs a) {
         return;
     }
     GSR_TS(2);
+    if (w == 0 && threadIdx.x == 0) {
+        // round 6: the host's poll ends HERE (every workgroup's share arrived before its barrier arrival), ~20 us into the
+        // kernel instead of at its end: the four sort passes and the scan no longer stand between K3 and the host
+        const unsigned long long dsum = __hip_atomic_load(a.early, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.host_total, clamp_pair_count(dsum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(a.host_total + 1, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     // later barriers cannot dead-lock (the whole grid is resident): a second without progress is a fault (barrier_fault)
     const uint64_t forever = 100000000ull;
     // ------------------------------------------------------------------ four LSD passes over the depth bits
@@ -831,10 +873,7 @@ bin_prepare_persist_kernel(const PrepPersistArgs a) {
         carry += tot;
     }
     if (w == G - 1 && threadIdx.x == 0) {  // the last workgroup owns the last tile: its carry is the pair count
-        const uint32_t D = carry >= 0xFFFFFFFEull ? 0xFFFFFFFEu : (uint32_t)carry;  // (0xFFFFFFFF is PAIRS_ABORTED)
-        a.offsets[P] = D;
-        __hip_atomic_store(a.host_total, D, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(a.host_total + 1, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        a.offsets[P] = clamp_pair_count(carry);  // (the host has had the count since the first barrier)
     }
     GSR_TS(31);
 }
@@ -986,7 +1025,13 @@ bin_sort_persist_kernel(const SortPersistArgs a) {
     long long D = a.D;
     if (a.bounded) {
         const long long dd = a.offsets[P];
-        if (dd > D) {  // does not fit (or the prepare kernel aborted): every workgroup leaves, nothing is written
+        if (dd > D) {
+            // does not fit (or the prepare kernel aborted): every workgroup leaves and no list is written -- but the range
+            // table is left EMPTY, not untouched (round 6: the composite kernel is launched before the host has seen the
+            // count; it then draws the background, and the caller repeats sort and composite with exact sizes)
+            for (int t = w * PS_THREADS + threadIdx.x; t < a.ranges_words; t += G * PS_THREADS)
+                reinterpret_cast<uint32_t *>(a.ranges)[t] = 0u;
+            if (w == 0 && threadIdx.x < 2) a.ranges[a.ranges_words + threadIdx.x] = a.hull[threadIdx.x];
             if (w == 0 && threadIdx.x == 0 && a.done_seq)
                 __hip_atomic_store(a.done_word, a.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             return;

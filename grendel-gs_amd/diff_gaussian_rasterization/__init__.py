@@ -795,11 +795,53 @@ def _bin_gaussians_captured(cap_ctx, means2D, depths, radii, conic_opacity, comp
     return point_list, ranges, cap
 
 
-def bin_gaussians(means2D, depths, radii, conic_opacity, compute_locally, width, height, cuda_args=None):
+class PendingPairs:
+    """The pair count of a view whose K3-K7 (and, by the time finish() is called, K8) are already in flight (round 6).
+    The kernels that consume the lists read the range table, never the count, so the host need not stand between the
+    tile sort and the composite kernel: it launches both against the CAPACITY of the kept scratch and looks at the
+    count afterwards.  finish() -> (D, new_point_list or None): None when the count fitted the capacity (the lists in
+    flight are complete); otherwise the bounded sort wrote nothing and left every range empty (the composite kernel drew
+    the background), the tile sort has been repeated HERE with exact sizes into a new point_list, and the caller
+    launches its consumer again (same outputs, same stream: stream order makes the repeat invisible to later work)."""
+
+    def __init__(self, ticket, sorted_, cap, P, width, height, mask, prep, ranges, dev, stream, key, cuda_args):
+        self.ticket, self.sorted, self.cap = ticket, sorted_, cap
+        self.P, self.width, self.height = P, width, height
+        self.mask, self.prep, self.ranges = mask, prep, ranges  # (keeps the prepare workspace alive for a repeat)
+        self.dev, self.stream, self.key, self.cuda_args = dev, stream, key, cuda_args
+        self.D = None
+
+    def finish(self):
+        with _on(self.dev), torch.cuda.stream(self.stream):
+            stream = _stream()
+            D = ctypes.c_int64(0)
+            rc = lib.gsr_bin_count_wait(self.ticket, ctypes.byref(D), stream)
+            if rc != GSR_ERETRY:
+                check(rc, "gsr_bin_count_wait")
+            self.D = D = int(D.value)
+            if D > _MAX_PAIRS.get(self.key, 0):
+                _MAX_PAIRS[self.key] = D
+            if rc == 0 and self.sorted and D <= self.cap:
+                self.prep = None
+                return D, None
+            sort_bytes = lib.gsr_bin_sort_bytes(self.P, D, self.width, self.height)
+            scratch = _sort_scratch(max(sort_bytes, 4), self.dev)
+            point_list = torch.empty((_bucket(max(D, 1) * 4) // 4,), dtype=torch.int32, device=self.dev)[:max(D, 1)]
+            with zhx_range(self.cuda_args, "50 SortPairs time"):
+                check(lib.gsr_bin_sort(self.P, self.width, self.height, _ptr(self.mask), _ptr(self.prep), D,
+                                       _ptr(scratch), sort_bytes, _ptr(point_list), _ptr(self.ranges), stream),
+                      "gsr_bin_sort")
+            self.prep = None
+            return D, point_list
+
+
+def bin_gaussians(means2D, depths, radii, conic_opacity, compute_locally, width, height, cuda_args=None, defer=False):
     """K3-K7: returns (point_list uint32-as-int32 [D], ranges int32 [tiles,2], D).  One host read-back (the pair count
     D, like the reference's own num_rendered) -- but the GPU does not wait for it: once a view of this size has been
     sorted, the next sort is launched for the CAPACITY of the scratch kept from then, the kernels take D from device
     memory, and the host reads D while they run (it only re-sorts if D outgrew the capacity).
+    `defer` (round 6): do not even read D here -- returns (point_list [capacity], ranges, PendingPairs) and the caller
+    calls .finish() after it has launched the consumer of the lists.
     Per tile the list is the reference's (depth, then index) order restricted to the Gaussians that
     can reach alpha >= 1/255 somewhere in the tile's neighbourhood (see include/gsraster.h)."""
     if _CAPTURE[0] is not None:
@@ -825,27 +867,35 @@ def bin_gaussians(means2D, depths, radii, conic_opacity, compute_locally, width,
         cap = min(int(lib.gsr_bin_sort_capacity(P, kept.numel(), width, height)), _bucket(4 * _MAX_PAIRS.get(key, 0)) // 4)
         if cap > 0:
             point_list = torch.empty((cap,), dtype=torch.int32, device=dev)
-    D, status = ctypes.c_int64(0), ctypes.c_int(1)
-    # ONE host-side call: K3-K4, the tile sort at the scratch's capacity, the pair count (include/gsraster.h)
-    with zhx_range(cuda_args, "24 updateDistributedStatLocally.updateTileTouched time"), \
-            zhx_range(cuda_args, "50 SortPairs time"):
-        check(lib.gsr_bin_speculative(P, width, height, _ptr(means2D), _ptr(depths), _ptr(radii), _ptr(conic_opacity),
-                                      _ptr(compute_locally), _ptr(prep), prep_bytes, cap if cap > 0 else 0,
-                                      _ptr(kept) if cap > 0 else None, kept.numel() if cap > 0 else 0,
-                                      _ptr(point_list) if cap > 0 else None, _ptr(ranges), ctypes.byref(D),
-                                      ctypes.byref(status), stream), "gsr_bin_speculative")
-    D = int(D.value)
-    if D > _MAX_PAIRS.get(key, 0):
-        _MAX_PAIRS[key] = D
-    if status.value == 0:
-        return point_list[:max(D, 1)], ranges, D
-    sort_bytes = lib.gsr_bin_sort_bytes(P, D, width, height)
-    scratch = _sort_scratch(max(sort_bytes, 4), dev)
-    point_list = torch.empty((_bucket(max(D, 1) * 4) // 4,), dtype=torch.int32, device=dev)[:max(D, 1)]
-    with zhx_range(cuda_args, "50 SortPairs time"):
-        check(lib.gsr_bin_sort(P, width, height, _ptr(compute_locally), _ptr(prep), D, _ptr(scratch), sort_bytes,
-                               _ptr(point_list), _ptr(ranges), stream), "gsr_bin_sort")
-    return point_list, ranges, D
+    ticket, sorted_ = ctypes.c_uint32(0), ctypes.c_int(0)
+    if _zhx_on(cuda_args):
+        # the native timer log wants the reference's two stages apart (analyze_statistic.py:1972-1991): two host calls
+        with zhx_range(cuda_args, "24 updateDistributedStatLocally.updateTileTouched time"):
+            check(lib.gsr_bin_prepare_async(P, width, height, _ptr(means2D), _ptr(depths), _ptr(radii),
+                                            _ptr(conic_opacity), _ptr(compute_locally), _ptr(prep), prep_bytes,
+                                            ctypes.byref(ticket), stream), "gsr_bin_prepare_async")
+        if cap > 0 and ticket.value != 0:
+            with zhx_range(cuda_args, "50 SortPairs time"):
+                check(lib.gsr_bin_sort_bounded(P, width, height, _ptr(compute_locally), _ptr(prep), cap, _ptr(kept),
+                                               kept.numel(), _ptr(point_list), _ptr(ranges), stream),
+                      "gsr_bin_sort_bounded")
+            sorted_.value = 1
+    else:
+        # ONE host-side call: K3-K4 and the tile sort at the scratch's capacity (include/gsraster.h)
+        check(lib.gsr_bin_speculative_async(P, width, height, _ptr(means2D), _ptr(depths), _ptr(radii),
+                                            _ptr(conic_opacity), _ptr(compute_locally), _ptr(prep), prep_bytes,
+                                            cap if cap > 0 else 0, _ptr(kept) if cap > 0 else None,
+                                            kept.numel() if cap > 0 else 0, _ptr(point_list) if cap > 0 else None,
+                                            _ptr(ranges), ctypes.byref(ticket), ctypes.byref(sorted_), stream),
+              "gsr_bin_speculative_async")
+    pend = PendingPairs(ticket.value, bool(sorted_.value), cap, P, width, height, compute_locally, prep, ranges, dev,
+                        torch.cuda.current_stream(dev), key, cuda_args)
+    if defer and sorted_.value:
+        return point_list, ranges, pend
+    D, again = pend.finish()
+    if again is not None:
+        return again, ranges, D
+    return point_list[:max(D, 1)], ranges, D
 
 
 class _RenderGaussians(torch.autograd.Function):
@@ -885,8 +935,12 @@ class _RenderGaussians(torch.autograd.Function):
                 ev1 = torch.cuda.Event(enable_timing=True)
                 ev0.record()
             with kernel_timer.range("binning", P=P, tiles=gx * gy) as kt:
-                point_list, ranges, D = bin_gaussians(means2D, depths, radii, conic_opacity, mask, W, H, cuda_args)
-                kt.meta["D"] = D
+                # (round 6) the pair count is looked at AFTER K8 has been launched -- by the caller, after ALL its cameras
+                # have been launched, when it hands a list through cuda_args["_gsr_pending"] (gaussian_renderer.render_final)
+                point_list, ranges, D = bin_gaussians(means2D, depths, radii, conic_opacity, mask, W, H, cuda_args,
+                                                      defer=True)
+            pend = D if isinstance(D, PendingPairs) else None
+            kt.meta["D"] = D = (0 if pend is not None else D)
             out = torch.empty((3, H, W), dtype=torch.float32, device=dev)
             final_T = torch.empty((H, W), dtype=torch.float32, device=dev)
             n_contrib = torch.empty((H, W), dtype=torch.int32, device=dev)
@@ -905,12 +959,39 @@ class _RenderGaussians(torch.autograd.Function):
             if any(ctx.needs_input_grad[:3]) and (_SEGMENTS[0] == "always" or (_SEGMENTS[0] and thin)):
                 seg_bytes = int(lib.gsr_render_seg_bytes(W, H))
                 seg_ws = torch.empty((seg_bytes,), dtype=torch.uint8, device=dev)
-            with kernel_timer.range("composite_forward", P=P, D=D, **ctx.px_meta), zhx_range(cuda_args, "70 render time"):
-                check(lib.gsr_render_forward_seg(P, W, H, _ptr(ranges), _ptr(point_list), _ptr(means2D),
-                                                 _ptr(conic_opacity), _ptr(rgb), _ptr(mask), _ptr(bg), _ptr(out),
-                                                 _ptr(final_T), _ptr(n_contrib), _ptr(seg_ws), seg_bytes, row_lo, row_hi,
-                                                 _stream()), "gsr_render_forward_seg")
+            lists = [point_list]  # (a list: a late pair count may replace the point_list, see settle below)
+
+            def launch_k8(meta_D):
+                with kernel_timer.range("composite_forward", P=P, D=meta_D, **ctx.px_meta) as k8t, \
+                        zhx_range(cuda_args, "70 render time"):
+                    check(lib.gsr_render_forward_seg(P, W, H, _ptr(ranges), _ptr(lists[0]), _ptr(means2D),
+                                                     _ptr(conic_opacity), _ptr(rgb), _ptr(mask), _ptr(bg), _ptr(out),
+                                                     _ptr(final_T), _ptr(n_contrib), _ptr(seg_ws), seg_bytes, row_lo,
+                                                     row_hi, _stream()), "gsr_render_forward_seg")
+                return k8t
+
+            k8t = launch_k8(D)
             ctx.seg = (seg_ws, seg_bytes, row_lo, row_hi)
+            ctx.lists = lists
+            ctx.num_rendered = D
+            _RenderGaussians.last_num_rendered = D
+            if pend is not None:
+                def settle(ctx=ctx, pend=pend, kt=kt, k8t=k8t, lists=lists):
+                    D, again = pend.finish()
+                    kt.meta["D"] = k8t.meta["D"] = D
+                    ctx.num_rendered = D
+                    _RenderGaussians.last_num_rendered = D
+                    if again is not None:  # the capacity did not hold: K8 drew the background; draw the view now
+                        lists[0] = again
+                        with _on(pend.dev), torch.cuda.stream(pend.stream):
+                            launch_k8(D)
+                    return D
+
+                collector = cuda_args.get("_gsr_pending") if isinstance(cuda_args, dict) else None
+                if isinstance(collector, list):  # (the caller settles after its last camera's launches)
+                    collector.append(settle)
+                else:
+                    settle()
             if timing != "off":
                 ev1.record()
                 ctx.fwd_events = (ev0, ev1)
@@ -922,12 +1003,10 @@ class _RenderGaussians(torch.autograd.Function):
         ctx.raster_settings = rs
         ctx.cuda_args = cuda_args
         ctx.timing = timing
-        ctx.num_rendered = D
-        _RenderGaussians.last_num_rendered = D
         # the image itself is an input of the segmented backward (the colour behind a boundary is reconstructed from it):
         # saved through autograd, so that an in-place edit of the output raises instead of corrupting gradients, and
         # no ctx -> output -> grad_fn cycle keeps the buffers alive until the cyclic collector runs
-        ctx.save_for_backward(means2D, conic_opacity, rgb, mask, bg, point_list, ranges, final_T, n_contrib,
+        ctx.save_for_backward(means2D, conic_opacity, rgb, mask, bg, ranges, final_T, n_contrib,
                               out if seg_ws is not None else None)
         ctx.mark_non_differentiable(n_contrib)
         return out, n_contrib
@@ -936,7 +1015,8 @@ class _RenderGaussians(torch.autograd.Function):
     def backward(ctx, g_out, _g_ncontrib):
         global _last_backward_ms
         rs = ctx.raster_settings
-        means2D, conic_opacity, rgb, mask, bg, point_list, ranges, final_T, n_contrib, out_img = ctx.saved_tensors
+        means2D, conic_opacity, rgb, mask, bg, ranges, final_T, n_contrib, out_img = ctx.saved_tensors
+        point_list = ctx.lists[0]  # (not a saved tensor: a late pair count may have replaced it, see forward)
         H, W = int(rs.image_height), int(rs.image_width)
         P = means2D.shape[0]
         dev = means2D.device
@@ -1011,7 +1091,9 @@ class GaussianRasterizer(nn.Module):
         """-> (image [3,H,W], n_render, n_consider, n_contrib).  Pixels of tiles with
         compute_locally == False are exactly 0.  The last three values are debug statistics the
         reference's callers discard (gaussian_renderer/__init__.py:1271): n_render = number of
-        (tile, Gaussian) pairs as a Python int, n_consider = None, n_contrib = per-pixel int32 map."""
+        (tile, Gaussian) pairs as a Python int (0 when the caller collects the late pair counts itself through
+        cuda_args["_gsr_pending"]: the count is then known when it settles them), n_consider = None, n_contrib =
+        per-pixel int32 map."""
         if cuda_args is None:
             cuda_args = {}
         fn = _RenderGaussians

@@ -85,6 +85,9 @@ SIGNATURES = {
     "gsr_bin_speculative": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_size_t, c_int64, c_void_p, c_size_t, c_void_p, c_void_p, ctypes.POINTER(c_int64),
                                     ctypes.POINTER(c_int), c_void_p]),
+    "gsr_bin_speculative_async": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_size_t, c_int64, c_void_p, c_size_t, c_void_p, c_void_p,
+                                          ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(c_int), c_void_p]),
     "gsr_set_bin_persistent": (c_int, [c_int]),
     "gsr_set_tile_cull": (c_int, [c_int]),
     "gsr_bin_persist_status": (c_int, [ctypes.POINTER(ctypes.c_uint32)]),

@@ -818,8 +818,13 @@ def _fill(pkg, redistributed, sizes):
 
 
 def _render_cameras(pkg, batched_strategies):
+    """-> (images, masks, late): `late` = the pair counts the render ops have NOT looked at yet (callables): every
+    camera's K3-K7 and K8 are enqueued against the capacity of the kept sort scratch before the host reads the first
+    count (diff_gaussian_rasterization.PendingPairs) -- round 6: the host used to stand between every camera's tile sort
+    and its composite kernel (gaussian_renderer/__init__.py:1271-1282 is the reference's call site, whose rasterizer
+    reads num_rendered back at the same place)."""
     timers = utils.get_timers()
-    images, masks = [], []
+    images, masks, late = [], [], []
     for k, strategy in enumerate(batched_strategies):
         if utils.GLOBAL_RANK not in strategy.gpu_ids:
             images.append(None)
@@ -845,15 +850,26 @@ def _render_cameras(pkg, batched_strategies):
         else:
             rows_of = getattr(strategy, "_my_rows", None)  # host-known tile rows of this rank's band (the mask's rows)
             cuda_args["_gsr_band"] = rows_of() if rows_of is not None else None
-            image, _, _, _ = pkg["batched_rasterizers"][k].render_gaussians(
-                means2D=means2D, conic_opacity=conic_opacity, rgb=rgb,
-                depths=pkg["batched_depths_redistributed"][k], radii=pkg["batched_radii_redistributed"][k],
-                compute_locally=compute_locally, extended_compute_locally=extended, cuda_args=cuda_args)
+            cuda_args["_gsr_pending"] = late
+            try:
+                image, _, _, _ = pkg["batched_rasterizers"][k].render_gaussians(
+                    means2D=means2D, conic_opacity=conic_opacity, rgb=rgb,
+                    depths=pkg["batched_depths_redistributed"][k], radii=pkg["batched_radii_redistributed"][k],
+                    compute_locally=compute_locally, extended_compute_locally=extended, cuda_args=cuda_args)
+            finally:
+                cuda_args.pop("_gsr_pending", None)
         if timers is not None:
             timers.stop("forward_render_gaussians")
         images.append(image)
         masks.append(compute_locally)
-    return images, masks
+    return images, masks, late
+
+
+def _settle(late):
+    """look at the pair counts of the cameras just enqueued; a count that outgrew its capacity repeats that camera's
+    tile sort and composite kernel in place (diff_gaussian_rasterization.PendingPairs)"""
+    for settle in late:
+        settle()
 
 
 def render_final(batched_screenspace_pkg, batched_strategies, tile_size=16):
@@ -864,10 +880,12 @@ def render_final(batched_screenspace_pkg, batched_strategies, tile_size=16):
     counts -- the asynchronous copy of the exchange's counts is then long complete, so the check waits for nothing --
     and, had a slab overflowed, exchange and render are repeated with exact sizes."""
     pkg = batched_screenspace_pkg
-    images, masks = _render_cameras(pkg, batched_strategies)
+    images, masks, late = _render_cameras(pkg, batched_strategies)
+    _settle(late)
     verify = pkg.get("_exchange_pending")
     if verify is not None and not verify():
-        images, masks = _render_cameras(pkg, batched_strategies)
+        images, masks, late = _render_cameras(pkg, batched_strategies)
+        _settle(late)
     return images, masks
 
 

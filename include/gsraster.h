@@ -149,6 +149,17 @@ int gsr_bin_speculative(int P, int width, int height, const float *means2D, cons
                         const float *conic_opacity, const uint8_t *compute_locally, void *prep, size_t prep_bytes,
                         int64_t capacity, void *scratch, size_t scratch_bytes, uint32_t *point_list, int32_t *ranges,
                         int64_t *num_rendered_host, int *status, gsr_stream_t stream);
+/* gsr_bin_speculative without its wait (ABI 12): prepare, then -- `capacity` > 0 -- the bounded sort; *ticket names the pair
+ * count for gsr_bin_count_wait, *sorted = 1 when the bounded sort was launched.  The kernels that consume the lists (K8,
+ * K10) read the range table, never the count, so the caller launches them FIRST and looks at the count afterwards: had it
+ * outgrown the capacity (or gsr_bin_count_wait returned GSR_ERETRY) the bounded sort wrote nothing and left every range
+ * empty -- the consumer drew the background -- and the caller repeats gsr_bin_sort + the consumer with exact sizes.
+ * Stands where the reference's rasterizer reads `num_rendered` back between its sort-key emission and its sort
+ * (analyze_statistic.py:1972-1991 stage list: "24 updateDistributedStatLocally.updateTileTouched" -> "50 SortPairs"). */
+int gsr_bin_speculative_async(int P, int width, int height, const float *means2D, const float *depths,
+                              const int32_t *radii, const float *conic_opacity, const uint8_t *compute_locally, void *prep,
+                              size_t prep_bytes, int64_t capacity, void *scratch, size_t scratch_bytes,
+                              uint32_t *point_list, int32_t *ranges, uint32_t *ticket, int *sorted, gsr_stream_t stream);
 /* K3-K7 run as TWO persistent launches whose workgroups meet at grid-wide barriers (ABI 11; csrc/binning_persist.h)
  * instead of the nine launches of the look-back pipeline, when the device can hold the grid at once, the frame has
  * <= 256 x 256 tiles and P <= 8 x 4096 x CUs.  Lists, ranges and offsets are bit-identical.  A barrier kernel needs
