@@ -261,6 +261,85 @@ def percentile(xs, q):
     return xs[lo] + (xs[hi] - xs[lo]) * (k - lo)
 
 
+def densify_leg(a, model, opt, train_step, timed, state, steps, dgr):
+    """configs[4] says "densification on" (densification.py:5-86 of the reference: statistics every
+    iteration, densify_and_prune every 100 iterations between backward and optimizer step).  Three timed regions of the
+    same `steps` steps: plain; + the per-iteration statistics (max_radii2D, add_densification_stats); + densify_and_prune
+    every --densify-every-th step (a quantile threshold clones / splits ~2 % of the rows, opacity < 0.005 prunes).  What
+    a densification EVENT costs the loop is (t3 - t2) / events: the row surgery on 59 floats + 2 x 59 moments per
+    Gaussian, the new sizes' first pass through the caching allocator, the regrowth of the sort scratch when the pair
+    count outgrows it, the re-keyed FusedAdam state -- amortised over the reference's interval of 100 iterations."""
+    import densification_ops as D
+
+    every = int(a.densify_every)
+    dev = model._xyz.device
+    model.optimizer = opt
+    model.percent_dense = 0.01
+
+    def fresh_stats():
+        n = model._xyz.shape[0]
+        model.xyz_gradient_accum = torch.zeros((n, 1), device=dev)
+        model.denom = torch.zeros((n, 1), device=dev)
+        model.max_radii2D = torch.zeros((n,), device=dev)
+        model.sum_visible_count_in_one_batch = torch.zeros((n,), device=dev)
+        model.send_to_gpui_cnt = None
+
+    fresh_stats()
+    ev = {"events": 0, "rows": [int(model._xyz.shape[0])], "mode": "stats", "each_ms": []}
+    scratch0 = sum(int(b.numel()) for b in dgr._SORT_SCRATCH.values())
+
+    def hook(pkg):
+        with torch.no_grad():  # densification.py:13-25
+            for k in range(len(pkg["batched_locally_preprocessed_radii"])):
+                D.update_densification_stats(model, pkg["batched_locally_preprocessed_mean2D"][k],
+                                             pkg["batched_locally_preprocessed_radii"][k])
+            if ev["mode"] == "densify" and state["it"] % every == 0:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                gr = (model.xyz_gradient_accum / model.denom.clamp(min=1)).squeeze(1)
+                # the threshold that selects ~2 % of the rows (the reference's is a constant of the real scene, 0.0002)
+                thr = torch.kthvalue(gr[:4_000_000], max(int(0.98 * min(gr.numel(), 4_000_000)), 1)).values.item()
+                D.densify_and_prune(model, max(thr, 1e-30), 0.005, 4.0, None)
+                torch.cuda.synchronize()
+                ev["each_ms"].append(round(1e3 * (time.perf_counter() - t0), 3))
+                ev["events"] += 1
+                ev["rows"].append(int(model._xyz.shape[0]))
+
+    t_plain = timed(train_step, steps)
+    state["densify"] = hook
+    timed(train_step, min(steps, 5))  # (the statistics' temporaries are new to the caching allocator)
+    t_stats = timed(train_step, steps)
+    ev["mode"] = "densify"
+    it0 = state["it"]
+    state["it"] = 0  # events at steps every, 2 * every, ...
+    n_dens = max(steps, 3 * every)
+    t_dens = timed(train_step, n_dens)
+    state["it"] = it0
+    state["densify"] = None
+    scratch1 = sum(int(b.numel()) for b in dgr._SORT_SCRATCH.values())
+    # what an event costs the LOOP: the region's excess over the same steps without events, per event; the first event pays
+    # one-off costs (code objects of the torch kernels densification uses are loaded at first use), hence `steady`
+    per_event = (t_dens / n_dens - t_stats / steps) * n_dens / max(ev["events"], 1)
+    steady = sorted(ev["each_ms"][1:])[len(ev["each_ms"][1:]) // 2] * 1e-3 if len(ev["each_ms"]) > 1 else per_event
+    return {"every": every, "steps_plain": steps, "steps_with_events": n_dens, "events": ev["events"],
+            "gaussians": ev["rows"],
+            "ms_per_step_plain": round(1e3 * t_plain / steps, 4),
+            "ms_per_step_with_statistics": round(1e3 * t_stats / steps, 4),
+            "ms_per_step_with_events": round(1e3 * t_dens / n_dens, 4),
+            "ms_per_event_in_loop_mean": round(1e3 * per_event, 3),
+            "ms_per_event_each": ev["each_ms"],
+            "ms_per_event_steady": round(1e3 * steady, 3),
+            "ms_per_step_amortised_at_100": round(1e3 * (t_stats / steps + steady / 100.0), 4),
+            "sort_scratch_bytes": [scratch0, scratch1],
+            "note": "statistics = max_radii2D + add_densification_stats every iteration; event = densify_and_prune "
+                    "(clone + split at the 98th percentile of the accumulated statistic, prune opacity < 0.005) between "
+                    "backward and optimizer step, timed between two device synchronisations (each) and as the region's "
+                    "excess (in_loop_mean); steady = median of the events after the first (which loads the code objects "
+                    "of torch kernels at first use); amortised_at_100 = statistics + one steady event per 100 iterations, the "
+                    "reference's densification_interval; the eager loop has no graph to re-capture (a GraphedIteration "
+                    "re-captures once per event: its sizes are part of the capture)"}
+
+
 def run_workload(a, name, world, rank, dev, steps, warmup, repeats, render_steps, single_view=False,
                  collect_kernels=True, two_kernel_leg=None):
     """-> dict of measurements of one workload on the current process group view (world ranks)"""
@@ -269,6 +348,7 @@ def run_workload(a, name, world, rank, dev, steps, warmup, repeats, render_steps
     import utils.general_utils as utils
     from fused_optim import FusedAdam
     from gaussian_renderer import distributed_preprocess3dgs_and_all2all_final, render_final
+    from gaussian_renderer import settle as settle_views
     from gaussian_renderer.loss_distribution import batched_loss_computation, load_camera_from_cpu_to_all_gpu
     dgr.release_workspaces()  # a previous workload's sort scratch (GBs at the 40 M / 4K shape) is not this one's
     torch.cuda.empty_cache()
@@ -314,24 +394,45 @@ def run_workload(a, name, world, rank, dev, steps, warmup, repeats, render_steps
         state["it"] += 1
         return [cameras[(s + j) % n_views] for j in range(bsz)]
 
+    host_phases = {} if os.environ.get("GSR_HOST_PHASES") == "1" else None  # diagnostics: host seconds per call site
+
+    def _ph(name, t0):
+        t1 = time.perf_counter()
+        if host_phases is not None:
+            e = host_phases.setdefault(name, [0.0, 0])
+            e[0] += t1 - t0
+            e[1] += 1
+        return t1
+
     def iteration(cams, strategies, tasks, between=None):
         """GT staging .. optimizer step of one batch (train_internal.py:134-208, 316-329); `between` runs where the
         reference calls finish_strategy_final, between backward and step"""
+        t = time.perf_counter()
         load_camera_from_cpu_to_all_gpu(cams, strategies, tasks)
+        t = _ph("load_camera", t)
         pkg = distributed_preprocess3dgs_and_all2all_final(cams, model, pipe, bg, batched_strategies=strategies,
                                                            mode="train")
+        t = _ph("preprocess_and_exchange", t)
         images, masks = render_final(pkg, strategies)
+        t = _ph("render_final", t)
         stats = [ca["stats_collector"] for ca in pkg["batched_cuda_args"]]
         loss, _ = batched_loss_computation(images, cams, masks, strategies, stats)
+        t = _ph("loss", t)
         loss.backward()
+        t = _ph("backward", t)
         if between is not None:
             between(stats)
+        t = _ph("finish_strategy", t)
+        if state.get("densify") is not None:
+            state["densify"](pkg)
         opt.step()
+        t = _ph("optimizer_step", t)
         opt.zero_grad(set_to_none=True)
         for cam in cams:
             cam.original_image = None
         state["sizes"] = pkg["gpui_to_gpuj_imgk_size"]
         state["loss"] = loss
+        _ph("tail", t)
         return loss
 
     # --graph: the iteration replayed as ONE hipGraph (graphed_step.py) whenever nothing consumes per-iteration timings
@@ -415,6 +516,8 @@ def run_workload(a, name, world, rank, dev, steps, warmup, repeats, render_steps
     for _ in range(warmup):
         train_step()
     dgr.kernel_timer.reset()
+    if host_phases is not None:
+        host_phases.clear()  # (diagnostics: the timed region and what follows only, not the cold steps)
     it0 = state["it"]
     dt = timed(train_step, steps)  # THE timed region of the contract: exactly `steps` steps between two fences
     # Per-kernel HIP events: an instrumented REPLAY of the same steps (same cameras in the same order, hence the same
@@ -454,6 +557,14 @@ def run_workload(a, name, world, rank, dev, steps, warmup, repeats, render_steps
         dt_unfused = min(timed(train_step, steps), timed(train_step, steps))
         opt.set_fuse_backward(True)
 
+    densification = None
+    if getattr(a, "densify_every", 0) and world == 1 and graphed is None:
+        densification = densify_leg(a, model, opt, train_step, timed, state, steps, dgr)
+        n_total = int(model._xyz.shape[0])
+
+    if host_phases:
+        print("# host phases (us per call, from the timed region on): " + ", ".join(
+            f"{k} {1e6 * v[0] / max(v[1], 1):.0f}" for k, v in host_phases.items()), file=sys.stderr, flush=True)
     lrs = {g.get("name", str(i)): g["lr"] for i, g in enumerate(opt.param_groups)}
     out = {"name": name, "desc": desc, "learning_rates": lrs, "gaussians_total": n_total, "gaussians_this_rank": int(model._xyz.shape[0]),
            "image": [W, H], "bsz": bsz, "world": world, "scene": scene, "dt": dt, "steps": steps,
@@ -467,6 +578,7 @@ def run_workload(a, name, world, rank, dev, steps, warmup, repeats, render_steps
                                  "tests/test_gpu_loss_and_step.py); *_two_kernels = the same steps with K11 and Adam "
                                  "as separate launches, best of two regions timed after the contract's regions"},
            "graph": (dict(graphed.stats) if graphed is not None else None),
+           "densification": densification,
            "timing": {"repeats": len(per_step), "ms_per_step_median": round(percentile(per_step, 0.5), 4),
                       "ms_per_step_p10": round(percentile(per_step, 0.1), 4),
                       "ms_per_step_p90": round(percentile(per_step, 0.9), 4),
@@ -477,12 +589,13 @@ def run_workload(a, name, world, rank, dev, steps, warmup, repeats, render_steps
         dt_r = timed(render_step, render_steps)
         out["rendered_views_per_sec_one_stream"] = bsz * render_steps / dt_r
         out["render_host_ms_per_view"] = 1e3 * host_enqueue.get("render_step", 0.0) / (bsz * render_steps)
+        # `rendered_views_per_sec` IS the sequential loop on one stream -- the reference's render driver (render.py:87-95);
+        # the two loops below are extensions of this build and are reported under their own keys only (advisor r05)
         out["rendered_views_per_sec"] = out["rendered_views_per_sec_one_stream"]
         if world == 1 and dev.type == "cuda" and os.environ.get("GSR_RENDER_STREAMS", "2") != "1":
-            # Forward-only views are independent (the reference's render driver walks the cameras one after the other,
-            # render.py:87-95): consecutive views go to TWO streams alternately, so that a view's binning (latency chains:
-            # VALU 0.4 busy, 0.2 of HBM) runs beside the previous view's composite (VALU-bound, 0.07 of HBM).  Same kernels,
-            # same images; `rendered_views_per_sec` is this loop, `..._one_stream` the sequential one.
+            # Forward-only views are independent: consecutive views go to TWO streams alternately, so that a view's
+            # binning (latency chains: VALU 0.4 busy, 0.2 of HBM) runs beside the previous view's composite (VALU-bound,
+            # 0.07 of HBM).  Same kernels, same images.
             side = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
             turn = [0]
 
@@ -492,6 +605,25 @@ def run_workload(a, name, world, rank, dev, steps, warmup, repeats, render_steps
                 with torch.cuda.stream(st):
                     return render_step()
 
+            # ... and PIPELINED (round 6): view i's pair count is settled after view i + 1 has been enqueued
+            # (render_final(..., late=[...]) + gaussian_renderer.settle): the host never waits for a kernel it has just
+            # launched.  A view's image is final once its count is settled -- one view later, like a render server that
+            # sends frame i while frame i + 1 is being drawn.
+            pending = [[], []]
+
+            def render_step_pipelined():
+                k = turn[0] & 1
+                st = side[k]
+                turn[0] += 1
+                with torch.cuda.stream(st), torch.no_grad():
+                    cams = batch()
+                    strategies, tasks = start_strategy_final(cams, history)
+                    pkg = distributed_preprocess3dgs_and_all2all_final(cams, model, pipe, bg, batched_strategies=strategies,
+                                                                       mode="test")
+                    images, _ = render_final(pkg, strategies, late=pending[k])
+                settle_views(pending[k ^ 1])  # the previous view (other stream): its kernels have long started
+                return images
+
             for st in side:
                 st.wait_stream(torch.cuda.current_stream(dev))
             for _ in range(4):
@@ -500,8 +632,14 @@ def run_workload(a, name, world, rank, dev, steps, warmup, repeats, render_steps
             out["rendered_views_per_sec_two_streams"] = bsz * render_steps / dt_2
             out["render_host_ms_per_view_two_streams"] = 1e3 * host_enqueue.get("render_step_two_streams", 0.0) / (
                 bsz * render_steps)
-            out["rendered_views_per_sec"] = max(out["rendered_views_per_sec_one_stream"],
-                                                out["rendered_views_per_sec_two_streams"])
+            for _ in range(4):
+                render_step_pipelined()
+            settle_views(pending[0]), settle_views(pending[1])
+            dt_3 = timed(render_step_pipelined, render_steps)
+            settle_views(pending[0]), settle_views(pending[1])
+            out["rendered_views_per_sec_pipelined"] = bsz * render_steps / dt_3
+            out["render_host_ms_per_view_pipelined"] = 1e3 * host_enqueue.get("render_step_pipelined", 0.0) / (
+                bsz * render_steps)
             torch.cuda.current_stream(dev).wait_stream(side[0])
             torch.cuda.current_stream(dev).wait_stream(side[1])
 
@@ -626,6 +764,9 @@ def main():
                          "the load balancer; the partition is frozen in between (0: never freeze -> no graph)")
     ap.add_argument("--no-1gpu-leg", action="store_true", help="N > 1: skip the same-workload single-GPU leg")
     ap.add_argument("--render-steps", type=int, default=20, help="forward-only views/sec leg (untimed by driver)")
+    ap.add_argument("--densify-every", type=int, default=0,
+                    help="also time the steps with the densification statistics every iteration and densify_and_prune "
+                         "every N-th (densification.py:5-86 of the reference): reported as `densification`")
     ap.add_argument("--pmc-calib", action="store_true", help="also run a 256 MiB streaming multiply (PMC calibration)")
     a = ap.parse_args()
 
@@ -707,13 +848,18 @@ def main():
 
         # the same JSON line tells the rest of the story: north_star's 4K, the hard (low-opacity:
         # tile lists walked ~3x deeper) variant of the headline scene, and configs[2]'s 6 M Gaussians on one GPU
-        for wname, over in (("c1_4k", {}), ("c1", {"opacity_logit_mean": -2.0, "opacity_logit_std": 1.0}), ("c2", {})):
+        variants = {"opacity_logit_mean": "low opacity: logit ~ N(-2, 1)",
+                    "bsz": "bsz 4 on one GPU: Grendel's batched multi-view mode (configs[3]'s mode; train_internal.py:95-101)",
+                    "densify_every": "densification in the loop (configs[4] says 'densification on'): see `densification`"}
+        for wname, over in (("c1_4k", {}), ("c1", {"opacity_logit_mean": -2.0, "opacity_logit_std": 1.0}), ("c2", {}),
+                            ("c1", {"bsz": 4}), ("c1", {"densify_every": 10})):
             b = copy.copy(a)
             for k_, v_ in over.items():
                 setattr(b, k_, v_)
             try:
-                r = run_workload(b, wname, 1, 0, dev, 10, 3, 1, 5, two_kernel_leg=True)
-                r["variant"] = "low opacity: logit ~ N(-2, 1)" if over else None
+                r = run_workload(b, wname, 1, 0, dev, 10, 3, 1, 0 if over.get("densify_every") else 5,
+                                 two_kernel_leg=not over.get("densify_every"))
+                r["variant"] = next((v for k_, v in variants.items() if k_ in over), None)
             except Exception as e:  # noqa: BLE001
                 r = {"name": wname, "error": f"{type(e).__name__}: {e}"}
                 torch.cuda.empty_cache()
@@ -847,6 +993,7 @@ def main():
                                  if main_res["optimizer"]["fuse_backward"] else "FusedAdam after K11 (two kernels)")},
         "optimizer": main_res["optimizer"],
         "graph": main_res.get("graph"),
+        **({"densification": main_res["densification"]} if main_res.get("densification") else {}),
         "timing": main_res["timing"],
         "setup": {"priming_steps": main_res["priming_steps"],
                   "note": "untimed pass over the distinct synthetic cameras before the W warmup steps (large / multi-rank "
@@ -857,15 +1004,22 @@ def main():
         "rendered_views": {"one_stream": round(main_res.get("rendered_views_per_sec_one_stream", 0.0), 3),
                            "two_streams": (round(main_res["rendered_views_per_sec_two_streams"], 3)
                                            if "rendered_views_per_sec_two_streams" in main_res else None),
+                           "two_streams_pipelined": (round(main_res["rendered_views_per_sec_pipelined"], 3)
+                                                     if "rendered_views_per_sec_pipelined" in main_res else None),
                            "host_ms_per_view": (round(main_res["render_host_ms_per_view"], 4)
                                                 if "render_host_ms_per_view" in main_res else None),
                            "host_ms_per_view_two_streams": (round(main_res["render_host_ms_per_view_two_streams"], 4)
                                                             if "render_host_ms_per_view_two_streams" in main_res else None),
-                           "note": "host_ms_per_view = time the host needs to enqueue a view (the loop is device-bound "
-                                   "while this is below 1 / views_per_sec); "
-                                   "forward-only views at the workload's resolution; two_streams = consecutive views "
-                                   "alternate between two HIP streams (binning of view k+1 beside the composite of view k); "
-                                   "rendered_views_per_sec is the better of the two"},
+                           "host_ms_per_view_pipelined": (round(main_res["render_host_ms_per_view_pipelined"], 4)
+                                                          if "render_host_ms_per_view_pipelined" in main_res else None),
+                           "note": "rendered_views_per_sec = one_stream = the reference's sequential render loop "
+                                   "(render.py:87-95), every image final before the next view starts.  Extensions of this "
+                                   "build, own keys only: two_streams = consecutive views alternate between two HIP "
+                                   "streams (binning of view k+1 beside the composite of view k); two_streams_pipelined = "
+                                   "the same with view k's pair count settled after view k+1 has been enqueued "
+                                   "(render_final(late=...) + gaussian_renderer.settle: an image is final one view later). "
+                                   "host_ms_per_view* = wall time of the host's loop per view before the final fence "
+                                   "(includes the time it waits for a pair count)"},
         "kernels": kern,
         "roofline": roofline,
         "reference_published": {"a100_bicycle_1gpu_images_per_s": 16.6, "note": "README.md:342 of the reference; "
@@ -895,7 +1049,8 @@ def main():
                                                   **({"frac_hbm_peak": v_["frac_hbm_peak"]}
                                                      if "frac_hbm_peak" in v_ else {}),
                                                   **({"hbm_walked_frac": v_["hbm_walked_frac"]}
-                                                     if "hbm_walked_frac" in v_ else {})} for k_, v_ in top}})
+                                                     if "hbm_walked_frac" in v_ else {})} for k_, v_ in top},
+                        **({"densification": r["densification"]} if r.get("densification") else {})})
         out["extra_workloads"] = ews
     if world > 1:
         out["config"]["balance_timing"] = a.balance_timing

@@ -127,7 +127,7 @@ int gsr_render_forward(int P, int width, int height, const int32_t *ranges, cons
     if (!ranges || !compute_locally || !bg || !out_color || !final_T || !n_contrib) return GSR_EINVAL;
     if (P > 0 && (!means2D || !conic_opacity || !rgb)) return GSR_EINVAL;
     return gsr_launch_composite_forward(P, width, height, ranges, point_list, means2D, conic_opacity, rgb,
-                                        compute_locally, bg, out_color, final_T, n_contrib, nullptr, 0, 0, 0,
+                                        compute_locally, bg, out_color, final_T, n_contrib, nullptr, 0, 0, 0, nullptr, 0,
                                         reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -146,7 +146,20 @@ int gsr_render_forward_seg(int P, int width, int height, const int32_t *ranges, 
     if (P > 0 && (!means2D || !conic_opacity || !rgb)) return GSR_EINVAL;
     return gsr_launch_composite_forward(P, width, height, ranges, point_list, means2D, conic_opacity, rgb,
                                         compute_locally, bg, out_color, final_T, n_contrib, seg_ws, seg_bytes, row_lo,
-                                        row_hi, reinterpret_cast<hipStream_t>(stream));
+                                        row_hi, nullptr, 0, reinterpret_cast<hipStream_t>(stream));
+}
+
+int gsr_render_forward_seg_z(int P, int width, int height, const int32_t *ranges, const uint32_t *point_list,
+                             const float *means2D, const float *conic_opacity, const float *rgb,
+                             const uint8_t *compute_locally, const float *bg, float *out_color, float *final_T,
+                             int32_t *n_contrib, void *seg_ws, size_t seg_bytes, int row_lo, int row_hi, void *zero_ptr,
+                             size_t zero_bytes, gsr_stream_t stream) {
+    if (P < 0 || width <= 0 || height <= 0) return GSR_EINVAL;
+    if (!ranges || !compute_locally || !bg || !out_color || !final_T || !n_contrib) return GSR_EINVAL;
+    if (P > 0 && (!means2D || !conic_opacity || !rgb)) return GSR_EINVAL;
+    return gsr_launch_composite_forward(P, width, height, ranges, point_list, means2D, conic_opacity, rgb,
+                                        compute_locally, bg, out_color, final_T, n_contrib, seg_ws, seg_bytes, row_lo,
+                                        row_hi, zero_ptr, zero_bytes, reinterpret_cast<hipStream_t>(stream));
 }
 
 int gsr_render_backward_seg(int P, int width, int height, const int32_t *ranges, const uint32_t *point_list,
@@ -162,7 +175,24 @@ int gsr_render_backward_seg(int P, int width, int height, const int32_t *ranges,
         return GSR_EINVAL;
     return gsr_launch_composite_backward(P, width, height, ranges, point_list, means2D, conic_opacity, rgb,
                                          compute_locally, bg, final_T, n_contrib, dL_dpixels, dL_record, out_color,
-                                         seg_ws, seg_bytes, row_lo, row_hi, reinterpret_cast<hipStream_t>(stream));
+                                         seg_ws, seg_bytes, row_lo, row_hi, 0, reinterpret_cast<hipStream_t>(stream));
+}
+
+int gsr_render_backward_seg_z(int P, int width, int height, const int32_t *ranges, const uint32_t *point_list,
+                              const float *means2D, const float *conic_opacity, const float *rgb,
+                              const uint8_t *compute_locally, const float *bg, const float *final_T,
+                              const int32_t *n_contrib, const float *dL_dpixels, float *dL_record,
+                              const float *out_color, void *seg_ws, size_t seg_bytes, int row_lo, int row_hi,
+                              int record_is_zero, gsr_stream_t stream) {
+    if (P < 0 || width <= 0 || height <= 0) return GSR_EINVAL;
+    if (P == 0) return 0;
+    if (!ranges || !compute_locally || !bg || !final_T || !n_contrib || !dL_dpixels || !means2D || !conic_opacity ||
+        !rgb || !dL_record)
+        return GSR_EINVAL;
+    return gsr_launch_composite_backward(P, width, height, ranges, point_list, means2D, conic_opacity, rgb,
+                                         compute_locally, bg, final_T, n_contrib, dL_dpixels, dL_record, out_color,
+                                         seg_ws, seg_bytes, row_lo, row_hi, record_is_zero ? 1 : 0,
+                                         reinterpret_cast<hipStream_t>(stream));
 }
 
 int gsr_render_backward(int P, int width, int height, const int32_t *ranges, const uint32_t *point_list,
@@ -176,7 +206,7 @@ int gsr_render_backward(int P, int width, int height, const int32_t *ranges, con
         return GSR_EINVAL;
     return gsr_launch_composite_backward(P, width, height, ranges, point_list, means2D, conic_opacity, rgb,
                                          compute_locally, bg, final_T, n_contrib, dL_dpixels, dL_record, nullptr,
-                                         nullptr, 0, 0, 0, reinterpret_cast<hipStream_t>(stream));
+                                         nullptr, 0, 0, 0, 0, reinterpret_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

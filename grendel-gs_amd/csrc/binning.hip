@@ -134,7 +134,12 @@ touch_count_kernel(int P, int gx, int gy, const float2 *__restrict__ means2D, co
                    const uint8_t *__restrict__ mask, RadixPlan plan, uint32_t *__restrict__ tt,
                    uint32_t *__restrict__ keys, uint32_t *__restrict__ vals, TileRect *__restrict__ rects,
                    uint32_t *__restrict__ ghist, uint32_t *__restrict__ tile_hist, int32_t *__restrict__ hull_out,
-                   int cull, unsigned long long *__restrict__ early, uint32_t *__restrict__ host_total, uint32_t seq) {
+                   int cull, unsigned long long *__restrict__ early, uint32_t *__restrict__ host_total, uint32_t seq,
+                   uint4 *__restrict__ zero16, size_t zero16_n) {
+    // (round 6) the control block of the tile sort that follows on this stream is cleared here instead of by a fill
+    // launch between the two steps (gsr_bin_speculative_async)
+    for (size_t i = (size_t)blockIdx.x * TC_THREADS + threadIdx.x; i < zero16_n; i += (size_t)gridDim.x * TC_THREADS)
+        zero16[i] = make_uint4(0u, 0u, 0u, 0u);
     __shared__ int s_lo, s_hi;
     __shared__ unsigned long long s_nsum[TC_THREADS / 64];
     unsigned long long nsum = 0;  // this thread's share of the pair count D = sum of tiles_touched
@@ -603,6 +608,8 @@ struct PrepCall {
     void *prep;
     hipStream_t stream;
     bool persistent;
+    void *zero_ptr;     // the control block of the tile sort launched behind this prepare step (16-byte aligned), or null
+    size_t zero_bytes;  // a multiple of 16
 };
 PrepCall g_prep_calls[64][TOTAL_SLOTS];
 
@@ -639,7 +646,8 @@ int prepare_lookback(const PrepCall &c, uint32_t *ticket) {
                        reinterpret_cast<const float4 *>(c.conic_opacity), c.compute_locally, plan, tt, kA, vA, rects,
                        reinterpret_cast<uint32_t *>(ctrl + L.C.ghist), tile_hist,
                        reinterpret_cast<int32_t *>(base + L.hull), tile_hist ? tile_cull_on(gx * gy) : 0,
-                       reinterpret_cast<unsigned long long *>(base + L.early), host_total, seq);
+                       reinterpret_cast<unsigned long long *>(base + L.early), host_total, seq,
+                       reinterpret_cast<uint4 *>(c.zero_ptr), c.zero_bytes / 16);
     int in_first = 1;
     rc = radix_sort_pairs(kA, vA, kB, vB, P, plan, ctrl, L.C, &in_first, stream, nullptr);
     if (rc) return rc;
@@ -711,6 +719,8 @@ int prepare_persistent(const PrepCall &c, uint32_t *ticket) {
     a.cull = a.tile_hist ? tile_cull_on(gx * gy) : 0;
     a.hull_out = reinterpret_cast<int32_t *>(base + L.hull);
     a.early = reinterpret_cast<unsigned long long *>(base + L.early);
+    a.zero16 = reinterpret_cast<uint4 *>(c.zero_ptr);
+    a.zero16_n = c.zero_bytes / 16;
     const int ngroups = (G + GB_FAN - 1) / GB_FAN;
     a.sync.leaf = reinterpret_cast<uint32_t *>(ctrl + PL.sync);
     a.sync.root = a.sync.leaf + (size_t)ngroups * GB_LEAF_STRIDE;
@@ -733,9 +743,21 @@ int prepare_persistent(const PrepCall &c, uint32_t *ticket) {
 }
 }  // namespace
 
+namespace {
+int prepare_async_impl(int P, int width, int height, const float *means2D, const float *depths, const int32_t *radii,
+                       const float *conic_opacity, const uint8_t *compute_locally, void *prep, size_t prep_bytes,
+                       uint32_t *ticket, gsr_stream_t stream_, void *zero_ptr, size_t zero_bytes);
+}
 extern "C" int gsr_bin_prepare_async(int P, int width, int height, const float *means2D, const float *depths,
                                      const int32_t *radii, const float *conic_opacity, const uint8_t *compute_locally,
                                      void *prep, size_t prep_bytes, uint32_t *ticket, gsr_stream_t stream_) {
+    return prepare_async_impl(P, width, height, means2D, depths, radii, conic_opacity, compute_locally, prep, prep_bytes,
+                              ticket, stream_, nullptr, 0);
+}
+namespace {
+int prepare_async_impl(int P, int width, int height, const float *means2D, const float *depths, const int32_t *radii,
+                       const float *conic_opacity, const uint8_t *compute_locally, void *prep, size_t prep_bytes,
+                       uint32_t *ticket, gsr_stream_t stream_, void *zero_ptr, size_t zero_bytes) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     if (P < 0 || width <= 0 || height <= 0 || !ticket) return GSR_EINVAL;
     *ticket = 0;  // 0: nothing was launched, the count is 0
@@ -745,7 +767,8 @@ extern "C" int gsr_bin_prepare_async(int P, int width, int height, const float *
     if (prep_bytes < prep_layout_full(P, width, height).total) return GSR_ENOSPACE;
     const int gx = (width + GSR_BLOCK_X - 1) / GSR_BLOCK_X, gy = (height + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y;
     if (gx > 0xFFFF || gy > 0xFFFF) return GSR_EINVAL;
-    PrepCall c{P, width, height, means2D, depths, radii, conic_opacity, compute_locally, prep, stream, true};
+    PrepCall c{P, width, height, means2D, depths, radii, conic_opacity, compute_locally, prep, stream, true,
+               zero_ptr, zero_bytes};
     {
         int dev0 = 0;
         GSR_HIP(hipGetDevice(&dev0));
@@ -760,9 +783,12 @@ extern "C" int gsr_bin_prepare_async(int P, int width, int height, const float *
     if (rc) return rc;
     int dev = 0;
     GSR_HIP(hipGetDevice(&dev));
+    c.zero_ptr = nullptr;  // (a repeat through gsr_bin_count_wait must not clear the control block of a sort in flight)
+    c.zero_bytes = 0;
     if (dev >= 0 && dev < 64) g_prep_calls[dev][*ticket % TOTAL_SLOTS] = c;
     return 0;
 }
+}  // namespace
 
 extern "C" int gsr_set_depth_tie_order(int mode) {
     if (mode != 0 && mode != 1) return GSR_EINVAL;
@@ -895,7 +921,7 @@ namespace {
 // `bounded`: D is a CAPACITY; the kernels read the pair count from the prep workspace (K4's total) and do nothing past it
 int bin_sort_impl(int P, int width, int height, const uint8_t *compute_locally, const void *prep, int64_t D,
                   void *scratch, size_t scratch_bytes, uint32_t *point_list, int32_t *ranges, hipStream_t stream,
-                  bool bounded) {
+                  bool bounded, bool ctrl_zeroed = false) {
     if (P < 0 || width <= 0 || height <= 0 || D < 0 || !ranges) return GSR_EINVAL;
     const int gx = (width + GSR_BLOCK_X - 1) / GSR_BLOCK_X, gy = (height + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y;
     if (D == 0 || P == 0 || !yx_path(gx, gy))  // (the (row, column) path clears the table inside its first kernel)
@@ -941,7 +967,7 @@ int bin_sort_impl(int P, int width, int height, const uint8_t *compute_locally, 
         const long long admit = want ? persist_admit(dev, stream) : -1;
         if (admit >= 0) {
             const PersistLayoutS PS = persist_layout_s(G);
-            GSR_HIP(hipMemsetAsync(ctrl, 0, PS.zero_bytes, stream));
+            if (!ctrl_zeroed) GSR_HIP(hipMemsetAsync(ctrl, 0, PS.zero_bytes, stream));
             SortPersistArgs a{};
             a.P = P; a.gx = gx; a.xbits = bits_for(gx); a.ybits = bits_for(gy);
             a.D = D; a.bounded = bounded ? 1 : 0;
@@ -970,7 +996,7 @@ int bin_sort_impl(int P, int width, int height, const uint8_t *compute_locally, 
             return 0;
         }
     }
-    GSR_HIP(hipMemsetAsync(ctrl, 0, S.C.total, stream));
+    if (!ctrl_zeroed) GSR_HIP(hipMemsetAsync(ctrl, 0, S.C.total, stream));
     if (yx_path(gx, gy)) {
         const int xbits = bits_for(gx), ybits = bits_for(gy);
         const uint32_t *thist = reinterpret_cast<const uint32_t *>(pbase + L.thist);
@@ -1036,12 +1062,30 @@ extern "C" int gsr_bin_speculative_async(int P, int width, int height, const flo
                                          int32_t *ranges, uint32_t *ticket, int *sorted, gsr_stream_t stream_) {
     if (!ticket || !sorted) return GSR_EINVAL;
     *sorted = 0;
-    int rc = gsr_bin_prepare_async(P, width, height, means2D, depths, radii, conic_opacity, compute_locally, prep,
-                                   prep_bytes, ticket, stream_);
+    // the tile sort's control block (either pipeline's: they share the space) is cleared by the prepare step's first
+    // kernel instead of by a fill launch between the two steps
+    void *zero_ptr = nullptr;
+    size_t zero_bytes = 0;
+    const bool spec = capacity > 0 && scratch && point_list && P > 0 && width > 0 && height > 0;
+    if (spec) {
+        const int gx = (width + GSR_BLOCK_X - 1) / GSR_BLOCK_X, gy = (height + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y;
+        if (yx_path(gx, gy) && capacity <= RADIX_MAX_N) {
+            const RadixPlan plan = radix_plan(0, tile_bits(gx * gy));
+            const SortLayout S = sort_layout(capacity, plan.passes < 2 ? 2 : plan.passes);
+            if (scratch_bytes >= S.total) {
+                const size_t zp = persist_layout_s(persist_grid_bound_s(capacity)).zero_bytes;
+                zero_ptr = reinterpret_cast<char *>(scratch) + S.ctrl;
+                zero_bytes = (((S.C.total > zp ? S.C.total : zp) + 15) / 16) * 16;
+                if (S.ctrl + zero_bytes > scratch_bytes || (S.ctrl & 15)) { zero_ptr = nullptr; zero_bytes = 0; }
+            }
+        }
+    }
+    int rc = prepare_async_impl(P, width, height, means2D, depths, radii, conic_opacity, compute_locally, prep, prep_bytes,
+                                ticket, stream_, zero_ptr, zero_bytes);
     if (rc) return rc;
     if (capacity > 0 && *ticket != 0 && scratch && point_list) {
-        rc = gsr_bin_sort_bounded(P, width, height, compute_locally, prep, capacity, scratch, scratch_bytes, point_list,
-                                  ranges, stream_);
+        rc = bin_sort_impl(P, width, height, compute_locally, prep, capacity, scratch, scratch_bytes, point_list, ranges,
+                           reinterpret_cast<hipStream_t>(stream_), true, zero_ptr != nullptr);
         if (rc) return rc;
         *sorted = 1;
     }

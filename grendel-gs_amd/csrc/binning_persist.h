@@ -557,6 +557,8 @@ struct PrepPersistArgs {
     int cull;             // exact tile culling (gsr_tile_mask); only with tile_hist (the (row, column) path)
     int32_t *hull_out;
     unsigned long long *early;  // { sum of tiles_touched, arrivals }: zero before the launch
+    uint4 *zero16;              // the control block of the tile sort that follows (cleared here), or null
+    size_t zero16_n;
     GridSync sync;
     uint32_t *cnt;  // [4][G][256]
     uint32_t *grp;  // [4][ngroups][256], zero before the launch
@@ -593,6 +595,8 @@ bin_prepare_persist_kernel(const PrepPersistArgs a) {
     uint32_t epoch = 0;
     GSR_TS(0);
     uint32_t key[PP_ITEMS], val[PP_ITEMS];
+    for (size_t i = (size_t)w * PP_THREADS + threadIdx.x; i < a.zero16_n; i += (size_t)G * PP_THREADS)
+        a.zero16[i] = make_uint4(0u, 0u, 0u, 0u);  // (the next kernel's control block: see touch_count_kernel)
 
     // ------------------------------------------------------------------ T: K3 (see touch_count_kernel)
     if (threadIdx.x <= RADIX_DIGITS) ex.dxy[0][threadIdx.x] = ex.dxy[1][threadIdx.x] = 0;

@@ -148,11 +148,11 @@ int gsr_launch_composite_forward(int P, int W, int H, const int32_t *ranges, con
                                  const float *means2D, const float *conic_opacity, const float *rgb,
                                  const uint8_t *compute_locally, const float *bg, float *out_color, float *final_T,
                                  int32_t *n_contrib, void *seg_ws, size_t seg_bytes, int row_lo, int row_hi,
-                                 hipStream_t stream);
+                                 void *zero_ptr, size_t zero_bytes, hipStream_t stream);
 size_t gsr_composite_seg_bytes(int W, int H);
 int gsr_launch_composite_backward(int P, int W, int H, const int32_t *ranges, const uint32_t *point_list,
                                   const float *means2D, const float *conic_opacity, const float *rgb,
                                   const uint8_t *compute_locally, const float *bg, const float *final_T,
                                   const int32_t *n_contrib, const float *dL_dpixels, float *dL_record,
                                   const float *out_color, void *seg_ws, size_t seg_bytes, int row_lo, int row_hi,
-                                  hipStream_t stream);
+                                  int record_is_zero, hipStream_t stream);

@@ -252,8 +252,14 @@ composite_forward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
                          const float4 *__restrict__ conic_opacity, const float *__restrict__ rgb,
                          const uint8_t *__restrict__ compute_locally, const float *__restrict__ bg,
                          float *__restrict__ out_color, float *__restrict__ final_T, int32_t *__restrict__ n_contrib,
-                         const SegWs seg, int band_first, int band_tiles) {
+                         const SegWs seg, int band_first, int band_tiles, uint4 *__restrict__ zero16,
+                         size_t zero16_n) {
     const size_t HW = (size_t)H * W;
+    // Round 6: a buffer the BACKWARD needs zeroed (K10's [P,9] gradient record, 36 MB per 10^6 Gaussians) is cleared
+    // here, by every workgroup's share of 16-byte stores before it starts on its tile: this kernel is bound by VALU issue
+    // and leaves the memory pipes idle, the fill launch it replaces ran at the head of every backward.
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < zero16_n; i += (size_t)gridDim.x * 256)
+        zero16[i] = make_uint4(0u, 0u, 0u, 0u);
     int tile;
     if (BAND) {
         // The caller knows the rows of its band on the HOST (Grendel's strategies do): the grid covers the band's tiles
@@ -800,8 +806,13 @@ int gsr_launch_composite_forward(int P, int W, int H, const int32_t *ranges, con
                                  const float *means2D, const float *conic_opacity, const float *rgb,
                                  const uint8_t *compute_locally, const float *bg, float *out_color, float *final_T,
                                  int32_t *n_contrib, void *seg_ws, size_t seg_bytes, int row_lo, int row_hi,
-                                 hipStream_t stream) {
+                                 void *zero_ptr, size_t zero_bytes, hipStream_t stream) {
     (void)P;
+    if (zero_bytes && (!zero_ptr || ((uintptr_t)zero_ptr & 15) || (zero_bytes & 3))) return GSR_EINVAL;
+    // the 16-byte body goes through the kernel, a tail of < 16 bytes (P odd: 36 P is a multiple of 4 only) through a fill
+    const size_t zero16_n = zero_bytes / 16;
+    if (zero_bytes & 15)
+        GSR_HIP(hipMemsetAsync(reinterpret_cast<char *>(zero_ptr) + zero16_n * 16, 0, zero_bytes & 15, stream));
     const int gx = (W + GSR_BLOCK_X - 1) / GSR_BLOCK_X, gy = (H + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y;
     const bool band = row_lo >= 0 && row_lo < row_hi && row_hi <= gy && !(row_lo == 0 && row_hi == gy);
     const int band_first = band ? row_lo * gx : 0, band_tiles = band ? (row_hi - row_lo) * gx : 0;
@@ -812,7 +823,7 @@ int gsr_launch_composite_forward(int P, int W, int H, const int32_t *ranges, con
         hipLaunchKernelGGL(kern, dim3(band ? band_tiles : gx * gy), dim3(256), 0, stream, W, H, gx,
                            reinterpret_cast<const int2 *>(ranges), point_list, reinterpret_cast<const float2 *>(means2D),
                            reinterpret_cast<const float4 *>(conic_opacity), rgb, compute_locally, bg, out_color, final_T,
-                           n_contrib, seg, band_first, band_tiles);
+                           n_contrib, seg, band_first, band_tiles, reinterpret_cast<uint4 *>(zero_ptr), zero16_n);
     };
     if (seg_ws && band) launch(composite_forward_kernel<true, true>);
     else if (seg_ws) launch(composite_forward_kernel<true, false>);
@@ -827,8 +838,9 @@ int gsr_launch_composite_backward(int P, int W, int H, const int32_t *ranges, co
                                   const uint8_t *compute_locally, const float *bg, const float *final_T,
                                   const int32_t *n_contrib, const float *dL_dpixels, float *dL_record,
                                   const float *out_color, void *seg_ws, size_t seg_bytes, int row_lo, int row_hi,
-                                  hipStream_t stream) {
-    GSR_HIP(hipMemsetAsync(dL_record, 0, sizeof(float) * 9 * (size_t)P, stream));
+                                  int record_is_zero, hipStream_t stream) {
+    // (record_is_zero: the forward launch cleared it, gsr_render_forward_seg_z)
+    if (!record_is_zero) GSR_HIP(hipMemsetAsync(dL_record, 0, sizeof(float) * 9 * (size_t)P, stream));
     if (P == 0) return 0;
     const int gx = (W + GSR_BLOCK_X - 1) / GSR_BLOCK_X, gy = (H + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y;
     const bool band = row_lo >= 0 && row_lo < row_hi && row_hi <= gy && !(row_lo == 0 && row_hi == gy);

@@ -9,6 +9,8 @@
 // off so that integer outputs (radii, tile rects) are reproducible against a plain C evaluation.
 #include "common.h"
 
+#include <cstdlib>
+
 // no FMA contraction in this file: see the header comment (memory-bound kernels, no cost)
 #pragma clang fp contract(off)
 
@@ -1756,7 +1758,8 @@ extern "C" int gsr_preprocess_backward_adam_raw_batched_dyn(
     if (al & 15) return GSR_EINVAL;  // 16-byte accesses on the moments and the _features_rest block
     ad.grad_scale = grad_scale;
     const dim3 grid(gsr_div_up(P, K11_BLOCK)), block(K11_BLOCK);
-    if (B == 1 && tanfov0) {  // one camera: the leaner kernel without accumulators (160 registers instead of 270)
+    static const bool one_cam_batched = [] { const char *e = getenv("GSR_K11_ONE_BATCHED"); return e && *e == '1'; }();
+    if (B == 1 && tanfov0 && !one_cam_batched) {  // one camera: the leaner kernel without accumulators
         GSR_DISPATCH_DEG(sh_degree,
                          hipLaunchKernelGGL(preprocess_backward_adam_kernel<DEG>, grid, block, 0,
                                             reinterpret_cast<hipStream_t>(stream), P, xyz, scaling, scale_modifier,

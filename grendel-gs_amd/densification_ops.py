@@ -276,10 +276,28 @@ def redistribute_gaussians(self, destination=None, group=None):
 # ----------------------------------------------------------------------- statistics / opacity reset
 def add_densification_stats(self, viewspace_point_tensor, update_filter):
     """scene/gaussian_model.py:1046-1052: accumulate |d loss / d means2D| (the op's NDC-scaled gradient) of the
-    Gaussians visible in this view"""
-    self.xyz_gradient_accum[update_filter] += torch.norm(viewspace_point_tensor.grad[update_filter, :2], dim=-1,
-                                                         keepdim=True)
-    self.denom[update_filter] += 1
+    Gaussians visible in this view.  Same values as the reference's `x[filter] += norm(grad[filter, :2])` for ANY filter,
+    without its boolean indexing (a `nonzero` host sync + gather + scatter per statement): the rows outside the filter
+    receive + 0."""
+    f = update_filter.view(-1, 1)
+    n = torch.linalg.vector_norm(viewspace_point_tensor.grad[:, :2], dim=-1, keepdim=True)
+    self.xyz_gradient_accum += torch.where(f, n, torch.zeros((), dtype=n.dtype, device=n.device))
+    self.denom += f
+
+
+def update_densification_stats(self, viewspace_point_tensor, radii):
+    """What densification.py:13-25 of the reference does after every backward of the densification phase -- for the
+    visible Gaussians (radii > 0): max_radii2D = max(max_radii2D, radii), then add_densification_stats -- WITHOUT the
+    boolean indexing (two `nonzero` host syncs and six gather / scatter kernels per camera and iteration: measured 0.54 ms
+    of a 1.18 ms step at 10^6 Gaussians).  The mask is implied by the data: an invisible Gaussian has radius 0 (the maximum
+    leaves max_radii2D alone, radii are never negative) and a means2D gradient of exactly 0 (K10 never touches its row
+    of the zero-initialised record; the mirror exchange scatter-adds into zeros), so the unmasked updates change the
+    same rows by the same amounts, bit for bit; `denom` counts the rows with radius > 0."""
+    r = radii if radii.dtype == torch.float32 else radii.float()
+    torch.maximum(self.max_radii2D, r.view_as(self.max_radii2D), out=self.max_radii2D)
+    g = viewspace_point_tensor.grad
+    self.xyz_gradient_accum += torch.linalg.vector_norm(g[:, :2], dim=-1, keepdim=True)
+    self.denom += (radii > 0).view_as(self.denom)
 
 
 def replace_tensor_to_optimizer(self, tensor, name):
@@ -314,6 +332,7 @@ def install(cls):
     """graft level B3: make these functions the methods of the reference's GaussianModel class"""
     for fn in (prune_points, cat_tensors_to_optimizer, densification_postfix, densify_and_clone, densify_and_split,
                densify_and_prune, need_redistribute_gaussians, redistribute_gaussians, add_densification_stats,
+               update_densification_stats,
                replace_tensor_to_optimizer, reset_opacity):
         setattr(cls, fn.__name__, fn)
     return cls

@@ -657,6 +657,7 @@ def release_workspaces():
 _SPECULATIVE_SORT = [os.environ.get("GSR_SPECULATIVE_SORT", "1") != "0"]  # env: A/B measurements only
 _SEGMENTS = [{"0": False, "always": "always"}.get(os.environ.get("GSR_SEGMENTS", "1"), True)]  # env: A/B only
 _BAND_GRID = [os.environ.get("GSR_BAND_GRID", "1") != "0"]  # env: A/B measurements only
+_ZERO_IN_FORWARD = [os.environ.get("GSR_ZERO_IN_FORWARD", "1") != "0"]  # env: A/B measurements only
 
 
 def set_list_segments(on):
@@ -960,14 +961,22 @@ class _RenderGaussians(torch.autograd.Function):
                 seg_bytes = int(lib.gsr_render_seg_bytes(W, H))
                 seg_ws = torch.empty((seg_bytes,), dtype=torch.uint8, device=dev)
             lists = [point_list]  # (a list: a late pair count may replace the point_list, see settle below)
+            # K10's [P,9] gradient record (means2D 0:2, rgb 2:5, conic_opacity 5:9) is allocated HERE when a backward can
+            # follow, and cleared by K8's own workgroups (include/gsraster.h: gsr_render_forward_seg_z) instead of by a
+            # 36 MB fill launch at the head of the backward
+            record = None
+            if any(ctx.needs_input_grad[:3]) and P > 0 and _ZERO_IN_FORWARD[0]:
+                record = torch.empty((P, 9), dtype=torch.float32, device=dev)
+            ctx.record = record
 
             def launch_k8(meta_D):
                 with kernel_timer.range("composite_forward", P=P, D=meta_D, **ctx.px_meta) as k8t, \
                         zhx_range(cuda_args, "70 render time"):
-                    check(lib.gsr_render_forward_seg(P, W, H, _ptr(ranges), _ptr(lists[0]), _ptr(means2D),
-                                                     _ptr(conic_opacity), _ptr(rgb), _ptr(mask), _ptr(bg), _ptr(out),
-                                                     _ptr(final_T), _ptr(n_contrib), _ptr(seg_ws), seg_bytes, row_lo,
-                                                     row_hi, _stream()), "gsr_render_forward_seg")
+                    check(lib.gsr_render_forward_seg_z(P, W, H, _ptr(ranges), _ptr(lists[0]), _ptr(means2D),
+                                                       _ptr(conic_opacity), _ptr(rgb), _ptr(mask), _ptr(bg), _ptr(out),
+                                                       _ptr(final_T), _ptr(n_contrib), _ptr(seg_ws), seg_bytes, row_lo,
+                                                       row_hi, _ptr(record), 36 * P if record is not None else 0,
+                                                       _stream()), "gsr_render_forward_seg_z")
                 return k8t
 
             k8t = launch_k8(D)
@@ -1025,7 +1034,12 @@ class _RenderGaussians(torch.autograd.Function):
         g_out = g_out.float().contiguous()
         # ONE [P,9] record (means2D 0:2, rgb 2:5, conic_opacity 5:9): K10 flushes a (tile, Gaussian) pair's nine sums
         # from nine adjacent lanes into one row; K11 and the exchange read the record through its row stride
-        record = torch.empty((P, 9), dtype=torch.float32, device=dev)
+        # (cleared by the forward's composite kernel when it was allocated there; a second backward over the same
+        # forward -- retain_graph, gradcheck -- takes a fresh one and the fill)
+        record, ctx.record = ctx.record, None
+        record_is_zero = record is not None
+        if record is None:
+            record = torch.empty((P, 9), dtype=torch.float32, device=dev)
         d_means2D, d_rgb, d_conic_opacity = record[:, 0:2], record[:, 2:5], record[:, 5:9]
         timing = ctx.timing
         with _on(dev):
@@ -1036,11 +1050,11 @@ class _RenderGaussians(torch.autograd.Function):
             with kernel_timer.range("composite_backward", P=P, D=ctx.num_rendered, **ctx.px_meta), \
                     zhx_range(ctx.cuda_args, "b10 render time"):
                 seg_ws, seg_bytes, row_lo, row_hi = ctx.seg
-                check(lib.gsr_render_backward_seg(P, W, H, _ptr(ranges), _ptr(point_list), _ptr(means2D),
-                                                  _ptr(conic_opacity), _ptr(rgb), _ptr(mask), _ptr(bg), _ptr(final_T),
-                                                  _ptr(n_contrib), _ptr(g_out), _ptr(record), _ptr(out_img),
-                                                  _ptr(seg_ws), seg_bytes, row_lo, row_hi, _stream()),
-                      "gsr_render_backward_seg")
+                check(lib.gsr_render_backward_seg_z(P, W, H, _ptr(ranges), _ptr(point_list), _ptr(means2D),
+                                                    _ptr(conic_opacity), _ptr(rgb), _ptr(mask), _ptr(bg), _ptr(final_T),
+                                                    _ptr(n_contrib), _ptr(g_out), _ptr(record), _ptr(out_img),
+                                                    _ptr(seg_ws), seg_bytes, row_lo, row_hi, 1 if record_is_zero else 0,
+                                                    _stream()), "gsr_render_backward_seg_z")
             if timing != "off":
                 ev1.record()
         stats = ctx.cuda_args.get("stats_collector") if isinstance(ctx.cuda_args, dict) else None

@@ -98,6 +98,11 @@ SIGNATURES = {
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int,
                                        c_void_p]),
     "gsr_render_backward_seg": (c_int, [c_int, c_int, c_int] + [c_void_p] * 13 + [c_size_t, c_int, c_int, c_void_p]),
+    "gsr_render_forward_seg_z": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int,
+                                         c_int, c_void_p, c_size_t, c_void_p]),
+    "gsr_render_backward_seg_z": (c_int, [c_int, c_int, c_int] + [c_void_p] * 13 + [c_size_t, c_int, c_int, c_int,
+                                                                                   c_void_p]),
     "gsr_composite_walked": (c_int, [ctypes.POINTER(ctypes.c_ulonglong), c_int]),
     "gsr_publish_flag": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_uint32, c_void_p]),
     "gsr_exchange_check": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, ctypes.c_uint64, c_int, c_void_p,

@@ -870,17 +870,30 @@ def _settle(late):
     tile sort and composite kernel in place (diff_gaussian_rasterization.PendingPairs)"""
     for settle in late:
         settle()
+    del late[:]
 
 
-def render_final(batched_screenspace_pkg, batched_strategies, tile_size=16):
+settle = _settle  # public name: the counterpart of render_final(..., late=[...])
+
+
+def render_final(batched_screenspace_pkg, batched_strategies, tile_size=16, late=None):
     """-> (images, masks) per camera: a [3,H,W] image (zero outside this rank's row band), a scalar
     stand-in when fewer than 10 Gaussians arrived (keeps the autograd graph and the exchange's
     backward alive, gaussian_renderer/__init__.py:1260-1269), or None when this rank renders no part
     of the camera.  A speculative exchange (capacity slabs) is verified HERE, after the renders have polled their pair
     counts -- the asynchronous copy of the exchange's counts is then long complete, so the check waits for nothing --
-    and, had a slab overflowed, exchange and render are repeated with exact sizes."""
+    and, had a slab overflowed, exchange and render are repeated with exact sizes.
+    `late` (extension of this build, forward-only rendering on one rank): a list that receives the cameras' unsettled
+    pair counts instead of having them settled here -- a render loop then enqueues view i + 1 before it calls
+    gaussian_renderer.settle(late) for view i, whose image is FINAL only after that call (a view whose pair count
+    outgrew the kept sort scratch is drawn again in place by it).  The reference's render driver consumes every image
+    before it starts the next (render.py:87-95): leave `late` alone to get exactly that."""
     pkg = batched_screenspace_pkg
-    images, masks, late = _render_cameras(pkg, batched_strategies)
+    images, masks, mine = _render_cameras(pkg, batched_strategies)
+    if late is not None and pkg.get("_exchange_pending") is None:
+        late.extend(mine)
+        return images, masks
+    late = mine
     _settle(late)
     verify = pkg.get("_exchange_pending")
     if verify is not None and not verify():

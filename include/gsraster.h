@@ -274,6 +274,23 @@ int gsr_render_backward_seg(int P, int width, int height, const int32_t *ranges,
                             const int32_t *n_contrib, const float *dL_dpixels, float *dL_record,
                             const float *out_color, void *seg_ws, size_t seg_bytes, int row_lo, int row_hi,
                             gsr_stream_t stream);
+/* The same pair with the backward's fill moved into the forward (ABI 12).  K10 adds into the [P,9] record with atomics,
+ * so the record starts at zero: gsr_render_backward[_seg] clears it with a fill launch at the head of every backward
+ * (36 MB per 10^6 Gaussians).  gsr_render_forward_seg_z additionally clears [zero_ptr, zero_ptr + zero_bytes) -- 16-byte
+ * aligned, a multiple of 4 bytes; the caller passes the record it will hand to the backward -- from the composite
+ * kernel's own workgroups (the kernel is bound by VALU issue, its memory pipes are idle), and
+ * gsr_render_backward_seg_z(record_is_zero = 1) skips the fill.  Nothing else may write the record in between. */
+int gsr_render_forward_seg_z(int P, int width, int height, const int32_t *ranges, const uint32_t *point_list,
+                             const float *means2D, const float *conic_opacity, const float *rgb,
+                             const uint8_t *compute_locally, const float *bg, float *out_color, float *final_T,
+                             int32_t *n_contrib, void *seg_ws, size_t seg_bytes, int row_lo, int row_hi, void *zero_ptr,
+                             size_t zero_bytes, gsr_stream_t stream);
+int gsr_render_backward_seg_z(int P, int width, int height, const int32_t *ranges, const uint32_t *point_list,
+                              const float *means2D, const float *conic_opacity, const float *rgb,
+                              const uint8_t *compute_locally, const float *bg, const float *final_T,
+                              const int32_t *n_contrib, const float *dL_dpixels, float *dL_record, const float *out_color,
+                              void *seg_ws, size_t seg_bytes, int row_lo, int row_hi, int record_is_zero,
+                              gsr_stream_t stream);
 /* Measurement aid (bench.py's roofline leg; the reference has nothing to bind here): list entries the composite kernels
  * WALKED since the last reset, summed over launches -- out2[0] K8, out2[1] K10; per tile the entries its longest-walking
  * quadrant goes through (K8: up to the chunk in which the last pixel saturates; K10: the largest n_contrib of the

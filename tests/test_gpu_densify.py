@@ -192,6 +192,44 @@ def test_training_with_densification_end_to_end(device):
     assert sum(losses[-6:]) < sum(losses[:6]), (losses[:6], losses[-6:])  # still improving after two re-sizings
 
 
+def test_densification_statistics_without_boolean_indexing(device):
+    """add_densification_stats / update_densification_stats (round 6: no `nonzero` host syncs in the per-iteration
+    statistics) against the reference's statements with boolean indexing (densification.py:13-25,
+    scene/gaussian_model.py:1046-1052), bit for bit, accumulated over three views"""
+    n = 20011
+    g = torch.Generator().manual_seed(4)
+
+    class M:
+        pass
+
+    a, b, c = M(), M(), M()
+    for m in (a, b, c):
+        m.xyz_gradient_accum = torch.zeros((n, 1), device=device)
+        m.denom = torch.zeros((n, 1), device=device)
+        m.max_radii2D = torch.zeros((n,), device=device)
+    for view in range(3):
+        radii = torch.randint(0, 40, (n,), generator=g).to(torch.int32)
+        radii[torch.rand(n, generator=g) < 0.3] = 0
+        radii = radii.to(device)
+        vis = radii > 0
+        rec = torch.randn((n, 9), generator=g).to(device)
+        rec[~vis] = 0.0  # K10 never touches the row of an invisible Gaussian
+        vp = M()
+        vp.grad = rec[:, 0:2]  # a strided view of the [P,9] record, like the op's means2D gradient
+        # the reference's statements
+        a.max_radii2D[vis] = torch.max(a.max_radii2D[vis], radii[vis].float())
+        a.xyz_gradient_accum[vis] += torch.norm(vp.grad[vis, :2], dim=-1, keepdim=True)
+        a.denom[vis] += 1
+        # this build: the method with the reference's signature, and the fused form the loop uses
+        b.max_radii2D = torch.maximum(b.max_radii2D, radii.float())
+        D.add_densification_stats(b, vp, vis)
+        D.update_densification_stats(c, vp, radii)
+    for m in (b, c):
+        assert torch.equal(m.max_radii2D, a.max_radii2D)
+        assert torch.equal(m.xyz_gradient_accum, a.xyz_gradient_accum)
+        assert torch.equal(m.denom, a.denom)
+
+
 def test_reset_opacity_matches_reference_rule(device):
     m = _model(device, n=5000)
     before = m.get_opacity.detach().clone()

@@ -48,11 +48,17 @@ def worker(rank, world, port, profile, gaussians, size):
         bench.main()
         pr.disable()
         s = io.StringIO()
-        pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(30)
-        print(s.getvalue()[:7000], flush=True)
+        st = pstats.Stats(pr, stream=s)
+        st.sort_stats("tottime").print_stats(30)
+        # what the iteration itself costs: this package's functions by cumulative time, and who calls the tensor methods
+        # that may wait for the device
+        st.sort_stats("cumtime").print_stats(r"grendel-gs_amd|bench\.py", 45)
+        st.print_callers(r"method 'to' of|method 'item' of|method 'cpu' of|method 'tolist' of|synchronize|method 'copy_'")
+        print(s.getvalue()[:24000], flush=True)
     else:
         bench.main()
-    dist.destroy_process_group()
+    if dist.is_initialized():
+        dist.destroy_process_group()
 
 
 def main():
