@@ -33,6 +33,10 @@ from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianR
 
 import diff_gaussian_rasterization as _dgr
 
+import contextlib
+
+_NULL = contextlib.nullcontext()
+
 
 def _keep_grad_view(t):
     """What the reference's `means2D.retain_grad()` (gaussian_renderer/__init__.py:953) is there for -- densification
@@ -174,7 +178,8 @@ def all_to_all_communication_final(batched_rasterizers, batched_screenspace_para
 #               reach the host before the all-to-all is launched (no `.cpu()` between K1 and the render)
 #   group     : ONE exchange for the whole batch when every rank renders (a band of) at most one of its cameras
 _EXCHANGE_OPTIONS = {"overlap": True, "speculate": True, "forced": False,
-                     "group": os.environ.get("GSR_EXCHANGE_GROUP", "1") != "0"}  # (env: A/B measurements only)
+                     "group": os.environ.get("GSR_EXCHANGE_GROUP", "1") != "0",  # (env: A/B measurements only)
+                     "camera_streams": int(os.environ.get("GSR_CAMERA_STREAMS", "1") or 1)}
 _SIDE_STREAMS = {}
 _BANDS_CACHE = {}
 _PLANNERS = {}
@@ -186,6 +191,15 @@ def set_exchange_overlap(enabled):
     runs beside camera k-1's K3-K8 in the forward and beside camera k+1's K10 in the backward (north_star); off: one
     exchange for the whole batch on the current stream"""
     _EXCHANGE_OPTIONS["overlap"] = bool(enabled)
+
+
+def set_camera_streams(n):
+    """n = 2: the cameras a rank renders in one batch (bsz > 1) alternate between two side HIP streams, so that camera
+    k + 1's K3-K7 (latency chains) run beside camera k's K8 / loss kernels (VALU-bound) in the forward and the K10s of
+    two cameras beside each other in the backward (autograd runs a node's backward on its forward's stream); images
+    and gradients are those of the one-stream order (the kernels and their inputs are the same).  1 (default): one
+    stream, the reference's order (gaussian_renderer/__init__.py:1217-1291 renders its cameras one after the other)."""
+    _EXCHANGE_OPTIONS["camera_streams"] = 2 if int(n) >= 2 else 1
 
 
 def set_exchange_grouping(enabled):
@@ -825,6 +839,16 @@ def _render_cameras(pkg, batched_strategies):
     reads num_rendered back at the same place)."""
     timers = utils.get_timers()
     images, masks, late = [], [], []
+    mine = [k for k, st in enumerate(batched_strategies) if utils.GLOBAL_RANK in st.gpu_ids]
+    dev0 = pkg["batched_means2D_redistributed"][mine[0]].device if mine else None
+    two = (_EXCHANGE_OPTIONS["camera_streams"] > 1 and len(mine) > 1 and dev0 is not None and dev0.type == "cuda"
+           and _dgr.capturing() is None)
+    if two:
+        main = torch.cuda.current_stream(dev0)
+        sides = [_side_stream(dev0, "camera0"), _side_stream(dev0, "camera1")]
+        for s_ in sides:
+            s_.wait_stream(main)  # K1's outputs (and the exchange's, whose events are waited for below)
+    turn = 0
     for k, strategy in enumerate(batched_strategies):
         if utils.GLOBAL_RANK not in strategy.gpu_ids:
             images.append(None)
@@ -833,35 +857,42 @@ def _render_cameras(pkg, batched_strategies):
         compute_locally = strategy.get_compute_locally()
         extended = strategy.get_extended_compute_locally()
         cuda_args = pkg["batched_cuda_args"][k]
-        ev = pkg.get("_exchange_events", None)
-        if ev is not None and ev[k] is not None:
-            torch.cuda.current_stream().wait_event(ev[k])  # camera k's exchange ran on the side stream
-        means2D = pkg["batched_means2D_redistributed"][k]
-        rgb = pkg["batched_rgb_redistributed"][k]
-        conic_opacity = pkg["batched_conic_opacity_redistributed"][k]
-        if timers is not None:
-            timers.start("forward_render_gaussians")
-        if means2D.shape[0] < 10:
-            image = means2D.sum() + conic_opacity.sum() + rgb.sum()
-            if cuda_args.get("_exchange_token") is not None:
-                image = image + 0.0 * cuda_args["_exchange_token"].sum()
-            st = cuda_args["stats_collector"]
-            st["forward_render_time"] = st["backward_render_time"] = st["forward_loss_time"] = 0.0
-        else:
-            rows_of = getattr(strategy, "_my_rows", None)  # host-known tile rows of this rank's band (the mask's rows)
-            cuda_args["_gsr_band"] = rows_of() if rows_of is not None else None
-            cuda_args["_gsr_pending"] = late
-            try:
-                image, _, _, _ = pkg["batched_rasterizers"][k].render_gaussians(
-                    means2D=means2D, conic_opacity=conic_opacity, rgb=rgb,
-                    depths=pkg["batched_depths_redistributed"][k], radii=pkg["batched_radii_redistributed"][k],
-                    compute_locally=compute_locally, extended_compute_locally=extended, cuda_args=cuda_args)
-            finally:
-                cuda_args.pop("_gsr_pending", None)
-        if timers is not None:
-            timers.stop("forward_render_gaussians")
+        with (torch.cuda.stream(sides[turn & 1]) if two else _NULL):
+            turn += 1
+            ev = pkg.get("_exchange_events", None)
+            if ev is not None and ev[k] is not None:
+                torch.cuda.current_stream().wait_event(ev[k])  # camera k's exchange ran on the side stream
+            means2D = pkg["batched_means2D_redistributed"][k]
+            rgb = pkg["batched_rgb_redistributed"][k]
+            conic_opacity = pkg["batched_conic_opacity_redistributed"][k]
+            if timers is not None:
+                timers.start("forward_render_gaussians")
+            if means2D.shape[0] < 10:
+                image = means2D.sum() + conic_opacity.sum() + rgb.sum()
+                if cuda_args.get("_exchange_token") is not None:
+                    image = image + 0.0 * cuda_args["_exchange_token"].sum()
+                st = cuda_args["stats_collector"]
+                st["forward_render_time"] = st["backward_render_time"] = st["forward_loss_time"] = 0.0
+            else:
+                rows_of = getattr(strategy, "_my_rows", None)  # host-known tile rows of this rank's band (the mask's rows)
+                cuda_args["_gsr_band"] = rows_of() if rows_of is not None else None
+                cuda_args["_gsr_pending"] = late
+                try:
+                    image, _, _, _ = pkg["batched_rasterizers"][k].render_gaussians(
+                        means2D=means2D, conic_opacity=conic_opacity, rgb=rgb,
+                        depths=pkg["batched_depths_redistributed"][k], radii=pkg["batched_radii_redistributed"][k],
+                        compute_locally=compute_locally, extended_compute_locally=extended, cuda_args=cuda_args)
+                finally:
+                    cuda_args.pop("_gsr_pending", None)
+            if two:
+                image.record_stream(main)  # (allocated on the side stream, consumed by the loss on the caller's)
+            if timers is not None:
+                timers.stop("forward_render_gaussians")
         images.append(image)
         masks.append(compute_locally)
+    if two:
+        for s_ in sides:
+            main.wait_stream(s_)
     return images, masks, late
 
 
