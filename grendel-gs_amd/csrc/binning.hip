@@ -38,16 +38,22 @@
 #define GSR_EMIT_DECODE_BATCH 2
 #endif
 #include "binning_persist.h"
+#include "binning_rows.h"
 
 namespace {
 
 // ------------------------------------------------------------ K4: offsets = exclusive scan of tt[ids[.]]
 // Single pass with decoupled look-back (wave 0 inspects 64 predecessors per round).  out[n] = total.
 __global__ void __launch_bounds__(SCAN_THREADS)
-scan_gather_lookback_kernel(const uint32_t *__restrict__ src, const uint32_t *__restrict__ idx,
-                            uint32_t *__restrict__ out, long long n, unsigned long long *__restrict__ state,
-                            uint32_t *__restrict__ ticket, int nb, uint32_t *__restrict__ host_total,
-                            uint32_t seq) {
+scan_gather_lookback_kernel(const uint32_t *__restrict__ src, const uint32_t *__restrict__ src2,
+                            const uint32_t *__restrict__ idx, uint32_t *__restrict__ out, uint32_t *__restrict__ out2,
+                            long long n, unsigned long long *__restrict__ state, uint32_t *__restrict__ ticket, int nb,
+                            uint32_t *__restrict__ host_total, uint32_t seq,
+                            const unsigned long long *__restrict__ early) {
+    // Two scans in one sweep (round 6): out = exclusive scan of src[idx[.]] (pairs per Gaussian -> the offsets of the
+    // Gaussian-major emission) and out2 = exclusive scan of src2[idx[.]] (rows of the Gaussian's rect -> its row segments,
+    // binning_rows.h).  Both running sums stay below 2^31 (RADIX_MAX_N) and share the 62 value bits of the look-back
+    // word: low 31 bits pairs, high 31 bits segments.
     __shared__ uint32_t smem[4];
     __shared__ uint32_t s_bid;
     __shared__ unsigned long long s_excl;
@@ -57,17 +63,22 @@ scan_gather_lookback_kernel(const uint32_t *__restrict__ src, const uint32_t *__
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // each thread owns SCAN_ITEMS CONSECUTIVE elements so that one workgroup scan suffices
     const long long base = (long long)bid * SCAN_TILE + (long long)threadIdx.x * SCAN_ITEMS;
-    uint32_t v[SCAN_ITEMS];
-    uint32_t s = 0;
+    uint32_t v[SCAN_ITEMS], v2[SCAN_ITEMS];
+    uint32_t s = 0, s2 = 0;
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; k++) {
-        v[k] = (base + k < n) ? src[idx[base + k]] : 0u;
+        const uint32_t id = (base + k < n) ? idx[base + k] : 0u;
+        v[k] = (base + k < n) ? src[id] : 0u;
+        v2[k] = (base + k < n) ? src2[id] : 0u;
         s += v[k];
+        s2 += v2[k];
     }
-    uint32_t tot;
+    uint32_t tot, tot2;
     const uint32_t local = block_exclusive_scan(s, smem, &tot);
+    const uint32_t local2 = block_exclusive_scan(s2, smem, &tot2);
+    const unsigned long long tot64 = (unsigned long long)tot | ((unsigned long long)tot2 << 31);
     if (wave == 0) {
-        if (lane == 0) st_agent64(&state[bid], (unsigned long long)tot | (bid == 0 ? LB64_PRE : LB64_AGG));
+        if (lane == 0) st_agent64(&state[bid], tot64 | (bid == 0 ? LB64_PRE : LB64_AGG));
         unsigned long long excl = 0;
         if (bid > 0) {
             long long top = (long long)bid - 1;
@@ -93,25 +104,32 @@ scan_gather_lookback_kernel(const uint32_t *__restrict__ src, const uint32_t *__
             }
         }
         if (lane == 0) {
-            if (bid > 0) st_agent64(&state[bid], (excl + tot) | LB64_PRE);
+            if (bid > 0) st_agent64(&state[bid], ((excl + tot64) & LB64_VAL) | LB64_PRE);
             s_excl = excl;
             if ((int)bid == nb - 1) {
-                out[n] = (uint32_t)(excl + tot);
-                // (round 6: the host gets the count from K3 -- publish_pair_count -- ~100 us earlier; a caller that still
-                // hands the pinned words to this kernel gets the value then the call's sequence tag, as before)
+                // (the pair count on the device comes from K3's clean 64-bit sum when given: the packed low half would
+                // wrap at 2^31 pairs, which the callers must see as "too many"; the host gets it from K3 as well)
+                const unsigned long long dsum = early ? *early : ((excl + tot64) & 0x7FFFFFFFull);
+                out[n] = clamp_pair_count(dsum);
+                out2[n] = (uint32_t)((excl + tot64) >> 31) & 0x7FFFFFFFu;
                 if (host_total) {
-                    __hip_atomic_store(host_total, (uint32_t)(excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(host_total, clamp_pair_count(dsum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     __hip_atomic_store(host_total + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
                 }
             }
         }
     }
     __syncthreads();
-    uint32_t run = (uint32_t)s_excl + local;
+    uint32_t run = (uint32_t)(s_excl & 0x7FFFFFFFull) + local;
+    uint32_t run2 = (uint32_t)((s_excl >> 31) & 0x7FFFFFFFull) + local2;
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; k++) {
-        if (base + k < n) out[base + k] = run;
+        if (base + k < n) {
+            out[base + k] = run;
+            out2[base + k] = run2;
+        }
         run += v[k];
+        run2 += v2[k];
     }
 }
 
@@ -133,7 +151,8 @@ touch_count_kernel(int P, int gx, int gy, const float2 *__restrict__ means2D, co
                    const int32_t *__restrict__ radii, const float4 *__restrict__ conic_opacity,
                    const uint8_t *__restrict__ mask, RadixPlan plan, uint32_t *__restrict__ tt,
                    uint32_t *__restrict__ keys, uint32_t *__restrict__ vals, TileRect *__restrict__ rects,
-                   uint32_t *__restrict__ ghist, uint32_t *__restrict__ tile_hist, int32_t *__restrict__ hull_out,
+                   uint32_t *__restrict__ hh, uint32_t *__restrict__ ghist, uint32_t *__restrict__ tile_hist,
+                   int32_t *__restrict__ hull_out,
                    int cull, unsigned long long *__restrict__ early, uint32_t *__restrict__ host_total, uint32_t seq,
                    uint4 *__restrict__ zero16, size_t zero16_n) {
     // (round 6) the control block of the tile sort that follows on this stream is cleared here instead of by a fill
@@ -147,9 +166,9 @@ touch_count_kernel(int P, int gx, int gy, const float2 *__restrict__ means2D, co
     // digit histograms of the TILE sort (keys (y, x): pass 0 = column, pass 1 = row), known here without looking at
     // a single pair: a rect of w x h tiles adds h to every column digit in [minx, maxx) and w to every row digit in
     // [miny, maxy) -- two +/- entries in a difference array each, prefix-summed once per workgroup
-    __shared__ int32_t dxy[2][RADIX_DIGITS + 1];
+    __shared__ int32_t dxy[3][RADIX_DIGITS + 1];
     __shared__ uint32_t tc_scan[TC_THREADS / 64];
-    if (threadIdx.x <= RADIX_DIGITS) dxy[0][threadIdx.x] = dxy[1][threadIdx.x] = 0;
+    if (threadIdx.x <= RADIX_DIGITS) dxy[0][threadIdx.x] = dxy[1][threadIdx.x] = dxy[2][threadIdx.x] = 0;
     if (threadIdx.x == 0) { s_lo = gy; s_hi = 0; }
     if (threadIdx.x < RADIX_DIGITS)
         for (int p = 0; p < RADIX_MAX_PASSES; p++) mh[p][threadIdx.x] = 0;
@@ -203,6 +222,7 @@ touch_count_kernel(int P, int gx, int gy, const float2 *__restrict__ means2D, co
             if (n) key = __float_as_uint(depths[i]);
             nsum += n;
             tt[i] = n;
+            hh[i] = n ? (rect.ys >> 16) - (rect.ys & 0xFFFFu) : 0u;  // rows of the rect: its row segments (binning_rows.h)
             rects[i] = rect;
             keys[i] = key;
             vals[i] = (uint32_t)i;
@@ -220,7 +240,7 @@ touch_count_kernel(int P, int gx, int gy, const float2 *__restrict__ means2D, co
     multihist_flush(mh, plan, ghist);
     if (tile_hist) {  // kernel-uniform
         const uint32_t xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u;  // HW_REG_XCC_ID[3:0]
-        for (int p = 0; p < 2; p++) {
+        for (int p = 0; p < 3; p++) {
             const uint32_t v = threadIdx.x < RADIX_DIGITS ? (uint32_t)dxy[p][threadIdx.x] : 0u;
             uint32_t all;
             const uint32_t c = block_exclusive_scan_n<TC_THREADS / 64>(v, tc_scan, &all) + v;  // inclusive: the count
@@ -455,7 +475,7 @@ copy_u32_kernel(long long n, const uint32_t *__restrict__ src, uint32_t *__restr
 }
 
 struct PrepLayout {
-    size_t tt, kA, vA, kB, vB, offsets, rects, hull, early, thist, ctrl, total;
+    size_t tt, hh, kA, vA, kB, vB, offsets, segoff, rects, hull, early, thist, ctrl, total;
     CtrlLayout C;
 };
 PrepLayout prep_layout(int P, int W, int H) {
@@ -464,6 +484,8 @@ PrepLayout prep_layout(int P, int W, int H) {
     size_t o = 0;
     const size_t np = align_up((size_t)(P + 1) * 4);
     L.tt = o; o += np;
+    L.hh = o; o += np;      // rows of each Gaussian's rect
+    L.segoff = o; o += np;  // exclusive scan of hh[sorted id]: the row segments (round 6, binning_rows.h)
     L.kA = o; o += np;
     L.vA = o; o += np;
     L.kB = o; o += np;
@@ -644,7 +666,7 @@ int prepare_lookback(const PrepCall &c, uint32_t *ticket) {
     hipLaunchKernelGGL(touch_count_kernel, dim3(blocks), dim3(TC_THREADS), 0, stream, P, gx, gy,
                        reinterpret_cast<const float2 *>(c.means2D), c.depths, c.radii,
                        reinterpret_cast<const float4 *>(c.conic_opacity), c.compute_locally, plan, tt, kA, vA, rects,
-                       reinterpret_cast<uint32_t *>(ctrl + L.C.ghist), tile_hist,
+                       reinterpret_cast<uint32_t *>(base + L.hh), reinterpret_cast<uint32_t *>(ctrl + L.C.ghist), tile_hist,
                        reinterpret_cast<int32_t *>(base + L.hull), tile_hist ? tile_cull_on(gx * gy) : 0,
                        reinterpret_cast<unsigned long long *>(base + L.early), host_total, seq,
                        reinterpret_cast<uint4 *>(c.zero_ptr), c.zero_bytes / 16);
@@ -663,9 +685,12 @@ int prepare_lookback(const PrepCall &c, uint32_t *ticket) {
                            stream, (long long)P, in_first ? kA : kB, sorted_ids,
                            reinterpret_cast<const float2 *>(c.means2D));
     const int nbs = gsr_div_up(P, SCAN_TILE);
-    hipLaunchKernelGGL(scan_gather_lookback_kernel, dim3(nbs), dim3(SCAN_THREADS), 0, stream, tt, sorted_ids, offsets,
-                       (long long)P, reinterpret_cast<unsigned long long *>(ctrl + L.C.scan_state),
-                       reinterpret_cast<uint32_t *>(ctrl + L.C.tickets), nbs, (uint32_t *)nullptr, seq);
+    hipLaunchKernelGGL(scan_gather_lookback_kernel, dim3(nbs), dim3(SCAN_THREADS), 0, stream, tt,
+                       reinterpret_cast<const uint32_t *>(base + L.hh), sorted_ids, offsets,
+                       reinterpret_cast<uint32_t *>(base + L.segoff), (long long)P,
+                       reinterpret_cast<unsigned long long *>(ctrl + L.C.scan_state),
+                       reinterpret_cast<uint32_t *>(ctrl + L.C.tickets), nbs, (uint32_t *)nullptr, seq,
+                       reinterpret_cast<const unsigned long long *>(base + L.early));
     GSR_LAUNCH_CHECK();
     *ticket = seq;
     return 0;
@@ -714,6 +739,8 @@ int prepare_persistent(const PrepCall &c, uint32_t *ticket) {
     a.kA = reinterpret_cast<uint32_t *>(base + L.kA); a.vA = reinterpret_cast<uint32_t *>(base + L.vA);
     a.kB = reinterpret_cast<uint32_t *>(base + L.kB); a.vB = reinterpret_cast<uint32_t *>(base + L.vB);
     a.offsets = reinterpret_cast<uint32_t *>(base + L.offsets);
+    a.hh = reinterpret_cast<uint32_t *>(base + L.hh);
+    a.segoff = reinterpret_cast<uint32_t *>(base + L.segoff);
     a.rects = reinterpret_cast<TileRect *>(base + L.rects);
     a.tile_hist = yx_path(gx, gy) ? reinterpret_cast<uint32_t *>(base + L.thist) : nullptr;
     a.cull = a.tile_hist ? tile_cull_on(gx * gy) : 0;
@@ -892,7 +919,7 @@ struct SortLayout {
     size_t kA, vA, kB, vB, ctrl, total;
     CtrlLayout C;
 };
-SortLayout sort_layout(int64_t D, int passes) {
+SortLayout sort_layout(int64_t D, int passes, int gx = 0, int gy = 0) {
     SortLayout L;
     size_t o = 0;
     const size_t nd = align_up((size_t)(D + 1) * 4);
@@ -904,17 +931,55 @@ SortLayout sort_layout(int64_t D, int passes) {
     L.C = ctrl_layout(D, passes, false);
     const size_t need = persist_layout_s(persist_grid_bound_s(D)).total;  // (either pipeline's control block)
     o += L.C.total > need ? L.C.total : need;
+    if (gx > 0 && gy > 0) {  // the row-major pipeline (binning_rows.h) lays the same scratch out its own way
+        const size_t rows = rows_layout(D, gx, gy).total;
+        if (rows > o) o = rows;
+    }
     L.total = o;
     return L;
 }
+
+// K5-K7 with one D-sized pass (binning_rows.h): on by default where it applies -- frames of <= 256 x 256 tiles, uncut rects
+std::atomic<int> g_rows_override{-1};  // gsr_set_bin_rowmajor: -1 = environment (GSR_BIN_ROWS = 0 | 1, default 1)
+bool rows_path(int gx, int gy) {
+    int mode = g_rows_override.load(std::memory_order_relaxed);
+    if (mode < 0) {
+        static const int env_mode = [] {
+            const char *e = getenv("GSR_BIN_ROWS");
+            return (e && *e == '0') ? 0 : 1;
+        }();
+        mode = env_mode;
+    }
+    return mode == 1 && yx_path(gx, gy) && !tile_cull_on(gx * gy);
+}
 }  // namespace
+
+#ifdef GSR_ROWS_TS
+extern "C" int gsr_debug_rows_ts(unsigned long long *out, int words) {
+    GSR_HIP(hipDeviceSynchronize());
+    GSR_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rows_ts), sizeof(unsigned long long) * (size_t)words));
+    return 0;
+}
+extern "C" int gsr_debug_rows_ts2(unsigned long long *out, int words) {
+    GSR_HIP(hipDeviceSynchronize());
+    GSR_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rows_ts2), sizeof(unsigned long long) * (size_t)words));
+    return 0;
+}
+#endif
+
+extern "C" int gsr_set_bin_rowmajor(int mode) {
+    if (mode < -1 || mode > 1) return GSR_EINVAL;
+    g_rows_override.store(mode, std::memory_order_relaxed);
+    return 0;
+}
 
 extern "C" size_t gsr_bin_sort_bytes(int P, int64_t num_rendered, int width, int height) {
     (void)P;
     if (num_rendered < 0 || width <= 0 || height <= 0) return 0;
     const int gx = (width + GSR_BLOCK_X - 1) / GSR_BLOCK_X, gy = (height + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y;
     const int passes = radix_plan(0, tile_bits(gx * gy)).passes;
-    return sort_layout(num_rendered, passes < 2 ? 2 : passes).total;  // the (row, column) path always runs 2 passes
+    // (the (row, column) path always runs 2 passes; the row-major pipeline's layout fits the same buffer)
+    return sort_layout(num_rendered, passes < 2 ? 2 : passes, yx_path(gx, gy) ? gx : 0, gy).total;
 }
 
 namespace {
@@ -930,7 +995,7 @@ int bin_sort_impl(int P, int width, int height, const uint8_t *compute_locally, 
     if (!compute_locally || !prep || !scratch || !point_list) return GSR_EINVAL;
     if (D > RADIX_MAX_N) return GSR_EINVAL;
     const RadixPlan plan = radix_plan(0, tile_bits(gx * gy));
-    const SortLayout S = sort_layout(D, plan.passes < 2 ? 2 : plan.passes);
+    const SortLayout S = sort_layout(D, plan.passes < 2 ? 2 : plan.passes, yx_path(gx, gy) ? gx : 0, gy);
     if (scratch_bytes < S.total) return GSR_ENOSPACE;
     const PrepLayout L = prep_layout(P, width, height);
     const char *pbase = reinterpret_cast<const char *>(prep);
@@ -948,6 +1013,53 @@ int bin_sort_impl(int P, int width, int height, const uint8_t *compute_locally, 
         GSR_HIP(hipGetDevice(&dev0));
         const int fault = persist_fault_check(dev0);
         if (fault) return fault;
+    }
+    if (rows_path(gx, gy)) {
+        // ---- the row-major pipeline (binning_rows.h): segments by row, their scan, ONE pass over the pairs
+        const RowsLayout R = rows_layout(D, gx, gy);
+        if (scratch_bytes < R.total) return GSR_ENOSPACE;
+        if (!ctrl_zeroed) GSR_HIP(hipMemsetAsync(sbase + R.ctrl, 0, R.ctrl_bytes, stream));
+        const int xbits = bits_for(gx), ybits = bits_for(gy);
+        const uint32_t *thist = reinterpret_cast<const uint32_t *>(pbase + L.thist);
+        const uint32_t *segoff = reinterpret_cast<const uint32_t *>(pbase + L.segoff);
+        uint32_t *tickets = reinterpret_cast<uint32_t *>(sbase + R.tickets);
+        uint32_t *seg_key = reinterpret_cast<uint32_t *>(sbase + R.seg_key);
+        uint32_t *seg_gid = reinterpret_cast<uint32_t *>(sbase + R.seg_gid);
+        uint32_t *pairoff = reinterpret_cast<uint32_t *>(sbase + R.pairoff);
+        int32_t *tdiff = reinterpret_cast<int32_t *>(sbase + R.tdiff);
+        // grids: tiles are taken by ticket inside the kernels, so a grid only has to fill the device (the segment count
+        // is not known on the host, and the pair count only as a capacity in a bounded launch)
+        int dev = 0, cus = 256;
+        GSR_HIP(hipGetDevice(&dev));
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        constexpr int TILE_B = 8 * ROWS_THREADS_B, TILE_D = 8 * ROWS_THREADS_D;
+        auto tickets_of = [](long long tiles) { return (tiles + TICKET_TILES - 1) / TICKET_TILES; };
+        const long long nbB = (D + TILE_B - 1) / TILE_B;
+        const int fill_b = cus * 2, fill_d = cus * (ROWS_THREADS_D >= 1024 ? 2 : 4);
+        const int grid_b = (int)(tickets_of(nbB) < fill_b ? tickets_of(nbB) : fill_b);
+        const long long nbs = (D + SEGSCAN_TILE - 1) / SEGSCAN_TILE;
+        // (every workgroup costs a ticket -- an atomic on one word, ~15 ns each when hammered -- whether it finds work or not,
+        // and the segment count is typically D / 3..6: a grid of two workgroups per CU loops over the tiles instead)
+        const int grid_c = (int)(tickets_of(nbs) < cus * 2 ? tickets_of(nbs) : cus * 2);
+        const long long nbt = (D + TILE_D - 1) / TILE_D + gy;
+        const int grid_d = (int)(tickets_of(nbt) < fill_d ? tickets_of(nbt) : fill_d);
+        uint32_t *tilebase = reinterpret_cast<uint32_t *>(sbase + R.tilebase);
+        int32_t *chunk_owner = reinterpret_cast<int32_t *>(sbase + R.chunk_owner);
+        hipLaunchKernelGGL((seg_scatter_kernel<8, ROWS_THREADS_B>), dim3(grid_b), dim3(ROWS_THREADS_B), 0, stream, P, (long long)D,
+                           ybits, rects, sorted_ids, offsets, segoff, thist + 2 * RADIX_DIGITS,
+                           reinterpret_cast<uint32_t *>(sbase + R.seg_state), tickets, seg_key, seg_gid, bounded, ranges,
+                           2 * gx * gy, reinterpret_cast<const int32_t *>(pbase + L.hull), tdiff, RADIX_REPLICAS * gy * (gx + 1));
+        hipLaunchKernelGGL(seg_scan_kernel, dim3(grid_c), dim3(SCAN_THREADS), 0, stream, P, (long long)D, gx, gy, offsets,
+                           segoff, seg_key, pairoff, reinterpret_cast<unsigned long long *>(sbase + R.scan_state),
+                           tickets + 1, tdiff, thist, chunk_owner, bounded);
+        hipLaunchKernelGGL(tile_base_kernel, dim3(gy), dim3(GSR_ONE_DIM_BLOCK), 0, stream, P, (long long)D, gx, gy, offsets,
+                           thist, tdiff, compute_locally, tilebase, reinterpret_cast<int2 *>(ranges), bounded);
+        hipLaunchKernelGGL((pair_scatter_kernel<8, ROWS_THREADS_D>), dim3(grid_d), dim3(ROWS_THREADS_D), 0, stream, P,
+                           (long long)D, gx, gy, xbits, offsets, segoff, seg_key, seg_gid, pairoff, thist, tilebase,
+                           chunk_owner, reinterpret_cast<uint32_t *>(sbase + R.pair_state), tickets + 2, point_list,
+                           bounded);
+        GSR_LAUNCH_CHECK();
+        return 0;
     }
     if (yx_path(gx, gy) && (persist_effective_mode() & PERSIST_S)) {
         // K5-K7 as ONE persistent launch (binning_persist.h) when the device can hold the grid and no barrier kernel of
@@ -1071,8 +1183,13 @@ extern "C" int gsr_bin_speculative_async(int P, int width, int height, const flo
         const int gx = (width + GSR_BLOCK_X - 1) / GSR_BLOCK_X, gy = (height + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y;
         if (yx_path(gx, gy) && capacity <= RADIX_MAX_N) {
             const RadixPlan plan = radix_plan(0, tile_bits(gx * gy));
-            const SortLayout S = sort_layout(capacity, plan.passes < 2 ? 2 : plan.passes);
-            if (scratch_bytes >= S.total) {
+            const SortLayout S = sort_layout(capacity, plan.passes < 2 ? 2 : plan.passes, gx, gy);
+            if (scratch_bytes >= S.total && rows_path(gx, gy)) {
+                const RowsLayout RL = rows_layout(capacity, gx, gy);
+                zero_ptr = reinterpret_cast<char *>(scratch) + RL.ctrl;
+                zero_bytes = ((RL.ctrl_bytes + 15) / 16) * 16;
+                if (RL.ctrl + zero_bytes > scratch_bytes || (RL.ctrl & 15)) { zero_ptr = nullptr; zero_bytes = 0; }
+            } else if (scratch_bytes >= S.total) {
                 const size_t zp = persist_layout_s(persist_grid_bound_s(capacity)).zero_bytes;
                 zero_ptr = reinterpret_cast<char *>(scratch) + S.ctrl;
                 zero_bytes = (((S.C.total > zp ? S.C.total : zp) + 15) / 16) * 16;

@@ -328,7 +328,8 @@ __device__ __forceinline__ uint32_t gsr_select_bit(unsigned long long m, uint32_
 }
 
 // K3's tail for one Gaussian with a non-empty rect: the tile mask, the tile count and the tile sort's digit histograms
-// (dxy[0]: column digits, dxy[1]: row digits, both as difference arrays) -- shared by the two pipelines' K3.
+// (dxy[0]: column digits, dxy[1]: row digits, dxy[2]: Gaussians per row -- uncut rects only --, all as difference
+// arrays) -- shared by the two pipelines' K3.
 __device__ __forceinline__ uint32_t gsr_rect_tiles(const float2 xy, const float4 co, int minx, int miny, int maxx, int maxy,
                                                    bool cull, int32_t (*dxy)[RADIX_DIGITS + 1], TileRect &out) {
     const int w = maxx - minx, h = maxy - miny;
@@ -341,6 +342,8 @@ __device__ __forceinline__ uint32_t gsr_rect_tiles(const float2 xy, const float4
             atomicAdd(&dxy[0][maxx], -h);
             atomicAdd(&dxy[1][miny], w);
             atomicAdd(&dxy[1][maxy], -w);
+            atomicAdd(&dxy[2][miny], 1);  // (round 6) row SEGMENTS per tile row: one per Gaussian and row of its rect
+            atomicAdd(&dxy[2][maxy], -1);
         }
         return (uint32_t)(w * h);
     }
@@ -552,6 +555,7 @@ struct PrepPersistArgs {
     const float4 *conic_opacity;
     const uint8_t *mask;
     uint32_t *tt, *kA, *vA, *kB, *vB, *offsets;
+    uint32_t *hh, *segoff;  // rows of a Gaussian's rect; exclusive scan of hh[sorted id] (segoff[P] = row segments R)
     TileRect *rects;
     uint32_t *tile_hist;  // [8 replicas][4][256] or null (frames above 256 x 256 tiles)
     int cull;             // exact tile culling (gsr_tile_mask); only with tile_hist (the (row, column) path)
@@ -573,7 +577,7 @@ struct PrepPersistArgs {
 };
 
 struct PPExtra {
-    int32_t dxy[2][RADIX_DIGITS + 1];
+    int32_t dxy[3][RADIX_DIGITS + 1];
     int s_lo, s_hi;
 };
 
@@ -599,7 +603,7 @@ bin_prepare_persist_kernel(const PrepPersistArgs a) {
         a.zero16[i] = make_uint4(0u, 0u, 0u, 0u);  // (the next kernel's control block: see touch_count_kernel)
 
     // ------------------------------------------------------------------ T: K3 (see touch_count_kernel)
-    if (threadIdx.x <= RADIX_DIGITS) ex.dxy[0][threadIdx.x] = ex.dxy[1][threadIdx.x] = 0;
+    if (threadIdx.x <= RADIX_DIGITS) ex.dxy[0][threadIdx.x] = ex.dxy[1][threadIdx.x] = ex.dxy[2][threadIdx.x] = 0;
     if (threadIdx.x == 0) { ex.s_lo = a.gy; ex.s_hi = 0; }
     clear_wtab(sm);
     __syncthreads();
@@ -673,6 +677,7 @@ bin_prepare_persist_kernel(const PrepPersistArgs a) {
                 if (n) key[r] = __float_as_uint(dep[q4]);
                 nsum += n;
                 st_agent(&a.tt[i], n);  // (gathered by other workgroups in the scan phase)
+                st_agent(&a.hh[i], n ? (rect.ys >> 16) - (rect.ys & 0xFFFFu) : 0u);  // rows of the rect (row segments)
                 a.rects[i] = rect;
                 if (!keep) {
                     st_agent(&a.kA[i], key[r]);
@@ -707,7 +712,7 @@ bin_prepare_persist_kernel(const PrepPersistArgs a) {
     }
     if (a.tile_hist) {  // the tile sort's digit histograms, for the look-back tile sort (large D, contended device)
         const uint32_t xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u;  // HW_REG_XCC_ID[3:0]
-        for (int p = 0; p < 2; p++) {
+        for (int p = 0; p < 3; p++) {
             const uint32_t v = threadIdx.x < RADIX_DIGITS ? (uint32_t)ex.dxy[p][threadIdx.x] : 0u;
             uint32_t all;
             const uint32_t c = block_exclusive_scan_n<PP_WAVES>(v, sm.scan_tmp, &all) + v;  // inclusive: the count
@@ -821,17 +826,23 @@ bin_prepare_persist_kernel(const PrepPersistArgs a) {
     }
     // four passes: the sorted (key, id) pairs are back in (kA, vA)
     // ------------------------------------------------------------------ S: offsets = exclusive scan of tt[vA[.]]
-    uint32_t v[PP_ITEMS];
+    // (and, round 6, segoff = exclusive scan of hh[vA[.]]: the row segments of the row-major emission, binning_rows.h;
+    // the two running sums travel in one 64-bit word -- both stay below 2^31, RADIX_MAX_N -- low half pairs, high half
+    // segments)
+    uint32_t v[PP_ITEMS], hv[PP_ITEMS];
     unsigned long long wsum = 0;
     for (long long t = t0; t < t1; t++) {
         const long long base = t * PP_TILE + (long long)threadIdx.x * PP_ITEMS;  // four CONSECUTIVE elements per thread
-        uint32_t s = 0;
+        uint32_t s = 0, sh = 0;
 #pragma unroll
         for (int k = 0; k < PP_ITEMS; k++) {
-            v[k] = (base + k < P) ? ld_agent(&a.tt[ld_agent(&a.vA[base + k])]) : 0u;
+            const uint32_t id = (base + k < P) ? ld_agent(&a.vA[base + k]) : 0u;
+            v[k] = (base + k < P) ? ld_agent(&a.tt[id]) : 0u;
+            hv[k] = (base + k < P) ? ld_agent(&a.hh[id]) : 0u;
             s += v[k];
+            sh += hv[k];
         }
-        wsum += s;
+        wsum += (unsigned long long)s | ((unsigned long long)sh << 32);
     }
     wsum = wave_sum64(wsum);
     if (lane == 0) sm.scan64[wave] = wsum;
@@ -859,25 +870,40 @@ bin_prepare_persist_kernel(const PrepPersistArgs a) {
     }
     for (long long t = t0; t < t1; t++) {
         const long long base = t * PP_TILE + (long long)threadIdx.x * PP_ITEMS;
-        uint32_t s = 0;
+        uint32_t s = 0, sh = 0;
         if (!keep) {
 #pragma unroll
-            for (int k = 0; k < PP_ITEMS; k++) v[k] = (base + k < P) ? ld_agent(&a.tt[ld_agent(&a.vA[base + k])]) : 0u;
+            for (int k = 0; k < PP_ITEMS; k++) {
+                const uint32_t id = (base + k < P) ? ld_agent(&a.vA[base + k]) : 0u;
+                v[k] = (base + k < P) ? ld_agent(&a.tt[id]) : 0u;
+                hv[k] = (base + k < P) ? ld_agent(&a.hh[id]) : 0u;
+            }
         }
-#pragma unroll
-        for (int k = 0; k < PP_ITEMS; k++) s += v[k];
-        uint32_t tot;
-        const uint32_t local = block_exclusive_scan_n<PP_WAVES>(s, sm.scan_tmp, &tot);
-        uint32_t run = (uint32_t)carry + local;
 #pragma unroll
         for (int k = 0; k < PP_ITEMS; k++) {
-            if (base + k < P) a.offsets[base + k] = run;
-            run += v[k];
+            s += v[k];
+            sh += hv[k];
         }
-        carry += tot;
+        uint32_t tot, toth;
+        const uint32_t local = block_exclusive_scan_n<PP_WAVES>(s, sm.scan_tmp, &tot);
+        const uint32_t localh = block_exclusive_scan_n<PP_WAVES>(sh, sm.scan_tmp, &toth);
+        uint32_t run = (uint32_t)carry + local, runh = (uint32_t)(carry >> 32) + localh;
+#pragma unroll
+        for (int k = 0; k < PP_ITEMS; k++) {
+            if (base + k < P) {
+                a.offsets[base + k] = run;
+                a.segoff[base + k] = runh;
+            }
+            run += v[k];
+            runh += hv[k];
+        }
+        carry += (unsigned long long)tot | ((unsigned long long)toth << 32);
     }
-    if (w == G - 1 && threadIdx.x == 0) {  // the last workgroup owns the last tile: its carry is the pair count
-        a.offsets[P] = clamp_pair_count(carry);  // (the host has had the count since the first barrier)
+    if (w == G - 1 && threadIdx.x == 0) {  // the last workgroup owns the last tile: its carry holds the totals
+        // (the host has had the count since the first barrier; the device copy comes from the same clean 64-bit sum -- the
+        // packed carry's low half would wrap silently at 2^32 pairs, which the callers must see as "too many")
+        a.offsets[P] = clamp_pair_count(__hip_atomic_load(a.early, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        a.segoff[P] = (uint32_t)(carry >> 32);
     }
     GSR_TS(31);
 }

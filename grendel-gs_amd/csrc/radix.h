@@ -28,7 +28,10 @@ constexpr long long RADIX_MAX_N = (1ll << 31) - 1;  // prefixes share a word wit
 // (an aggregate is at most one tile, 4096, so "+ 1" can never reach bit 31).  31 value bits: up to 2^31 - 1 pairs --
 // one MI355X holds the 1.2e9 pairs of the 40 M-Gaussian 4K frame (configs[4]) in ~25 GB of its 288 GB.
 constexpr uint32_t LB_PRE = 0x80000000u, LB_VAL = 0x7FFFFFFFu;
-constexpr int LB_WINDOW = 4;  // independent state loads in flight per thread (look-back is short in practice)
+#ifndef GSR_LB_WINDOW
+#define GSR_LB_WINDOW 4
+#endif
+constexpr int LB_WINDOW = GSR_LB_WINDOW;  // independent state loads in flight per thread and look-back round
 // 64-bit variant for the offsets scan (values up to 2^32)
 constexpr unsigned long long LB64_PRE = 2ull << 62, LB64_AGG = 1ull << 62, LB64_VAL = (1ull << 62) - 1ull;
 

@@ -684,6 +684,13 @@ def set_bin_persistent(mode):
     check(lib.gsr_set_bin_persistent(code), "gsr_set_bin_persistent")
 
 
+def set_bin_rowmajor(mode):
+    """K5-K7 with one pass over the pairs (csrc/binning_rows.h; include/gsraster.h: gsr_set_bin_rowmajor): "env"
+    (GSR_BIN_ROWS, default on), True / "on", False / "off" (the two-pass split-key pipelines).  Same lists either way."""
+    code = {"env": -1, False: 0, "off": 0, True: 1, "on": 1}[mode]
+    check(lib.gsr_set_bin_rowmajor(code), "gsr_set_bin_rowmajor")
+
+
 def bin_persist_status():
     """-> dict(done, fault_code, faults, solo_recoveries) of the persistent binning launches on the current device
     (include/gsraster.h: gsr_bin_persist_status).  `solo_recoveries` counts the views whose tile sort was finished by one

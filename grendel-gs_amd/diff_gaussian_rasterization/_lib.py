@@ -90,6 +90,7 @@ SIGNATURES = {
                                           ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(c_int), c_void_p]),
     "gsr_set_bin_persistent": (c_int, [c_int]),
     "gsr_set_tile_cull": (c_int, [c_int]),
+    "gsr_set_bin_rowmajor": (c_int, [c_int]),
     "gsr_bin_persist_status": (c_int, [ctypes.POINTER(ctypes.c_uint32)]),
     "gsr_bin_timeline": (c_int, [c_int, c_void_p, c_int, ctypes.POINTER(c_int)]),
     "gsr_flag_if_greater": (c_int, [c_void_p, ctypes.c_uint32, c_void_p, ctypes.c_uint32, c_void_p, c_void_p]),

@@ -174,6 +174,14 @@ int gsr_bin_speculative_async(int P, int width, int height, const float *means2D
  * status words and the next binning call on the device returns GSR_EFAULT.  mode: -1 the environment's GSR_BIN_PERSIST (0 | 1 | p | s,
  * default 1), 0 off, 1 prepare only, 2 sort only, 3 both. */
 int gsr_set_bin_persistent(int mode);
+/* K5-K7 with ONE pass over the D (tile, Gaussian) pairs (ABI 12; csrc/binning_rows.h): the h ROW SEGMENTS of every rect
+ * (R = sum of heights ~ D / 3..6) are sorted stably by tile row, the pairs are emitted from that order and scattered
+ * stably by column inside their row, straight into point_list; the ranges follow from per-tile counts.  Replaces the two
+ * D-sized sort passes + K7 of the split-key pipelines (their ranking is bound by VALU issue at every size: 0.28-0.33 of
+ * the HBM peak) where it applies: frames of <= 256 x 256 tiles, uncut rects (gsr_set_tile_cull off).  Lists, ranges and
+ * counts are bit-identical.  mode: -1 the environment's GSR_BIN_ROWS (0 | 1, default 1), 0 off, 1 on.
+ * Reference stages replaced: 40 duplicateWithKeys, 50 SortPairs, 60 identifyTileRanges (analyze_statistic.py:1972-1991). */
+int gsr_set_bin_rowmajor(int mode);
 /* Exact tile culling in K3 (ABI 11; csrc/binning_persist.h: gsr_tile_mask): per tile row of a Gaussian's rect the exact span
  * of tiles its alpha >= 1/255 ellipse reaches (the quadratic form and tolerance of the composite kernels' own skip test),
  * kept as a 64-bit mask (rects of <= 64 tiles on frames of <= 256 x 256 tiles).  The lists stay order-preserving

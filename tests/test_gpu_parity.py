@@ -208,26 +208,33 @@ def test_persistent_binning_equals_the_lookback_pipeline(device, monkeypatch, gr
     got = {}
     dgr.set_tile_cull(cull)  # (exact tile spans: both pipelines' K3 and emissions, the sort kernel's rect-derived counts)
     try:
-        for mode in ("off", "both", "prepare", "sort"):
-            dgr.set_bin_persistent(mode)
-            for spec in (False, True):
-                dgr.release_workspaces()
-                dgr.set_speculative_sort(spec)
-                for i, name in enumerate(order):
-                    pl, rg, D = dgr.bin_gaussians(*views[name], W, H)
-                    got[(mode, spec, i)] = (pl.clone(), rg.clone(), D)
+        # (round 6) ... and the row-major pipeline (csrc/binning_rows.h: segments sorted by row, ONE pass over the pairs)
+        # behind either prepare step -- with exact tile spans on it hands over to the two-pass pipelines by itself
+        for rows in (False, True):
+            dgr.set_bin_rowmajor(rows)
+            for mode in ("off", "both", "prepare", "sort"):
+                if rows and mode in ("both", "sort"):
+                    continue  # (the persistent SORT kernel is not reached while the row-major pipeline applies)
+                dgr.set_bin_persistent(mode)
+                for spec in (False, True):
+                    dgr.release_workspaces()
+                    dgr.set_speculative_sort(spec)
+                    for i, name in enumerate(order):
+                        pl, rg, D = dgr.bin_gaussians(*views[name], W, H)
+                        got[(rows, mode, spec, i)] = (pl.clone(), rg.clone(), D)
     finally:
         dgr.set_bin_persistent("env")
+        dgr.set_bin_rowmajor("env")
         dgr.set_tile_cull("env")
         dgr.set_speculative_sort(True)
         dgr.release_workspaces()
-    assert got[("off", False, 3)][2] > got[("off", False, 0)][2] > got[("off", False, 2)][2] > 0
-    for (mode, spec, i), (pl, rg, D) in got.items():
-        rpl, rrg, rD = got[("off", False, i)]
-        assert D == rD, (mode, spec, order[i])
-        assert torch.equal(rg, rrg), (mode, spec, order[i])
+    assert got[(False, "off", False, 3)][2] > got[(False, "off", False, 0)][2] > got[(False, "off", False, 2)][2] > 0
+    for (rows, mode, spec, i), (pl, rg, D) in got.items():
+        rpl, rrg, rD = got[(False, "off", False, i)]
+        assert D == rD, (rows, mode, spec, order[i])
+        assert torch.equal(rg, rrg), (rows, mode, spec, order[i])
         if D:
-            assert pl.numel() == D and torch.equal(pl, rpl), (mode, spec, order[i])
+            assert pl.numel() == D and torch.equal(pl, rpl), (rows, mode, spec, order[i])
 
 
 def test_late_pair_count_equals_the_polled_path_and_survives_an_overflow(device):
@@ -273,16 +280,18 @@ def test_late_pair_count_equals_the_polled_path_and_survives_an_overflow(device)
             ref[name], pairs[name] = finish(gg, img, nc), n_render
             # K10 adds a Gaussian's tiles with float atomics in whatever order they finish: the SAME path run twice
             # gives the yardstick for "equal gradients"
-            noise[name] = {k: 1e-5 for k in KEYS}
-            for _ in range(3):  # (heavy-tailed: a few ill-conditioned splats dominate; the bar is 10 x the worst of three)
+            noise[name] = {k: 0.0 for k in KEYS}
+            for _ in range(2):  # the SAME path again: the yardstick for "equal gradients" (printed, not asserted on)
                 again = finish(*run(name, None)[:3])
                 assert torch.equal(again[0], ref[name][0]) and torch.equal(again[1], ref[name][1])
                 for k in KEYS:
-                    noise[name][k] = max(noise[name][k], 10.0 * rel_err(again[2][k], ref[name][2][k]))
-        print("run-to-run gradient noise (x10, floor 1e-5):", noise)
-        # (measured: up to 2.3e-5 raw on the large-splat scene's means3D between two IDENTICAL runs -- inside
-        # north_star's 1e-4; the bar below is relative to it, never tighter than 1e-5)
-        assert all(v < 1e-3 for d in noise.values() for v in d.values()), noise
+                    noise[name][k] = max(noise[name][k], rel_err(again[2][k], ref[name][2][k]))
+        # K10 adds a Gaussian's tiles with float atomics in whatever order they finish; the deviation between two
+        # IDENTICAL runs is heavy-tailed (a few ill-conditioned large splats): typically 1e-6, measured up to 2.3e-5 on
+        # the large-splat scene.  The bar for the late path is north_star's 1e-4.
+        print("run-to-run gradient deviation of the polled path:", noise)
+        for name in scenes:
+            noise[name] = {k: 1e-4 for k in KEYS}
         assert pairs["large"] > 2 * pairs["small"] > 0, pairs
         dgr.release_workspaces()
         dgr.set_speculative_sort(True)
@@ -351,6 +360,7 @@ def test_persistent_binning_survives_an_aborted_first_barrier(device, monkeypatc
         if grid_s is not None:
             monkeypatch.setenv("GSR_BIN_GRID_S", str(grid_s))
         torch.cuda.synchronize()
+        dgr.set_bin_rowmajor(False)  # (the persistent SORT kernel is what is under test)
         dgr.set_bin_persistent("both")  # (also ends the back-off an earlier recovery may have started)
         before = dgr.bin_persist_status()
         for spec in (False, True):
@@ -371,6 +381,7 @@ def test_persistent_binning_survives_an_aborted_first_barrier(device, monkeypatc
             assert after["solo_recoveries"] == before["solo_recoveries"]
     finally:
         dgr.set_bin_persistent("env")
+        dgr.set_bin_rowmajor("env")
         dgr.set_speculative_sort(True)
         dgr.release_workspaces()
 
@@ -386,6 +397,7 @@ def _shared_device_worker(rank, q, iters):
                 sys.path.insert(0, p)
         os.environ["GSR_BIN_PERSIST_MAXD"] = "1000000000"
         os.environ["GSR_BIN_SORT_TIMEOUT_MS"] = "20"
+        os.environ["GSR_BIN_ROWS"] = "0"  # (the persistent SORT kernel is what is under test)
         import diff_gaussian_rasterization as dgr
 
         device = torch.device("cuda:0")
