@@ -45,15 +45,16 @@ namespace {
 // ------------------------------------------------------------ K4: offsets = exclusive scan of tt[ids[.]]
 // Single pass with decoupled look-back (wave 0 inspects 64 predecessors per round).  out[n] = total.
 __global__ void __launch_bounds__(SCAN_THREADS)
-scan_gather_lookback_kernel(const uint32_t *__restrict__ src, const uint32_t *__restrict__ src2,
+scan_gather_lookback_kernel(const uint32_t *__restrict__ src, int packed,
                             const uint32_t *__restrict__ idx, uint32_t *__restrict__ out, uint32_t *__restrict__ out2,
                             long long n, unsigned long long *__restrict__ state, uint32_t *__restrict__ ticket, int nb,
                             uint32_t *__restrict__ host_total, uint32_t seq,
                             const unsigned long long *__restrict__ early) {
-    // Two scans in one sweep (round 6): out = exclusive scan of src[idx[.]] (pairs per Gaussian -> the offsets of the
-    // Gaussian-major emission) and out2 = exclusive scan of src2[idx[.]] (rows of the Gaussian's rect -> its row segments,
-    // binning_rows.h).  Both running sums stay below 2^31 (RADIX_MAX_N) and share the 62 value bits of the look-back
-    // word: low 31 bits pairs, high 31 bits segments.
+    // Two scans in one sweep (round 6): out = exclusive scan of the pairs per Gaussian (-> the offsets of the Gaussian-major
+    // emission) and out2 = exclusive scan of the rows of the Gaussian's rect (-> its row segments, binning_rows.h).  K3
+    // leaves both in ONE word per Gaussian (`packed`: pairs | rows << 20 on frames of <= 256 x 256 tiles; else the pairs
+    // alone): one random gather per element, as before the second scan existed.  Both running sums stay below 2^31
+    // (RADIX_MAX_N) and share the 62 value bits of the look-back word: low 31 bits pairs, high 31 bits segments.
     __shared__ uint32_t smem[4];
     __shared__ uint32_t s_bid;
     __shared__ unsigned long long s_excl;
@@ -67,9 +68,9 @@ scan_gather_lookback_kernel(const uint32_t *__restrict__ src, const uint32_t *__
     uint32_t s = 0, s2 = 0;
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; k++) {
-        const uint32_t id = (base + k < n) ? idx[base + k] : 0u;
-        v[k] = (base + k < n) ? src[id] : 0u;
-        v2[k] = (base + k < n) ? src2[id] : 0u;
+        const uint32_t x = (base + k < n) ? src[idx[base + k]] : 0u;
+        v[k] = packed ? (x & TT_MASK) : x;
+        v2[k] = packed ? (x >> TT_SHIFT) : 0u;
         s += v[k];
         s2 += v2[k];
     }
@@ -151,8 +152,7 @@ touch_count_kernel(int P, int gx, int gy, const float2 *__restrict__ means2D, co
                    const int32_t *__restrict__ radii, const float4 *__restrict__ conic_opacity,
                    const uint8_t *__restrict__ mask, RadixPlan plan, uint32_t *__restrict__ tt,
                    uint32_t *__restrict__ keys, uint32_t *__restrict__ vals, TileRect *__restrict__ rects,
-                   uint32_t *__restrict__ hh, uint32_t *__restrict__ ghist, uint32_t *__restrict__ tile_hist,
-                   int32_t *__restrict__ hull_out,
+                   uint32_t *__restrict__ ghist, uint32_t *__restrict__ tile_hist, int32_t *__restrict__ hull_out,
                    int cull, unsigned long long *__restrict__ early, uint32_t *__restrict__ host_total, uint32_t seq,
                    uint4 *__restrict__ zero16, size_t zero16_n) {
     // (round 6) the control block of the tile sort that follows on this stream is cleared here instead of by a fill
@@ -221,8 +221,8 @@ touch_count_kernel(int P, int gx, int gy, const float2 *__restrict__ means2D, co
             }
             if (n) key = __float_as_uint(depths[i]);
             nsum += n;
-            tt[i] = n;
-            hh[i] = n ? (rect.ys >> 16) - (rect.ys & 0xFFFFu) : 0u;  // rows of the rect: its row segments (binning_rows.h)
+            // (with the rows of the rect -- its row segments, binning_rows.h -- in the upper bits on the (row, column) path)
+            tt[i] = (tile_hist && n) ? (n | (((rect.ys >> 16) - (rect.ys & 0xFFFFu)) << TT_SHIFT)) : n;
             rects[i] = rect;
             keys[i] = key;
             vals[i] = (uint32_t)i;
@@ -475,7 +475,7 @@ copy_u32_kernel(long long n, const uint32_t *__restrict__ src, uint32_t *__restr
 }
 
 struct PrepLayout {
-    size_t tt, hh, kA, vA, kB, vB, offsets, segoff, rects, hull, early, thist, ctrl, total;
+    size_t tt, kA, vA, kB, vB, offsets, segoff, rects, hull, early, thist, ctrl, total;
     CtrlLayout C;
 };
 PrepLayout prep_layout(int P, int W, int H) {
@@ -483,8 +483,7 @@ PrepLayout prep_layout(int P, int W, int H) {
     PrepLayout L;
     size_t o = 0;
     const size_t np = align_up((size_t)(P + 1) * 4);
-    L.tt = o; o += np;
-    L.hh = o; o += np;      // rows of each Gaussian's rect
+    L.tt = o; o += np;      // pairs of each Gaussian (| the rows of its rect << 20 on the (row, column) path)
     L.segoff = o; o += np;  // exclusive scan of hh[sorted id]: the row segments (round 6, binning_rows.h)
     L.kA = o; o += np;
     L.vA = o; o += np;
@@ -666,7 +665,7 @@ int prepare_lookback(const PrepCall &c, uint32_t *ticket) {
     hipLaunchKernelGGL(touch_count_kernel, dim3(blocks), dim3(TC_THREADS), 0, stream, P, gx, gy,
                        reinterpret_cast<const float2 *>(c.means2D), c.depths, c.radii,
                        reinterpret_cast<const float4 *>(c.conic_opacity), c.compute_locally, plan, tt, kA, vA, rects,
-                       reinterpret_cast<uint32_t *>(base + L.hh), reinterpret_cast<uint32_t *>(ctrl + L.C.ghist), tile_hist,
+                       reinterpret_cast<uint32_t *>(ctrl + L.C.ghist), tile_hist,
                        reinterpret_cast<int32_t *>(base + L.hull), tile_hist ? tile_cull_on(gx * gy) : 0,
                        reinterpret_cast<unsigned long long *>(base + L.early), host_total, seq,
                        reinterpret_cast<uint4 *>(c.zero_ptr), c.zero_bytes / 16);
@@ -686,7 +685,7 @@ int prepare_lookback(const PrepCall &c, uint32_t *ticket) {
                            reinterpret_cast<const float2 *>(c.means2D));
     const int nbs = gsr_div_up(P, SCAN_TILE);
     hipLaunchKernelGGL(scan_gather_lookback_kernel, dim3(nbs), dim3(SCAN_THREADS), 0, stream, tt,
-                       reinterpret_cast<const uint32_t *>(base + L.hh), sorted_ids, offsets,
+                       tile_hist ? 1 : 0, sorted_ids, offsets,
                        reinterpret_cast<uint32_t *>(base + L.segoff), (long long)P,
                        reinterpret_cast<unsigned long long *>(ctrl + L.C.scan_state),
                        reinterpret_cast<uint32_t *>(ctrl + L.C.tickets), nbs, (uint32_t *)nullptr, seq,
@@ -739,7 +738,6 @@ int prepare_persistent(const PrepCall &c, uint32_t *ticket) {
     a.kA = reinterpret_cast<uint32_t *>(base + L.kA); a.vA = reinterpret_cast<uint32_t *>(base + L.vA);
     a.kB = reinterpret_cast<uint32_t *>(base + L.kB); a.vB = reinterpret_cast<uint32_t *>(base + L.vB);
     a.offsets = reinterpret_cast<uint32_t *>(base + L.offsets);
-    a.hh = reinterpret_cast<uint32_t *>(base + L.hh);
     a.segoff = reinterpret_cast<uint32_t *>(base + L.segoff);
     a.rects = reinterpret_cast<TileRect *>(base + L.rects);
     a.tile_hist = yx_path(gx, gy) ? reinterpret_cast<uint32_t *>(base + L.thist) : nullptr;
@@ -1035,7 +1033,7 @@ int bin_sort_impl(int P, int width, int height, const uint8_t *compute_locally, 
         constexpr int TILE_B = 8 * ROWS_THREADS_B, TILE_D = 8 * ROWS_THREADS_D;
         auto tickets_of = [](long long tiles) { return (tiles + TICKET_TILES - 1) / TICKET_TILES; };
         const long long nbB = (D + TILE_B - 1) / TILE_B;
-        const int fill_b = cus * 2, fill_d = cus * (ROWS_THREADS_D >= 1024 ? 2 : 4);
+        const int fill_b = cus * 2, fill_d = cus * env_cap("GSR_ROWS_FILL_D", 4);  // (env: A/B measurements only)
         const int grid_b = (int)(tickets_of(nbB) < fill_b ? tickets_of(nbB) : fill_b);
         const long long nbs = (D + SEGSCAN_TILE - 1) / SEGSCAN_TILE;
         // (every workgroup costs a ticket -- an atomic on one word, ~15 ns each when hammered -- whether it finds work or not,

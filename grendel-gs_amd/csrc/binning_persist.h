@@ -40,6 +40,9 @@
 
 namespace {
 
+// K3's word per Gaussian on the (row, column) path: pairs (<= 256 x 256 tiles: 17 bits) | rows of the rect << 20 (9 bits)
+constexpr int TT_SHIFT = 20;
+constexpr uint32_t TT_MASK = (1u << TT_SHIFT) - 1u;
 constexpr uint32_t GB_ABORT = 0x80000000u;
 constexpr int GB_FAN = 32;          // workgroups per leaf counter of the barrier tree and per count aggregate
 constexpr int GB_LEAF_STRIDE = 32;  // words between leaf counters (128 bytes: one line each)
@@ -555,7 +558,7 @@ struct PrepPersistArgs {
     const float4 *conic_opacity;
     const uint8_t *mask;
     uint32_t *tt, *kA, *vA, *kB, *vB, *offsets;
-    uint32_t *hh, *segoff;  // rows of a Gaussian's rect; exclusive scan of hh[sorted id] (segoff[P] = row segments R)
+    uint32_t *segoff;  // exclusive scan of the rects' rows in depth order (segoff[P] = row segments R)
     TileRect *rects;
     uint32_t *tile_hist;  // [8 replicas][4][256] or null (frames above 256 x 256 tiles)
     int cull;             // exact tile culling (gsr_tile_mask); only with tile_hist (the (row, column) path)
@@ -676,8 +679,9 @@ bin_prepare_persist_kernel(const PrepPersistArgs a) {
                 }
                 if (n) key[r] = __float_as_uint(dep[q4]);
                 nsum += n;
-                st_agent(&a.tt[i], n);  // (gathered by other workgroups in the scan phase)
-                st_agent(&a.hh[i], n ? (rect.ys >> 16) - (rect.ys & 0xFFFFu) : 0u);  // rows of the rect (row segments)
+                // (gathered by other workgroups in the scan phase; the rows of the rect -- its row segments -- ride in the
+                // upper bits on the (row, column) path)
+                st_agent(&a.tt[i], (a.tile_hist && n) ? (n | (((rect.ys >> 16) - (rect.ys & 0xFFFFu)) << TT_SHIFT)) : n);
                 a.rects[i] = rect;
                 if (!keep) {
                     st_agent(&a.kA[i], key[r]);
@@ -836,9 +840,9 @@ bin_prepare_persist_kernel(const PrepPersistArgs a) {
         uint32_t s = 0, sh = 0;
 #pragma unroll
         for (int k = 0; k < PP_ITEMS; k++) {
-            const uint32_t id = (base + k < P) ? ld_agent(&a.vA[base + k]) : 0u;
-            v[k] = (base + k < P) ? ld_agent(&a.tt[id]) : 0u;
-            hv[k] = (base + k < P) ? ld_agent(&a.hh[id]) : 0u;
+            const uint32_t x = (base + k < P) ? ld_agent(&a.tt[ld_agent(&a.vA[base + k])]) : 0u;
+            v[k] = a.tile_hist ? (x & TT_MASK) : x;
+            hv[k] = a.tile_hist ? (x >> TT_SHIFT) : 0u;
             s += v[k];
             sh += hv[k];
         }
@@ -874,9 +878,9 @@ bin_prepare_persist_kernel(const PrepPersistArgs a) {
         if (!keep) {
 #pragma unroll
             for (int k = 0; k < PP_ITEMS; k++) {
-                const uint32_t id = (base + k < P) ? ld_agent(&a.vA[base + k]) : 0u;
-                v[k] = (base + k < P) ? ld_agent(&a.tt[id]) : 0u;
-                hv[k] = (base + k < P) ? ld_agent(&a.hh[id]) : 0u;
+                const uint32_t x = (base + k < P) ? ld_agent(&a.tt[ld_agent(&a.vA[base + k])]) : 0u;
+                v[k] = a.tile_hist ? (x & TT_MASK) : x;
+                hv[k] = a.tile_hist ? (x >> TT_SHIFT) : 0u;
             }
         }
 #pragma unroll

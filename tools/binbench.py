@@ -20,8 +20,8 @@ from diff_gaussian_rasterization import _lib  # noqa: E402
 def load(path):
     lib = ctypes.CDLL(path)
     for name in ("gsr_bin_prepare_bytes", "gsr_bin_prepare", "gsr_bin_sort_bytes", "gsr_bin_sort", "gsr_set_bin_persistent",
-                 "gsr_set_tile_cull"):
-        if name in ("gsr_set_bin_persistent", "gsr_set_tile_cull") and not hasattr(lib, name):
+                 "gsr_set_tile_cull", "gsr_set_bin_rowmajor"):
+        if name in ("gsr_set_bin_persistent", "gsr_set_tile_cull", "gsr_set_bin_rowmajor") and not hasattr(lib, name):
             continue  # (a library built before ABI 11)
         res, args = _lib.SIGNATURES[name]
         fn = getattr(lib, name)
@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--modes", nargs="*", default=["off", "prepare", "sort", "both"],
                     help="gsr_set_bin_persistent modes to time on the production library (lists compared bitwise)")
     ap.add_argument("--cull", nargs="*", type=int, default=[0], help="gsr_set_tile_cull modes to time (0 off, 1 on)")
+    ap.add_argument("--rows", nargs="*", type=int, default=[0, 1],
+                    help="gsr_set_bin_rowmajor modes to time (0: the two-pass pipelines, 1: one pass over the pairs)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     W, H = a.width, a.height
@@ -62,14 +64,15 @@ def main():
     ptr = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     codes = {"off": 0, "prepare": 1, "sort": 2, "both": 3}
-    libs = [(f"production[{m}, cull {c}]", _lib.LIB_PATH, (codes[m], c)) for c in a.cull for m in a.modes] + \
-           [(os.path.basename(p), p, None) for p in a.lib]
+    libs = [(f"production[{m}, cull {c}, rows {r}]", _lib.LIB_PATH, (codes[m], c, r)) for c in a.cull for r in a.rows
+            for m in a.modes if not (r and m in ("sort", "both"))] + [(os.path.basename(p), p, None) for p in a.lib]
     ref_lists, ref_cull = None, None
     for name, path, mode in libs:
         lib = load(path)
         if mode is not None:
             assert lib.gsr_set_bin_persistent(mode[0]) == 0
             assert lib.gsr_set_tile_cull(mode[1]) == 0
+            assert lib.gsr_set_bin_rowmajor(mode[2]) == 0
             if mode[1] != ref_cull:
                 ref_lists, ref_cull = None, mode[1]  # (lists are compared between modes of ONE culling setting)
         ranges = torch.empty((gx * gy + 1, 2), dtype=torch.int32, device=dev)
