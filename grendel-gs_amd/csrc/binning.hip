@@ -939,7 +939,17 @@ SortLayout sort_layout(int64_t D, int passes, int gx = 0, int gy = 0) {
 
 // K5-K7 with one D-sized pass (binning_rows.h): on by default where it applies -- frames of <= 256 x 256 tiles, uncut rects
 std::atomic<int> g_rows_override{-1};  // gsr_set_bin_rowmajor: -1 = environment (GSR_BIN_ROWS = 0 | 1, default 1)
-bool rows_path(int gx, int gy) {
+// ... from ~5 million pairs on: below, its four launches (three latency chains of one tile each) lose to the persistent sort
+// kernel / the two look-back passes -- measured (tools/binbench.py, K5-K7 alone, exact sizes): 1.8 M pairs 71 against 54 us,
+// 5.6 M 107 against 101 us, 13.6 M 157 against 188 us (profiles/r06_rows_pipeline.txt).  GSR_BIN_ROWS_MIN overrides
+// (tests set 1 to run it on small scenes).
+long long rows_min_pairs() {
+    const char *e = getenv("GSR_BIN_ROWS_MIN");
+    const long long v = e ? atoll(e) : 0;
+    return v > 0 ? v : (5ll << 20);
+}
+bool rows_path(int gx, int gy, long long D = -1) {
+    if (D >= 0 && D < rows_min_pairs()) return false;
     int mode = g_rows_override.load(std::memory_order_relaxed);
     if (mode < 0) {
         static const int env_mode = [] {
@@ -1012,7 +1022,7 @@ int bin_sort_impl(int P, int width, int height, const uint8_t *compute_locally, 
         const int fault = persist_fault_check(dev0);
         if (fault) return fault;
     }
-    if (rows_path(gx, gy)) {
+    if (rows_path(gx, gy, D)) {
         // ---- the row-major pipeline (binning_rows.h): segments by row, their scan, ONE pass over the pairs
         const RowsLayout R = rows_layout(D, gx, gy);
         if (scratch_bytes < R.total) return GSR_ENOSPACE;
@@ -1182,7 +1192,7 @@ extern "C" int gsr_bin_speculative_async(int P, int width, int height, const flo
         if (yx_path(gx, gy) && capacity <= RADIX_MAX_N) {
             const RadixPlan plan = radix_plan(0, tile_bits(gx * gy));
             const SortLayout S = sort_layout(capacity, plan.passes < 2 ? 2 : plan.passes, gx, gy);
-            if (scratch_bytes >= S.total && rows_path(gx, gy)) {
+            if (scratch_bytes >= S.total && rows_path(gx, gy, capacity)) {
                 const RowsLayout RL = rows_layout(capacity, gx, gy);
                 zero_ptr = reinterpret_cast<char *>(scratch) + RL.ctrl;
                 zero_bytes = ((RL.ctrl_bytes + 15) / 16) * 16;

@@ -64,17 +64,20 @@ def test_preprocess_forward_matches_c_oracle(device, N, W, H, sc, seed, ci, sh_d
     assert m2[culled].abs().sum().item() == 0 and co[culled].abs().sum().item() == 0
 
 
-@pytest.mark.parametrize("cull", [False, True])
+@pytest.mark.parametrize("cull,rows", [(False, False), (True, False), (False, True)])
 @pytest.mark.parametrize("N,W,H,sc,seed,ci", SCENES)
-def test_binning_is_ordered_subsequence_of_reference_lists(device, N, W, H, sc, seed, ci, cull):
+def test_binning_is_ordered_subsequence_of_reference_lists(device, monkeypatch, N, W, H, sc, seed, ci, cull, rows):
     """per tile: the HIP list is a SUBSEQUENCE of the reference-order list (depth, then index), and
     every Gaussian dropped from a tile has alpha < 1/255 on all of the tile's pixels (float64 check),
     i.e. the reference algorithm would have skipped it on every pixel -- with the bounding rect of the
-    alpha >= 1/255 ellipse and with the exact per-row tile spans (gsr_set_tile_cull)"""
+    alpha >= 1/255 ellipse, with the exact per-row tile spans (gsr_set_tile_cull), and (round 6) through the row-major
+    pipeline (csrc/binning_rows.h: sorted row segments, one pass over the pairs), which production takes from 5 M pairs
+    on and GSR_BIN_ROWS_MIN=1 forces on these small scenes"""
     import diff_gaussian_rasterization as dgr
     from diff_gaussian_rasterization import bin_gaussians
     from oracle import cref as C
 
+    monkeypatch.setenv("GSR_BIN_ROWS_MIN", "1" if rows else "1000000000000")
     dgr.set_tile_cull(cull)
     try:
         _binning_subsequence_case(device, N, W, H, sc, seed, ci, cull, bin_gaussians, C)
@@ -181,6 +184,7 @@ def test_persistent_binning_equals_the_lookback_pipeline(device, monkeypatch, gr
     # (grid_p = 2 without max_tpw: 9000 Gaussians take the 8192-element tiles, 20000 fall back to the look-back pipeline;
     # GSR_BIN_PERSIST_MAXD: the sort kernel whatever the pair count)
     monkeypatch.setenv("GSR_BIN_PERSIST_MAXD", "1000000000")
+    monkeypatch.setenv("GSR_BIN_ROWS_MIN", "1")  # (the row-major pipeline whatever the pair count)
     for name, v in (("GSR_BIN_GRID_P", grid_p), ("GSR_BIN_GRID_S", grid_s), ("GSR_BIN_OWNERS", owners),
                     ("GSR_BIN_MAX_TPW", max_tpw)):
         if v is not None:
