@@ -96,6 +96,39 @@ GroupLayout group_layout(long long N) {
 }
 }  // namespace
 
+// The per-iteration densification statistics (densification.py:13-25 of the reference, after every backward of the
+// densification phase -- half of a 30 000-iteration run): for the Gaussians visible in the view (radius > 0)
+//   max_radii2D = max(max_radii2D, radius);  xyz_gradient_accum += |d loss / d means2D|;  denom += 1
+// as ONE launch over the P rows instead of the reference's boolean indexing (two `nonzero` host syncs, six gather / scatter
+// kernels).  `grad`: the means2D gradient, rows `grad_stride` floats apart (2 for a dense [P,2]; 9 for the view of K10's
+// [P,9] record the operator hands out).  An invisible Gaussian's gradient row is exactly 0 (K10 never touches it), so the
+// accumulators of invisible rows keep their bits whether or not the row is skipped; it IS skipped (radius 0).
+__global__ void __launch_bounds__(256)
+densify_stats_kernel(long long P, const int32_t *__restrict__ radii, const float *__restrict__ grad,
+                     long long grad_stride, float *__restrict__ max_radii2D, float *__restrict__ accum,
+                     float *__restrict__ denom) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const int32_t r = radii[i];
+    if (r <= 0) return;
+    const float gx = grad[i * grad_stride], gy = grad[i * grad_stride + 1];
+    max_radii2D[i] = fmaxf(max_radii2D[i], (float)r);
+    accum[i] += sqrtf(__builtin_fmaf(gy, gy, __fmul_rn(gx, gx)));
+    denom[i] += 1.0f;
+}
+
+extern "C" int gsr_densify_stats(int64_t P, const int32_t *radii, const float *grad, int64_t grad_stride,
+                                 float *max_radii2D, float *accum, float *denom, gsr_stream_t stream) {
+    if (P < 0 || grad_stride < 2) return GSR_EINVAL;
+    if (P == 0) return 0;
+    if (!radii || !grad || !max_radii2D || !accum || !denom) return GSR_EINVAL;
+    hipLaunchKernelGGL(densify_stats_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), (long long)P, radii, grad, (long long)grad_stride,
+                       max_radii2D, accum, denom);
+    GSR_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" size_t gsr_group_rows_bytes(int64_t N) {
     if (N < 0) return 0;
     return group_layout(N).total;

@@ -293,9 +293,14 @@ def update_densification_stats(self, viewspace_point_tensor, radii):
     leaves max_radii2D alone, radii are never negative) and a means2D gradient of exactly 0 (K10 never touches its row
     of the zero-initialised record; the mirror exchange scatter-adds into zeros), so the unmasked updates change the
     same rows by the same amounts, bit for bit; `denom` counts the rows with radius > 0."""
+    g = viewspace_point_tensor.grad
+    if (radii.dtype == torch.int32 and g.dtype == torch.float32 and g.dim() == 2 and g.stride(1) == 1 and
+            all(t.dtype == torch.float32 and t.is_contiguous() for t in (self.max_radii2D, self.xyz_gradient_accum,
+                                                                         self.denom))):
+        dgr.densify_stats(radii, g, self.max_radii2D, self.xyz_gradient_accum, self.denom)  # ONE launch
+        return
     r = radii if radii.dtype == torch.float32 else radii.float()
     torch.maximum(self.max_radii2D, r.view_as(self.max_radii2D), out=self.max_radii2D)
-    g = viewspace_point_tensor.grad
     self.xyz_gradient_accum += torch.linalg.vector_norm(g[:, :2], dim=-1, keepdim=True)
     self.denom += (radii > 0).view_as(self.denom)
 

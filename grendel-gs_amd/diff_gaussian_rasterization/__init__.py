@@ -29,7 +29,7 @@ from ._lib import check, lib
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "_C", "load_image_tiles_by_pos",
            "merge_image_tiles_by_pos", "set_timing_mode", "fused_l1_ssim_band", "fused_band_loss", "fused_activations", "pack_camera",
            "preprocess_gaussians_raw_batched", "knn_mean_dist2", "group_rows", "gather_rows", "exchange_need",
-           "exchange_count", "exchange_pack", "exchange_pack_slab", "exchange_unpack", "zeros_async", "scatter_add_rows",
+           "exchange_count", "exchange_pack", "exchange_pack_slab", "exchange_unpack", "zeros_async", "scatter_add_rows", "densify_stats",
            "set_tie_order", "scatter_rows", "local_pixels", "GraphCapture", "capturing"]
 
 BLOCK_X, BLOCK_Y, ONE_DIM_BLOCK_SIZE = 16, 16, 256
@@ -676,12 +676,24 @@ def set_speculative_sort(on):
 GSR_ERETRY = -3
 
 
-def set_bin_persistent(mode):
+_PERSIST_USER = [None]  # the mode a caller chose explicitly (None: the environment's)
+
+
+def set_bin_persistent(mode, _internal=False):
     """K3-K7 as two persistent launches with grid-wide barriers (default) or as the nine launches of the look-back
     pipeline: "env" (GSR_BIN_PERSIST, default on), False / "off", "prepare", "sort", True / "both"
-    (include/gsraster.h: gsr_set_bin_persistent).  Lists are bit-identical either way."""
+    (include/gsraster.h: gsr_set_bin_persistent).  Lists are bit-identical either way.  A choice made through this
+    function is the caller's: the package's own temporary switches (gaussian_renderer: look-back pipeline while an
+    exchange overlaps on the side stream) never override it."""
     code = {"env": -1, False: 0, "off": 0, "prepare": 1, "sort": 2, True: 3, "both": 3}[mode]
+    if not _internal:
+        _PERSIST_USER[0] = None if mode == "env" else mode
     check(lib.gsr_set_bin_persistent(code), "gsr_set_bin_persistent")
+
+
+def bin_persistent_user_choice():
+    """the mode set_bin_persistent was last given by a caller, or None (the environment decides)"""
+    return _PERSIST_USER[0]
 
 
 def set_bin_rowmajor(mode):
@@ -1435,6 +1447,22 @@ def scatter_add_rows(idx, src, n_rows, dst=None):
     with _on(src.device):
         check(lib.gsr_scatter_add_rows(src.shape[0], _ptr(idx), _ptr(src), _ptr(dst), _stream()), "gsr_scatter_add_rows")
     return dst
+
+
+def densify_stats(radii, grad, max_radii2D, accum, denom):
+    """the per-iteration densification statistics in one launch (include/gsraster.h: gsr_densify_stats); in place.
+    radii int32 [P]; grad float32 [P, >=2] with contiguous rows (any row stride: a column view of K10's record is fine);
+    max_radii2D [P], accum [P,1], denom [P,1] float32 dense"""
+    P = radii.shape[0]
+    for t, n in ((radii, "radii"), (grad, "grad"), (max_radii2D, "max_radii2D"), (accum, "accum"), (denom, "denom")):
+        if not t.is_cuda:
+            raise RuntimeError(f"diff_gaussian_rasterization: `{n}` must live on the gfx950 device (no CPU fallback)")
+    if radii.dtype != torch.int32 or grad.dtype != torch.float32 or grad.dim() != 2 or grad.stride(1) != 1 or \
+            any(t.dtype != torch.float32 or not t.is_contiguous() for t in (max_radii2D, accum, denom)):
+        raise ValueError("densify_stats: int32 radii, float32 grad rows and dense float32 accumulators expected")
+    with _on(radii.device):
+        check(lib.gsr_densify_stats(P, _ptr(radii.contiguous()), _ptr(grad), grad.stride(0) if P > 1 else 2,
+                                    _ptr(max_radii2D), _ptr(accum), _ptr(denom), _stream()), "gsr_densify_stats")
 
 
 def knn_mean_dist2(points):

@@ -57,6 +57,7 @@ SIGNATURES = {
     "gsr_scatter_add_rows": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gsr_knn_workspace_bytes": (c_size_t, [c_int]),
     "gsr_knn_mean_dist2": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "gsr_densify_stats": (c_int, [c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gsr_group_rows_bytes": (c_size_t, [c_int64]),
     "gsr_group_rows": (c_int, [c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "gsr_gather_rows": (c_int, [c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -597,17 +597,20 @@ def _batched_exchange_final(m2_views, rgb_views, co_views, radii_views, depths_v
     side = _side_stream(dev) if overlap else None
     if overlap:
         side.wait_stream(cur)  # K1's outputs and the counts are ready
-        if not _EXCHANGE_OPTIONS.get("_persist_checked"):
+        if not _EXCHANGE_OPTIONS.get("_persist_off"):
             # A collective of camera k+1 runs on the side stream WHILE camera k is binned and rendered.  The persistent
-            # binning kernels (csrc/binning_persist.h) need their whole grid resident: behind an all-to-all that waits
-            # for a late peer they would sit at their first barrier for as long as the peer is late and serialise the
-            # overlap this stream exists for.  With the exchange overlapped the binning therefore takes the look-back
-            # pipeline (many small launches that run beside the collective), unless GSR_BIN_PERSIST says otherwise.
-            _EXCHANGE_OPTIONS["_persist_checked"] = True
-            import os as _os
-
-            if not _os.environ.get("GSR_BIN_PERSIST"):
-                _dgr.set_bin_persistent("off")
+            # prepare kernel (csrc/binning_persist.h) needs its whole grid resident: behind an all-to-all that waits for a
+            # late peer it would sit at its first barrier until its 50 ms time-out sends the view to the look-back
+            # pipeline anyway.  While exchanges overlap, the binning therefore takes the look-back pipeline (many small
+            # launches that run beside the collective) -- unless the caller chose a mode (set_bin_persistent) or the
+            # environment names one (GSR_BIN_PERSIST); the switch is undone by the first batch without overlap (below).
+            if _dgr.bin_persistent_user_choice() is None and not os.environ.get("GSR_BIN_PERSIST"):
+                _dgr.set_bin_persistent("off", _internal=True)
+                _EXCHANGE_OPTIONS["_persist_off"] = True
+    elif _EXCHANGE_OPTIONS.get("_persist_off") and cap_ctx is None:
+        if _dgr.bin_persistent_user_choice() is None:
+            _dgr.set_bin_persistent("env", _internal=True)
+        _EXCHANGE_OPTIONS["_persist_off"] = False
     out = ([None] * B, [None] * B, [None] * B, [None] * B, [None] * B)
     events = [None] * B
     holder = {"rec": None}  # the backward's shared [B*P, 9] gradient record

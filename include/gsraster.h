@@ -429,6 +429,15 @@ size_t gsr_knn_workspace_bytes(int P);
 int gsr_knn_mean_dist2(int P, const float *points, float *mean_dist2, void *workspace, size_t workspace_bytes,
                        gsr_stream_t stream);
 
+/* N4: the per-iteration densification statistics in ONE launch (ABI 12) -- densification.py:13-25 of the reference, run after
+ * every backward of the densification phase: for the rows with radii > 0
+ *   max_radii2D = max(max_radii2D, radii);  xyz_gradient_accum += |grad[:, :2]|;  denom += 1
+ * (scene/gaussian_model.py:1046-1052 `add_densification_stats` + the max_radii2D update in front of it), without the
+ * reference's boolean indexing (two `nonzero` host syncs + six gather / scatter kernels per camera and iteration).
+ * grad: the means2D gradient (NDC-scaled, as the op returns it), rows `grad_stride` floats apart -- 9 for the view of K10's
+ * [P,9] record that the operator hands out as means2D.grad, 2 for a dense [P,2]. */
+int gsr_densify_stats(int64_t P, const int32_t *radii, const float *grad, int64_t grad_stride, float *max_radii2D,
+                      float *accum, float *denom, gsr_stream_t stream);
 /* ---------------------------------------------------------------------------------------------
  * N4  row primitives for densification / redistribution of the Gaussian shard.  The reference selects rows
  * with boolean indexing once PER TENSOR (and per destination rank): prune_points / _prune_optimizer

@@ -226,8 +226,13 @@ def test_densification_statistics_without_boolean_indexing(device):
         D.update_densification_stats(c, vp, radii)
     for m in (b, c):
         assert torch.equal(m.max_radii2D, a.max_radii2D)
-        assert torch.equal(m.xyz_gradient_accum, a.xyz_gradient_accum)
         assert torch.equal(m.denom, a.denom)
+    assert torch.equal(b.xyz_gradient_accum, a.xyz_gradient_accum)  # torch's own norm, no indexing
+    # the one-launch HIP kernel (gsr_densify_stats): sqrt(fma(gy, gy, gx * gx)) -- torch's reduction may round the sum of
+    # squares differently in the last bit
+    dev_ = (c.xyz_gradient_accum - a.xyz_gradient_accum).abs().max().item()
+    assert dev_ <= 4e-7 * a.xyz_gradient_accum.abs().max().item(), dev_
+    print("max |fused - torch| of the accumulated gradient norms:", dev_)
 
 
 def test_reset_opacity_matches_reference_rule(device):
