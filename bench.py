@@ -84,8 +84,14 @@ def algorithmic_bytes(kernel, m):
     if kernel == "binning":  # the reference's algorithm: 64-bit (tile | depth) keys, LSD passes of 8 bits
         key_bits = 32 + max(1, math.ceil(math.log2(max(m["tiles"], 2))))
         return m["P"] * 16 + m["D"] * 12 + m["D"] * 24 * math.ceil(key_bits / 8) + m["D"] * 8
-    if kernel == "binning_own":  # what THIS build's binning moves by construction: 64 B / Gaussian
-        return 64 * m["P"] + 40 * m["D"]  # (K3 + four depth passes + scan) and 40 B / pair (emission, tile sort, ranges)
+    if kernel == "binning_own":  # what THIS build's binning moves by construction
+        # prepare step: 64 B / Gaussian as in rounds 1-5 (K3, four depth passes, the offsets scan) + 4 (the segment offsets).
+        # Row-major pipeline (round 6, from 5 M pairs on; R = row segments, measured per launch): 28 B / segment (sorted
+        # word + index written 8, read by the scan 4, its offset written 4, all three read by the pair pass 12) + 4 B /
+        # pair (its index, written once).  Two-pass pipelines (below that, or R unknown): 40 B / pair.
+        if m.get("R") and m["D"] >= (5 << 20):
+            return 68 * m["P"] + 28 * m["R"] + 4 * m["D"]
+        return 64 * m["P"] + 40 * m["D"]
     if kernel == "composite_forward":
         return 40 * m["D"] + 20 * m["Px"]
     if kernel == "composite_backward":
@@ -684,8 +690,12 @@ def run_workload(a, name, world, rank, dev, steps, warmup, repeats, render_steps
             # bytes THIS build's split-key binning moves by construction; the reference's 64-bit-key
             # algorithm would move `reference_algorithm_MB` -- a speed-up statement, not a roofline
             own = sum(algorithmic_bytes("binning_own", dict(meta)) for _, meta in recs)
+            R_sum = sum((meta.get("R") or 0) for _, meta in recs)
             k.update({"bound": "hbm / launch latency", "algo_MB": round(own / n / 1e6, 3),
-                      "algo_note": "64 B x P + 40 B x D: what this build's split-key binning moves",
+                      "mean_row_segments_R": R_sum // n,
+                      "algo_note": "row-major pipeline (>= 5 M pairs): 68 B x P + 28 B x R + 4 B x D; two-pass pipelines: "
+                                   "64 B x P + 40 B x D -- what this build's binning moves by construction",
+                      "algo_two_pass_MB": round(sum(64 * meta["P"] + 40 * (meta.get("D") or 0) for _, meta in recs) / n / 1e6, 3),
                       "GBps": round(own / (tot_ms * 1e-3) / 1e9, 1) if tot_ms > 0 else None,
                       "frac_hbm_peak": round(own / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if tot_ms > 0 else None,
                       "reference_algorithm_MB": round(tot_b / n / 1e6, 3)})

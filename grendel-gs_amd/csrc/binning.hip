@@ -1246,6 +1246,11 @@ extern "C" size_t gsr_bin_total_offset(int P, int width, int height) {
     return prep_layout(P, width, height).offsets + sizeof(uint32_t) * (size_t)P;  // offsets[P]: K4's total
 }
 
+extern "C" size_t gsr_bin_segments_offset(int P, int width, int height) {
+    if (P < 0 || width <= 0 || height <= 0) return 0;
+    return prep_layout(P, width, height).segoff + sizeof(uint32_t) * (size_t)P;  // segoff[P]: the row segments R
+}
+
 extern "C" int64_t gsr_bin_sort_capacity(int P, size_t scratch_bytes, int width, int height) {
     if (width <= 0 || height <= 0) return 0;
     const int gx = (width + GSR_BLOCK_X - 1) / GSR_BLOCK_X, gy = (height + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y;

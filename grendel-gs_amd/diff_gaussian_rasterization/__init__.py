@@ -677,6 +677,7 @@ GSR_ERETRY = -3
 
 
 _PERSIST_USER = [None]  # the mode a caller chose explicitly (None: the environment's)
+_LAST_SEGMENTS = [0]    # row segments of the last view binned while kernel_timer was enabled
 
 
 def set_bin_persistent(mode, _internal=False):
@@ -910,6 +911,11 @@ def bin_gaussians(means2D, depths, radii, conic_opacity, compute_locally, width,
               "gsr_bin_speculative_async")
     pend = PendingPairs(ticket.value, bool(sorted_.value), cap, P, width, height, compute_locally, prep, ranges, dev,
                         torch.cuda.current_stream(dev), key, cuda_args)
+    if kernel_timer.enabled and ticket.value:
+        # bench.py's instrumented replay only (a device read-back): the row segments R of this view, for the bytes of the
+        # row-major pipeline (include/gsraster.h: gsr_bin_segments_offset)
+        off = int(lib.gsr_bin_segments_offset(P, width, height))
+        _LAST_SEGMENTS[0] = int(prep[off:off + 4].view(torch.int32).item())
     if defer and sorted_.value:
         return point_list, ranges, pend
     D, again = pend.finish()
@@ -961,6 +967,8 @@ class _RenderGaussians(torch.autograd.Function):
                                                       defer=True)
             pend = D if isinstance(D, PendingPairs) else None
             kt.meta["D"] = D = (0 if pend is not None else D)
+            if kernel_timer.enabled:
+                kt.meta["R"] = _LAST_SEGMENTS[0]
             out = torch.empty((3, H, W), dtype=torch.float32, device=dev)
             final_T = torch.empty((H, W), dtype=torch.float32, device=dev)
             n_contrib = torch.empty((H, W), dtype=torch.int32, device=dev)

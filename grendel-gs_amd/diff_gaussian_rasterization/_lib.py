@@ -83,6 +83,7 @@ SIGNATURES = {
                                                      [c_void_p] * 5 + [c_int, c_int] + [c_void_p] * 6 + [c_int] +
                                                      [c_void_p] * 7 + [c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gsr_bin_total_offset": (c_size_t, [c_int, c_int, c_int]),
+    "gsr_bin_segments_offset": (c_size_t, [c_int, c_int, c_int]),
     "gsr_bin_speculative": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_size_t, c_int64, c_void_p, c_size_t, c_void_p, c_void_p, ctypes.POINTER(c_int64),
                                     ctypes.POINTER(c_int), c_void_p]),

@@ -204,6 +204,10 @@ int gsr_bin_timeline(int which, unsigned long long *out, int max_words, int *gri
  * cannot take D through gsr_bin_count_wait inside a replay: they copy the word out / test it with
  * gsr_flag_if_greater.  Stands where the reference reads `num_rendered` back (its rasterizer's forward). */
 size_t gsr_bin_total_offset(int P, int width, int height);
+/* The same for the uint32 count of ROW SEGMENTS R = sum of the rects' heights (ABI 12; the R-sized steps of
+ * csrc/binning_rows.h work on it; 0 on frames above 256 x 256 tiles).  A measurement aid: bench.py reads it in its
+ * instrumented replay to state the bytes the row-major pipeline moves (68 P + 28 R + 4 D). */
+size_t gsr_bin_segments_offset(int P, int width, int height);
 
 /* Capacity checks of a captured (hipGraph) training iteration -- the reference sizes everything from counts it reads
  * back (num_rendered; the exchange's i2j sizes, gaussian_renderer/__init__.py:572-585), a replayed graph cannot.

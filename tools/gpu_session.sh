@@ -9,7 +9,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 export TMPDIR=/tmp
-BENCH="python $R/bench.py --no-cpu-baseline --no-extra --steps 16 --warmup 4 --repeats 1 --render-steps 8"
+BENCH="python $R/bench.py --no-cpu-baseline --no-extra --steps 16 --warmup 4 --repeats 1 --render-steps 8 ${GSR_SESSION_BENCH_ARGS:-}"
 has() { [[ " $STAGES " == *" $1 "* ]]; }
 cd $R
 if has test; then
@@ -31,7 +31,7 @@ for st in trace sq fetch write; do
   esac
   EXTRA=""; [[ $st == fetch || $st == write ]] && EXTRA="--pmc-calib"
   rm -rf $O/prof_$st
-  timeout 900 rocprofv3 --kernel-trace $PMC -d $O/prof_$st -- $BENCH $EXTRA > $O/prof_$st.log 2>&1
+  timeout -k 10 600 rocprofv3 --kernel-trace $PMC -d $O/prof_$st -- $BENCH $EXTRA > $O/prof_$st.log 2>&1 < /dev/null
   echo "rocprofv3 $st exit $?"
 done
 cd $R

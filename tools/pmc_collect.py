@@ -33,7 +33,8 @@ GROUPS = [  # (group, substrings of the kernel symbol, substring that marks ONE 
     ("preprocess_backward", ["preprocess_backward"], "preprocess_backward"),
     # (one call = one K3: the look-back pipeline's touch_count_kernel or the persistent prepare kernel of round 5)
     ("binning", ["touch_count_kernel", "radix_onesweep_kernel", "scan_gather_lookback_kernel", "emit_scatter_kernel",
-                 "emit_pairs_kernel", "tile_ranges", "bin_prepare_persist_kernel", "bin_sort_persist_kernel"],
+                 "emit_pairs_kernel", "tile_ranges", "bin_prepare_persist_kernel", "bin_sort_persist_kernel",
+                 "seg_scatter_kernel", "seg_scan_kernel", "tile_base_kernel", "pair_scatter_kernel"],
      ("touch_count_kernel", "bin_prepare_persist_kernel")),
     ("l1_ssim_forward", ["l1_ssim_forward_kernel", "l1_ssim_finalize_kernel"], "l1_ssim_forward_kernel"),
     ("l1_ssim_backward", ["l1_ssim_backward_kernel"], "l1_ssim_backward_kernel"),
