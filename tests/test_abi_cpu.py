@@ -35,7 +35,32 @@ def test_pure_host_entry_points():
     assert b"invalid" in dgr._lib.lib.gsr_error_string(-1)
     assert dgr._lib.lib.gsr_bin_prepare_bytes(1000, 1920, 1080) > 0
     assert dgr._lib.lib.gsr_bin_sort_bytes(1000, 5000, 1920, 1080) > 5000 * 16
+    lib = dgr._lib.lib
+    assert b"barrier" in lib.gsr_error_string(-4)  # GSR_EFAULT (ABI 12: no kernel traps; a late barrier fault is reported)
+    # workspace arithmetic of the sort (pure host code): the scratch for D pairs holds both layouts (two-pass pipelines:
+    # 16 B / pair; row-major pipeline: 12 B / segment with R <= D, per-tile tables, look-back words), grows with D, and
+    # gsr_bin_sort_capacity inverts it
+    prev = 0
+    for D in (1, 4095, 4096, 1 << 20, (5 << 20) - 1, 5 << 20, 14_000_000, 100_000_000):
+        nbytes = lib.gsr_bin_sort_bytes(1000, D, 1920, 1080)
+        assert nbytes >= 16 * D and nbytes >= prev, (D, nbytes)
+        cap = lib.gsr_bin_sort_capacity(1000, nbytes, 1920, 1080)
+        assert cap >= D and lib.gsr_bin_sort_bytes(1000, cap, 1920, 1080) <= nbytes, (D, cap)
+        prev = nbytes
+    assert lib.gsr_bin_sort_capacity(1000, 1 << 30, 8000, 8000) == 0  # > 256 x 256 tiles: no bounded sort
+    # the device words a caller may read from the prepare workspace lie inside it
+    for P in (1, 1000, 1_000_000):
+        total = lib.gsr_bin_prepare_bytes(P, 1920, 1080)
+        assert 0 < lib.gsr_bin_total_offset(P, 1920, 1080) < total
+        assert 0 < lib.gsr_bin_segments_offset(P, 1920, 1080) < total
+        assert lib.gsr_bin_total_offset(P, 1920, 1080) != lib.gsr_bin_segments_offset(P, 1920, 1080)
+    for mode in (-1, 0, 1):
+        assert lib.gsr_set_bin_rowmajor(mode) == 0
+    assert lib.gsr_set_bin_rowmajor(2) == -1 and lib.gsr_set_bin_rowmajor(-1) == 0
     # argument validation happens before any device work
+    assert lib.gsr_densify_stats(-1, None, None, 9, None, None, None, None) == -1
+    assert lib.gsr_densify_stats(10, None, None, 1, None, None, None, None) == -1  # a row holds at least (x, y)
+    assert lib.gsr_densify_stats(0, None, None, 9, None, None, None, None) == 0
     rc = dgr._lib.lib.gsr_preprocess_forward(-1, 3, 16, *([None] * 2), 1.0, *([None] * 6), 10, 10, 1.0, 1.0,
                                              *([None] * 8))
     assert rc == -1
