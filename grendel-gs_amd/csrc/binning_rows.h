@@ -14,14 +14,15 @@
 //                        heights, written by the prepare step beside the pair offsets) and scattered by row in one
 //                        one-sweep pass; a segment travels as one word (row, minx, maxx) + the Gaussian's index.
 //   seg_scan_kernel      R-sized.  pairoff = exclusive scan of the segments' widths in the sorted order (the position of
-//                        a segment's first pair in the row-major emission), and the per-tile pair counts as a per-row
-//                        difference array (+1 at minx, -1 at maxx), pre-aggregated in LDS.
+//                        a segment's first pair in the row-major emission); the per-tile pair counts as per-row
+//                        difference arrays (+1 at minx, -1 at maxx), pre-aggregated in LDS, one replica per XCD; the
+//                        segment that owns the first pair of every 512-pair chunk.
+//   tile_base_kernel     one workgroup per tile row: the start of every (row, column) list = the row's pair prefix + the
+//                        prefix of the row's tile counts, and the ranges -- no K7 pass over sorted keys, no key array.
 //   pair_scatter_kernel  D-sized, the only one.  Tiles of 4096 pairs never straddle a tile row; a tile decodes its pairs
 //                        (flag-word decode over pairoff, as emit_scatter_kernel does over the Gaussian-major offsets),
-//                        ranks them by column and writes ONLY the Gaussian index, straight into point_list: the global
-//                        start of a (row, column) list is the row's pair prefix + the prefix of the row's tile counts,
-//                        the look-back runs inside the row.  The first tile of a row also writes the row's ranges --
-//                        no K7 pass over the sorted keys, no key array at all.
+//                        ranks them by column and writes ONLY the Gaussian index, straight into point_list; the
+//                        look-back runs inside the row.
 //
 // Pair traffic: 4 B written per pair (was 8 + 8 + 8 + 4 read / written over two passes and K7); the R-sized steps move
 // ~12 B per segment.  Lists, ranges and counts are identical to both older pipelines
@@ -51,7 +52,7 @@ __device__ unsigned long long g_rows_ts2[16384 * 8];  // the same for seg_scatte
 #endif
 
 constexpr int SEG_ROW_SHIFT = 18;  // segment word: row << 18 | minx << 9 | maxx  (minx < 256, maxx <= 256, row < 256)
-constexpr int ROWS_LDS = 4;        // tile rows whose count differences a scan workgroup keeps in LDS (its 2048 sorted
+constexpr int ROWS_LDS = 4;        // tile rows whose count differences a scan workgroup keeps in LDS (its 8192 sorted
                                    // segments rarely span more; the rest go to global atomics directly)
 
 // Tiles are handed out by ticket (a workgroup only ever waits for tiles that running workgroups own).  A ticket may grant
