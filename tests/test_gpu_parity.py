@@ -36,6 +36,7 @@ SCENES = [
     (5000, 333, 211, 0.02, 7, 2),        # non-multiple-of-16 image, big splats, long lists
     (20000, 979, 546, 0.006, 5, 3),      # BASELINE config[3] image shape (62 x 35 tiles, ragged right / bottom edge)
     (4000, 80, 4128, 0.01, 9, 0),        # 258 tile rows: beyond the (row, column)-key path -> generic tile-id sort
+    (3000, 4096, 64, 0.02, 4, 0),        # exactly 256 tile columns: the widest frame of the (row, column) / row-major paths
 ]
 
 
