@@ -16,7 +16,7 @@ const char *gsr_error_string(int code) {
     return "gsraster: unknown error";
 }
 
-int gsr_abi_version(void) { return 12; }
+int gsr_abi_version(void) { return 13; }
 
 int gsr_get_block_xy(int *block_x, int *block_y, int *one_dim_block) {
     if (!block_x || !block_y || !one_dim_block) return GSR_EINVAL;

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(HERE)
 OUT_DIR = os.path.join(ROOT, "diff_gaussian_rasterization")
 SO = os.path.join(OUT_DIR, "libgsraster.so")
 UNITS = ["preprocess", "binning", "composite", "loss", "optim", "activations", "knn", "compact", "exchange", "api"]
-HEADERS = [os.path.join(HERE, "common.h"), os.path.join(HERE, "radix.h"), os.path.join(HERE, "binning_persist.h"), os.path.join(os.path.dirname(ROOT), "include", "gsraster.h")]
+HEADERS = [os.path.join(HERE, "common.h"), os.path.join(HERE, "radix.h"), os.path.join(HERE, "binning_persist.h"), os.path.join(HERE, "binning_rows.h"), os.path.join(os.path.dirname(ROOT), "include", "gsraster.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall",
          "-Wno-unused-function"]
 

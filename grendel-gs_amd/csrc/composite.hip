@@ -261,6 +261,7 @@ composite_forward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < zero16_n; i += (size_t)gridDim.x * 256)
         zero16[i] = make_uint4(0u, 0u, 0u, 0u);
     int tile;
+    bool idle = false;
     if (BAND) {
         // The caller knows the rows of its band on the HOST (Grendel's strategies do): the grid covers the band's tiles
         // only.  With a grid over all tiles the 7/8 of the workgroups that are not ours on a 1/8 band still have to be
@@ -268,7 +269,18 @@ composite_forward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
         // launch whatever the band (K10: 0.388 / 0.224 / 0.154 / 0.117 ms for 1 / 2 / 4 / 8 bands = 0.06 + 0.33 / W).
         // The pixels outside the band must still be exactly 0 (SUM assembly): the band's workgroups clear them together,
         // with coalesced stores, before they start on their tiles.
-        tile = band_first + gsr_xcd_span_of_block(blockIdx.x, band_tiles);
+        // band_first < 0 (a launch captured in a hipGraph that has to serve every band, graphed_step.py): `band_tiles`
+        // is a CAPACITY, the band itself is the row hull the binning left behind the range table; the workgroups above
+        // the band's tile count only help to clear the pixels outside.
+        if (band_first < 0) {
+            const int gy = (H + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y;
+            int2 hull = ranges[gx * gy];
+            if (hull.x < 0 || hull.y > gy || hull.x >= hull.y) hull = make_int2(0, 0);
+            band_first = hull.x * gx;
+            band_tiles = min((hull.y - hull.x) * gx, band_tiles);
+            idle = (int)blockIdx.x >= band_tiles;
+        }
+        tile = band_first + (idle ? 0 : gsr_xcd_span_of_block(blockIdx.x, band_tiles));
     } else {
         tile = composite_tile_of_block(ranges, gx, (int)gridDim.x);
     }
@@ -288,6 +300,10 @@ composite_forward_kernel(int W, int H, int gx, const int2 *__restrict__ ranges,
             n_contrib[q] = 0;
         }
     };
+    if (idle) {
+        clear_outside();
+        return;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tx = tile % gx, ty = tile / gx;
     const int qx0 = tx * GSR_BLOCK_X + (wave & 1) * 8, qy0 = ty * GSR_BLOCK_Y + (wave >> 1) * 8;
@@ -751,6 +767,14 @@ composite_backward_kernel(int W, int H, int gx, int tiles, const int2 *__restric
     // device) by atomic ticket.
     const int nstatic = band_tiles > 0 ? band_tiles : tiles;
     const bool worker = (int)blockIdx.x >= nstatic;
+    if (band_first < 0 && band_tiles > 0) {  // a capacity grid (see K8): the band is the hull behind the range table
+        const int gy = tiles / gx;
+        int2 hull = ranges[tiles];
+        if (hull.x < 0 || hull.y > gy || hull.x >= hull.y) hull = make_int2(0, 0);
+        band_first = hull.x * gx;
+        band_tiles = min((hull.y - hull.x) * gx, band_tiles);
+        if (!worker && (int)blockIdx.x >= band_tiles) return;
+    }
     __shared__ uint32_t s_item;
     const uint32_t count = worker ? min(seg.hdr[0], seg.cap) : 0u;
     for (;;) {
@@ -814,8 +838,11 @@ int gsr_launch_composite_forward(int P, int W, int H, const int32_t *ranges, con
     if (zero_bytes & 15)
         GSR_HIP(hipMemsetAsync(reinterpret_cast<char *>(zero_ptr) + zero16_n * 16, 0, zero_bytes & 15, stream));
     const int gx = (W + GSR_BLOCK_X - 1) / GSR_BLOCK_X, gy = (H + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y;
-    const bool band = row_lo >= 0 && row_lo < row_hi && row_hi <= gy && !(row_lo == 0 && row_hi == gy);
-    const int band_first = band ? row_lo * gx : 0, band_tiles = band ? (row_hi - row_lo) * gx : 0;
+    // row_lo == -1: `row_hi` tile rows are a CAPACITY, the band is read from the device (see composite_forward_kernel)
+    const bool dyn = row_lo == -1 && row_hi > 0 && row_hi <= gy;
+    const bool band = dyn || (row_lo >= 0 && row_lo < row_hi && row_hi <= gy && !(row_lo == 0 && row_hi == gy));
+    const int band_first = dyn ? -1 : band ? row_lo * gx : 0;
+    const int band_tiles = dyn ? row_hi * gx : band ? (row_hi - row_lo) * gx : 0;
     if (seg_ws && seg_bytes < seg_ws_bytes(gx * gy, SEG_CAP)) return GSR_ENOSPACE;
     const SegWs seg = seg_ws_of(seg_ws, gx * gy, SEG_CAP);
     if (seg_ws) GSR_HIP(hipMemsetAsync(seg_ws, 0, 64, stream));  // { segments queued, the backward's ticket }
@@ -843,8 +870,11 @@ int gsr_launch_composite_backward(int P, int W, int H, const int32_t *ranges, co
     if (!record_is_zero) GSR_HIP(hipMemsetAsync(dL_record, 0, sizeof(float) * 9 * (size_t)P, stream));
     if (P == 0) return 0;
     const int gx = (W + GSR_BLOCK_X - 1) / GSR_BLOCK_X, gy = (H + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y;
-    const bool band = row_lo >= 0 && row_lo < row_hi && row_hi <= gy && !(row_lo == 0 && row_hi == gy);
-    const int band_first = band ? row_lo * gx : 0, band_tiles = band ? (row_hi - row_lo) * gx : 0;
+    // row_lo == -1: `row_hi` tile rows are a CAPACITY, the band is read from the device (see composite_forward_kernel)
+    const bool dyn = row_lo == -1 && row_hi > 0 && row_hi <= gy;
+    const bool band = dyn || (row_lo >= 0 && row_lo < row_hi && row_hi <= gy && !(row_lo == 0 && row_hi == gy));
+    const int band_first = dyn ? -1 : band ? row_lo * gx : 0;
+    const int band_tiles = dyn ? row_hi * gx : band ? (row_hi - row_lo) * gx : 0;
     if (seg_ws && (seg_bytes < seg_ws_bytes(gx * gy, SEG_CAP) || !out_color)) return GSR_EINVAL;
     const SegWs seg = seg_ws_of(seg_ws, gx * gy, SEG_CAP);
     // the workers' ticket is reset per launch, so that a second backward over the same forward (retain_graph, gradcheck)

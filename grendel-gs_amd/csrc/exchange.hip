@@ -467,7 +467,28 @@ __global__ void publish_flag_kernel(const uint32_t *__restrict__ flag, const uin
         __hip_atomic_store(w + 1, s, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
+// compute_locally of B row bands whose rows are DEVICE data: mask[k][ty][tx] = lo_k <= ty < hi_k, band_rows = B records
+// of `stride` int32 words that begin with { lo, hi }
+__global__ void __launch_bounds__(256) band_mask_kernel(int gx, int gy, int B, const int32_t *__restrict__ band_rows,
+                                                         int stride, uint8_t *__restrict__ mask) {
+    const int tiles = gx * gy;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < tiles * B; i += gridDim.x * 256) {
+        const int k = i / tiles, ty = (i - k * tiles) / gx;
+        const int lo = band_rows[(size_t)k * stride], hi = band_rows[(size_t)k * stride + 1];
+        mask[i] = (ty >= lo && ty < hi) ? 1 : 0;
+    }
+}
 }  // namespace
+
+extern "C" int gsr_band_mask(int grid_x, int grid_y, int B, const int32_t *band_rows_dev, int stride_words,
+                             uint8_t *mask, gsr_stream_t stream_) {
+    if (grid_x <= 0 || grid_y <= 0 || B <= 0 || !band_rows_dev || stride_words < 2 || !mask) return GSR_EINVAL;
+    const int n = grid_x * grid_y * B;
+    hipLaunchKernelGGL(band_mask_kernel, dim3(min(gsr_div_up(n, 256), 256)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream_), grid_x, grid_y, B, band_rows_dev, stride_words, mask);
+    GSR_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int gsr_publish_flag(const uint32_t *flag_dev, const uint32_t *seq_dev, uint32_t *host_ring_pinned,
                                 uint32_t slots, gsr_stream_t stream_) {

@@ -54,14 +54,32 @@ __device__ __forceinline__ float block_sum(float v, float *smem) {
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 // workgroup -> (channel, tile row, tile column); tile id = the index of the workgroup's partial sums
-__device__ __forceinline__ int loss_tile(int gxT, int gyT, int &c, int &ox, int &oy) {
-    const int lin = gsr_xcd_span_of_block(blockIdx.x, gridDim.x);
+__device__ __forceinline__ int loss_tile(int gxT, int gyT, int &c, int &ox, int &oy, int nwg) {
+    const int lin = gsr_xcd_span_of_block(blockIdx.x, nwg);
     c = lin / (gxT * gyT);
     const int rem = lin - c * (gxT * gyT);
     const int by = rem / gxT;
     ox = (rem - by * gxT) * TW;
     oy = by * TH;
     return lin;
+}
+// A launch whose band is DEVICE data (gsr_l1_ssim_*_band: one captured launch serves every band of a camera): `rows` is
+// then the capacity the buffers were sized for -- ground truth and maps keep the capacity's channel stride -- and
+// band = { first pixel row, end row } of the image.  The workgroups are mapped over the band's own tiles, so tile ids and
+// the order in which the finalize adds the partial sums are those of a launch sized for the band; the workgroups
+// above that count publish zero sums.  -> false: nothing to do for this workgroup
+__device__ __forceinline__ bool loss_band(const int *__restrict__ band, int rows_cap, int W, int gxT, int &rows, int &gyT,
+                                          int &nwg, long long &row_off) {
+    nwg = gridDim.x;
+    row_off = 0;
+    if (!band) return true;
+    const int channels = nwg / (gxT * gyT);
+    const int y0 = band[0], y1 = band[1];
+    rows = max(0, min(y1 - y0, rows_cap));
+    gyT = (rows + TH - 1) / TH;
+    nwg = channels * gxT * gyT;
+    row_off = (long long)y0 * W;
+    return (int)blockIdx.x < nwg;
 }
 constexpr int HV = (TW + 16) / 4;  // aligned 4-element vectors per halo row: columns [ox - 8, ox + TW + 8)
 static_assert(HH * HV <= LT, "one halo vector per thread");
@@ -70,17 +88,23 @@ template <bool VEC>
 __global__ void __launch_bounds__(LT)
 l1_ssim_forward_kernel(int rows, int W, int gxT, int gyT, const float *__restrict__ image, long long img_cstride,
                        const uint8_t *__restrict__ gt, float *__restrict__ partials, float *__restrict__ M1,
-                       float *__restrict__ M2, float *__restrict__ M3) {
+                       float *__restrict__ M2, float *__restrict__ M3, const int *__restrict__ band) {
     __shared__ v2f sXY[HH][HW + 1];     // (x, y): rendered band / ground truth
     __shared__ v2f hAB[HH][HSTR];       // horizontal pass of (x, y)
     __shared__ v2f hCD[HH][HSTR];       // ... of (x^2, y^2)
     __shared__ float hE[HH][HSTR];      // ... of x y
     __shared__ float red[LT / 64];
-    int c, ox, oy;
-    const int tile_id = loss_tile(gxT, gyT, c, ox, oy);
+    int c, ox, oy, nwg;
+    long long row_off;
+    const int rows_cap = rows;
+    if (!loss_band(band, rows_cap, W, gxT, rows, gyT, nwg, row_off)) {
+        if (threadIdx.x < 2) partials[2 * (size_t)blockIdx.x + threadIdx.x] = 0.f;
+        return;
+    }
+    const int tile_id = loss_tile(gxT, gyT, c, ox, oy, nwg);
     const int tid = threadIdx.x;
-    const float *img_c = image + (long long)c * img_cstride;
-    const uint8_t *gt_c = gt + (size_t)c * rows * W;
+    const float *img_c = image + (long long)c * img_cstride + row_off;
+    const uint8_t *gt_c = gt + (size_t)c * rows_cap * W;
     if (VEC) {
         if (tid < HH * HV) {
             const int ly = tid / HV, q = tid - ly * HV;
@@ -186,7 +210,7 @@ l1_ssim_forward_kernel(int rows, int W, int gxT, int gyT, const float *__restric
             ssim_sum += ssim;
             l1 += fabsf(x - y);
             if (M1) {
-                const size_t off = ((size_t)c * rows + gy) * W + gx;
+                const size_t off = ((size_t)c * rows_cap + gy) * W + gx;
                 M1[off] = 2.f * mu2 * (B - A) * inv - ssim * 2.f * mu1 * (Dd - Cd) * inv;
                 M2[off] = -ssim * inv_d;
                 M3[off] = 2.f * A * inv;
@@ -207,13 +231,16 @@ l1_ssim_backward_kernel(int rows, int W, int gxT, int gyT, const float *__restri
                         const uint8_t *__restrict__ gt, const float *__restrict__ M1, const float *__restrict__ M2,
                         const float *__restrict__ M3, const float *__restrict__ grad_l1_sum,
                         const float *__restrict__ grad_ssim_sum, float scale_l1, float scale_ssim,
-                        float *__restrict__ grad_image, long long grad_cstride) {
+                        float *__restrict__ grad_image, long long grad_cstride, const int *__restrict__ band) {
     __shared__ float sM[3][HH][HW + 1];
     __shared__ float hor[3][HH][HSTR];
-    int c, ox, oy;
-    loss_tile(gxT, gyT, c, ox, oy);
+    int c, ox, oy, nwg;
+    long long row_off;
+    const int rows_cap = rows;
+    if (!loss_band(band, rows_cap, W, gxT, rows, gyT, nwg, row_off)) return;
+    loss_tile(gxT, gyT, c, ox, oy, nwg);
     const int tid = threadIdx.x;
-    const size_t cbase = (size_t)c * rows * W;
+    const size_t cbase = (size_t)c * rows_cap * W;
     if (VEC) {
         if (tid < HH * HV) {
             const int ly = tid / HV, q = tid - ly * HV;
@@ -292,11 +319,11 @@ l1_ssim_backward_kernel(int rows, int W, int gxT, int gyT, const float *__restri
     for (int o = 0; o < VO; o++) {
         const int gy = oy + ty0 + o;
         if (gy >= rows) break;
-        const float x = image[(long long)c * img_cstride + (size_t)gy * W + gx];
+        const float x = image[(long long)c * img_cstride + row_off + (size_t)gy * W + gx];
         const float y = (float)gt[cbase + (size_t)gy * W + gx] * (1.0f / 255.0f);
         const float d = x - y;
         const float sgn = (d > 0.f ? 1.f : 0.f) - (d < 0.f ? 1.f : 0.f);
-        grad_image[(long long)c * grad_cstride + (size_t)gy * W + gx] =
+        grad_image[(long long)c * grad_cstride + row_off + (size_t)gy * W + gx] =
             gl1 * sgn + gss * (cv[0][o] + 2.f * x * cv[1][o] + y * cv[2][o]);
     }
 }
@@ -350,9 +377,9 @@ extern "C" int gsr_l1_ssim_num_partials(int channels, int rows, int width) {
     return channels * gsr_div_up(rows, TS) * gsr_div_up(width, TS);
 }
 
-extern "C" int gsr_l1_ssim_forward(int channels, int rows, int width, const float *image, int64_t image_channel_stride,
-                                   const uint8_t *gt, float *partials, float *dm_dmu1, float *dm_dE11,
-                                   float *dm_dE12, gsr_stream_t stream) {
+static int l1_ssim_forward_impl(int channels, int rows, int width, const float *image, int64_t image_channel_stride,
+                                const uint8_t *gt, float *partials, float *dm_dmu1, float *dm_dE11, float *dm_dE12,
+                                const int *band, gsr_stream_t stream) {
     if (channels <= 0 || rows < 0 || width <= 0) return GSR_EINVAL;
     if (rows == 0) return 0;
     if (!image || !gt || !partials) return GSR_EINVAL;
@@ -363,20 +390,36 @@ extern "C" int gsr_l1_ssim_forward(int channels, int rows, int width, const floa
     if (vec)
         hipLaunchKernelGGL(l1_ssim_forward_kernel<true>, grid, dim3(LT), 0, reinterpret_cast<hipStream_t>(stream), rows,
                            width, gxT, gyT, image, (long long)image_channel_stride, gt, partials, dm_dmu1, dm_dE11,
-                           dm_dE12);
+                           dm_dE12, band);
     else
         hipLaunchKernelGGL(l1_ssim_forward_kernel<false>, grid, dim3(LT), 0, reinterpret_cast<hipStream_t>(stream), rows,
                            width, gxT, gyT, image, (long long)image_channel_stride, gt, partials, dm_dmu1, dm_dE11,
-                           dm_dE12);
+                           dm_dE12, band);
     GSR_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int gsr_l1_ssim_backward(int channels, int rows, int width, const float *image,
-                                    int64_t image_channel_stride, const uint8_t *gt, const float *dm_dmu1,
-                                    const float *dm_dE11, const float *dm_dE12, const float *grad_l1_sum,
-                                    const float *grad_ssim_sum, float scale_l1, float scale_ssim, float *grad_image,
-                                    int64_t grad_channel_stride, gsr_stream_t stream) {
+extern "C" int gsr_l1_ssim_forward(int channels, int rows, int width, const float *image, int64_t image_channel_stride,
+                                   const uint8_t *gt, float *partials, float *dm_dmu1, float *dm_dE11,
+                                   float *dm_dE12, gsr_stream_t stream) {
+    return l1_ssim_forward_impl(channels, rows, width, image, image_channel_stride, gt, partials, dm_dmu1, dm_dE11,
+                                dm_dE12, nullptr, stream);
+}
+
+extern "C" int gsr_l1_ssim_forward_band(int channels, int rows_capacity, int width, const float *image,
+                                        int64_t image_channel_stride, const uint8_t *gt, float *partials,
+                                        float *dm_dmu1, float *dm_dE11, float *dm_dE12, const int32_t *band_rows,
+                                        gsr_stream_t stream) {
+    if (!band_rows || rows_capacity <= 0) return GSR_EINVAL;
+    return l1_ssim_forward_impl(channels, rows_capacity, width, image, image_channel_stride, gt, partials, dm_dmu1,
+                                dm_dE11, dm_dE12, band_rows, stream);
+}
+
+static int l1_ssim_backward_impl(int channels, int rows, int width, const float *image,
+                                 int64_t image_channel_stride, const uint8_t *gt, const float *dm_dmu1,
+                                 const float *dm_dE11, const float *dm_dE12, const float *grad_l1_sum,
+                                 const float *grad_ssim_sum, float scale_l1, float scale_ssim, float *grad_image,
+                                 int64_t grad_channel_stride, const int *band, gsr_stream_t stream) {
     if (channels <= 0 || rows < 0 || width <= 0) return GSR_EINVAL;
     if (rows == 0) return 0;
     if (!image || !gt || !dm_dmu1 || !dm_dE11 || !dm_dE12 || !grad_l1_sum || !grad_ssim_sum || !grad_image)
@@ -387,13 +430,37 @@ extern "C" int gsr_l1_ssim_backward(int channels, int rows, int width, const flo
     if (vec)
         hipLaunchKernelGGL(l1_ssim_backward_kernel<true>, grid, dim3(LT), 0, reinterpret_cast<hipStream_t>(stream), rows,
                            width, gxT, gyT, image, (long long)image_channel_stride, gt, dm_dmu1, dm_dE11, dm_dE12,
-                           grad_l1_sum, grad_ssim_sum, scale_l1, scale_ssim, grad_image, (long long)grad_channel_stride);
+                           grad_l1_sum, grad_ssim_sum, scale_l1, scale_ssim, grad_image, (long long)grad_channel_stride,
+                           band);
     else
         hipLaunchKernelGGL(l1_ssim_backward_kernel<false>, grid, dim3(LT), 0, reinterpret_cast<hipStream_t>(stream), rows,
                            width, gxT, gyT, image, (long long)image_channel_stride, gt, dm_dmu1, dm_dE11, dm_dE12,
-                           grad_l1_sum, grad_ssim_sum, scale_l1, scale_ssim, grad_image, (long long)grad_channel_stride);
+                           grad_l1_sum, grad_ssim_sum, scale_l1, scale_ssim, grad_image, (long long)grad_channel_stride,
+                           band);
     GSR_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int gsr_l1_ssim_backward(int channels, int rows, int width, const float *image,
+                                    int64_t image_channel_stride, const uint8_t *gt, const float *dm_dmu1,
+                                    const float *dm_dE11, const float *dm_dE12, const float *grad_l1_sum,
+                                    const float *grad_ssim_sum, float scale_l1, float scale_ssim, float *grad_image,
+                                    int64_t grad_channel_stride, gsr_stream_t stream) {
+    return l1_ssim_backward_impl(channels, rows, width, image, image_channel_stride, gt, dm_dmu1, dm_dE11, dm_dE12,
+                                 grad_l1_sum, grad_ssim_sum, scale_l1, scale_ssim, grad_image, grad_channel_stride,
+                                 nullptr, stream);
+}
+
+extern "C" int gsr_l1_ssim_backward_band(int channels, int rows_capacity, int width, const float *image,
+                                         int64_t image_channel_stride, const uint8_t *gt, const float *dm_dmu1,
+                                         const float *dm_dE11, const float *dm_dE12, const float *grad_l1_sum,
+                                         const float *grad_ssim_sum, float scale_l1, float scale_ssim,
+                                         float *grad_image, int64_t grad_channel_stride, const int32_t *band_rows,
+                                         gsr_stream_t stream) {
+    if (!band_rows || rows_capacity <= 0) return GSR_EINVAL;
+    return l1_ssim_backward_impl(channels, rows_capacity, width, image, image_channel_stride, gt, dm_dmu1, dm_dE11,
+                                 dm_dE12, grad_l1_sum, grad_ssim_sum, scale_l1, scale_ssim, grad_image,
+                                 grad_channel_stride, band_rows, stream);
 }
 
 extern "C" int gsr_l1_ssim_finalize(int num_partials, const float *partials, float c_l1, float c_ssim, float bias,

@@ -979,7 +979,10 @@ class _RenderGaussians(torch.autograd.Function):
             # mask must be false outside): the launches then cover the band's tiles only
             band = cuda_args.get("_gsr_band") if (isinstance(cuda_args, dict) and _BAND_GRID[0]) else None
             row_lo, row_hi = (int(band[0]), int(band[1])) if band else (0, 0)
-            thin = 0 < (row_hi - row_lo) * gx <= 2048  # at most two rounds of resident workgroups
+            # (-1, capacity): the band is device data -- the mask's row hull, left behind the range table by the tile
+            # sort -- and the launches are sized for `capacity` tile rows (include/gsraster.h; graphed_step.py)
+            band_rows = row_hi if row_lo == -1 else row_hi - row_lo
+            thin = 0 < band_rows * gx <= 2048  # at most two rounds of resident workgroups
             # list segments for the backward (include/gsraster.h: gsr_render_forward_seg) when a backward can follow and
             # the band is THIN: measured (profiles/r04_ab_segments.txt) -9 us net on a 1/8 band, nothing on a whole image
             # (its lists finish in staggered rounds anyway) where the checkpoints only cost the forward 4-9 us
@@ -1211,14 +1214,20 @@ class _FusedBandLoss(torch.autograd.Function):
     _coef_cache = {}
 
     @staticmethod
-    def forward(ctx, image, gt_u8, y0, y1, lambda_dssim, n):
+    def forward(ctx, image, gt_u8, y0, y1, lambda_dssim, n, band_rows=None):
         if not image.is_cuda:
             raise RuntimeError("fused_band_loss: device tensors required (no CPU fallback)")
         ctx.set_materialize_grads(False)
         image = image.float().contiguous()
         C, H, W = image.shape
-        rows = y1 - y0
         gt_u8 = gt_u8.contiguous()
+        # band_rows (int32 [2] on the device: { y0, y1 }): the band is DEVICE data, `gt_u8` [C, capacity, W] carries it in
+        # the first y1 - y0 rows of every channel and y0 / y1 are not looked at (graphed_step.py: one captured launch for
+        # every band; include/gsraster.h: gsr_l1_ssim_forward_band)
+        dyn = band_rows is not None
+        if dyn and (band_rows.dtype != torch.int32 or not band_rows.is_cuda or band_rows.numel() < 2):
+            raise ValueError("band_rows must be an int32 device tensor { y0, y1 }")
+        rows = int(gt_u8.shape[1]) if dyn else y1 - y0
         if gt_u8.dtype != torch.uint8 or tuple(gt_u8.shape) != (C, rows, W):
             raise ValueError(f"gt band must be uint8 [{C},{rows},{W}], got {gt_u8.dtype} {tuple(gt_u8.shape)}")
         dev = image.device
@@ -1228,16 +1237,20 @@ class _FusedBandLoss(torch.autograd.Function):
         maps = torch.empty((3, C, rows, W), dtype=torch.float32, device=dev) if need_grad else None
         out3 = torch.empty((3,), dtype=torch.float32, device=dev)
         c_l1, c_ssim = (1.0 - lambda_dssim) / n, -lambda_dssim / n
-        band_ptr = ctypes.c_void_p(image.data_ptr() + 4 * y0 * W)
+        m = [_ptr(maps[i]) if need_grad else None for i in range(3)]
         with _on(dev):
             with kernel_timer.range("l1_ssim_forward", Px=rows * W):
-                check(lib.gsr_l1_ssim_forward(C, rows, W, band_ptr, H * W, _ptr(gt_u8), _ptr(partials),
-                                              _ptr(maps[0]) if need_grad else None,
-                                              _ptr(maps[1]) if need_grad else None,
-                                              _ptr(maps[2]) if need_grad else None, _stream()), "gsr_l1_ssim_forward")
+                if dyn:
+                    check(lib.gsr_l1_ssim_forward_band(C, rows, W, _ptr(image), H * W, _ptr(gt_u8), _ptr(partials), m[0],
+                                                       m[1], m[2], _ptr(band_rows), _stream()),
+                          "gsr_l1_ssim_forward_band")
+                else:
+                    band_ptr = ctypes.c_void_p(image.data_ptr() + 4 * y0 * W)
+                    check(lib.gsr_l1_ssim_forward(C, rows, W, band_ptr, H * W, _ptr(gt_u8), _ptr(partials), m[0], m[1],
+                                                  m[2], _stream()), "gsr_l1_ssim_forward")
             check(lib.gsr_l1_ssim_finalize(nb, _ptr(partials), c_l1, c_ssim, lambda_dssim, 1.0 / n, _ptr(out3),
                                            _stream()), "gsr_l1_ssim_finalize")
-        ctx.y0, ctx.y1, ctx.coef = y0, y1, (c_l1, c_ssim)
+        ctx.y0, ctx.y1, ctx.coef, ctx.band_rows = y0, y1, (c_l1, c_ssim), band_rows
         if need_grad:
             ctx.save_for_backward(image, gt_u8, maps)
         loss, Ll1, ssim = out3[0], out3[1], out3[2]
@@ -1247,28 +1260,36 @@ class _FusedBandLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, _g1, _g2):
         if g_loss is None:
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
         image, gt_u8, maps = ctx.saved_tensors
         C, H, W = image.shape
         y0, y1 = ctx.y0, ctx.y1
-        rows = y1 - y0
+        dyn = ctx.band_rows is not None
+        rows = int(gt_u8.shape[1]) if dyn else y1 - y0
         dev = image.device
         g_loss = g_loss if (g_loss.dtype == torch.float32 and g_loss.is_contiguous()) else g_loss.float().contiguous()
         # (dL/dS_l1, dL/dS_ssim) = dL/dloss * (c_l1, c_ssim): the product is formed inside the kernel
-        grad = torch.empty_like(image) if rows == H else torch.zeros_like(image)
-        band_ptr = ctypes.c_void_p(image.data_ptr() + 4 * y0 * W)
-        gband_ptr = ctypes.c_void_p(grad.data_ptr() + 4 * y0 * W)
+        grad = torch.empty_like(image) if (rows == H and not dyn) else torch.zeros_like(image)
         with _on(dev), kernel_timer.range("l1_ssim_backward", Px=rows * W):
-            check(lib.gsr_l1_ssim_backward(C, rows, W, band_ptr, H * W, _ptr(gt_u8), _ptr(maps[0]), _ptr(maps[1]),
-                                           _ptr(maps[2]), _ptr(g_loss), _ptr(g_loss), float(ctx.coef[0]),
-                                           float(ctx.coef[1]), gband_ptr, H * W, _stream()),
-                  "gsr_l1_ssim_backward")
-        return grad, None, None, None, None, None
+            if dyn:
+                check(lib.gsr_l1_ssim_backward_band(C, rows, W, _ptr(image), H * W, _ptr(gt_u8), _ptr(maps[0]),
+                                                    _ptr(maps[1]), _ptr(maps[2]), _ptr(g_loss), _ptr(g_loss),
+                                                    float(ctx.coef[0]), float(ctx.coef[1]), _ptr(grad), H * W,
+                                                    _ptr(ctx.band_rows), _stream()), "gsr_l1_ssim_backward_band")
+            else:
+                band_ptr = ctypes.c_void_p(image.data_ptr() + 4 * y0 * W)
+                gband_ptr = ctypes.c_void_p(grad.data_ptr() + 4 * y0 * W)
+                check(lib.gsr_l1_ssim_backward(C, rows, W, band_ptr, H * W, _ptr(gt_u8), _ptr(maps[0]), _ptr(maps[1]),
+                                               _ptr(maps[2]), _ptr(g_loss), _ptr(g_loss), float(ctx.coef[0]),
+                                               float(ctx.coef[1]), gband_ptr, H * W, _stream()),
+                      "gsr_l1_ssim_backward")
+        return grad, None, None, None, None, None, None
 
 
-def fused_band_loss(image, gt_u8, y0, y1, lambda_dssim, n):
-    """-> (loss, Ll1, ssim) of rows [y0, y1) of image [C,H,W]; n = H*W*3 of the full image"""
-    return _FusedBandLoss.apply(image, gt_u8, int(y0), int(y1), float(lambda_dssim), float(n))
+def fused_band_loss(image, gt_u8, y0, y1, lambda_dssim, n, band_rows=None):
+    """-> (loss, Ll1, ssim) of rows [y0, y1) of image [C,H,W]; n = H*W*3 of the full image.  band_rows (int32 [2] on
+    the device): the rows are device data and gt_u8 is a [C, capacity, W] buffer (see _FusedBandLoss.forward)"""
+    return _FusedBandLoss.apply(image, gt_u8, int(y0), int(y1), float(lambda_dssim), float(n), band_rows)
 
 
 # ------------------------------------------------------------------------- a19: fused activations

@@ -45,6 +45,11 @@ SIGNATURES = {
                                     c_void_p, c_void_p]),
     "gsr_l1_ssim_backward": (c_int, [c_int, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_float, c_float, c_void_p, c_int64, c_void_p]),
+    "gsr_l1_ssim_forward_band": (c_int, [c_int, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_void_p]),
+    "gsr_l1_ssim_backward_band": (c_int, [c_int, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_void_p, c_float, c_float, c_void_p, c_int64, c_void_p, c_void_p]),
+    "gsr_band_mask": (c_int, [c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "gsr_l1_ssim_finalize": (c_int, [c_int, c_void_p, c_float, c_float, c_float, c_float, c_void_p, c_void_p]),
     "gsr_exchange_need": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p]),
@@ -115,7 +120,7 @@ SIGNATURES = {
     "gsr_render_backward": (c_int, [c_int, c_int, c_int] + [c_void_p] * 12),
 }
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 def _load():

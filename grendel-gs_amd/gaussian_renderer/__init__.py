@@ -240,6 +240,9 @@ def _side_stream(dev, purpose="exchange"):
 def _bands_tensor(batched_strategies, W, dev):
     """int32 [B, W, 2] tile rows [lo, hi) of camera k rendered by global rank g, on the device; cached per partition
     (static strategies -- bsz >= W, frozen heuristics -- hit the cache every step: no host-to-device copy)"""
+    dyn = getattr(batched_strategies[0], "_gsr_dyn_all_bands", None) if batched_strategies else None
+    if dyn is not None:  # a band-agnostic hipGraph capture (graphed_step.py): the table is refreshed in front of a replay
+        return dyn
     key = (dev.index, W) + tuple((tuple(s.gpu_ids), tuple(s.division_pos)) for s in batched_strategies)
     t = _BANDS_CACHE.get(key)
     if t is None:

@@ -189,14 +189,20 @@ def batched_loss_computation(batched_image, batched_cameras, batched_compute_loc
                 raise RuntimeError("batched_loss_computation: images must live on the gfx950 device (no CPU path)")
             # the whole band loss in one autograd node (map kernel + finalize); HIP events instead of the
             # reference's two device syncs per camera (loss_distribution.py:2566,2578)
-            j = strategy.gpu_ids.index(utils.GLOBAL_RANK)
-            y0, y1 = get_coverage_y_min_max(strategy.division_pos[j], strategy.division_pos[j + 1])
+            # (a band-agnostic hipGraph capture, graphed_step.py: the rows are device data and camera.original_image is
+            # a capacity-sized buffer that carries the band in its first rows)
+            band_rows = getattr(strategy, "_gsr_dyn_band", None)
+            if band_rows is None:
+                j = strategy.gpu_ids.index(utils.GLOBAL_RANK)
+                y0, y1 = get_coverage_y_min_max(strategy.division_pos[j], strategy.division_pos[j + 1])
+            else:
+                y0 = y1 = 0
             timed = _timings_wanted()
             if timed:
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record()
             loss, Ll1, ssim = _FUSED_LOSS(image, camera.original_image, y0, y1, args.lambda_dssim,
-                                          utils.get_num_pixels() * 3)
+                                          utils.get_num_pixels() * 3, band_rows)
             if timed:
                 ev1.record()
                 stats["_loss_events"] = (ev0, ev1)

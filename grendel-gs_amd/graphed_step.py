@@ -19,7 +19,15 @@ A raised flag makes the optimizer launch of that replay -- and, the flag being s
 host looks at the flag one iteration late (so it never waits for the replay it has just launched), and on a raised flag
 repeats the affected iterations EAGERLY, in order: results are those of the eager loop, iteration by iteration.
 
-One graph per (partition, image size, camera intrinsics, shard size, capacities); a key's first `warmup` sights run
+One graph per (image size, camera intrinsics, shard size, capacities) -- and NOT per partition (round 6): with more
+than one rank the row bands are device data too.  The captured launches are sized for a band CAPACITY (the tallest band
+this rank has been given, plus slack) and read the band itself at execution time: the exchange from the [B,W,2] table it
+always read, compute_locally from a launch that rebuilds the masks out of the same block (gsr_band_mask), K8 / K10 from
+the row hull the tile sort leaves behind the range table (row_lo = -1), the loss kernels from { y0, y1 }
+(gsr_l1_ssim_*_band); the ground-truth band lands in the first rows of a capacity-sized buffer.  The host only checks
+that a band fits the capacity.  So every camera of a live partition -- the reference keeps cut points PER CAMERA and
+moves them with the measured times (workload_division.py:806-849) -- replays the same graph; only a change of the SET of
+ranks that render a camera (bsz > 1) or a band above the capacity is a new key.  A key's first `warmup` sights run
 eagerly (they teach the capacities).  Usable when nothing consumes per-iteration timings (frozen load-balancer
 heuristics: events recorded inside a capture cannot be read).
 
@@ -46,13 +54,51 @@ def _dbg(*a):
 
 
 class _Entry:
-    __slots__ = ("graph", "proxies", "out", "ctx", "caps_key", "pair_cap")
+    __slots__ = ("graph", "proxies", "out", "ctx", "caps_key", "pair_cap", "sproxies", "tasks", "band_cap", "masks")
+
+
+class _BandProxy:
+    """stands in for a DivisionStrategyFinal while an iteration is captured for ANY band of at most `cap` tile rows: the
+    band's rows are device words the replay refreshes.  Reading division_pos on the host would bake one partition into
+    the graph, so it raises (a capture that trips over it fails, and the iteration stays eager)."""
+
+    def __init__(self, real, cap, mask, band_rows, all_bands):
+        import utils.general_utils as utils
+
+        self.camera, self.world_size, self.gpu_ids, self.rank = real.camera, real.world_size, list(real.gpu_ids), real.rank
+        self._renders = utils.GLOBAL_RANK in self.gpu_ids
+        self._cap, self._mask = int(cap), mask
+        self._gsr_dyn_band = band_rows        # int32 [2] on the device: { y0, y1 } pixel rows of this rank's band
+        self._gsr_dyn_all_bands = all_bands   # int32 [B,W,2] on the device: tile rows of every rank and camera
+
+    @property
+    def division_pos(self):
+        raise RuntimeError("band-agnostic graph capture: division_pos is device data here (graphed_step._BandProxy)")
+
+    def _my_rows(self):
+        return (-1, self._cap) if self._renders else None  # (include/gsraster.h: row_lo == -1)
+
+    def get_compute_locally(self):
+        return self._mask if self._renders else None
+
+    def get_compute_locally_all(self):
+        raise RuntimeError("band-agnostic graph capture: get_compute_locally_all is not captured")
+
+    def get_extended_compute_locally(self):
+        return None
+
+    def get_local2j_ids_bool(self, *a, **k):
+        raise RuntimeError("band-agnostic graph capture: the exchange reads the band table, not a strategy")
+
+    get_local2j_ids = get_local2j_ids_bool
 
 
 class GraphedIteration:
-    def __init__(self, optimizer, body, warmup=3, max_graphs=8, enabled=True):
+    def __init__(self, optimizer, body, warmup=3, max_graphs=8, enabled=True, dynamic_bands=True):
         self.opt, self.body, self.warmup, self.max_graphs = optimizer, body, int(warmup), int(max_graphs)
         self.enabled = bool(enabled)
+        self.dynamic_bands = bool(dynamic_bands)  # False: one graph per partition (rounds 3-5)
+        self._band_cap = 0                        # tile rows the band-agnostic launches are sized for
         self.entries, self._seen = {}, {}
         self._inflight = None       # (event, cameras, strategies, tasks) of the replay nobody has validated yet
         self._flag = self._dyn = None
@@ -75,12 +121,37 @@ class GraphedIteration:
         planner = gr._planner(group, group.size(), B)
         return planner, planner.caps
 
+    def _dynamic(self, strategies):
+        """bands as device data: whenever a camera is split among ranks"""
+        return self.dynamic_bands and any(len(s.gpu_ids) > 1 for s in strategies)
+
+    @staticmethod
+    def _my_bands(strategies):
+        """[(lo, hi) tile rows of this rank's band, or None] per camera"""
+        import utils.general_utils as utils
+
+        out = []
+        for s in strategies:
+            if utils.GLOBAL_RANK in s.gpu_ids:
+                j = s.gpu_ids.index(utils.GLOBAL_RANK)
+                out.append((int(s.division_pos[j]), int(s.division_pos[j + 1])))
+            else:
+                out.append(None)
+        return out
+
     def _key(self, cameras, strategies):
         import utils.general_utils as utils
 
         p0 = self.opt.param_groups[0]["params"][0]
         _, caps = self._planner_caps(len(cameras))
-        return (tuple((tuple(s.gpu_ids), tuple(s.division_pos)) for s in strategies), utils.get_img_size(),
+        if self._dynamic(strategies):
+            rows = max([b[1] - b[0] for b in self._my_bands(strategies) if b is not None] or [0])
+            if rows > self._band_cap:  # a taller band than any before: a new capacity (and a new key) with slack
+                self._band_cap = min(int(utils.TILE_Y), rows + max(2, rows // 4))
+            part = ("bands<=", self._band_cap) + tuple(tuple(s.gpu_ids) for s in strategies)
+        else:
+            part = tuple((tuple(s.gpu_ids), tuple(s.division_pos)) for s in strategies)
+        return (part, utils.get_img_size(),
                 tuple((float(c.FoVx), float(c.FoVy), int(c.image_height), int(c.image_width)) for c in cameras),
                 p0.data_ptr(), tuple(p0.shape), None if caps is None else caps.tobytes())
 
@@ -144,13 +215,48 @@ class GraphedIteration:
             proxies.append(px)
         return proxies
 
-    def _refresh(self, proxies, cameras, slot):
-        """stage this iteration's inputs: camera records into the pinned block of `slot` (they travel with Adam's
-        constants), ground-truth bands by one strided copy each"""
+    def _strategy_proxies(self, entry, strategies, dev):
+        """band-agnostic capture: stand-ins of the strategies (-> (proxies, tasks for the ground-truth staging)) whose
+        masks one captured launch rebuilds from the band words of the device block"""
+        import utils.general_utils as utils
+
+        B, W, cap = len(strategies), self._world, entry.band_cap
+        i32 = self._dyn.view(torch.int32)
+        gy, gx = int(utils.TILE_Y), int(utils.TILE_X)
+        entry.masks = torch.zeros((B, gy, gx), dtype=torch.uint8, device=dev)
+        all_bands = i32[self.ALLB:self.ALLB + 2 * W * B].view(B, W, 2)
+        sproxies = [_BandProxy(s, cap, entry.masks[k].view(torch.bool),
+                               i32[self.BANDS + 4 * k + 2:self.BANDS + 4 * k + 4], all_bands)
+                    for k, s in enumerate(strategies)]
+        tasks = [[] for _ in range(max(W, utils.GLOBAL_RANK + 1))]
+        tasks[utils.GLOBAL_RANK] = [(k, 0, cap) for k, s in enumerate(strategies) if utils.GLOBAL_RANK in s.gpu_ids]
+        return sproxies, tasks
+
+    def _refresh(self, entry, cameras, strategies, slot):
+        """stage this iteration's inputs: camera records -- and, for a band-agnostic graph, the bands of every rank --
+        into the pinned block of `slot` (they travel with Adam's constants), ground-truth bands by one strided copy each"""
+        from gaussian_renderer.loss_distribution import get_coverage_y_min_max
+
+        proxies = entry.proxies
+        mine = self._my_bands(strategies) if entry.sproxies is not None else None
+        if mine is not None:
+            W = self._world
+            words = self._hyper_seq[slot]
+            for k, s in enumerate(strategies):
+                lo, hi = mine[k] or (0, 0)
+                y0, y1 = get_coverage_y_min_max(lo, hi) if mine[k] else (0, 0)
+                words[self.BANDS + 4 * k:self.BANDS + 4 * k + 4] = (lo, hi, y0, y1)
+                row = words[self.ALLB + 2 * W * k:self.ALLB + 2 * W * (k + 1)]
+                row[:] = 0
+                for j, g in enumerate(s.gpu_ids):
+                    row[2 * g], row[2 * g + 1] = s.division_pos[j], s.division_pos[j + 1]
         for k, (px, cam) in enumerate(zip(proxies, cameras)):
             self._hyper_np[slot, 16 + 40 * k:16 + 40 * (k + 1)] = self._packed_host(cam)
             if px._gsr_band is not None:
                 y0, y1, band = px._gsr_band
+                if mine is not None:  # the band of THIS iteration, in the first rows of the capacity-sized buffer
+                    y0, y1 = get_coverage_y_min_max(*mine[k])
+                    band = band[:, :y1 - y0, :]
                 band.copy_(cam.original_image_backup[:, y0:y1, :], non_blocking=True)
             px.uid = getattr(cam, "uid", None)
 
@@ -162,8 +268,16 @@ class GraphedIteration:
             self._flag = torch.zeros((1,), dtype=torch.int32, device=dev)
             # device block the captured launches read at execution time: 12 Adam constants, the replay's sequence number
             # (word 12) and the batch's camera records (40 floats each, from word 16)
-            self._dyn = torch.zeros((16 + 40 * self.MAXB,), dtype=torch.float32, device=dev)
-            self._hyper_host = torch.zeros((self.RING, 16 + 40 * self.MAXB), dtype=torch.float32).pin_memory()
+            # ... and, from word BANDS, the row bands (int32): { lo, hi, y0, y1 } of this rank per camera, then from word
+            # ALLB the [B,W,2] table of every rank's tile rows that the exchange reads
+            import utils.general_utils as utils
+
+            self._world = W = max(int(utils.DEFAULT_GROUP.size()), 1)
+            self.BANDS = 16 + 40 * self.MAXB
+            self.ALLB = self.BANDS + 4 * self.MAXB
+            words = self.ALLB + 2 * W * self.MAXB
+            self._dyn = torch.zeros((words,), dtype=torch.float32, device=dev)
+            self._hyper_host = torch.zeros((self.RING, words), dtype=torch.float32).pin_memory()
             self._hyper_np = self._hyper_host.numpy()
             self._hyper_seq = self._hyper_host.view(torch.int32).numpy()
             # pinned, device-mapped ring the LAST launch of every replay stores { flag, sequence number } into
@@ -189,8 +303,13 @@ class GraphedIteration:
 
         if getattr(utils.get_args(), "distributed_dataset_storage", False) and utils.DEFAULT_GROUP.size() > 1:
             raise RuntimeError("distributed dataset storage stages its ground truth with point-to-point sends: not graphed")
-        e.proxies = self._make_proxies(cameras, tasks)
-        self._stage(e, cameras)
+        e.sproxies = e.tasks = e.masks = None
+        e.band_cap = self._band_cap
+        body_strategies, body_tasks = strategies, tasks
+        if self._dynamic(strategies):
+            e.sproxies, e.tasks = body_strategies, body_tasks = self._strategy_proxies(e, strategies, dev)
+        e.proxies = self._make_proxies(cameras, body_tasks)
+        self._stage(e, cameras, strategies)
         e.ctx = _dgr.GraphCapture(self._flag, self._dyn)
         planner, caps = self._planner_caps(len(cameras))
         if caps is not None:
@@ -204,7 +323,11 @@ class GraphedIteration:
             # while this thread captures; in the default (global) mode HIP fails those polls and the watchdog aborts the
             # process (measured on RCCL 2.26 / ROCm 7.0)
             with torch.cuda.graph(e.graph, capture_error_mode="thread_local"):
-                e.out = self.body(e.proxies, strategies, tasks)
+                if e.sproxies is not None:  # compute_locally of every camera from the band words of this replay
+                    _dgr.check(_dgr.lib.gsr_band_mask(int(e.masks.shape[2]), int(e.masks.shape[1]), len(cameras),
+                                                      self._dyn.data_ptr() + 4 * self.BANDS, 4, e.masks.data_ptr(),
+                                                      _dgr._stream()), "gsr_band_mask")
+                e.out = self.body(e.proxies, body_strategies, body_tasks)
                 _dgr.check(_dgr.lib.gsr_publish_flag(self._flag.data_ptr(), self._dyn.data_ptr() + 48,
                                                      self._ring.data_ptr(), self.RING, _dgr._stream()),
                            "gsr_publish_flag")
@@ -232,16 +355,16 @@ class GraphedIteration:
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
         return bool(int(t.item()))
 
-    def _stage(self, entry, cameras):
+    def _stage(self, entry, cameras, strategies):
         """-> sequence number of the replay these inputs are staged for"""
         self._seq = seq = (self._seq + 1) & 0x3FFFFFFF or 1
         slot = seq % self.RING
         B = len(cameras)
-        self._refresh(entry.proxies, cameras, slot)
+        self._refresh(entry, cameras, strategies, slot)
         if self.opt.__dict__.get("_graph_owners") is not None:
             self._hyper_np[slot, :12] = self.opt.graph_hyper()
         self._hyper_seq[slot, 12] = seq
-        n = 16 + 40 * B
+        n = 16 + 40 * B if entry.sproxies is None else self.ALLB + 2 * self._world * B
         self._dyn[:n].copy_(self._hyper_host[slot, :n], non_blocking=True)
         return seq
 
@@ -341,7 +464,7 @@ class GraphedIteration:
                     self.stats["disabled"] = err or "the capture failed on another rank"
             return out
         # replay: inputs + hyper-parameters (one host-to-device copy, one band copy per camera), then ONE launch
-        seq = self._stage(entry, cameras)
+        seq = self._stage(entry, cameras, strategies)
         _dbg("replay", seq)
         entry.graph.replay()
         if _DEBUG:

@@ -225,6 +225,12 @@ size_t gsr_bin_segments_offset(int P, int width, int height);
  *                         stamp last) into words 2 s, 2 s + 1 of a pinned, device-accessible ring of `slots` pairs,
  *                         s = *seq_dev % slots; seq_dev is a device word the host refreshes in front of every replay.
  *                         The host polls the stamp instead of synchronising the stream. */
+/* compute_locally of B row bands from DEVICE data (ABI 13): mask uint8 [B][grid_y][grid_x], mask[k][ty][.] = lo_k <= ty <
+ * hi_k with { lo_k, hi_k } = the first two words of record k of band_rows_dev (records of stride_words int32).  What
+ * DivisionStrategyFinal.get_compute_locally (workload_division.py:773-787 of the reference) builds on the host per
+ * partition, as a launch a hipGraph can replay for any partition. */
+int gsr_band_mask(int grid_x, int grid_y, int B, const int32_t *band_rows_dev, int stride_words, uint8_t *mask,
+                  gsr_stream_t stream);
 int gsr_publish_flag(const uint32_t *flag_dev, const uint32_t *seq_dev, uint32_t *host_ring_pinned, uint32_t slots,
                      gsr_stream_t stream);
 int gsr_flag_if_greater(const uint32_t *value_dev, uint32_t limit, uint32_t *flag_dev, uint32_t bit,
@@ -273,7 +279,14 @@ int gsr_render_backward(int P, int width, int height, const int32_t *ranges, con
  * [row_lo, row_hi): the TILE ROWS of the caller's band when it knows them on the host (Grendel's strategies do:
  * compute_locally must then be false outside these rows), else 0, 0.  The launches then cover the band's tiles only; a
  * grid over all tiles costs a constant ~30 us (forward) / ~60 us (backward) of workgroup dispatch for tiles that are not
- * ours, whatever the band.  The forward still leaves every pixel outside the band exactly 0. */
+ * ours, whatever the band.  The forward still leaves every pixel outside the band exactly 0.
+ * row_lo == -1 (ABI 13): the band is DEVICE data -- row_hi (1 .. grid rows) is only the CAPACITY of the launch in tile
+ * rows, the band itself is the row hull of compute_locally that the tile sort left behind the range table (row `tiles`
+ * of `ranges`, written by gsr_bin_sort / _bounded / _speculative* on the device; a band of more rows than row_hi is the
+ * caller's error: its last rows are not drawn).  One launch captured in a hipGraph then serves every band of at most
+ * row_hi rows (graphed_step.py: one graph for all cameras of a live partition, workload_division.py:806-849 of the
+ * reference moves the cut points per camera); workgroups above the band's tile count only help clearing the pixels
+ * outside. */
 size_t gsr_render_seg_bytes(int width, int height);
 int gsr_render_forward_seg(int P, int width, int height, const int32_t *ranges, const uint32_t *point_list,
                            const float *means2D, const float *conic_opacity, const float *rgb,
@@ -332,6 +345,20 @@ int gsr_l1_ssim_backward(int channels, int rows, int width, const float *image, 
                          const uint8_t *gt, const float *dm_dmu1, const float *dm_dE11, const float *dm_dE12,
                          const float *grad_l1_sum, const float *grad_ssim_sum, float scale_l1, float scale_ssim,
                          float *grad_image, int64_t grad_channel_stride, gsr_stream_t stream);
+/* The same pair for a band whose rows are DEVICE data (ABI 13; one captured launch for every band of a camera):
+ * band_rows = { y0, y1 } int32 pixel rows of `image` (NOT offset: the full image's base pointer) on the device;
+ * rows_capacity >= y1 - y0 sizes the launch, the partials (gsr_l1_ssim_num_partials(C, rows_capacity, width): the slots
+ * above the band's own count receive zeros) and the CHANNEL STRIDE of gt and dm_* ([C, rows_capacity, width], the band
+ * in the first y1 - y0 rows of every channel).  Tile ids and the order of the partial sums are those of a launch sized
+ * for the band: the finalized loss is bit-equal to gsr_l1_ssim_forward's on the same rows. */
+int gsr_l1_ssim_forward_band(int channels, int rows_capacity, int width, const float *image, int64_t image_channel_stride,
+                             const uint8_t *gt, float *partials, float *dm_dmu1, float *dm_dE11, float *dm_dE12,
+                             const int32_t *band_rows, gsr_stream_t stream);
+int gsr_l1_ssim_backward_band(int channels, int rows_capacity, int width, const float *image,
+                              int64_t image_channel_stride, const uint8_t *gt, const float *dm_dmu1, const float *dm_dE11,
+                              const float *dm_dE12, const float *grad_l1_sum, const float *grad_ssim_sum, float scale_l1,
+                              float scale_ssim, float *grad_image, int64_t grad_channel_stride, const int32_t *band_rows,
+                              gsr_stream_t stream);
 /* finalize: adds the partials up (fixed order, fp64 accumulation) and forms the band's loss terms in one
  * launch: out3[0] = c_l1 * S_l1 + c_ssim * S_ssim + bias  (batched_loss_computation's
  * (1 - lambda) * Ll1 + lambda * (1 - ssim) with c_l1 = (1-lambda)/n, c_ssim = -lambda/n, bias = lambda;

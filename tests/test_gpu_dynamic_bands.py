@@ -1,0 +1,243 @@
+"""Row bands as DEVICE data (ABI 13): the launches a hipGraph replays for every band of a live partition.
+
+  * gsr_l1_ssim_*_band (band rows read on the device, capacity-sized ground truth / maps) == the launches sized for the
+    band, bit for bit;
+  * K8 / K10 with row_lo = -1 (a capacity grid, the band = the row hull the tile sort left behind the range table) ==
+    the launches whose grid is the band: image bitwise, gradients to K10's atomic-order noise;
+  * gsr_band_mask == DivisionStrategyFinal.get_compute_locally;
+  * GraphedIteration on one rank of a 4-rank world whose 8 cameras all have their OWN cut points (the reference keeps
+    them per camera, workload_division.py:806-849): ONE graph replays all of them and the results are the eager
+    loop's."""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+pytestmark = pytest.mark.gpu
+
+NAMES = ["_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"]
+
+
+def test_loss_with_a_device_band_is_bit_equal_to_the_band_sized_launch(device):
+    import diff_gaussian_rasterization as dgr
+
+    g = torch.Generator(device="cpu").manual_seed(5)
+    C, H, W = 3, 300, 424
+    image0 = torch.rand((C, H, W), generator=g).to(device)
+    gt = (torch.rand((C, H, W), generator=g) * 255).to(torch.uint8).to(device)
+    n = float(H * W * 3)
+    for (y0, y1, cap) in [(0, 300, 300), (16, 112, 96), (16, 112, 160), (48, 81, 64), (288, 300, 32), (0, 1, 40)]:
+        rows = y1 - y0
+        a = image0.clone().requires_grad_(True)
+        loss_a, l1_a, ss_a = dgr.fused_band_loss(a, gt[:, y0:y1].contiguous(), y0, y1, 0.2, n)
+        loss_a.backward()
+        b = image0.clone().requires_grad_(True)
+        gt_cap = torch.full((C, cap, W), 77, dtype=torch.uint8, device=device)  # (rows above the band: never read)
+        gt_cap[:, :rows] = gt[:, y0:y1]
+        band_rows = torch.tensor([y0, y1], dtype=torch.int32, device=device)
+        loss_b, l1_b, ss_b = dgr.fused_band_loss(b, gt_cap, 0, 0, 0.2, n, band_rows)
+        loss_b.backward()
+        torch.cuda.synchronize()
+        assert loss_a.item() == loss_b.item() and l1_a.item() == l1_b.item() and ss_a.item() == ss_b.item(), (y0, y1, cap)
+        assert torch.equal(a.grad, b.grad), (y0, y1, cap)
+        assert float(b.grad[:, :y0].abs().max() if y0 else 0.0) == 0.0
+        assert float(b.grad[:, y1:].abs().max() if y1 < H else 0.0) == 0.0
+        # the same launch serves another band of the capacity without being rebuilt: refresh the device words only
+        if cap >= 48 and H >= 64 + 48:
+            band_rows.copy_(torch.tensor([64, 64 + 48], dtype=torch.int32))
+            gt_cap[:, :48] = gt[:, 64:112]
+            c = image0.clone().requires_grad_(True)
+            loss_c, _, _ = dgr.fused_band_loss(c, gt_cap, 0, 0, 0.2, n, band_rows)
+            d = image0.clone().requires_grad_(True)
+            loss_d, _, _ = dgr.fused_band_loss(d, gt[:, 64:112].contiguous(), 64, 112, 0.2, n)
+            assert loss_c.item() == loss_d.item()
+
+
+def test_band_mask_kernel_equals_the_strategy_mask(device):
+    import diff_gaussian_rasterization as dgr
+
+    gx, gy, B = 40, 23, 3
+    words = torch.tensor([[3, 9, 48, 144], [0, 23, 0, 368], [0, 0, 0, 0]], dtype=torch.int32, device=device)
+    mask = torch.full((B, gy, gx), 7, dtype=torch.uint8, device=device)
+    dgr.check(dgr.lib.gsr_band_mask(gx, gy, B, words.data_ptr(), 4, mask.data_ptr(), dgr._stream()), "gsr_band_mask")
+    want = torch.zeros((B, gy, gx), dtype=torch.uint8, device=device)
+    want[0, 3:9] = 1
+    want[1, :] = 1
+    assert torch.equal(mask, want)
+
+
+def _scene(device, N=60000, W=640, H=368):
+    import synthetic_scene as S
+
+    model = S.SyntheticGaussianModel(N, W, H, seed=3, device=device, scale_coef=0.008)
+    cam = S.orbit_cameras(4, W, H, device=device)[1]
+    return model, cam, W, H
+
+
+@pytest.mark.parametrize("segments", [False, "always"])
+def test_composite_with_a_device_band_equals_the_band_grid(device, segments):
+    import math
+
+    import diff_gaussian_rasterization as dgr
+
+    model, cam, W, H = _scene(device)
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    rs = dgr.GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5),
+        bg=torch.tensor([0.1, 0.2, 0.3], device=device), scale_modifier=1.0, viewmatrix=cam.world_view_transform,
+        projmatrix=cam.full_proj_transform, sh_degree=3, campos=cam.camera_center, prefiltered=False, debug=False)
+    rast = dgr.GaussianRasterizer(rs)
+    with torch.no_grad():
+        m2, rgb, co, radii, depths = rast.preprocess_gaussians(model.get_xyz, model.get_scaling, model.get_rotation,
+                                                               model.get_features, model.get_opacity, {})
+    gsum = torch.rand((3, H, W), generator=torch.Generator().manual_seed(1)).to(device)
+    dgr.set_list_segments(segments)
+    try:
+        for (lo, hi, cap) in [(5, 11, 6), (5, 11, 9), (0, 4, 8), (17, 23, 23), (0, 23, 23)]:
+            mask = torch.zeros((gy, gx), dtype=torch.bool, device=device)
+            mask[lo:hi] = True
+            outs = []
+            for band in [(lo, hi), (-1, cap)]:
+                a, b, c = [t.detach().clone().requires_grad_(True) for t in (m2, co, rgb)]
+                img, _, _, _ = rast.render_gaussians(a, b, c, depths, radii, mask, None, {"_gsr_band": band})
+                (img * gsum).sum().backward()
+                outs.append((img.detach(), a.grad, b.grad, c.grad))
+            torch.cuda.synchronize()
+            assert torch.equal(outs[0][0], outs[1][0]), (lo, hi, cap)
+            assert float(outs[1][0][:, :lo * 16].abs().max() if lo else 0.0) == 0.0
+            assert float(outs[1][0][:, min(hi * 16, H):].abs().max() if hi * 16 < H else 0.0) == 0.0
+            for x, y in zip(outs[0][1:], outs[1][1:]):
+                err = float((x.double() - y.double()).norm() / (x.double().norm() + 1e-30))
+                assert err < 1e-4, (lo, hi, cap, err)  # (K10 adds with atomics: the order differs between launches)
+    finally:
+        dgr.set_list_segments(True)
+
+
+# ------------------------------------------------------------------------------------------------ one graph, every band
+@pytest.fixture
+def fake_world():
+    """one rank of a world of W identical ranks in this process (tools/fake_world_bench.py: device-local stand-ins of the
+    collectives); restores torch.distributed and the mirror's globals afterwards"""
+    import torch.distributed as dist
+
+    import gaussian_renderer as gr
+    import utils.general_utils as utils
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fake_world_bench as fw
+
+    saved = {n: getattr(dist, n) for n in ("all_gather_into_tensor", "all_to_all_single", "barrier", "all_reduce")}
+    saved_utils = (utils.GLOBAL_RANK, utils.LOCAL_RANK, utils.WORLD_SIZE, utils.DEFAULT_GROUP, utils.IN_NODE_GROUP)
+    fw.install_fake_collectives()
+    try:
+        yield fw
+    finally:
+        for n, f in saved.items():
+            setattr(dist, n, f)
+        utils.GLOBAL_RANK, utils.LOCAL_RANK, utils.WORLD_SIZE, utils.DEFAULT_GROUP, utils.IN_NODE_GROUP = saved_utils
+        gr._PLANNERS.clear()
+
+
+def _train(device, fw, steps, graph, world=4, rank=1, n_cams=8, dynamic=True, same_cuts=False, snap_at=24):
+    import diff_gaussian_rasterization as dgr
+    import gaussian_renderer as gr
+    import synthetic_scene as S
+    import utils.general_utils as utils
+    from fused_optim import FusedAdam
+    from gaussian_renderer import distributed_preprocess3dgs_and_all2all_final, render_final
+    from gaussian_renderer.loss_distribution import batched_loss_computation, load_camera_from_cpu_to_all_gpu
+    from gaussian_renderer.workload_division import DivisionStrategyHistoryFinal, start_strategy_final
+    from graphed_step import GraphedIteration
+
+    N, W, H = 40000, 640, 368
+    utils.GLOBAL_RANK, utils.LOCAL_RANK, utils.WORLD_SIZE = rank, 0, world
+    utils.DEFAULT_GROUP = utils.IN_NODE_GROUP = fw.FakeGroup(world, rank)
+    utils.set_args(utils.default_args(bsz=1, no_heuristics_update=True))
+    utils.set_img_size(H, W)
+    utils.set_cur_iter(1)
+    gr._PLANNERS.clear()
+    dgr.release_workspaces()
+    cams = S.orbit_cameras(n_cams, W, H, device=device)
+    for k, c in enumerate(cams):
+        c.original_image_backup = S.make_gt_image(W, H, seed=50 + k, device=device)
+    hist = DivisionStrategyHistoryFinal(S.SyntheticDataset(cams), world, rank)
+    rows = int(utils.TILE_Y)
+    ramp = torch.arange(rows, dtype=torch.float32) / rows
+    for k, c in enumerate(cams):  # per-camera row costs -> per-camera cut points (frozen: nothing consumes timings)
+        tilt = 0.0 if same_cuts else (k - n_cams / 2) / n_cams * 1.6
+        hist.accum_heuristic[c.uid] = 1.0 + tilt * (ramp - 0.5) + (0.0 if same_cuts else 0.3 * ((k * 7) % 5) * ramp * ramp)
+    model = S.SyntheticGaussianModel(N, W, H, seed=11, device=device, scale_coef=0.008)
+    bg = torch.tensor([0.1, 0.2, 0.3], device=device)
+    pipe = type("P", (), {"debug": False})()
+    opt = FusedAdam(model.param_groups(), lr=0.0, eps=1e-15, fuse_backward=True, grad_scale=1.0)
+
+    def body(batch, strategies, tasks):
+        load_camera_from_cpu_to_all_gpu(batch, strategies, tasks)
+        pkg = distributed_preprocess3dgs_and_all2all_final(batch, model, pipe, bg, batched_strategies=strategies,
+                                                           mode="train")
+        images, masks = render_final(pkg, strategies)
+        stats = [ca["stats_collector"] for ca in pkg["batched_cuda_args"]]
+        loss, _ = batched_loss_computation(images, batch, masks, strategies, stats)
+        loss.backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        return loss
+
+    step = GraphedIteration(opt, body, warmup=2, enabled=graph, dynamic_bands=dynamic)
+    losses, bands, snap = [], set(), None
+    for it in range(steps):
+        if it == snap_at:
+            torch.cuda.synchronize()
+            snap = {n: getattr(model, n).detach().clone() for n in NAMES}
+        batch = [cams[it % n_cams]]
+        utils.set_cur_iter(utils.get_cur_iter() + 1)
+        for g in opt.param_groups:
+            if g["name"] == "xyz":
+                g["lr"] = 0.00016 * (0.99 ** it)
+        strategies, tasks = start_strategy_final(batch, hist)
+        bands.add(tuple(strategies[0].division_pos))
+        loss = step(batch, strategies, tasks)
+        redo = step.validate()
+        losses.append(float((redo if redo is not None else loss).detach()))
+    torch.cuda.synchronize()
+    init = S.SyntheticGaussianModel(N, W, H, seed=11, device=device, scale_coef=0.008)
+    # (the parameters are compared after `snap_at` steps: K10 adds with atomics, and Adam with eps = 1e-15 turns that
+    # noise into sign flips of tiny gradients -- two EAGER runs of 120 steps differ by 5-9 % in what the parameters moved)
+    delta = {n: ((snap[n] if snap is not None else getattr(model, n).detach()) - getattr(init, n).detach()) for n in NAMES}
+    opt.set_fuse_backward(False)
+    return losses, delta, dict(step.stats), bands
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+
+def test_one_graph_replays_every_camera_of_a_live_partition(device, fake_world):
+    steps = 120
+    ref = _train(device, fake_world, steps, graph=False)
+    run = _train(device, fake_world, steps, graph=True)
+    losses, delta, st, bands = run
+    print("graph stats", st, "distinct partitions", len(bands))
+    assert len(bands) >= 5, bands  # the cameras really have their own cut points
+    assert st["disabled"] is None, st
+    assert st["redone"] <= 2, st  # (a camera whose band brings more pairs / rows than any before: repeated eagerly)
+    assert st["captured"] <= 3, st  # (capacities settle during the first cycle through the cameras)
+    assert st["replayed"] >= 0.9 * steps, st
+    for a, b in zip(losses, ref[0]):
+        assert abs(a - b) <= 2e-4 * abs(b), (losses[:12], ref[0][:12])
+    print("graph vs eager after 24 steps", {n: _rel(delta[n], ref[1][n]) for n in NAMES})
+    for n in NAMES:
+        e = _rel(delta[n], ref[1][n])
+        assert e < 5e-3, f"{n}: the parameters moved differently under the graph: rel {e:.2e}"
+
+
+def test_a_graph_per_partition_needs_one_capture_per_camera(device, fake_world):
+    """the rounds 3-5 behaviour (dynamic_bands=False) on the same run: the key carries the partition, so every camera
+    with its own cut points is its own graph -- what the band-agnostic capture removes"""
+    steps = 40
+    _, _, st, bands = _train(device, fake_world, steps, graph=True, dynamic=False)
+    assert st["disabled"] is None, st
+    assert st["captured"] >= min(len(bands), 4), (st, len(bands))
