@@ -97,7 +97,8 @@ class GraphedIteration:
     def __init__(self, optimizer, body, warmup=3, max_graphs=8, enabled=True, dynamic_bands=True):
         self.opt, self.body, self.warmup, self.max_graphs = optimizer, body, int(warmup), int(max_graphs)
         self.enabled = bool(enabled)
-        self.dynamic_bands = bool(dynamic_bands)  # False: one graph per partition (rounds 3-5)
+        # False (or GSR_GRAPH_DYNAMIC_BANDS=0, for A/B measurements): one graph per partition (rounds 3-5)
+        self.dynamic_bands = bool(dynamic_bands) and _os.environ.get("GSR_GRAPH_DYNAMIC_BANDS", "1") != "0"
         self._band_cap = 0                        # tile rows the band-agnostic launches are sized for
         self.entries, self._seen = {}, {}
         self._inflight = None       # (event, cameras, strategies, tasks) of the replay nobody has validated yet

@@ -113,7 +113,7 @@ def _install_balancer_hooks(wd, utils):
     _SHARED["torch"] = _torch
 
 
-def _end_of_round(tile_y):
+def _end_of_round(tile_y, per_camera=False):
     """per-row costs of every camera from the round's measurements (all rank positions), the reference's update rule"""
     torch_ = _SHARED["torch"]
     spread = []
@@ -132,12 +132,14 @@ def _end_of_round(tile_y):
         _SHARED["heur"][uid] = new
         if times:
             spread.append(max(times) / (sum(times) / len(times)))
-    # ONE partition for all cameras: the mean of the per-camera row costs.  A captured iteration bakes its partition in
-    # (grid sizes, band rows of the loss), so per-camera cut points would need one graph per camera; the cameras'
-    # profiles differ by a few percent only (printed: max / mean band time of the per-camera partitions)
-    mean = sum(_SHARED["heur"].values()) / max(len(_SHARED["heur"]), 1)
-    for uid in list(_SHARED["heur"]):
-        _SHARED["heur"][uid] = mean.clone()
+    # ONE partition for all cameras (default): the mean of the per-camera row costs.  Rounds 3-5 a captured iteration
+    # baked its partition in (grid sizes, band rows of the loss), so per-camera cut points needed one graph per camera;
+    # --per-camera keeps every camera's own costs, as the reference does (workload_division.py:806-849) -- since round 6
+    # the bands are device data and one graph serves them all (graphed_step.py)
+    if not per_camera:
+        mean = sum(_SHARED["heur"].values()) / max(len(_SHARED["heur"]), 1)
+        for uid in list(_SHARED["heur"]):
+            _SHARED["heur"][uid] = mean.clone()
     _SHARED["round"] = {}
     return sum(spread) / max(len(spread), 1)
 
@@ -155,6 +157,8 @@ def main():
                     help="balance the row partition with Grendel's own rule over ROUNDS rounds (every rank position "
                          "measured in turn), then measure EVERY rank position on the converged partition")
     ap.add_argument("--profile", action="store_true", help="cProfile the host side of the steps (top functions by own time)")
+    ap.add_argument("--per-camera", action="store_true",
+                    help="with --balanced: every camera keeps its OWN converged cut points (the reference's behaviour)")
     a0 = ap.parse_args()
 
     import bench
@@ -206,7 +210,7 @@ def main():
             for rnd in range(a0.balanced):
                 for r in range(W):
                     one_run(W, r, "off", 8, 2, True, timed_probe=True, collect=False)
-                imb = _end_of_round(utils.TILE_Y)
+                imb = _end_of_round(utils.TILE_Y, a0.per_camera)
                 print(f"# W={W} round {rnd}: max / mean band time of the measured partition {imb:.3f}", flush=True)
             per_rank = []
             for r in range(W):
