@@ -410,6 +410,8 @@ def run_workload(a, name, world, rank, dev, steps, warmup, repeats, render_steps
             e[1] += 1
         return t1
 
+    from diff_gaussian_rasterization import capturing as _dgr_capturing
+
     def iteration(cams, strategies, tasks, between=None):
         """GT staging .. optimizer step of one batch (train_internal.py:134-208, 316-329); `between` runs where the
         reference calls finish_strategy_final, between backward and step"""
@@ -422,6 +424,8 @@ def run_workload(a, name, world, rank, dev, steps, warmup, repeats, render_steps
         images, masks = render_final(pkg, strategies)
         t = _ph("render_final", t)
         stats = [ca["stats_collector"] for ca in pkg["batched_cuda_args"]]
+        if _dgr_capturing() is None:  # (a capture's run of this body records no events: its dicts hold placeholders)
+            state["stats"] = stats
         loss, _ = batched_loss_computation(images, cams, masks, strategies, stats)
         t = _ph("loss", t)
         loss.backward()
@@ -448,7 +452,10 @@ def run_workload(a, name, world, rank, dev, steps, warmup, repeats, render_steps
     graphed = None
     if getattr(a, "graph", "off") == "on" and opt.fuse_backward:
         from graphed_step import GraphedIteration
-        graphed = GraphedIteration(opt, iteration)
+        # timings: with live heuristics the replays carry device timestamps, so that the load balancer keeps running
+        # on replayed iterations (round 6; before, a graph needed frozen heuristics or --balance-every probes)
+        graphed = GraphedIteration(opt, iteration, timings=not utils.get_args().no_heuristics_update and
+                                   os.environ.get("GSR_GRAPH_TIMINGS", "1") != "0")
     state["graph"] = graphed
     every = max(int(getattr(a, "balance_every", 0) or 0), 0)
     args_ns = utils.get_args()
@@ -461,10 +468,14 @@ def run_workload(a, name, world, rank, dev, steps, warmup, repeats, render_steps
             args_ns.no_heuristics_update = (state["it"] % every) != 1  # probe iterations keep the reference's mode
         strategies, tasks = start_strategy_final(cams, history)
         state["bands"] = [(s.gpu_ids, s.division_pos) for s in strategies]
-        if graphed is not None and not timings_have_consumer():
+        if graphed is not None and (graphed.timings or not timings_have_consumer()):
+            state["stats"] = None
             graphed(cams, strategies, tasks)
             idle = {"forward_render_time": 0.0, "backward_render_time": 0.0, "forward_loss_time": 0.0}
-            finish_strategy_final(cams, history, strategies, [dict(idle) for _ in cams])  # frozen: nothing to gather
+            # a replay: its device timestamps (or zeros when nothing consumes timings); an iteration the wrapper ran
+            # eagerly (warm-up, a repeated one): the events its ops recorded
+            stats = graphed.last_stats or state.get("stats") or [dict(idle) for _ in cams]
+            finish_strategy_final(cams, history, strategies, stats)
             return
         if graphed is not None:
             graphed.validate()

@@ -467,6 +467,18 @@ __global__ void publish_flag_kernel(const uint32_t *__restrict__ flag, const uin
         __hip_atomic_store(w + 1, s, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
+// a device timestamp (s_memrealtime: 100 MHz, the same clock on every CU) into word `index` of slot seq % slots of a pinned,
+// device-mapped ring of `per_slot` words per slot: what a HIP event pair measures in the eager loop, for an iteration that
+// runs as a hipGraph replay (events recorded inside a capture cannot be read)
+__global__ void stamp_kernel(const uint32_t *__restrict__ seq, unsigned long long *__restrict__ host_ring, uint32_t slots,
+                             uint32_t per_slot, uint32_t index) {
+    if (threadIdx.x == 0) {
+        const uint32_t s = seq ? *seq : 0u;
+        __hip_atomic_store(host_ring + (size_t)(s % slots) * per_slot + index,
+                           (unsigned long long)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
 // compute_locally of B row bands whose rows are DEVICE data: mask[k][ty][tx] = lo_k <= ty < hi_k, band_rows = B records
 // of `stride` int32 words that begin with { lo, hi }
 __global__ void __launch_bounds__(256) band_mask_kernel(int gx, int gy, int B, const int32_t *__restrict__ band_rows,
@@ -495,6 +507,15 @@ extern "C" int gsr_publish_flag(const uint32_t *flag_dev, const uint32_t *seq_de
     if (!flag_dev || !seq_dev || !host_ring_pinned || slots == 0) return GSR_EINVAL;
     hipLaunchKernelGGL(publish_flag_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream_), flag_dev,
                        seq_dev, host_ring_pinned, slots);
+    GSR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gsr_stamp(const uint32_t *seq_dev, uint64_t *host_ring_pinned, uint32_t slots, uint32_t per_slot,
+                         uint32_t index, gsr_stream_t stream_) {
+    if (!host_ring_pinned || slots == 0 || index >= per_slot) return GSR_EINVAL;
+    hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream_), seq_dev,
+                       reinterpret_cast<unsigned long long *>(host_ring_pinned), slots, per_slot, index);
     GSR_LAUNCH_CHECK();
     return 0;
 }

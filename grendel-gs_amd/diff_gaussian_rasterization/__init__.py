@@ -750,6 +750,22 @@ class GraphCapture:
         self.slab_caps_dev = None  # device int32 [W*W*B]: the exchange planner's capacities, uploaded before the capture
         # pinned memory is allocated BEFORE the capture starts (hipHostMalloc is not a capturable call)
         self._words, self._next = torch.zeros((8192,), dtype=torch.int32).pin_memory(), 0
+        # device timestamps for the load balancer (include/gsraster.h: gsr_stamp): (pinned int64 ring, slots, words per
+        # slot), set by GraphedIteration(timings=True); `stamps` lists what was taken, in launch order, as (kind, tag)
+        self.stamp_ring = None
+        self.stamps = []
+
+    def stamp(self, kind, tag):
+        """a device timestamp at this point of the captured stream (kind: "fwd0" / "fwd1" around K3-K8, "loss0" /
+        "loss1" around the loss forward, "bwd0" / "bwd1" around K10; tag: the camera's stats_collector)"""
+        if self.stamp_ring is None:
+            return
+        ring, slots, per = self.stamp_ring
+        idx = len(self.stamps)
+        if idx >= per:
+            raise RuntimeError("graph capture: out of timestamp words")
+        check(lib.gsr_stamp(self.dyn.data_ptr() + 48, ring.data_ptr(), slots, per, idx, _stream()), "gsr_stamp")
+        self.stamps.append((kind, tag))
 
     def take_pinned(self, n):
         """-> a pinned int32 view of n words (from the block allocated before the capture)"""
@@ -960,6 +976,8 @@ class _RenderGaussians(torch.autograd.Function):
                 ev0 = torch.cuda.Event(enable_timing=True)
                 ev1 = torch.cuda.Event(enable_timing=True)
                 ev0.record()
+            if _CAPTURE[0] is not None:
+                _CAPTURE[0].stamp("fwd0", id(stats))
             with kernel_timer.range("binning", P=P, tiles=gx * gy) as kt:
                 # (round 6) the pair count is looked at AFTER K8 has been launched -- by the caller, after ALL its cameras
                 # have been launched, when it hands a list through cuda_args["_gsr_pending"] (gaussian_renderer.render_final)
@@ -1010,6 +1028,8 @@ class _RenderGaussians(torch.autograd.Function):
                 return k8t
 
             k8t = launch_k8(D)
+            if _CAPTURE[0] is not None:
+                _CAPTURE[0].stamp("fwd1", id(stats))
             ctx.seg = (seg_ws, seg_bytes, row_lo, row_hi)
             ctx.lists = lists
             ctx.num_rendered = D
@@ -1077,6 +1097,9 @@ class _RenderGaussians(torch.autograd.Function):
                 ev0 = torch.cuda.Event(enable_timing=True)
                 ev1 = torch.cuda.Event(enable_timing=True)
                 ev0.record()
+            cap_stats = ctx.cuda_args.get("stats_collector") if isinstance(ctx.cuda_args, dict) else None
+            if _CAPTURE[0] is not None:
+                _CAPTURE[0].stamp("bwd0", id(cap_stats))
             with kernel_timer.range("composite_backward", P=P, D=ctx.num_rendered, **ctx.px_meta), \
                     zhx_range(ctx.cuda_args, "b10 render time"):
                 seg_ws, seg_bytes, row_lo, row_hi = ctx.seg
@@ -1085,6 +1108,8 @@ class _RenderGaussians(torch.autograd.Function):
                                                     _ptr(n_contrib), _ptr(g_out), _ptr(record), _ptr(out_img),
                                                     _ptr(seg_ws), seg_bytes, row_lo, row_hi, 1 if record_is_zero else 0,
                                                     _stream()), "gsr_render_backward_seg_z")
+            if _CAPTURE[0] is not None:
+                _CAPTURE[0].stamp("bwd1", id(cap_stats))
             if timing != "off":
                 ev1.record()
         stats = ctx.cuda_args.get("stats_collector") if isinstance(ctx.cuda_args, dict) else None

@@ -49,6 +49,7 @@ SIGNATURES = {
                                          c_void_p, c_void_p, c_void_p]),
     "gsr_l1_ssim_backward_band": (c_int, [c_int, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_void_p, c_float, c_float, c_void_p, c_int64, c_void_p, c_void_p]),
+    "gsr_stamp": (c_int, [c_void_p, c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, c_void_p]),
     "gsr_band_mask": (c_int, [c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "gsr_l1_ssim_finalize": (c_int, [c_int, c_void_p, c_float, c_float, c_float, c_float, c_void_p, c_void_p]),
     "gsr_exchange_need": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -20,6 +20,7 @@ import utils.general_utils as utils
 # The fused HIP loss lives in this package's operator module.  A missing / unbuilt libgsraster.so makes this import
 # raise; there is no torch / conv2d restatement of the loss in the product (oracle/loss_oracle.py holds one for the
 # tests, pinned on the reference's own pixelwise_l1_with_mask / pixelwise_ssim_with_mask).
+from diff_gaussian_rasterization import capturing as _capturing
 from diff_gaussian_rasterization import fused_band_loss as _FUSED_LOSS
 from diff_gaussian_rasterization import fused_l1_ssim_band as _FUSED
 
@@ -201,8 +202,13 @@ def batched_loss_computation(batched_image, batched_cameras, batched_compute_loc
             if timed:
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record()
+            cap = _capturing()
+            if cap is not None:  # (a hipGraph capture: device timestamps instead of events, graphed_step.py)
+                cap.stamp("loss0", id(stats))
             loss, Ll1, ssim = _FUSED_LOSS(image, camera.original_image, y0, y1, args.lambda_dssim,
                                           utils.get_num_pixels() * 3, band_rows)
+            if cap is not None:
+                cap.stamp("loss1", id(stats))
             if timed:
                 ev1.record()
                 stats["_loss_events"] = (ev0, ev1)

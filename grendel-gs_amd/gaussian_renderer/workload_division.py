@@ -201,6 +201,9 @@ def start_strategy_final(batched_cameras, strategy_history):
 def _resolve_deferred_timings(st):
     """exact per-call milliseconds from the HIP event pairs the ops left behind (one wait on the last
     event instead of the reference's cuda.synchronize() pairs around every loss / render call)"""
+    stamps = st.pop("_gsr_stamps", None)
+    if stamps is not None:  # an iteration replayed as a hipGraph: device timestamps (graphed_step.GraphedIteration)
+        st.update(stamps())
     for key, evkey in (("forward_render_time", "_fwd_events"), ("backward_render_time", "_bwd_events"),
                        ("forward_loss_time", "_loss_events")):
         ev = st.pop(evkey, None)
@@ -332,7 +335,7 @@ def finish_strategy_final(batched_cameras, strategy_history, batched_strategies,
         # event wait and the all-gather + host read-back the reference pays every iteration (:953-966), so the
         # host keeps running ahead of the device.  The HIP event pairs are simply dropped.
         for st in batched_statistic_collector:
-            for evkey in ("_fwd_events", "_bwd_events", "_loss_events"):
+            for evkey in ("_fwd_events", "_bwd_events", "_loss_events", "_gsr_stamps"):
                 st.pop(evkey, None)
         return
 

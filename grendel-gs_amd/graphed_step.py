@@ -94,12 +94,20 @@ class _BandProxy:
 
 
 class GraphedIteration:
-    def __init__(self, optimizer, body, warmup=3, max_graphs=8, enabled=True, dynamic_bands=True):
+    def __init__(self, optimizer, body, warmup=3, max_graphs=8, enabled=True, dynamic_bands=True, timings=False):
         self.opt, self.body, self.warmup, self.max_graphs = optimizer, body, int(warmup), int(max_graphs)
         self.enabled = bool(enabled)
         # False (or GSR_GRAPH_DYNAMIC_BANDS=0, for A/B measurements): one graph per partition (rounds 3-5)
         self.dynamic_bands = bool(dynamic_bands) and _os.environ.get("GSR_GRAPH_DYNAMIC_BANDS", "1") != "0"
         self._band_cap = 0                        # tile rows the band-agnostic launches are sized for
+        # timings: the replays carry device timestamps around K3-K8, the loss forward and K10 of every camera (six
+        # one-thread launches per camera); `last_stats` is then, after a replay, what the eager ops leave in their
+        # stats_collector dicts -- per camera { forward_render_time, backward_render_time, forward_loss_time } in ms,
+        # resolved when somebody reads them (workload_division._resolve_deferred_timings) -- and None after an iteration
+        # that ran eagerly (the body's own stats carry HIP events then).  This is what lets the load balancer
+        # (finish_strategy_final) run on replayed iterations.
+        self.timings = bool(timings)
+        self.last_stats = None
         self.entries, self._seen = {}, {}
         self._inflight = None       # (event, cameras, strategies, tasks) of the replay nobody has validated yet
         self._flag = self._dyn = None
@@ -263,6 +271,7 @@ class GraphedIteration:
 
     # ------------------------------------------------------------------ capture
     RING = 16  # replays whose result slots / hyper-parameter blocks may be outstanding (two ever are)
+    STAMPS = 6 * MAXB  # device timestamps per replay
 
     def _ensure_buffers(self, dev):
         if self._flag is None:
@@ -284,6 +293,9 @@ class GraphedIteration:
             # pinned, device-mapped ring the LAST launch of every replay stores { flag, sequence number } into
             self._ring = torch.zeros((2 * self.RING,), dtype=torch.int32).pin_memory()
             self._ring_np = self._ring.numpy()
+            # ... and the device timestamps of a replay (timings=True): STAMPS words per slot
+            self._stamp_ring = torch.zeros((self.RING * self.STAMPS,), dtype=torch.int64).pin_memory()
+            self._stamp_np = self._stamp_ring.numpy()
             self._seq = 0
 
     def _capture(self, key, cameras, strategies, tasks):
@@ -312,6 +324,8 @@ class GraphedIteration:
         e.proxies = self._make_proxies(cameras, body_tasks)
         self._stage(e, cameras, strategies)
         e.ctx = _dgr.GraphCapture(self._flag, self._dyn)
+        if self.timings:
+            e.ctx.stamp_ring = (self._stamp_ring, self.RING, self.STAMPS)
         planner, caps = self._planner_caps(len(cameras))
         if caps is not None:
             e.ctx.slab_caps_dev = torch.tensor(caps.reshape(-1), dtype=torch.int32).to(dev)
@@ -368,6 +382,51 @@ class GraphedIteration:
         n = 16 + 40 * B if entry.sproxies is None else self.ALLB + 2 * self._world * B
         self._dyn[:n].copy_(self._hyper_host[slot, :n], non_blocking=True)
         return seq
+
+    # ------------------------------------------------------------------ timings of a replay
+    def _replay_stats(self, entry, seq, ev, strategies):
+        """-> per camera the dict an eager iteration's ops leave in stats_collector; the three times are filled in from the
+        replay's device timestamps when "_gsr_stamps" is resolved (waits for the replay's publish stamp, nothing else)"""
+        import utils.general_utils as utils
+
+        zero = {"forward_render_time": 0.0, "backward_render_time": 0.0, "forward_loss_time": 0.0}
+        if not self.timings or not entry.ctx.stamps:
+            return [dict(zero) for _ in strategies]
+        # stamps are tagged with the camera's stats_collector (an id): cameras in the order of their first stamp = the
+        # cameras this rank renders, in batch order (render_final walks the batch in order)
+        order, slots = [], {}
+        for idx, (kind, tag) in enumerate(entry.ctx.stamps):
+            if tag not in slots:
+                slots[tag] = {}
+                order.append(tag)
+            slots[tag][kind] = idx
+        rendered = [k for k, s in enumerate(strategies) if utils.GLOBAL_RANK in s.gpu_ids]
+        out = [dict(zero) for _ in strategies]
+        slot = seq % self.RING
+        base = slot * self.STAMPS
+
+        def resolver(idx_of):
+            def resolve():
+                spins = 0
+                while int(self._ring_np[2 * slot + 1]) != seq:
+                    spins += 1
+                    if spins > 2000:
+                        ev.synchronize()
+                        break
+                t = self._stamp_np
+
+                def ms(a, b):
+                    if a not in idx_of or b not in idx_of:
+                        return 0.0
+                    return max(float(int(t[base + idx_of[b]]) - int(t[base + idx_of[a]])) * 1e-5, 0.0)  # 100 MHz ticks
+
+                return {"forward_render_time": ms("fwd0", "fwd1"), "backward_render_time": ms("bwd0", "bwd1"),
+                        "forward_loss_time": ms("loss0", "loss1")}
+            return resolve
+
+        for k, tag in zip(rendered, order):
+            out[k]["_gsr_stamps"] = resolver(slots[tag])
+        return out
 
     # ------------------------------------------------------------------ validation (one iteration late)
     def _observe(self, entry):
@@ -439,6 +498,7 @@ class GraphedIteration:
 
     # ------------------------------------------------------------------ the step
     def __call__(self, cameras, strategies, tasks):
+        self.last_stats = None
         if not self.enabled:
             self.stats["eager"] += 1
             return self.body(cameras, strategies, tasks)
@@ -474,6 +534,7 @@ class GraphedIteration:
                  [(int(h[0]), c) for h, c in entry.ctx.pairs])
         ev = torch.cuda.Event()
         ev.record()
+        self.last_stats = self._replay_stats(entry, seq, ev, strategies)
         if self.opt.__dict__.get("_graph_owners") is not None:  # (a body without an optimizer step: nothing to count)
             self.opt.graph_advance(1)
         self.stats["replayed"] += 1
@@ -486,6 +547,7 @@ class GraphedIteration:
         self._inflight = (p_entry, p_seq, p_ev, p_queue + [(cameras, strategies, tasks, self._hyper_snapshot())])
         redo = self._check_inflight()
         if redo is not None:
+            self.last_stats = None  # (the iteration was repeated eagerly: the body's own stats carry its events)
             return redo
         self._inflight = (entry, seq, ev, [(cameras, strategies, tasks, self._hyper_snapshot())])
         return entry.out

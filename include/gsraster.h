@@ -225,6 +225,13 @@ size_t gsr_bin_segments_offset(int P, int width, int height);
  *                         stamp last) into words 2 s, 2 s + 1 of a pinned, device-accessible ring of `slots` pairs,
  *                         s = *seq_dev % slots; seq_dev is a device word the host refreshes in front of every replay.
  *                         The host polls the stamp instead of synchronising the stream. */
+/* A device timestamp inside a captured iteration (ABI 13): word `index` (< per_slot) of slot *seq_dev % slots of a pinned,
+ * device-accessible ring of uint64 receives the 100 MHz s_memrealtime counter when the launch runs (seq_dev NULL: slot 0).
+ * Two stamps around a group of launches are what the HIP event pair of the eager loop measures (events recorded inside a
+ * capture cannot be read): the load balancer's render / loss times (workload_division.py:953-966 of the reference) under
+ * graph replay.  Valid for the host once gsr_publish_flag's stamp of the same replay has landed. */
+int gsr_stamp(const uint32_t *seq_dev, uint64_t *host_ring_pinned, uint32_t slots, uint32_t per_slot, uint32_t index,
+              gsr_stream_t stream);
 /* compute_locally of B row bands from DEVICE data (ABI 13): mask uint8 [B][grid_y][grid_x], mask[k][ty][.] = lo_k <= ty <
  * hi_k with { lo_k, hi_k } = the first two words of record k of band_rows_dev (records of stride_words int32).  What
  * DivisionStrategyFinal.get_compute_locally (workload_division.py:773-787 of the reference) builds on the host per

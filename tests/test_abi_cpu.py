@@ -61,6 +61,13 @@ def test_pure_host_entry_points():
     assert lib.gsr_densify_stats(-1, None, None, 9, None, None, None, None) == -1
     assert lib.gsr_densify_stats(10, None, None, 1, None, None, None, None) == -1  # a row holds at least (x, y)
     assert lib.gsr_densify_stats(0, None, None, 9, None, None, None, None) == 0
+    # ABI 13 (row bands as device data): a launch without its band words, or without a capacity, is refused
+    assert lib.gsr_abi_version() == 13
+    assert lib.gsr_l1_ssim_forward_band(3, 64, 64, None, 0, None, None, None, None, None, None, None) == -1
+    assert lib.gsr_l1_ssim_backward_band(3, 0, 64, None, 0, None, None, None, None, None, None, 1.0, 1.0, None, 0, None,
+                                         None) == -1
+    assert lib.gsr_band_mask(40, 23, 1, None, 4, None, None) == -1
+    assert lib.gsr_band_mask(40, 23, 0, None, 4, None, None) == -1
     rc = dgr._lib.lib.gsr_preprocess_forward(-1, 3, 16, *([None] * 2), 1.0, *([None] * 6), 10, 10, 1.0, 1.0,
                                              *([None] * 8))
     assert rc == -1

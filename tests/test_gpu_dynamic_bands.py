@@ -141,7 +141,8 @@ def fake_world():
         gr._PLANNERS.clear()
 
 
-def _train(device, fw, steps, graph, world=4, rank=1, n_cams=8, dynamic=True, same_cuts=False, snap_at=24):
+def _train(device, fw, steps, graph, world=4, rank=1, n_cams=8, dynamic=True, same_cuts=False, snap_at=24,
+           timings=False):
     import diff_gaussian_rasterization as dgr
     import gaussian_renderer as gr
     import synthetic_scene as S
@@ -155,7 +156,8 @@ def _train(device, fw, steps, graph, world=4, rank=1, n_cams=8, dynamic=True, sa
     N, W, H = 40000, 640, 368
     utils.GLOBAL_RANK, utils.LOCAL_RANK, utils.WORLD_SIZE = rank, 0, world
     utils.DEFAULT_GROUP = utils.IN_NODE_GROUP = fw.FakeGroup(world, rank)
-    utils.set_args(utils.default_args(bsz=1, no_heuristics_update=True))
+    # (timings: somebody consumes the render / loss times -- the eager ops then record their HIP events)
+    utils.set_args(utils.default_args(bsz=1, no_heuristics_update=True, save_strategy_history=bool(timings)))
     utils.set_img_size(H, W)
     utils.set_cur_iter(1)
     gr._PLANNERS.clear()
@@ -174,20 +176,24 @@ def _train(device, fw, steps, graph, world=4, rank=1, n_cams=8, dynamic=True, sa
     pipe = type("P", (), {"debug": False})()
     opt = FusedAdam(model.param_groups(), lr=0.0, eps=1e-15, fuse_backward=True, grad_scale=1.0)
 
+    eager_stats = [None]
+
     def body(batch, strategies, tasks):
         load_camera_from_cpu_to_all_gpu(batch, strategies, tasks)
         pkg = distributed_preprocess3dgs_and_all2all_final(batch, model, pipe, bg, batched_strategies=strategies,
                                                            mode="train")
         images, masks = render_final(pkg, strategies)
         stats = [ca["stats_collector"] for ca in pkg["batched_cuda_args"]]
+        if dgr.capturing() is None:
+            eager_stats[0] = stats
         loss, _ = batched_loss_computation(images, batch, masks, strategies, stats)
         loss.backward()
         opt.step()
         opt.zero_grad(set_to_none=True)
         return loss
 
-    step = GraphedIteration(opt, body, warmup=2, enabled=graph, dynamic_bands=dynamic)
-    losses, bands, snap = [], set(), None
+    step = GraphedIteration(opt, body, warmup=2, enabled=graph, dynamic_bands=dynamic, timings=timings)
+    losses, bands, snap, times = [], set(), None, []
     for it in range(steps):
         if it == snap_at:
             torch.cuda.synchronize()
@@ -200,15 +206,23 @@ def _train(device, fw, steps, graph, world=4, rank=1, n_cams=8, dynamic=True, sa
         strategies, tasks = start_strategy_final(batch, hist)
         bands.add(tuple(strategies[0].division_pos))
         loss = step(batch, strategies, tasks)
+        replay_stats = step.last_stats
         redo = step.validate()
         losses.append(float((redo if redo is not None else loss).detach()))
+        if timings:  # what finish_strategy_final would be given for this iteration
+            from gaussian_renderer.workload_division import _resolve_deferred_timings
+
+            st = dict((replay_stats if (replay_stats is not None and redo is None) else eager_stats[0])[0])
+            _resolve_deferred_timings(st)
+            times.append((replay_stats is not None and redo is None, st["forward_render_time"], st["backward_render_time"],
+                          st["forward_loss_time"]))
     torch.cuda.synchronize()
     init = S.SyntheticGaussianModel(N, W, H, seed=11, device=device, scale_coef=0.008)
     # (the parameters are compared after `snap_at` steps: K10 adds with atomics, and Adam with eps = 1e-15 turns that
     # noise into sign flips of tiny gradients -- two EAGER runs of 120 steps differ by 5-9 % in what the parameters moved)
     delta = {n: ((snap[n] if snap is not None else getattr(model, n).detach()) - getattr(init, n).detach()) for n in NAMES}
     opt.set_fuse_backward(False)
-    return losses, delta, dict(step.stats), bands
+    return (losses, delta, dict(step.stats), bands) + ((times,) if timings else ())
 
 
 def _rel(a, b):
@@ -241,3 +255,27 @@ def test_a_graph_per_partition_needs_one_capture_per_camera(device, fake_world):
     _, _, st, bands = _train(device, fake_world, steps, graph=True, dynamic=False)
     assert st["disabled"] is None, st
     assert st["captured"] >= min(len(bands), 4), (st, len(bands))
+
+
+def test_replays_carry_the_load_balancers_timings(device, fake_world):
+    """GraphedIteration(timings=True): a replay leaves what the eager ops leave in stats_collector -- forward render,
+    backward render and loss-forward milliseconds of every camera (workload_division.py:953-966 of the reference consumes
+    them) -- from device timestamps, without changing the results"""
+    steps = 48
+    ref = _train(device, fake_world, steps, graph=False, timings=True)
+    run = _train(device, fake_world, steps, graph=True, timings=True)
+    st = run[2]
+    assert st["disabled"] is None and st["replayed"] >= steps // 2, st
+    for a, b in zip(run[0], ref[0]):
+        assert abs(a - b) <= 2e-4 * abs(b)
+    replayed = [t for t in run[4] if t[0]]
+    eager = [t for t in ref[4]]
+    assert len(replayed) >= steps // 2 and all(not t[0] for t in eager)
+    med = lambda xs: sorted(xs)[len(xs) // 2]  # noqa: E731
+    print("median ms (fwd render, bwd render, loss fwd): replayed", [round(med([t[i] for t in replayed]), 4) for i in (1, 2, 3)],
+          "eager", [round(med([t[i] for t in eager]), 4) for i in (1, 2, 3)])
+    for i in (1, 2, 3):
+        g, e = med([t[i] for t in replayed]), med([t[i] for t in eager])
+        assert all(0.0 < t[i] < 50.0 for t in replayed), [t[i] for t in replayed][:8]
+        # the same kernels between the same points of the stream; an eager iteration's events also see the host's gaps
+        assert 0.2 * e < g < 2.0 * e, (i, g, e)
