@@ -445,9 +445,10 @@ def run_workload(a, name, world, rank, dev, steps, warmup, repeats, render_steps
         _ph("tail", t)
         return loss
 
-    # --graph: the iteration replayed as ONE hipGraph (graphed_step.py) whenever nothing consumes per-iteration timings
-    # (frozen load-balancer heuristics); with live heuristics, `--balance-every R` makes every R-th iteration an eager,
-    # timed one that feeds the balancer and freezes the partition in between
+    # --graph: the iteration replayed as ONE hipGraph (graphed_step.py).  With live heuristics the replays carry device
+    # timestamps in place of the eager ops' HIP events (GraphedIteration(timings=True)) and the row bands are device data,
+    # so the balancer keeps moving the cut points under one graph; `--balance-every R` (rounds 4-5: every R-th iteration
+    # an eager, timed one, the partition frozen in between) is still there
     from gaussian_renderer.workload_division import timings_have_consumer
     graphed = None
     if getattr(a, "graph", "off") == "on" and opt.fuse_backward:
@@ -778,11 +779,13 @@ def main():
                     help="run K11 and Adam as two kernels (the parameter gradients go through HBM) instead of the fused "
                          "K11 + Adam launch")
     ap.add_argument("--graph", default="off", choices=["off", "on"],
-                    help="replay the training iteration as ONE hipGraph (graphed_step.py) whenever the load balancer's "
-                         "heuristics are frozen; results are the eager loop's (capacity overflows are repeated eagerly)")
+                    help="replay the training iteration as ONE hipGraph (graphed_step.py); with live load-balancer "
+                         "heuristics the replays carry device timestamps that feed finish_strategy_final (round 6: one "
+                         "graph serves every band); results are the eager loop's (capacity overflows are repeated eagerly)")
     ap.add_argument("--balance-every", type=int, default=0,
                     help="with --graph on and live heuristics: every R-th iteration is an eager, timed one that feeds "
-                         "the load balancer; the partition is frozen in between (0: never freeze -> no graph)")
+                         "the load balancer; the partition is frozen in between (0, default: every iteration feeds it -- "
+                         "replays through their device timestamps)")
     ap.add_argument("--no-1gpu-leg", action="store_true", help="N > 1: skip the same-workload single-GPU leg")
     ap.add_argument("--render-steps", type=int, default=20, help="forward-only views/sec leg (untimed by driver)")
     ap.add_argument("--densify-every", type=int, default=0,

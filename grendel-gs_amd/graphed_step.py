@@ -27,9 +27,14 @@ the row hull the tile sort leaves behind the range table (row_lo = -1), the loss
 (gsr_l1_ssim_*_band); the ground-truth band lands in the first rows of a capacity-sized buffer.  The host only checks
 that a band fits the capacity.  So every camera of a live partition -- the reference keeps cut points PER CAMERA and
 moves them with the measured times (workload_division.py:806-849) -- replays the same graph; only a change of the SET of
-ranks that render a camera (bsz > 1) or a band above the capacity is a new key.  A key's first `warmup` sights run
-eagerly (they teach the capacities).  Usable when nothing consumes per-iteration timings (frozen load-balancer
-heuristics: events recorded inside a capture cannot be read).
+ranks that render a camera (bsz > 1) is a new key.  A key's first `warmup` sights run eagerly (they teach the
+capacities); a band taller than the captured capacity, or an exchange slab the planner wants larger than the captured
+layout (the planner's capacities plus a quarter), replaces the graph after ONE eager iteration (_usable).
+timings=True: the replays carry device timestamps around K3-K8, the loss forward and K10 (gsr_stamp), which
+`last_stats` hands to finish_strategy_final in place of the eager ops' HIP events: the load balancer runs on replayed
+iterations (tests/test_gpu_dynamic_bands.py: 157 of 160 iterations replayed from 2 captures while the cut points moved
+127 times).  Without timings=True the wrapper is for loops in which nothing consumes per-iteration timings (frozen
+heuristics): events recorded inside a capture cannot be read.
 
     step = GraphedIteration(optimizer, body)      # body(cameras, strategies, tasks) -> loss: GT staging ... opt.step()
     loss = step(cameras, strategies, tasks)       # replays when it can, runs `body` eagerly when it cannot
@@ -152,17 +157,29 @@ class GraphedIteration:
         import utils.general_utils as utils
 
         p0 = self.opt.param_groups[0]["params"][0]
-        _, caps = self._planner_caps(len(cameras))
         if self._dynamic(strategies):
-            rows = max([b[1] - b[0] for b in self._my_bands(strategies) if b is not None] or [0])
-            if rows > self._band_cap:  # a taller band than any before: a new capacity (and a new key) with slack
-                self._band_cap = min(int(utils.TILE_Y), rows + max(2, rows // 4))
-            part = ("bands<=", self._band_cap) + tuple(tuple(s.gpu_ids) for s in strategies)
+            part = ("bands",) + tuple(tuple(s.gpu_ids) for s in strategies)
         else:
             part = tuple((tuple(s.gpu_ids), tuple(s.division_pos)) for s in strategies)
+        # (capacities -- the band's, the exchange slabs' -- are properties of the ENTRY, see _usable: a capacity that
+        # no longer holds replaces the graph after one eager iteration, without a new warm-up)
         return (part, utils.get_img_size(),
                 tuple((float(c.FoVx), float(c.FoVy), int(c.image_height), int(c.image_width)) for c in cameras),
-                p0.data_ptr(), tuple(p0.shape), None if caps is None else caps.tobytes())
+                p0.data_ptr(), tuple(p0.shape))
+
+    def _band_rows(self, strategies):
+        return max([b[1] - b[0] for b in self._my_bands(strategies) if b is not None] or [0])
+
+    def _usable(self, entry, cameras, strategies):
+        """do the capacities this graph was captured with still hold -- decided on the host BEFORE the replay, from
+        numbers every rank has (the partition, the exchange planner's capacities): the tallest band of this batch fits
+        the launches' band capacity, and the planner asks for no slab larger than the captured layout's"""
+        if entry.sproxies is not None and self._band_rows(strategies) > entry.band_cap:
+            return False
+        _, caps = self._planner_caps(len(cameras))
+        if (caps is None) != (entry.caps_key is None):
+            return False
+        return caps is None or (caps.shape == entry.caps_key.shape and bool((caps <= entry.caps_key).all()))
 
     @staticmethod
     def _packed(camera):
@@ -317,6 +334,12 @@ class GraphedIteration:
         if getattr(utils.get_args(), "distributed_dataset_storage", False) and utils.DEFAULT_GROUP.size() > 1:
             raise RuntimeError("distributed dataset storage stages its ground truth with point-to-point sends: not graphed")
         e.sproxies = e.tasks = e.masks = None
+        if self._dynamic(strategies):
+            import utils.general_utils as utils
+
+            # the tallest band this rank has been given, plus slack (idle workgroups are cheap, a new capture is not)
+            rows = self._band_rows(strategies)
+            self._band_cap = max(self._band_cap, min(int(utils.TILE_Y), rows + max(2, rows // 2)))
         e.band_cap = self._band_cap
         body_strategies, body_tasks = strategies, tasks
         if self._dynamic(strategies):
@@ -327,12 +350,22 @@ class GraphedIteration:
         if self.timings:
             e.ctx.stamp_ring = (self._stamp_ring, self.RING, self.STAMPS)
         planner, caps = self._planner_caps(len(cameras))
+        e.caps_key = None
         if caps is not None:
-            e.ctx.slab_caps_dev = torch.tensor(caps.reshape(-1), dtype=torch.int32).to(dev)
+            # the graph's own slab layout: the planner's capacities plus a quarter -- a layout is baked into the captured
+            # all-to-all, and while the partition still moves every slab that outgrows it would cost a capture (the
+            # eager path keeps the planner's own capacities: both layouts are self-consistent, and every rank derives
+            # both from the same all-gathered history)
+            e.caps_key = (caps * 5 // 4 + 255) // 256 * 256
+            e.ctx.slab_caps_dev = torch.tensor(e.caps_key.reshape(-1), dtype=torch.int32).to(dev)
         torch.cuda.synchronize(dev)
         e.graph = torch.cuda.CUDAGraph()
         _dbg("capture begins")
         _dgr._CAPTURE[0] = e.ctx
+        saved_caps = None
+        if e.caps_key is not None:
+            saved_caps = (planner.caps, planner.caps_list)
+            planner.caps, planner.caps_list = e.caps_key, e.caps_key.tolist()
         try:
             # thread_local: the process group's watchdog thread keeps polling the events of EARLIER (eager) collectives
             # while this thread captures; in the default (global) mode HIP fails those polls and the watchdog aborts the
@@ -348,6 +381,8 @@ class GraphedIteration:
                            "gsr_publish_flag")
         finally:
             _dgr._CAPTURE[0] = None
+            if saved_caps is not None:
+                planner.caps, planner.caps_list = saved_caps
         if len(self.entries) >= self.max_graphs:
             self.entries.pop(next(iter(self.entries)))
         self.entries[key] = e
@@ -504,6 +539,9 @@ class GraphedIteration:
             return self.body(cameras, strategies, tasks)
         key = self._key(cameras, strategies)
         entry = self.entries.get(key)
+        if entry is not None and not self._usable(entry, cameras, strategies):
+            del self.entries[key]  # (the key has had its warm-up: the next eager iteration ends with a new capture)
+            entry = None
         if entry is None:
             self._check_inflight()  # (a flagged replay is repeated here, before this iteration runs eagerly)
             self.stats["eager"] += 1

@@ -238,7 +238,7 @@ def test_one_graph_replays_every_camera_of_a_live_partition(device, fake_world):
     assert len(bands) >= 5, bands  # the cameras really have their own cut points
     assert st["disabled"] is None, st
     assert st["redone"] <= 2, st  # (a camera whose band brings more pairs / rows than any before: repeated eagerly)
-    assert st["captured"] <= 3, st  # (capacities settle during the first cycle through the cameras)
+    assert st["captured"] <= 5, st  # (capacities settle during the first cycle; a new capture costs ONE eager iteration)
     assert st["replayed"] >= 0.9 * steps, st
     for a, b in zip(losses, ref[0]):
         assert abs(a - b) <= 2e-4 * abs(b), (losses[:12], ref[0][:12])
@@ -279,3 +279,101 @@ def test_replays_carry_the_load_balancers_timings(device, fake_world):
         assert all(0.0 < t[i] < 50.0 for t in replayed), [t[i] for t in replayed][:8]
         # the same kernels between the same points of the stream; an eager iteration's events also see the host's gaps
         assert 0.2 * e < g < 2.0 * e, (i, g, e)
+
+
+def test_live_balancer_keeps_moving_the_cut_points_under_one_graph(device, fake_world):
+    """the reference's loop with LIVE heuristics (train_internal.py:134-208: start_strategy_final -> iteration ->
+    finish_strategy_final, per-camera row costs updated from every iteration's times, workload_division.py:944-998) on
+    one rank of a 4-rank world: the cut points of every camera keep moving, the iteration keeps being replayed from the
+    same graph, and the balancer is fed by the replays' device timestamps"""
+    import diff_gaussian_rasterization as dgr
+    import gaussian_renderer as gr
+    import gaussian_renderer.workload_division as wd
+    import synthetic_scene as S
+    import utils.general_utils as utils
+    from fused_optim import FusedAdam
+    from gaussian_renderer import distributed_preprocess3dgs_and_all2all_final, render_final
+    from gaussian_renderer.loss_distribution import batched_loss_computation, load_camera_from_cpu_to_all_gpu
+    from graphed_step import GraphedIteration
+
+    world, rank, n_cams, steps = 4, 2, 8, 160
+    N, W, H = 40000, 1280, 720  # (above the "small image" rule that freezes the heuristics, workload_division.py:968-978)
+    utils.GLOBAL_RANK, utils.LOCAL_RANK, utils.WORLD_SIZE = rank, 0, world
+    utils.DEFAULT_GROUP = utils.IN_NODE_GROUP = fake_world.FakeGroup(world, rank)
+    utils.set_args(utils.default_args(bsz=1, heuristic_decay=0.5))
+    utils.set_img_size(H, W)
+    utils.set_cur_iter(1)
+    gr._PLANNERS.clear()
+    dgr.release_workspaces()
+    # the other ranks' times: this rank's, scaled by a factor that differs per rank and changes from call to call (the
+    # stand-in ranks are identical; equal times would be a fixed point of the balancer) -- the cut points never settle,
+    # a harder case for the graph than a converging partition
+    saved = (utils.our_allgather_among_cpu_processes_float_list, wd._BALANCE["mode"])
+    calls = [0]
+
+    def gather(data, group):
+        calls[0] += 1
+        return [[d * (1.0 + 0.2 * ((5 * g + 3 * calls[0]) % 7)) if d >= 0 else d for d in data]
+                for g in range(group.size())]
+
+    utils.our_allgather_among_cpu_processes_float_list = gather
+    wd._BALANCE["mode"] = "exact"
+    try:
+        assert wd.timings_have_consumer()
+        cams = S.orbit_cameras(n_cams, W, H, device=device)
+        for k, c in enumerate(cams):
+            c.original_image_backup = S.make_gt_image(W, H, seed=70 + k, device=device)
+        hist = wd.DivisionStrategyHistoryFinal(S.SyntheticDataset(cams), world, rank)
+        model = S.SyntheticGaussianModel(N, W, H, seed=13, device=device, scale_coef=0.008)
+        bg = torch.tensor([0.1, 0.2, 0.3], device=device)
+        pipe = type("P", (), {"debug": False})()
+        opt = FusedAdam(model.param_groups(), lr=0.0, eps=1e-15, fuse_backward=True, grad_scale=1.0)
+        eager_stats = [None]
+
+        def body(batch, strategies, tasks):
+            load_camera_from_cpu_to_all_gpu(batch, strategies, tasks)
+            pkg = distributed_preprocess3dgs_and_all2all_final(batch, model, pipe, bg, batched_strategies=strategies,
+                                                               mode="train")
+            images, masks = render_final(pkg, strategies)
+            stats = [ca["stats_collector"] for ca in pkg["batched_cuda_args"]]
+            if dgr.capturing() is None:
+                eager_stats[0] = stats
+            loss, _ = batched_loss_computation(images, batch, masks, strategies, stats)
+            loss.backward()
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+            return loss
+
+        step = GraphedIteration(opt, body, warmup=2, timings=True)
+        partitions, fed_by_replays, losses = [], 0, []
+        for it in range(steps):
+            batch = [cams[it % n_cams]]
+            utils.set_cur_iter(utils.get_cur_iter() + 1)
+            for g in opt.param_groups:
+                if g["name"] == "xyz":
+                    g["lr"] = 0.00016
+            strategies, tasks = wd.start_strategy_final(batch, hist)
+            partitions.append(tuple(strategies[0].division_pos))
+            eager_stats[0] = None
+            loss = step(batch, strategies, tasks)
+            stats = step.last_stats or eager_stats[0]
+            fed_by_replays += step.last_stats is not None
+            wd.finish_strategy_final(batch, hist, strategies, stats)  # "exact": waits for this iteration's times
+            losses.append(loss)
+        step.validate()
+        torch.cuda.synchronize()
+        st = step.stats
+        distinct = len(set(partitions))
+        moved = sum(1 for a, b in zip(partitions[n_cams:], partitions[:-n_cams]) if a != b)  # same camera, one cycle on
+        print("graph stats", st, "distinct partitions", distinct, "cut points moved between visits", moved,
+              "iterations whose times came from device timestamps", fed_by_replays)
+        assert st["disabled"] is None, st
+        assert distinct >= 12 and moved >= 20, (distinct, moved)  # the balancer is alive
+        assert st["replayed"] >= 0.9 * steps and fed_by_replays >= 0.9 * steps, st
+        # (a capacity that a moving partition outgrows -- band rows, an exchange slab -- costs one eager iteration and
+        # a capture; the stand-in times thrash the partition far harder than a converging balancer does)
+        assert st["captured"] <= 16, st
+        vals = [float(x.detach()) for x in losses]
+        assert all(v == v and 0.0 < v < 10.0 for v in vals)
+    finally:
+        utils.our_allgather_among_cpu_processes_float_list, wd._BALANCE["mode"] = saved
