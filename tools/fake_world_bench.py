@@ -157,6 +157,9 @@ def main():
                     help="balance the row partition with Grendel's own rule over ROUNDS rounds (every rank position "
                          "measured in turn), then measure EVERY rank position on the converged partition")
     ap.add_argument("--profile", action="store_true", help="cProfile the host side of the steps (top functions by own time)")
+    ap.add_argument("--live-timings", action="store_true",
+                    help="with --graph on: the heuristics stay live, i.e. the replays carry the device timestamps that feed "
+                         "finish_strategy_final (the update itself stays switched off in this instrument, see below)")
     ap.add_argument("--per-camera", action="store_true",
                     help="with --balanced: every camera keeps its OWN converged cut points (the reference's behaviour)")
     a0 = ap.parse_args()
@@ -250,9 +253,9 @@ def main():
             pr.enable()
         if a0.graph == "on":
             # the instrument keeps the even partition anyway (above); say so to the mirror, so that no timing events
-            # are recorded and the iteration may be captured
+            # are recorded (--live-timings: leave the heuristics live -- the replays then carry device timestamps)
             _default_args = utils.default_args
-            utils.default_args = lambda **kw: _default_args(**{**kw, "no_heuristics_update": True})
+            utils.default_args = lambda **kw: _default_args(**{**kw, "no_heuristics_update": not a0.live_timings})
         res = bench.run_workload(a, a0.workload, W, rank if W > 1 else 0, dev, a0.steps, a0.warmup, 1, 0,
                                  single_view=(W == 1), collect_kernels=not a0.profile)
         if a0.profile:
