@@ -167,12 +167,16 @@ class GraphedIteration:
                 tuple((float(c.FoVx), float(c.FoVy), int(c.image_height), int(c.image_width)) for c in cameras),
                 p0.data_ptr(), tuple(p0.shape))
 
-    def _band_rows(self, strategies):
-        return max([b[1] - b[0] for b in self._my_bands(strategies) if b is not None] or [0])
+    @staticmethod
+    def _band_rows(strategies):
+        """the tallest band of the batch on ANY rank: replay-or-eager has to be ONE decision of the whole group (an eager
+        rank and a replaying one would run different slab layouts against each other), so it may only depend on what
+        every rank knows -- the partition -- and never on this rank's own band"""
+        return max([int(b) - int(a) for s in strategies for a, b in zip(s.division_pos[:-1], s.division_pos[1:])] or [0])
 
     def _usable(self, entry, cameras, strategies):
         """do the capacities this graph was captured with still hold -- decided on the host BEFORE the replay, from
-        numbers every rank has (the partition, the exchange planner's capacities): the tallest band of this batch fits
+        numbers every rank has (the partition, the exchange planner's capacities): the tallest band of this batch (on any rank) fits
         the launches' band capacity, and the planner asks for no slab larger than the captured layout's"""
         if entry.sproxies is not None and self._band_rows(strategies) > entry.band_cap:
             return False
@@ -337,7 +341,7 @@ class GraphedIteration:
         if self._dynamic(strategies):
             import utils.general_utils as utils
 
-            # the tallest band this rank has been given, plus slack (idle workgroups are cheap, a new capture is not)
+            # the tallest band any rank has been given, plus slack (idle workgroups are cheap, a new capture is not)
             rows = self._band_rows(strategies)
             self._band_cap = max(self._band_cap, min(int(utils.TILE_Y), rows + max(2, rows // 2)))
         e.band_cap = self._band_cap
