@@ -7,7 +7,9 @@ case $OUT in /*) ;; *) OUT=$R/$OUT ;; esac
 mkdir -p $(dirname $OUT)
 D=$(mktemp -d /tmp/kstats.XXXXXX)
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 240 rocprofv3 --kernel-trace --stats -d $D -- python $R/bench.py --no-cpu-baseline --no-extra --repeats 1 "$@" > $D/run.log 2>&1 < /dev/null
+# (KSTATS_CMD: another command of this repo instead of bench.py, e.g. "python $R/tools/fake_world_bench.py")
+CMD=${KSTATS_CMD:-"python $R/bench.py --no-cpu-baseline --no-extra --repeats 1"}
+timeout -k 10 ${KSTATS_TIMEOUT:-240} rocprofv3 --kernel-trace --stats -d $D -- $CMD "$@" > $D/run.log 2>&1 < /dev/null
 f=$(find $D -name "*.db" 2>/dev/null | head -1)
 if [ -n "$f" ] && [ -s "$f" ]; then
   python3 - "$f" > $OUT <<'PY'
