@@ -112,3 +112,58 @@ def test_replay_or_eager_is_one_decision_of_the_group():
     for g in (a, b):
         assert g["slabs_fit"] is True and g["slab_outgrown"] is False
         assert g["proxy_raises"] is True and g["proxy_rows"] == (-1, 24)
+
+
+def test_balancer_consumes_a_replays_timestamps_like_event_pairs():
+    """workload_division._resolve_deferred_timings: a stats_collector that carries "_gsr_stamps" (what
+    GraphedIteration.last_stats holds after a replay) ends up with the same three fields the HIP event pairs of an eager
+    iteration fill, and finish_strategy_final turns them into the next per-row costs (workload_division.py:944-998 of the
+    reference)"""
+    for p in (os.path.join(ROOT, "grendel-gs_amd"), ROOT):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import gaussian_renderer.workload_division as wd
+    import synthetic_scene as S
+    import utils.general_utils as utils
+
+    calls = []
+
+    def stamps():
+        calls.append(1)
+        return {"forward_render_time": 0.30, "backward_render_time": 0.50, "forward_loss_time": 0.10}
+
+    st = {"forward_render_time": 0.0, "backward_render_time": 0.0, "forward_loss_time": 0.0, "_gsr_stamps": stamps}
+    wd._resolve_deferred_timings(st)
+    assert calls == [1] and "_gsr_stamps" not in st
+    assert (st["forward_render_time"], st["backward_render_time"], st["forward_loss_time"]) == (0.30, 0.50, 0.10)
+
+    # rank 0 of two (the peer reports the same times): the resolved times reach the strategy history / the row costs
+    class TwoRanks:
+        def size(self):
+            return 2
+
+        def rank(self):
+            return 0
+
+    saved = (utils.GLOBAL_RANK, utils.WORLD_SIZE, utils.DEFAULT_GROUP, utils.our_allgather_among_cpu_processes_float_list,
+             wd._BALANCE["mode"])
+    try:
+        utils.GLOBAL_RANK, utils.WORLD_SIZE = 0, 2
+        utils.DEFAULT_GROUP = utils.IN_NODE_GROUP = TwoRanks()
+        utils.our_allgather_among_cpu_processes_float_list = lambda data, group: [list(data), list(data)]
+        wd._BALANCE["mode"] = "exact"
+        utils.set_args(utils.default_args(bsz=1, save_strategy_history=True))
+        utils.set_img_size(720, 1280)
+        utils.set_cur_iter(10)
+        cams = S.orbit_cameras(1, 1280, 720)
+        hist = wd.DivisionStrategyHistoryFinal(S.SyntheticDataset(cams), 2, 0)
+        strategies, _ = wd.start_strategy_final(cams, hist)
+        st = {"forward_render_time": 0.0, "backward_render_time": 0.0, "forward_loss_time": 0.0, "_gsr_stamps": stamps}
+        wd.finish_strategy_final(cams, hist, strategies, [st])
+        assert len(calls) == 2
+        rec = hist.history[-1]["batched_camera_info"][0]
+        assert abs(rec["each_gpu_running_time"][0] - (0.30 + 0.50 + 2 * 0.10)) < 1e-9, rec
+    finally:
+        utils.GLOBAL_RANK, utils.WORLD_SIZE, utils.DEFAULT_GROUP = saved[:3]
+        utils.IN_NODE_GROUP = saved[2]
+        utils.our_allgather_among_cpu_processes_float_list, wd._BALANCE["mode"] = saved[3], saved[4]
