@@ -238,7 +238,9 @@ def main():
         os.environ["WORLD_SIZE"] = str(W)
         utils.GLOBAL_RANK, utils.LOCAL_RANK, utils.WORLD_SIZE = (rank if W > 1 else 0), 0, W
         utils.DEFAULT_GROUP = utils.IN_NODE_GROUP = FakeGroup(W, rank) if W > 1 else utils.SingleGPUGroup()
-        wd._BALANCE["mode"] = "pipelined" if W > 1 else "exact"  # (set directly: no gloo group to create here)
+        # (set directly: no gloo group to create here; GSR_FAKE_BALANCE_MODE=exact: the reference's schedule -- the host
+        # waits for an iteration's times before it starts the next)
+        wd._BALANCE["mode"] = os.environ.get("GSR_FAKE_BALANCE_MODE", "pipelined") if W > 1 else "exact"
         import gaussian_renderer as gr
 
         gr._PLANNERS.clear()
