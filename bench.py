@@ -294,25 +294,49 @@ def densify_leg(a, model, opt, train_step, timed, state, steps, dgr):
     ev = {"events": 0, "rows": [int(model._xyz.shape[0])], "mode": "stats", "each_ms": []}
     scratch0 = sum(int(b.numel()) for b in dgr._SORT_SCRATCH.values())
 
+    def event_due():
+        return ev["mode"] == "densify" and state["it"] % every == 0
+
     def hook(pkg):
+        """pkg: inside the iteration, between backward and step (the reference's spot) -- the statistics (one captured
+        launch when the iteration is a hipGraph) and, in the eager loop, the event.  None: called by train_step AFTER a
+        graphed iteration (the event's host reads cannot be captured; the iteration's step is then applied before the
+        surgery instead of being dropped for the re-created parameters -- one step's difference per event)"""
         with torch.no_grad():  # densification.py:13-25
-            for k in range(len(pkg["batched_locally_preprocessed_radii"])):
-                D.update_densification_stats(model, pkg["batched_locally_preprocessed_mean2D"][k],
-                                             pkg["batched_locally_preprocessed_radii"][k])
-            if ev["mode"] == "densify" and state["it"] % every == 0:
+            if pkg is not None:
+                for k in range(len(pkg["batched_locally_preprocessed_radii"])):
+                    D.update_densification_stats(model, pkg["batched_locally_preprocessed_mean2D"][k],
+                                                 pkg["batched_locally_preprocessed_radii"][k])
+            graph = state.get("graph")
+            in_graph = graph is not None and graph.enabled
+            if event_due() and ((pkg is None) == in_graph):
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
+                parts = {}
+                if in_graph:
+                    # the graphs go FIRST: they hold the tensors the surgery is about to replace (and their private
+                    # pools), and with those alive the new rows come from fresh hipMallocs -- measured 246 ms per event
+                    # instead of 4-8 ms
+                    graph.reset()
+                    torch.cuda.synchronize()
+                    parts["graph_reset"] = time.perf_counter() - t0
                 gr = (model.xyz_gradient_accum / model.denom.clamp(min=1)).squeeze(1)
                 # the threshold that selects ~2 % of the rows (the reference's is a constant of the real scene, 0.0002)
                 thr = torch.kthvalue(gr[:4_000_000], max(int(0.98 * min(gr.numel(), 4_000_000)), 1)).values.item()
+                parts["threshold"] = time.perf_counter() - t0 - parts.get("graph_reset", 0.0)
+                t1 = time.perf_counter()
                 D.densify_and_prune(model, max(thr, 1e-30), 0.005, 4.0, None)
                 torch.cuda.synchronize()
+                parts["densify_and_prune"] = time.perf_counter() - t1
                 ev["each_ms"].append(round(1e3 * (time.perf_counter() - t0), 3))
+                ev.setdefault("parts_ms", []).append({k: round(1e3 * v, 3) for k, v in parts.items()})
                 ev["events"] += 1
                 ev["rows"].append(int(model._xyz.shape[0]))
 
     t_plain = timed(train_step, steps)
     state["densify"] = hook
+    if state.get("graph") is not None:
+        state["graph"].reset()  # (the body has changed: graphs captured without the statistics launch must not replay)
     timed(train_step, min(steps, 5))  # (the statistics' temporaries are new to the caching allocator)
     t_stats = timed(train_step, steps)
     ev["mode"] = "densify"
@@ -322,6 +346,8 @@ def densify_leg(a, model, opt, train_step, timed, state, steps, dgr):
     t_dens = timed(train_step, n_dens)
     state["it"] = it0
     state["densify"] = None
+    if state.get("graph") is not None:
+        state["graph"].reset()
     scratch1 = sum(int(b.numel()) for b in dgr._SORT_SCRATCH.values())
     # what an event costs the LOOP: the region's excess over the same steps without events, per event; the first event pays
     # one-off costs (code objects of the torch kernels densification uses are loaded at first use), hence `steady`
@@ -333,7 +359,7 @@ def densify_leg(a, model, opt, train_step, timed, state, steps, dgr):
             "ms_per_step_with_statistics": round(1e3 * t_stats / steps, 4),
             "ms_per_step_with_events": round(1e3 * t_dens / n_dens, 4),
             "ms_per_event_in_loop_mean": round(1e3 * per_event, 3),
-            "ms_per_event_each": ev["each_ms"],
+            "ms_per_event_each": ev["each_ms"], "ms_per_event_parts": ev.get("parts_ms"),
             "ms_per_event_steady": round(1e3 * steady, 3),
             "ms_per_step_amortised_at_100": round(1e3 * (t_stats / steps + steady / 100.0), 4),
             "sort_scratch_bytes": [scratch0, scratch1],
@@ -477,6 +503,8 @@ def run_workload(a, name, world, rank, dev, steps, warmup, repeats, render_steps
             # eagerly (warm-up, a repeated one): the events its ops recorded
             stats = graphed.last_stats or state.get("stats") or [dict(idle) for _ in cams]
             finish_strategy_final(cams, history, strategies, stats)
+            if state.get("densify") is not None:
+                state["densify"](None)  # (a densification event due now: after the replay, see densify_leg)
             return
         if graphed is not None:
             graphed.validate()
@@ -576,9 +604,17 @@ def run_workload(a, name, world, rank, dev, steps, warmup, repeats, render_steps
         opt.set_fuse_backward(True)
 
     densification = None
-    if getattr(a, "densify_every", 0) and world == 1 and graphed is None:
+    if getattr(a, "densify_every", 0) and world == 1:
+        if graphed is not None:  # --graph on: the statistics are part of the replays, an event drops the graphs
+            graphed.enabled = graphed.stats["disabled"] is None
+            before = dict(graphed.stats)
         densification = densify_leg(a, model, opt, train_step, timed, state, steps, dgr)
         n_total = int(model._xyz.shape[0])
+        if graphed is not None:
+            graphed.validate()
+            densification["graph"] = {k: (graphed.stats[k] - before[k] if isinstance(before[k], int) else graphed.stats[k])
+                                      for k in before}
+            graphed.enabled = False
 
     if host_phases:
         print("# host phases (us per call, from the timed region on): " + ", ".join(

@@ -330,6 +330,10 @@ class GraphedIteration:
                                "imported (HIP runtime issue with replays after eager launches); iteration stays eager")
         dev = self.opt.param_groups[0]["params"][0].device
         self._ensure_buffers(dev)
+        # (the six (group, parameter) pairs of the fused launch are re-discovered by this capture: after a densification
+        # event the ones of the previous capture name parameters that no longer exist)
+        if self.opt.__dict__.get("_graph_owners") is not None:
+            self.opt._graph_owners = None
         e = _Entry()
         if len(cameras) > self.MAXB:
             raise RuntimeError(f"batches above {self.MAXB} cameras are not graphed")
@@ -529,6 +533,16 @@ class GraphedIteration:
             g["lr"] = lr
         if it is not None:
             utils.set_cur_iter(it)
+
+    def reset(self):
+        """drop every captured graph (after validating the iteration in flight): call when tensors a capture has baked in
+        are replaced -- densification / pruning re-creates the parameters, Adam's moments and the statistics buffers;
+        the key would notice the parameters' new address or shape, but an allocator that hands a freed address out again
+        must never revive a stale graph.  The next iterations run eagerly (warm-up) and end with a new capture."""
+        out = self._check_inflight()
+        self.entries.clear()
+        self._seen.clear()
+        return out
 
     def validate(self):
         """wait for the iteration in flight and make sure it counted (repeating it eagerly if a capacity overflowed);

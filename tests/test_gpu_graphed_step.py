@@ -181,3 +181,93 @@ def test_replays_resume_after_eager_iterations(device):
     st = run[3]
     assert st["disabled"] is None and st["captured"] == 1 and st["replayed"] == steps - 2 - len(eager_at), st
     _compare(run, ref, steps)
+
+
+def test_replays_survive_densification_events(device):
+    """densification in the loop (densification.py:5-86 of the reference): the per-iteration statistics are ONE launch inside
+    the replayed iteration, an event (clone / split / prune: host reads, every parameter, moment and statistics tensor
+    re-created) runs between two iterations after GraphedIteration.reset() -- the graphs go first -- and the loop is back
+    on replays three iterations later.  Row counts follow the eager loop's (the selection thresholds a quantile of a
+    statistic that carries K10's atomic-order noise: equal to a few rows)."""
+    import densification_ops as D
+    import diff_gaussian_rasterization as dgr
+    import synthetic_scene as S
+    import utils.general_utils as utils
+    from fused_optim import FusedAdam
+    from gaussian_renderer import distributed_preprocess3dgs_and_all2all_final, render_final
+    from gaussian_renderer.loss_distribution import batched_loss_computation, load_camera_from_cpu_to_all_gpu
+    from gaussian_renderer.workload_division import DivisionStrategyHistoryFinal, start_strategy_final
+    from graphed_step import GraphedIteration
+
+    def run(graph):
+        N, W, H, cams = _setup(device, 1, False)
+        dgr.release_workspaces()
+        model = S.SyntheticGaussianModel(N, W, H, seed=9, device=device, scale_coef=0.008)
+        hist = DivisionStrategyHistoryFinal(S.SyntheticDataset(cams), 1, 0)
+        bg = torch.tensor([0.1, 0.2, 0.3], device=device)
+        pipe = type("P", (), {"debug": False})()
+        opt = FusedAdam(model.param_groups(), lr=0.0, eps=1e-15, fuse_backward=True, grad_scale=1.0)
+        for g in opt.param_groups:
+            if g["name"] == "xyz":
+                g["lr"] = 0.00016
+        model.optimizer, model.percent_dense = opt, 0.01
+
+        def fresh():
+            n = model._xyz.shape[0]
+            model.xyz_gradient_accum = torch.zeros((n, 1), device=device)
+            model.denom = torch.zeros((n, 1), device=device)
+            model.max_radii2D = torch.zeros((n,), device=device)
+            model.sum_visible_count_in_one_batch = torch.zeros((n,), device=device)
+            model.send_to_gpui_cnt = None
+
+        fresh()
+
+        def body(batch, strategies, tasks):
+            load_camera_from_cpu_to_all_gpu(batch, strategies, tasks)
+            pkg = distributed_preprocess3dgs_and_all2all_final(batch, model, pipe, bg, batched_strategies=strategies,
+                                                               mode="train")
+            images, masks = render_final(pkg, strategies)
+            stats = [ca["stats_collector"] for ca in pkg["batched_cuda_args"]]
+            loss, _ = batched_loss_computation(images, batch, masks, strategies, stats)
+            loss.backward()
+            with torch.no_grad():
+                D.update_densification_stats(model, pkg["batched_locally_preprocessed_mean2D"][0],
+                                             pkg["batched_locally_preprocessed_radii"][0])
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+            return loss
+
+        step = GraphedIteration(opt, body, warmup=2, enabled=graph)
+        rows, losses = [int(model._xyz.shape[0])], []
+        for it in range(1, 41):
+            batch = [cams[it % len(cams)]]
+            utils.set_cur_iter(utils.get_cur_iter() + 1)
+            strategies, tasks = start_strategy_final(batch, hist)
+            loss = step(batch, strategies, tasks)
+            if it % 10 == 0:
+                redo = step.reset()  # validates the iteration in flight, then drops the graphs
+                loss = redo if redo is not None else loss
+                with torch.no_grad():
+                    gr = (model.xyz_gradient_accum / model.denom.clamp(min=1)).squeeze(1)
+                    thr = torch.kthvalue(gr, max(int(0.97 * gr.numel()), 1)).values.item()
+                    D.densify_and_prune(model, max(thr, 1e-30), 0.005, 4.0, None)
+                rows.append(int(model._xyz.shape[0]))
+            if it % 10 in (0, 9):
+                redo = step.validate()
+                losses.append(float((redo if redo is not None else loss).detach()))
+        step.validate()
+        torch.cuda.synchronize()
+        opt.set_fuse_backward(False)
+        return rows, losses, dict(step.stats)
+
+    rows_e, losses_e, _ = run(False)
+    rows_g, losses_g, st = run(True)
+    print("rows eager", rows_e, "graph", rows_g, "stats", st)
+    assert st["disabled"] is None, st
+    assert st["captured"] >= 4 and st["replayed"] >= 20, st  # one capture per shard size, replays in between
+    assert rows_e[0] == rows_g[0] and len(rows_e) == len(rows_g) == 5
+    assert all(r != rows_g[0] for r in rows_g[1:])  # the events really changed the shard
+    for a, b in zip(rows_g, rows_e):
+        assert abs(a - b) <= max(0.003 * b, 30), (rows_g, rows_e)
+    for a, b in zip(losses_g, losses_e):
+        assert a == a and abs(a - b) <= 2e-2 * abs(b), (losses_g, losses_e)
