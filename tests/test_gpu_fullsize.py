@@ -13,9 +13,9 @@ from helpers import KEYS, cam_kwargs, elem_excess, oracle_c_chain, rel_err, sett
 pytestmark = pytest.mark.gpu
 
 
-def _chain(rast, gg, mask, wgt):
+def _chain(rast, gg, mask, wgt, cuda_args=None):
     m2, rgb, co, radii, depths = rast.preprocess_gaussians(*[gg[k] for k in KEYS], {})
-    img, _, _, _ = rast.render_gaussians(m2, co, rgb, depths, radii, mask, None, {})
+    img, _, _, _ = rast.render_gaussians(m2, co, rgb, depths, radii, mask, None, dict(cuda_args or {}))
     (img * wgt).sum().backward()
     return img.detach(), radii
 
@@ -43,12 +43,17 @@ def test_config1_1M_1080p_matches_c_oracle(device):
         assert elem_excess(gg[k].grad, ref[rk]) <= 1.0, f"{k}: p99 element-wise"
 
 
-@pytest.mark.parametrize("N,W,H,band,deg", [
-    (1_500_000, 1920, 1080, (17, 34), 3),   # BASELINE configs[2] per-rank shape: 6 M / 4 GPUs, a quarter-image band
-    (5_000_000, 3840, 2160, (51, 68), 3),   # BASELINE configs[4] per-rank shape: 40 M / 8 GPUs at 4K, an eighth band
-    (1_500_000, 1920, 1080, (51, 68), 1),   # the ragged last band (row 67 is half a tile), SH degree 1
+@pytest.mark.parametrize("N,W,H,band,deg,grid", [
+    (1_500_000, 1920, 1080, (17, 34), 3, None),   # BASELINE configs[2] per-rank shape: 6 M / 4 GPUs, a quarter-image band
+    (5_000_000, 3840, 2160, (51, 68), 3, None),   # BASELINE configs[4] per-rank shape: 40 M / 8 GPUs at 4K, an eighth band
+    (1_500_000, 1920, 1080, (51, 68), 1, None),   # the ragged last band (row 67 is half a tile), SH degree 1
+    # the launches a hipGraph replays for every band (ABI 13: the band read on the device, a grid of 24 / 20 tile rows)
+    (1_500_000, 1920, 1080, (17, 34), 3, (-1, 24)),
+    (1_500_000, 1920, 1080, (51, 68), 1, (-1, 20)),
+    # ... and the grid a host that knows its band launches (the mirror's default at W > 1)
+    (1_500_000, 1920, 1080, (17, 34), 3, "band"),
 ])
-def test_per_rank_band_shapes_match_c_oracle(device, N, W, H, band, deg):
+def test_per_rank_band_shapes_match_c_oracle(device, N, W, H, band, deg, grid):
     """what ONE rank of the multi-GPU configs computes -- its Gaussian shard projected, one row band rendered,
     backward -- against the C restatement on the box's host cores (the image outside the band is exactly 0)"""
     from diff_gaussian_rasterization import GaussianRasterizer
@@ -63,7 +68,8 @@ def test_per_rank_band_shapes_match_c_oracle(device, N, W, H, band, deg):
     ref = oracle_c_chain(g, cam, bg, mask, wgt, sh_degree=deg)
     rast = GaussianRasterizer(settings_from(cam, bg, sh_degree=deg))
     gg = {k: v.to(device).requires_grad_(True) for k, v in g.items()}
-    img, radii = _chain(rast, gg, mask.to(device), wgt.to(device))
+    cuda_args = {} if grid is None else {"_gsr_band": band if grid == "band" else grid}
+    img, radii = _chain(rast, gg, mask.to(device), wgt.to(device), cuda_args)
     assert (radii.cpu() != ref["radii"]).sum().item() <= N // 100000
     y0, y1 = band[0] * 16, min(band[1] * 16, H)
     assert float(img[:, :y0].abs().sum()) == 0.0 and float(img[:, y1:].abs().sum()) == 0.0
