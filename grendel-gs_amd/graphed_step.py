@@ -364,7 +364,8 @@ class GraphedIteration:
             # all-to-all, and while the partition still moves every slab that outgrows it would cost a capture (the
             # eager path keeps the planner's own capacities: both layouts are self-consistent, and every rank derives
             # both from the same all-gathered history)
-            e.caps_key = (caps * 5 // 4 + 255) // 256 * 256
+            slack = float(_os.environ.get("GSR_GRAPH_SLAB_SLACK", "1.25"))  # (1.0: the planner's own layout)
+            e.caps_key = ((caps * slack).astype(caps.dtype) + 255) // 256 * 256 if slack != 1.0 else caps.copy()
             e.ctx.slab_caps_dev = torch.tensor(e.caps_key.reshape(-1), dtype=torch.int32).to(dev)
         torch.cuda.synchronize(dev)
         e.graph = torch.cuda.CUDAGraph()
