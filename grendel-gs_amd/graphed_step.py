@@ -29,7 +29,7 @@ that a band fits the capacity.  So every camera of a live partition -- the refer
 moves them with the measured times (workload_division.py:806-849) -- replays the same graph; only a change of the SET of
 ranks that render a camera (bsz > 1) is a new key.  A key's first `warmup` sights run eagerly (they teach the
 capacities); a band taller than the captured capacity, or an exchange slab the planner wants larger than the captured
-layout (the planner's capacities plus a quarter), replaces the graph after ONE eager iteration (_usable).
+layout (the planner's capacities plus an eighth), replaces the graph after ONE eager iteration (_usable).
 timings=True: the replays carry device timestamps around K3-K8, the loss forward and K10 (gsr_stamp), which
 `last_stats` hands to finish_strategy_final in place of the eager ops' HIP events: the load balancer runs on replayed
 iterations (tests/test_gpu_dynamic_bands.py: 157 of 160 iterations replayed from 2 captures while the cut points moved
@@ -360,11 +360,11 @@ class GraphedIteration:
         planner, caps = self._planner_caps(len(cameras))
         e.caps_key = None
         if caps is not None:
-            # the graph's own slab layout: the planner's capacities plus a quarter -- a layout is baked into the captured
+            # the graph's own slab layout: the planner's capacities plus an eighth -- a layout is baked into the captured
             # all-to-all, and while the partition still moves every slab that outgrows it would cost a capture (the
             # eager path keeps the planner's own capacities: both layouts are self-consistent, and every rank derives
             # both from the same all-gathered history)
-            slack = float(_os.environ.get("GSR_GRAPH_SLAB_SLACK", "1.25"))  # (1.0: the planner's own layout)
+            slack = float(_os.environ.get("GSR_GRAPH_SLAB_SLACK", "1.125"))  # (1.0: the planner's own layout)
             e.caps_key = ((caps * slack).astype(caps.dtype) + 255) // 256 * 256 if slack != 1.0 else caps.copy()
             e.ctx.slab_caps_dev = torch.tensor(e.caps_key.reshape(-1), dtype=torch.int32).to(dev)
         torch.cuda.synchronize(dev)
