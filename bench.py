@@ -438,10 +438,6 @@ def run_workload(a, name, world, rank, dev, steps, warmup, repeats, render_steps
 
     from diff_gaussian_rasterization import capturing as _dgr_capturing
 
-    # (A/B: the autograd engine runs a CUDA graph's nodes on its device thread; every Python backward of this package is
-    # a hand-over of the GIL to it.  GSR_BACKWARD_SINGLE_THREAD=1 runs them on the calling thread)
-    single_thread_backward = os.environ.get("GSR_BACKWARD_SINGLE_THREAD", "0") == "1"
-
     def iteration(cams, strategies, tasks, between=None):
         """GT staging .. optimizer step of one batch (train_internal.py:134-208, 316-329); `between` runs where the
         reference calls finish_strategy_final, between backward and step"""
@@ -458,11 +454,7 @@ def run_workload(a, name, world, rank, dev, steps, warmup, repeats, render_steps
             state["stats"] = stats
         loss, _ = batched_loss_computation(images, cams, masks, strategies, stats)
         t = _ph("loss", t)
-        if single_thread_backward:
-            with torch.autograd.set_multithreading_enabled(False):
-                loss.backward()
-        else:
-            loss.backward()
+        loss.backward()
         t = _ph("backward", t)
         if between is not None:
             between(stats)

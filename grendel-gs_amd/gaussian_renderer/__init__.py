@@ -179,7 +179,8 @@ def all_to_all_communication_final(batched_rasterizers, batched_screenspace_para
 #   group     : ONE exchange for the whole batch when every rank renders (a band of) at most one of its cameras
 _EXCHANGE_OPTIONS = {"overlap": True, "speculate": True, "forced": False,
                      "group": os.environ.get("GSR_EXCHANGE_GROUP", "1") != "0",  # (env: A/B measurements only)
-                     "camera_streams": int(os.environ.get("GSR_CAMERA_STREAMS", "1") or 1)}
+                     "camera_streams": int(os.environ.get("GSR_CAMERA_STREAMS", "1") or 1),
+                     "single_thread_backward": os.environ.get("GSR_AUTOGRAD_MULTITHREAD", "0") != "1"}
 _SIDE_STREAMS = {}
 _BANDS_CACHE = {}
 _PLANNERS = {}
@@ -200,6 +201,18 @@ def set_camera_streams(n):
     and gradients are those of the one-stream order (the kernels and their inputs are the same).  1 (default): one
     stream, the reference's order (gaussian_renderer/__init__.py:1217-1291 renders its cameras one after the other)."""
     _EXCHANGE_OPTIONS["camera_streams"] = 2 if int(n) >= 2 else 1
+
+
+def set_single_thread_backward(enabled):
+    """True (default; GSR_AUTOGRAD_MULTITHREAD=1 in the environment: False): the training thread's backward runs the
+    autograd nodes of this package ON THAT THREAD.  PyTorch's engine hands a CUDA graph's nodes to a per-device worker
+    thread; every node of the hot path is a Python function (one or two C-ABI launches each), so every node is a
+    hand-over of the GIL -- measured on one rank of 8 (configs[2]'s shape): the eager iteration 1.14-1.34 -> 0.98 ms, and
+    the step time no longer moves with the box's host.  One process drives one GPU here (utils/general_utils.py:194-235 of
+    the reference), which is the case the worker threads do nothing for.  The setting is PyTorch's own
+    torch.autograd.set_multithreading_enabled -- thread-local -- applied at the top of every
+    distributed_preprocess3dgs_and_all2all_final(mode="train") on the calling thread."""
+    _EXCHANGE_OPTIONS["single_thread_backward"] = bool(enabled)
 
 
 def set_exchange_grouping(enabled):
@@ -693,6 +706,8 @@ def distributed_preprocess3dgs_and_all2all_final(batched_viewpoint_cameras, pc, 
     args = utils.get_args()
     assert utils.DEFAULT_GROUP.size() == 1 or (args.gaussians_distribution and args.image_distribution), \
         "Ensure distributed training given multiple GPU. "
+    if mode == "train" and _EXCHANGE_OPTIONS["single_thread_backward"] and torch.autograd.is_multithreading_enabled():
+        torch.autograd.set_multithreading_enabled(False)  # (thread-local; see set_single_thread_backward)
 
     # the operator records its render timings (HIP events, resolved by finish_strategy_final) only when the load
     # balancer or a saved strategy history will read them; asked for per call (cuda_args), not through the module-wide
