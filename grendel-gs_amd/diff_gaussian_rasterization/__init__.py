@@ -211,6 +211,23 @@ def _stream():
     return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
+_STREAM_OBJECTS = {}
+_NO_STREAM_CACHE = os.environ.get("GSR_STREAM_CACHE", "1") == "0"  # env: A/B measurements only
+
+
+def current_stream(dev=None):
+    """torch.cuda.current_stream(dev), without its three Python layers per call (~5-9 us; an eager iteration of one rank
+    asks a dozen times -- stream hand-overs, event records): the Stream object of a raw handle is built once"""
+    idx = dev.index if (dev is not None and dev.index is not None) else torch._C._cuda_getDevice()
+    if _NO_STREAM_CACHE:
+        return torch.cuda.current_stream(idx)
+    key = (idx, torch._C._cuda_getCurrentRawStream(idx))
+    s = _STREAM_OBJECTS.get(key)
+    if s is None:
+        s = _STREAM_OBJECTS[key] = torch.cuda.current_stream(idx)
+    return s
+
+
 def _f32c(t, name):
     if not t.is_cuda:
         raise RuntimeError(f"diff_gaussian_rasterization: `{name}` must live on the gfx950 device "
@@ -437,12 +454,12 @@ class PendingProjectionBackward:
         self.cams, self.radii, self.cov3D, self.clamped = cams, radii, cov3D, clamped
         self.g_means2D, self.g_conic_opacity, self.g_rgb, self.gstride = g_means2D, g_conic_opacity, g_rgb, gstride
         self.meta, self.tanfov0 = meta, tanfov0
-        self.stream = torch.cuda.current_stream(params[0].device) if params[0].is_cuda else None
+        self.stream = current_stream(params[0].device) if params[0].is_cuda else None
 
     def join_stream(self):
         """make the current stream wait for the stream the backward ran on (no-op when they are the same)"""
         if self.stream is not None:
-            cur = torch.cuda.current_stream(self.params[0].device)
+            cur = current_stream(self.params[0].device)
             if cur != self.stream:
                 cur.wait_stream(self.stream)
 
@@ -637,8 +654,8 @@ def _sort_scratch(nbytes, dev):
     """The sort's ping-pong buffers are dead when gsr_bin_sort's kernels have run, so consecutive calls on one stream
     can share ONE grow-only buffer (stream order makes the reuse safe; another stream gets its own).  Measured on the
     40 M-Gaussian / 4K shape: 260 -> ~30 ms of 'binning' per view were allocator misses on the 22 GB scratch."""
-    key = (dev.index if dev.index is not None else torch.cuda.current_device(),
-           int(torch.cuda.current_stream(dev).cuda_stream))
+    idx = dev.index if dev.index is not None else torch._C._cuda_getDevice()
+    key = (idx, int(torch._C._cuda_getCurrentRawStream(idx)))
     buf = _SORT_SCRATCH.get(key)
     if buf is None or buf.numel() < nbytes:
         _SORT_SCRATCH.pop(key, None)
@@ -849,7 +866,9 @@ class PendingPairs:
         self.D = None
 
     def finish(self):
-        with _on(self.dev), torch.cuda.stream(self.stream):
+        # (the stream guard only when the caller settles from another stream: entering / leaving it is ~15 us of Python)
+        same = (not _NO_STREAM_CACHE) and self.stream is current_stream(self.dev)
+        with _on(self.dev), (_NULL_RANGE if same else torch.cuda.stream(self.stream)):
             stream = _stream()
             D = ctypes.c_int64(0)
             rc = lib.gsr_bin_count_wait(self.ticket, ctypes.byref(D), stream)
@@ -926,7 +945,7 @@ def bin_gaussians(means2D, depths, radii, conic_opacity, compute_locally, width,
                                             _ptr(ranges), ctypes.byref(ticket), ctypes.byref(sorted_), stream),
               "gsr_bin_speculative_async")
     pend = PendingPairs(ticket.value, bool(sorted_.value), cap, P, width, height, compute_locally, prep, ranges, dev,
-                        torch.cuda.current_stream(dev), key, cuda_args)
+                        current_stream(dev), key, cuda_args)
     if kernel_timer.enabled and ticket.value:
         # bench.py's instrumented replay only (a device read-back): the row segments R of this view, for the bytes of the
         # row-major pipeline (include/gsraster.h: gsr_bin_segments_offset)
@@ -975,7 +994,7 @@ class _RenderGaussians(torch.autograd.Function):
             if timing != "off":
                 ev0 = torch.cuda.Event(enable_timing=True)
                 ev1 = torch.cuda.Event(enable_timing=True)
-                ev0.record()
+                ev0.record(current_stream(dev))
             if _CAPTURE[0] is not None:
                 _CAPTURE[0].stamp("fwd0", id(stats))
             with kernel_timer.range("binning", P=P, tiles=gx * gy) as kt:
@@ -1052,7 +1071,7 @@ class _RenderGaussians(torch.autograd.Function):
                 else:
                     settle()
             if timing != "off":
-                ev1.record()
+                ev1.record(current_stream(dev))
                 ctx.fwd_events = (ev0, ev1)
         if stats is not None:
             # placeholders are real floats so that a forward-only caller can read them; the backward
@@ -1096,7 +1115,7 @@ class _RenderGaussians(torch.autograd.Function):
             if timing != "off":
                 ev0 = torch.cuda.Event(enable_timing=True)
                 ev1 = torch.cuda.Event(enable_timing=True)
-                ev0.record()
+                ev0.record(current_stream(dev))
             cap_stats = ctx.cuda_args.get("stats_collector") if isinstance(ctx.cuda_args, dict) else None
             if _CAPTURE[0] is not None:
                 _CAPTURE[0].stamp("bwd0", id(cap_stats))
@@ -1111,7 +1130,7 @@ class _RenderGaussians(torch.autograd.Function):
             if _CAPTURE[0] is not None:
                 _CAPTURE[0].stamp("bwd1", id(cap_stats))
             if timing != "off":
-                ev1.record()
+                ev1.record(current_stream(dev))
         stats = ctx.cuda_args.get("stats_collector") if isinstance(ctx.cuda_args, dict) else None
         if stats is not None and timing != "off":
             f0, f1 = ctx.fwd_events

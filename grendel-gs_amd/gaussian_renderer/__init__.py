@@ -334,7 +334,7 @@ class _SlabPlanner:
             self._slot += 1
             host.copy_(all_counts, non_blocking=True)
             ev = torch.cuda.Event()
-            ev.record()
+            ev.record(_dgr.current_stream(all_counts.device))
         else:
             host, ev = all_counts.clone(), None
         self.pending = (ev, host, self.caps)
@@ -384,7 +384,7 @@ class _ExchangeGroup(torch.autograd.Function):
         m2_all, rgb_all, co_all, radii_all, depths_all = bases
         dev = radii_all.device
         n_send, n_recv = sum(send_splits), sum(recv_splits)
-        cur = torch.cuda.current_stream() if dev.type == "cuda" else None
+        cur = _dgr.current_stream(dev) if (dev.type == "cuda" and consumer_stream is not None) else None
         if layout[0] == "slab":  # capacities per (destination, camera); this iteration's counts stay on the device
             msg, send_idx = _dgr.exchange_pack_slab(m2_all, rgb_all, co_all, radii_all, depths_all, bands, chunkcnt,
                                                     counts, layout[1], k0, nb, width, height, count_cameras=cnt_B,
@@ -432,7 +432,7 @@ class _ExchangeGroup(torch.autograd.Function):
         k0, nb, P, B, send_splits, recv_splits, group, consumer_stream, holder = ctx.meta
         n_recv, n_send = sum(recv_splits), sum(send_splits)
         dev = send_idx.device
-        cur = torch.cuda.current_stream() if dev.type == "cuda" else None
+        cur = _dgr.current_stream(dev) if (dev.type == "cuda" and consumer_stream is not None) else None
         fdt = ctx.fdt  # fp32 (fp64 in the CPU tests)
         g_recv = None
         if not ctx.has_perm and all(g is not None and g.dtype == torch.float32 for g in (g_m2, g_rgb, g_co)):
@@ -609,7 +609,7 @@ def _batched_exchange_final(m2_views, rgb_views, co_views, radii_views, depths_v
     # aborts with hipErrorCapturedEvent); a captured iteration keeps its exchanges on the capturing stream
     overlap = pipelined and pipeline and dev.type == "cuda" and cap_ctx is None
     groups = [(k, 1) for k in range(B)] if pipelined else [(0, B)]
-    cur = torch.cuda.current_stream() if dev.type == "cuda" else None
+    cur = _dgr.current_stream(dev) if dev.type == "cuda" else None
     side = _side_stream(dev) if overlap else None
     if overlap:
         side.wait_stream(cur)  # K1's outputs and the counts are ready
@@ -882,7 +882,7 @@ def _render_cameras(pkg, batched_strategies):
             turn += 1
             ev = pkg.get("_exchange_events", None)
             if ev is not None and ev[k] is not None:
-                torch.cuda.current_stream().wait_event(ev[k])  # camera k's exchange ran on the side stream
+                _dgr.current_stream().wait_event(ev[k])  # camera k's exchange ran on the side stream
             means2D = pkg["batched_means2D_redistributed"][k]
             rgb = pkg["batched_rgb_redistributed"][k]
             conic_opacity = pkg["batched_conic_opacity_redistributed"][k]

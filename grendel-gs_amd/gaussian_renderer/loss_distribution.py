@@ -21,6 +21,7 @@ import utils.general_utils as utils
 # raise; there is no torch / conv2d restatement of the loss in the product (oracle/loss_oracle.py holds one for the
 # tests, pinned on the reference's own pixelwise_l1_with_mask / pixelwise_ssim_with_mask).
 from diff_gaussian_rasterization import capturing as _capturing
+from diff_gaussian_rasterization import current_stream as _current_stream
 from diff_gaussian_rasterization import fused_band_loss as _FUSED_LOSS
 from diff_gaussian_rasterization import fused_l1_ssim_band as _FUSED
 
@@ -154,14 +155,14 @@ def final_system_loss_computation(image, viewpoint_cam, compute_locally, strateg
     timed = _timings_wanted()
     if timed:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record()
+        ev0.record(_current_stream())
     # one HIP kernel each way (include/gsraster.h: gsr_l1_ssim_forward / _backward)
     l1_sum, ssim_sum = _FUSED(image, viewpoint_cam.original_image, y0, y1)
     Ll1, ssim = l1_sum / n, ssim_sum / n
     # no device sync here (the reference synchronises twice per camera, loss_distribution.py:2566,2578):
     # finish_strategy_final resolves the event pair when -- and only when -- the balancer needs it
     if timed:
-        ev1.record()
+        ev1.record(_current_stream())
         statistic_collector["_loss_events"] = (ev0, ev1)
     statistic_collector.setdefault("forward_loss_time", 0.0)
     return Ll1, ssim
@@ -201,7 +202,7 @@ def batched_loss_computation(batched_image, batched_cameras, batched_compute_loc
             timed = _timings_wanted()
             if timed:
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                ev0.record()
+                ev0.record(_current_stream())
             cap = _capturing()
             if cap is not None:  # (a hipGraph capture: device timestamps instead of events, graphed_step.py)
                 cap.stamp("loss0", id(stats))
@@ -210,7 +211,7 @@ def batched_loss_computation(batched_image, batched_cameras, batched_compute_loc
             if cap is not None:
                 cap.stamp("loss1", id(stats))
             if timed:
-                ev1.record()
+                ev1.record(_current_stream())
                 stats["_loss_events"] = (ev0, ev1)
             stats.setdefault("forward_loss_time", 0.0)
             parts.append([Ll1, ssim])
