@@ -179,9 +179,21 @@ def start_strategy_final(batched_cameras, strategy_history):
             strategies.append(DivisionStrategyFinal(camera, 1, [g], [0, rows], [(0, rows)]))
         return strategies, gpuid2tasks
 
-    heur = torch.cat([strategy_history.accum_heuristic[c.uid].to("cpu") for c in batched_cameras], dim=0)
-    cuts = division_pos_heuristic(heur, rows * len(batched_cameras), W, right=True)
-    cuts = _snap_cuts_to_image_borders(cuts, rows, args.border_divpos_coeff)
+    # the cut points are a function of the batch's row costs: a batch whose costs have not changed since it was last
+    # planned (frozen heuristics, a converged balancer, bsz >= W) is not planned again (~50 us of host per iteration)
+    hs = [strategy_history.accum_heuristic[c.uid] for c in batched_cameras]
+    key = (W, rows, float(args.border_divpos_coeff)) + tuple((c.uid, id(h), h._version) for c, h in zip(batched_cameras, hs))
+    cache = strategy_history.__dict__.setdefault("_gsr_cuts", {})
+    hit = cache.get(key)
+    if hit is not None and all(a is b for a, b in zip(hit[1], hs)):  # (the tensors themselves: an id may be reused)
+        cuts = list(hit[0])
+    else:
+        heur = torch.cat([h.to("cpu") for h in hs], dim=0)
+        cuts = division_pos_heuristic(heur, rows * len(batched_cameras), W, right=True)
+        cuts = _snap_cuts_to_image_borders(cuts, rows, args.border_divpos_coeff)
+        if len(cache) > 8192:
+            cache.clear()
+        cache[key] = (tuple(cuts), tuple(hs))
 
     for k, camera in enumerate(batched_cameras):
         lo, hi = k * rows, (k + 1) * rows
